@@ -1,0 +1,198 @@
+"""Pin the CPU oracle (oracle/rnnpose_oracle.py) against outputs of the reference itself
+(tests/golden/*.npz, produced by tests/golden/gen_golden.py from /root/reference).
+Tolerances: north_star's 1e-4 on correlation/flow quantities, 1e-5 on pose quantities,
+1e-7 relative on the fp64 normal equations (their inputs are fp32)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import rnnpose_oracle as orc
+from rnnpose_amd import synthetic as syn
+
+
+def T(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+def maxdiff(a, b):
+    a = a.numpy() if torch.is_tensor(a) else np.asarray(a)
+    b = b.numpy() if torch.is_tensor(b) else np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float(np.max(np.abs(a.astype(np.float64) - b.astype(np.float64)))) if a.size else 0.0
+
+
+def excess(a, b, atol, rtol):
+    """max(|a-b| - atol - rtol*|b|): <= 0 means within mixed tolerance (fp32 round-off scales with
+    magnitude: re-projections of near-zero depths reach thousands of pixels)."""
+    a = a.numpy() if torch.is_tensor(a) else np.asarray(a)
+    b = b.numpy() if torch.is_tensor(b) else np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    a = a.astype(np.float64); b = b.astype(np.float64)
+    return float(np.max(np.abs(a - b) - atol - rtol * np.abs(b)))
+
+
+def upd_weights(seed=0):
+    return syn.make_module_weights(orc.UPDATE_BLOCK_SHAPES, seed=seed)
+
+
+def test_corr_pyramid_and_lookup(golden):
+    g = golden("corr")
+    B, C, h, w = 2, 256, 16, 24
+    f1 = syn.normal("fmap1", (B, C, h, w), 11)
+    f2 = syn.normal("fmap2", (B, C, h, w), 11)
+    pyr = orc.corr_pyramid(f1, f2)
+    assert [tuple(p.shape) for p in pyr] == [(768, 16, 24), (768, 8, 12), (768, 4, 6), (768, 2, 3)]
+    assert maxdiff(pyr[0].reshape(B * h * w, h * w)[::5], g["level0_rows"]) < 1e-5
+    for l in (1, 2, 3):
+        assert maxdiff(pyr[l][:, None], g[f"level{l}"]) < 1e-5
+    assert abs(float(pyr[0].double().sum()) - float(g["level0_sum"])) < 1e-2
+    grid = orc.coords_grid_lowres(B, h, w)
+    cases = {
+        "int": grid.clone(),
+        "sub": grid + T(syn.uniform("lk_sub", (B, 2, h, w), 11, -3.0, 3.0)),
+        "oob": grid + T(syn.uniform("lk_oob", (B, 2, h, w), 11, -30.0, 30.0)),
+    }
+    for k, c in cases.items():
+        out = orc.corr_lookup(pyr, c)
+        assert out.shape == (B, 324, h, w)
+        assert maxdiff(out[:, :, ::2, ::3], g[f"lookup_{k}"]) < 1e-4, k
+
+
+def test_lookup_integer_coords_are_dot_products():
+    """KAT without the reference: at integer coords level-0 taps equal direct dot products / 16."""
+    B, C, h, w = 1, 256, 16, 16
+    f1 = syn.normal("a", (B, C, h, w), 1)
+    f2 = syn.normal("b", (B, C, h, w), 1)
+    pyr = orc.corr_pyramid(f1, f2)
+    out = orc.corr_lookup(pyr, orc.coords_grid_lowres(B, h, w))
+    Y, X = 7, 9
+    for i, j in ((4, 4), (0, 8), (8, 2)):   # channel i*9+j -> x offset i-4, y offset j-4
+        x2, y2 = X + i - 4, Y + j - 4
+        ref = float((f1[0, :, Y, X].astype(np.float64) * f2[0, :, y2, x2]).sum() / 16)
+        assert abs(float(out[0, i * 9 + j, Y, X]) - ref) < 1e-5
+
+
+def test_update_block(golden):
+    g = golden("update_block")
+    B, h, w = 1, 16, 20
+    hid = np.tanh(syn.normal("u_net", (B, 128, h, w), 3))
+    inp = np.maximum(syn.normal("u_inp", (B, 128, h, w), 3), 0)
+    corr = syn.normal("u_corr", (B, 324, h, w), 3)
+    flow = syn.normal("u_flow", (B, 2, h, w), 3, std=2.0)
+    net, mask, df = orc.update_block(upd_weights(), hid, inp, corr, flow)
+    assert maxdiff(net, g["net"]) < 1e-5
+    assert maxdiff(mask, g["mask"]) < 1e-4
+    assert maxdiff(df, g["dflow"]) < 1e-4
+
+
+def test_upsample_ctx_flowinit(golden):
+    g = golden("upsample_ctx")
+    B, h, w = 2, 16, 12
+    flow = syn.normal("up_flow", (B, 2, h, w), 5, std=3.0)
+    mask = syn.normal("up_mask", (B, 576, h, w), 5, std=2.0)
+    assert maxdiff(orc.convex_upsample(flow, mask), g["flow_up"]) < 1e-4
+    ctx = syn.normal("ctx", (1, 256, 64, 96), 5, std=0.1)
+    net, inp = orc.context_prep(ctx)
+    assert maxdiff(net, g["net"]) < 1e-6 and maxdiff(inp, g["inp"]) < 1e-6
+    finit = syn.normal("finit", (2, 2, 64, 96), 5, std=4.0)
+    keep = finit.copy()
+    assert maxdiff(orc.flow_init_to_coords1(finit), g["coords1"]) < 1e-5
+    assert np.array_equal(keep, finit), "oracle must not mutate flow_init"
+
+
+def test_induced_flow_and_weight(golden):
+    g = golden("geometry")
+    d = syn.make_inputs(2, 64, 96, seed=7, pose_sigma=0.03)
+    flow, vmask = orc.induced_flow(g["depth"], d["K"], g["G"])
+    assert excess(flow[:, None], g["flow_init"], 1e-4, 1e-6) <= 0
+    assert maxdiff(vmask[:, None, :, :, None], g["vmask"]) == 0
+    w = orc.corr_weight(d["g1"], d["g2"], T(g["target"])[:, 0], g["depth"], g["sigma"])
+    assert maxdiff(w[:, None, :, :, None], g["weight"]) < 1e-4
+
+
+@pytest.mark.parametrize("pat", ["desc", "ones", "sparse", "zero"])
+def test_lm_step(golden, pat):
+    g = golden("geometry")
+    d = syn.make_inputs(2, 64, 96, seed=7, pose_sigma=0.03)
+    B, H, W = 2, 64, 96
+    wgt = {
+        "desc": T(g["weight"])[:, 0, :, :, 0],
+        "ones": torch.ones(B, H, W),
+        "sparse": (T(syn.uniform("wsp", (B, 1, H, W, 1), 7)) > 0.97).float()[:, 0, :, :, 0] * 2.5,
+        "zero": torch.zeros(B, H, W),
+    }[pat]
+    tgt = T(g["target"])[:, 0]
+    Hm, b = orc.lm_normal_eq(tgt, wgt, g["depth"], d["K"], g["G"])
+    Hd = Hm + orc.EP_LMBDA * torch.eye(6, dtype=torch.float64) + orc.LM_LMBDA * Hm * torch.eye(6, dtype=torch.float64)
+    ref_H, ref_b = g[f"lm_{pat}_Hd0"][:, 0], g[f"lm_{pat}_b0"][:, 0]
+    # H,b are fp64 sums of Jacobians built from fp32 points: the fp32 part (G*X summation order inside the
+    # reference's einsum/bmm) bounds agreement at fp32-epsilon level, not fp64.
+    assert maxdiff(Hd, ref_H) <= 1e-7 * max(1.0, float(np.abs(ref_H).max()))
+    assert maxdiff(b, ref_b) <= 1e-7 * max(1.0, float(np.abs(ref_b).max()))
+    G1, _ = orc.lm_step(tgt, wgt, g["depth"], d["K"], g["G"], 1)
+    assert maxdiff(G1, g[f"lm_{pat}_G1"]) < 1e-5
+    G2, _ = orc.lm_step(tgt, wgt, g["depth"], d["K"], g["G"], 2)
+    assert maxdiff(G2, g[f"lm_{pat}_G"]) < 1e-5
+    if pat == "zero":                      # H = 100 I -> xi = 0 -> pose unchanged
+        assert maxdiff(G1, g["G"]) < 1e-7
+
+
+def test_exact_target_recovery(golden):
+    """KAT: identity start, exact projected targets, unit weights -> converges to G*."""
+    g = golden("geometry")
+    d = syn.make_inputs(2, 64, 96, seed=7)
+    G = torch.eye(4).repeat(2, 1, 1, 1)
+    tgt = T(g["rec_target"])[:, 0]
+    errs = []
+    for k in range(4):
+        G, _ = orc.lm_step(tgt, torch.ones(2, 64, 96), g["depth"], d["K"], G, 1)
+        assert maxdiff(G, g["rec_G"][k]) < 1e-5
+        errs.append(maxdiff(G, g["rec_Gstar"]))
+    assert errs[-1] < 1e-5 and errs[0] > errs[1] > errs[2]
+
+
+def test_solve_and_exp(golden):
+    g = golden("geometry")
+    # cholesky.solve has no damping: undo it by passing zero lambdas
+    x = orc.lm_solve(g["solve_H"], g["solve_b"], ep_lmbda=0.0, lm_lmbda=0.0)
+    assert maxdiff(x[:, None], g["solve_x"]) < 1e-6
+    assert np.all(np.abs(x) <= 1.0) and np.any(np.abs(x) == 1.0)      # clamp is exercised
+    assert maxdiff(orc.se3_exp(g["exp_xi"]), g["exp_G"]) < 1e-6
+    G0 = T(g["G"])[:1, 0].repeat(len(g["exp_xi"]), 1, 1)
+    assert maxdiff(orc.se3_increment(G0, g["exp_xi"]), g["inc_G"]) < 1e-6
+    # non-SPD -> NaN -> 0 (geometry/cholesky.py:43-44)
+    bad = -np.eye(6)[None]
+    assert np.all(orc.lm_solve(bad, np.ones((1, 6)), 0.0, 0.0) == 0)
+
+
+def test_encoder(golden):
+    g = golden("encoder")
+    W = syn.make_module_weights(orc.encoder_shapes(), seed=2)
+    assert sorted(W) == [k for k in g["keys"]]
+    img1 = syn.uniform("img_render", (2, 3, 64, 96), 2)
+    img2 = syn.uniform("img_target", (2, 3, 64, 96), 2)
+    f1, f2 = orc.image_encoder(W, img1, img2)
+    assert maxdiff(f1, g["fmap1"]) < 1e-4 and maxdiff(f2, g["fmap2"]) < 1e-4
+
+
+@pytest.mark.parametrize("name,shape,outer,inner,opt", [("loop_128", (2, 128, 128, 21), 1, 3, 1),
+                                                         ("loop_2x2", (2, 128, 160, 22), 2, 2, 2),
+                                                         ("loop_S1", (1, 240, 240, 23), 1, 3, 1)])
+def test_loop(golden, name, shape, outer, inner, opt):
+    g = golden(name)
+    B, H, W, seed = shape
+    d = syn.make_inputs(B, H, W, seed=seed)
+    res = orc.refine(d, {"upd": upd_weights()}, outer=outer, inner=inner, optim_iters=opt, capture=True)
+    Gi = torch.stack([t["Tij"] for t in res["trace"]])
+    assert maxdiff(Gi, g["G_iters"]) < 1e-5
+    assert maxdiff(res["G"], g["G_final"]) < 1e-5
+    fl = res["flow_up"]
+    if name == "loop_128":
+        assert maxdiff(fl, g["flow_last"]) < 1e-4
+        assert maxdiff(res["trace"][0]["flow_up"], g["flow_first"]) < 1e-4
+        assert maxdiff(res["weight"], g["w_last"]) < 1e-4
+    elif name == "loop_2x2":
+        assert maxdiff(fl[:, :, ::2, ::2], g["flow_last"]) < 1e-4
+    else:
+        assert maxdiff(fl[:, :, ::3, ::3], g["flow_last"]) < 1e-4
+        assert maxdiff(res["weight"][:, ::3, ::3], g["w_last"]) < 1e-4
