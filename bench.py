@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""bench.py -- RNNPose recurrent pose-refinement throughput on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One STEP = one full refinement of one batch: 3 outer x 8 inner iterations of the loop body
+(model/PoseRefiner.py:239-365) on synthetic 640x480 render+target pairs, batch 8 per GPU
+(BASELINE.json configs[1]); per outer iteration: RAFT encoder + correlation volume/pyramid + context prep;
+per inner iteration: induced flow -> pyramid lookup -> update block -> convex upsample -> descriptor
+weight -> LM step.  The renderer is outside the path: views are synthetic and fixed.
+Inputs are resident in HBM before the timed region.  value = refinement iterations/s (one iteration = the
+loop body for one rank's batch of 8), summed over ranks (weak scaling: every rank refines its own batch).
+
+Rank 0 prints ONE JSON line (see the task contract) carrying `roofline` for the correlation-volume kernel
+(measured live with HIP events on the launch stream) and `cpu_baseline` (the CPU oracle, timed on this
+box's host cores on a bounded sample, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU")
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--outer", type=int, default=3)
+    ap.add_argument("--inner", type=int, default=8)
+    ap.add_argument("--optim-iters", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-encoder", action="store_true", help="feed synthetic feature maps (kernel-only runs)")
+    ap.add_argument("--unfused", action="store_true", help="literal reference call sequence through the facade")
+    return ap.parse_args()
+
+
+def synth_views(B, H, W, device, seed, with_encoder):
+    """Synthetic, fixed, already-cropped views in HBM (shapes/ranges of SURVEY.md section 8d)."""
+    from rnnpose_amd import ops
+    from rnnpose_amd.pose_refiner import SyntheticRenderer
+    from rnnpose_amd.synthetic import intrinsics
+    g = torch.Generator(device=device)
+    g.manual_seed(1234 + seed)
+    rnd = lambda *s: torch.randn(*s, device=device, generator=g)
+    uni = lambda *s: torch.rand(*s, device=device, generator=g)
+    syn_img, image_crop = uni(B, 3, H, W), uni(B, 3, H, W)
+    cfea = rnd(B, 256, H, W).mul_(0.1)
+    g1, g2 = rnd(B, 32, H, W), rnd(B, 32, H, W)
+    g1 /= g1.norm(dim=1, keepdim=True)
+    g2 /= g2.norm(dim=1, keepdim=True)
+    depth = uni(B, 1, H, W) * 0.3 + 0.9
+    depth[:, :, : H // 4] = 0
+    K = torch.from_numpy(intrinsics(B, H, W)).to(device)
+    xi = rnd(B, 6) * 0.02
+    G0 = ops.se3_exp(xi).reshape(B, 1, 4, 4)
+    fm = (None, None) if with_encoder else (rnd(B, 256, H // 8, W // 8), rnd(B, 256, H // 8, W // 8))
+    rend = SyntheticRenderer(syn_img=syn_img, image_crop=image_crop, cfea=cfea, geofea1=g1, geofea2_crop=g2,
+                             syn_depth=depth, intrinsics_crop=K, fmap1=fm[0], fmap2=fm[1])
+    return rend, K, G0
+
+
+def cpu_baseline(refiner, rend, K, G0, args):
+    """CPU oracle (oracle/rnnpose_oracle.py, kind 'port') on a bounded sample of the same workload:
+    the full batch, 1 outer x 2 inner iterations; per-stage timers extrapolate to the 3x8 schedule."""
+    from oracle import rnnpose_oracle as orc
+    v = rend.views
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    inp = {"ctx": v["cfea"], "g1": v["geofea1"], "g2": v["geofea2_crop"], "depth": v["syn_depth"], "K": K, "G0": G0,
+           "sigma": refiner.sigma[0].detach()}
+    W = {"upd": {k: p.detach().cpu().numpy() for k, p in refiner.cf_net.update_block.state_dict().items()}}
+    if v["fmap1"] is None:
+        inp["img_render"], inp["img_target"] = v["syn_img"], v["image_crop"]
+        W["enc"] = {k: p.detach().cpu().numpy() for k, p in refiner.image_fea_enc.fnet.state_dict().items()}
+    else:
+        inp["fmap1"], inp["fmap2"] = v["fmap1"], v["fmap2"]
+    inp = {k: t.detach().cpu().numpy() for k, t in inp.items()}
+    tm = {}
+    t0 = time.perf_counter()
+    orc.refine(inp, W, outer=1, inner=2, optim_iters=args.optim_iters, stage_timer=tm)
+    wall = time.perf_counter() - t0
+    t_outer = tm.get("encoder", 0.0) + tm.get("corr_build_ctx", 0.0)
+    t_inner = (wall - t_outer) / 2.0
+    sched = args.outer * t_outer + args.outer * args.inner * t_inner
+    return {
+        "value": args.outer * args.inner / sched, "unit": "iters/s", "cores": cores, "kind": "port",
+        "sample": (f"full batch ({args.batch}x{args.height}x{args.width}), 1 outer x 2 inner iterations of the CPU oracle "
+                   f"({wall:.1f} s wall, torch {torch.__version__} CPU, {cores} threads); per-outer {t_outer:.2f} s and "
+                   f"per-inner {t_inner:.2f} s extrapolated to {args.outer}x{args.inner}"),
+        "stages_s": {k: round(x, 3) for k, x in tm.items()},
+    }
+
+
+def main():
+    args = parse()
+    from rnnpose_amd import distributed as D
+    rank, world, local = D.init_from_env()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: rnnpose_amd has no CPU product path")
+    if world != args.gpus and rank == 0:
+        print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    device = torch.device("cuda", local % torch.cuda.device_count())
+    torch.cuda.set_device(device)
+    from rnnpose_amd import build, ops
+    build.build()
+    from rnnpose_amd.pose_refiner import PoseRefiner, default_config
+    from rnnpose_amd.transformation import SE3Sequence
+
+    B, H, W = args.batch, args.height, args.width
+    torch.manual_seed(0)
+    rend, K, G0 = synth_views(B, H, W, device, seed=rank, with_encoder=not args.no_encoder)
+    cfg = default_config(RENDER_ITER_COUNT=args.outer, ITER_COUNT=args.inner, OPTIM_ITER_COUNT=args.optim_iters)
+    refiner = PoseRefiner(cfg, renderer=rend, fused=not args.unfused).to(device).eval()
+
+    def step():
+        return refiner(rend.views["image_crop"], SE3Sequence(matrix=G0.clone()), K)
+
+    for _ in range(args.warmup):
+        step()
+    hip_ops = ["rnnpose_corr_pyramid_f32", "rnnpose_corr_lookup_f32", "rnnpose_convex_upsample_f32",
+               "rnnpose_corr_weight_f32", "rnnpose_lm_step_f32", "rnnpose_context_prep_f32",
+               "rnnpose_induced_coords_lowres_f32", "rnnpose_gru_gate_f32", "rnnpose_gru_update_f32"]
+    D.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    with ops.profile(hip_ops) as rec:
+        for _ in range(args.steps):
+            out = step()
+        torch.cuda.synchronize()
+    D.barrier()
+    dt = D.max_over_ranks(time.perf_counter() - t0)
+    prof = ops.summarize(rec)
+
+    if rank != 0:
+        return
+    iters = args.outer * args.inner
+    value = world * args.steps * iters / dt
+    h, w = H // 8, W // 8
+    N = h * w
+    C = 256
+    # algorithmic work per launch (SURVEY.md section 8d formulas x batch)
+    lvl = sum((h >> l) * (w >> l) for l in range(4))
+    alg = {
+        "rnnpose_corr_pyramid_f32": dict(bytes=4 * (2 * N * C + N * lvl) * B, flops=2 * N * N * C * B),
+        "rnnpose_corr_lookup_f32": dict(bytes=4 * N * (4 * 100 + 4 * 81 + 2) * B),
+        "rnnpose_convex_upsample_f32": dict(bytes=(4 * N * (576 + 2) + 8 * H * W) * B),
+        "rnnpose_corr_weight_f32": dict(bytes=(4 * 32 * 2 + 8 + 4 + 4) * H * W * B),
+        "rnnpose_lm_step_f32": dict(bytes=16 * H * W * B * args.optim_iters),
+    }
+    kernels = {}
+    for name, (n, mean_ms, tot_ms) in prof.items():
+        e = {"launches": n, "mean_ms": round(mean_ms, 4), "share_of_step": round(tot_ms / (dt * 1e3), 4)}
+        if name in alg:
+            e["GBps"] = round(alg[name]["bytes"] / (mean_ms * 1e-3) / 1e9, 1)
+            e["hbm_frac"] = round(e["GBps"] / PEAK_HBM_GBS, 4)
+            if "flops" in alg[name]:
+                e["TFLOPps"] = round(alg[name]["flops"] / (mean_ms * 1e-3) / 1e12, 2)
+        kernels[name.replace("rnnpose_", "")] = e
+    cp = prof.get("rnnpose_corr_pyramid_f32")
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("corr_pyramid_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = None
+    if cp:
+        ach = alg["rnnpose_corr_pyramid_f32"]["flops"] / (cp[1] * 1e-3) / 1e12
+        roofline = {"kernel": "corr_pyramid_kernel (fp32 MFMA all-pairs correlation + fused 4-level pyramid)",
+                    "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                    "flops_per_launch": alg["rnnpose_corr_pyramid_f32"]["flops"],
+                    "algorithmic_bytes_per_launch": alg["rnnpose_corr_pyramid_f32"]["bytes"],
+                    "hbm_GBps": kernels["corr_pyramid_f32"]["GBps"], "hbm_frac": kernels["corr_pyramid_f32"]["hbm_frac"],
+                    "launches_timed": cp[0], "mean_ms": round(cp[1], 4)}
+    res = {
+        "metric": "pose-refine iters/sec (640x480, B=8, 3x8 recurrent)", "value": round(value, 3), "unit": "iters/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic", "image_iters_per_sec": round(value * B, 2),
+        "config": {"workload": f"synthetic {W}x{H} render+target pairs, batch {B}/GPU, {args.outer} outer x "
+                               f"{args.inner} inner refinement (BASELINE.json configs[1]); 1 step = 1 refinement = "
+                               f"{iters} iterations", "batch_per_gpu": B, "height": H, "width": W,
+                   "outer": args.outer, "inner": args.inner, "optim_iters": args.optim_iters,
+                   "encoder_in_timed_region": not args.no_encoder, "fused_schedule": not args.unfused,
+                   "weights": "random init", "lm_accumulation": "f64", "sharding": f"dp{world} (independent images, no collective in the path)"},
+        "roofline": roofline, "kernels": kernels,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(refiner, rend, K, G0, args)
+        res["speedup_vs_cpu"] = round(value / res["cpu_baseline"]["value"], 1)
+    else:
+        res["cpu_baseline"] = None
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,140 @@
+/*
+ * rnnpose_hip.h -- C ABI of librnnpose_hip.so: the MI355X (gfx950) implementation of RNNPose's
+ * recurrent-refinement hot path.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name starts with h_ (host);
+ *   - tensors are dense, row-major ("contiguous") in the shape given in the comment;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); calls only ENQUEUE work:
+ *     no host synchronisation, no device allocation, no D2H copy happens inside the library;
+ *   - return value 0 = success; nonzero = error, with a message in rnnpose_last_error()
+ *     (1 = invalid argument, 2 = HIP launch/runtime error).  The library never calls exit()
+ *     (the reference's only native precedent does: thirdparty/nn/src/nearest_neighborhood.cu:10-17).
+ *   - inference only (tools/eval.py:526 runs under no_grad): no backward entry points.
+ *
+ * Each entry point names the reference code it replaces (paths relative to the RNNPose repo).
+ */
+#ifndef RNNPOSE_HIP_H
+#define RNNPOSE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* rnnpose_stream_t;
+
+#define RNNPOSE_ABI_VERSION 1
+#define RNNPOSE_MAX_LEVELS 4
+
+int rnnpose_abi_version(void);
+const char* rnnpose_last_error(void);
+/* gfx arch name of device `dev` copied to h_name (e.g. "gfx950"), CU count to *h_cus */
+int rnnpose_device_info(int dev, char* h_name, int name_len, int* h_cus);
+
+/* ---- a1+a2: all-pairs correlation volume + pyramid ------------- thirdparty/raft/corr.py:13-34,59-67
+ * level 0: corr[b,i,j] = sum_c fmap1[b,c,i]*fmap2[b,c,j] / sqrt(C); level l = 2x2 mean of level l-1
+ * (floor cropping).  `pyramid` is ONE buffer holding all levels back to back, level l laid out as
+ * (B*h*w, h_l, w_l); sizes/offsets (in floats) come from rnnpose_corr_pyramid_layout.
+ * fmap1,fmap2: (B,C,h,w) fp32, C % 4 == 0.                                                       */
+int rnnpose_corr_pyramid_layout(int B, int h, int w, int levels, int64_t* h_offsets /*[levels+1]*/,
+                                int* h_hl /*[levels]*/, int* h_wl /*[levels]*/);
+int rnnpose_corr_pyramid_f32(const float* fmap1, const float* fmap2, int B, int C, int h, int w,
+                             int levels, float* pyramid, rnnpose_stream_t stream);
+
+/* ---- a3: pyramid lookup -------- thirdparty/raft/corr.py:36-57, thirdparty/raft/utils/utils.py:57-71
+ * coords (B,2,h,w) (ch0 = x, ch1 = y) -> out (B, levels*(2r+1)^2, h, w); channel
+ * l*(2r+1)^2 + i*(2r+1) + j samples level l at (x/2^l + i - r, y/2^l + j - r)  [x-major window],
+ * bilinear, align_corners=True, zero padding.  radius must be 4 (the only value the reference uses). */
+int rnnpose_corr_lookup_f32(const float* pyramid, const float* coords, int B, int h, int w, int levels,
+                            int radius, float* out, rnnpose_stream_t stream);
+
+/* ---- a5: GRU_CFUpdator glue -------------------------------------------- model/CFNet.py:124-144
+ * context_prep: ctx (B,C,H,W) -> bilinear (align_corners=True) resize to (h,w); first `hdim` channels
+ * -> net = tanh(.), remaining C-hdim -> inp = relu(.).
+ * flow_to_coords: coords1 (B,2,h,w) = pixel grid + resize(flow_init / (W/w)), flow_init (B,2,H,W);
+ * does NOT modify flow_init (the reference divides in place, CFNet.py:141).                        */
+int rnnpose_context_prep_f32(const float* ctx, int B, int C, int H, int W, int h, int w, int hdim,
+                             float* net, float* inp, rnnpose_stream_t stream);
+int rnnpose_flow_to_coords_f32(const float* flow_init, int B, int H, int W, int h, int w, float* coords1,
+                               rnnpose_stream_t stream);
+
+/* ---- a6: convex upsampling --------------------------------------------- model/CFNet.py:95-106
+ * flow (B,2,h,w), mask (B,9*s*s,h,w) -> flow_up (B,2,s*h,s*w); s must be 8.                       */
+int rnnpose_convex_upsample_f32(const float* flow, const float* mask, int B, int h, int w, int scale,
+                                float* flow_up, rnnpose_stream_t stream);
+
+/* ---- a7: induced flow of the relative pose --- geometry/transformation.py:184-198,
+ *      geometry/projective_ops.py:68-114, model/PoseRefiner.py:313,324-328
+ * depth (B,1,H,W) RAW rendered depth (0 = background; the kernel adds depth_eps as PoseRefiner.py:313
+ * does), K (B,3,3), G (B,4,4) -> flow (B,2,H,W) = (project(G*backproject) - grid) * [depth+eps > eps],
+ * vmask (B,H,W) float = [Z>0.1][Z'>0.1] (may be NULL).  mode 0: masked flow as above (PoseRefiner.py:327);
+ * mode 1: the raw re-projected coordinates (u,v) of SE3.transform, unmasked (transformation.py:184-198).
+ * induced_coords_lowres fuses a7 with flow_to_coords and evaluates only the 4 taps each 1/8-res pixel
+ * needs: coords1 (B,2,h,w).                                                                        */
+int rnnpose_induced_flow_f32(const float* depth, const float* K, const float* G, int B, int H, int W,
+                             float depth_eps, int mode, float* flow, float* vmask, rnnpose_stream_t stream);
+int rnnpose_induced_coords_lowres_f32(const float* depth, const float* K, const float* G, int B, int H,
+                                      int W, int h, int w, float depth_eps, float* coords1,
+                                      rnnpose_stream_t stream);
+
+/* ---- a8: descriptor reliability weight ---- model/PoseRefiner.py:342-345, projective_ops.py:11-23
+ * g1,g2 (B,D,H,W); weight (B,H,W) = exp(-|1 - <g1, bilinear(g2, target)>| / sigma) * [depth > 0];
+ * g2 is sampled at pixel ((2x/(W-1)-1+1)*W-1)/2 (the reference's align_corners mismatch), zero pad.
+ * target_mode 0: `target` is (B,H,W,2) absolute pixel coordinates (x,y interleaved);
+ * target_mode 1: `target` is a planar flow (B,2,H,W) and the pixel grid is added in-kernel.
+ * sigma: device pointer to one float (the nn.Parameter PoseRefiner.sigma[0]).                      */
+int rnnpose_corr_weight_f32(const float* g1, const float* g2, const float* target, int target_mode,
+                            const float* depth, const float* sigma, int B, int D, int H, int W,
+                            float* weight, rnnpose_stream_t stream);
+
+/* ---- a9: Gauss-Newton normal equations (fp64) -- geometry/transformation.py:274-297,
+ *      geometry/projective_ops.py:116-124, geometry/transformation.py:27-46
+ * Hm (B,6,6) = sum v*w*J^T J, bv (B,6) = sum v*w*J^T (target - x'), UNDAMPED, fp64.
+ * weight (B,H,W) fp32; target/target_mode as above; depth raw (+depth_eps inside).
+ * workspace: at least rnnpose_lm_workspace_bytes(B,H,W) bytes of device memory (block partials).   */
+size_t rnnpose_lm_workspace_bytes(int B, int H, int W);
+int rnnpose_lm_normal_eq_f64(const float* target, int target_mode, const float* weight, const float* depth,
+                             float depth_eps, const float* K, const float* G, int B, int H, int W,
+                             void* workspace, size_t workspace_bytes, double* Hm, double* bv,
+                             rnnpose_stream_t stream);
+
+/* ---- a10+a11: damped 6x6 Cholesky solve + SE(3) exp + left increment -- transformation.py:300-306,
+ *      geometry/cholesky.py:32-50, geometry/se3.py:228-281,303-306
+ * Hd = Hm + ep_lambda*I + lm_lambda*diag(Hm); xi = float(clamp(nan_to_zero(Hd^-1 bv), +-max_update));
+ * G_new = exp(xi) * G.  info[b] = 0, or k>0 if the leading minor of order k is not positive (the
+ * reference's torch.cholesky raises there; here xi becomes NaN->0 and the flag is left for the host). */
+int rnnpose_lm_solve_update_f32(const double* Hm, const double* bv, const float* G, int B, double ep_lambda,
+                                double lm_lambda, double max_update, float* G_new, float* xi, int* info,
+                                rnnpose_stream_t stream);
+
+/* fused a9+a10+a11: `num_iters` GN steps (reprojction_optim), G updated in place (B,4,4).
+ * Hm/bv/xi/info receive the LAST iteration's values.                                               */
+int rnnpose_lm_step_f32(const float* target, int target_mode, const float* weight, const float* depth,
+                        float depth_eps, const float* K, float* G, int B, int H, int W, int num_iters,
+                        double ep_lambda, double lm_lambda, double max_update, void* workspace,
+                        size_t workspace_bytes, double* Hm, double* bv, float* xi, int* info,
+                        rnnpose_stream_t stream);
+
+/* ---- a11/a12 helpers: batched SE(3) ------------------------- geometry/se3.py:194-209,228-306
+ * se3_exp: xi (B,6) -> (B,4,4);  se3_compose: out = A*Bm (B,4,4);  se3_inverse: out = A^-1.        */
+int rnnpose_se3_exp_f32(const float* xi, int B, float* out, rnnpose_stream_t stream);
+int rnnpose_se3_compose_f32(const float* A, const float* Bm, int B, float* out, rnnpose_stream_t stream);
+int rnnpose_se3_inverse_f32(const float* A, int B, float* out, rnnpose_stream_t stream);
+
+/* ---- a4: SepConvGRU pointwise stages ---------------------------- thirdparty/raft/update.py:45-60
+ * zr (B,2C,h,w) = pre-activation outputs of the fused z|r convolution, hcat (B,Ctot,h,w) whose first
+ * C channels are h: writes rh = sigmoid(r)*h into rhx[:, :C] (rhx (B,Ctot,h,w), channels >= C untouched)
+ * and z = sigmoid(z_pre) into z_out (B,C,h,w).
+ * gru_update: h_new = (1-z)*h + z*tanh(q_pre), written to hout (a (B,Ctot_out,h,w) buffer, first C ch). */
+int rnnpose_gru_gate_f32(const float* zr, const float* hcat, int B, int C, int Ctot, int hw, float* z_out,
+                         float* rhx, rnnpose_stream_t stream);
+int rnnpose_gru_update_f32(const float* z, const float* q_pre, const float* hcat, int B, int C, int Ctot_in,
+                           int hw, float* hout, int Ctot_out, rnnpose_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RNNPOSE_HIP_H */

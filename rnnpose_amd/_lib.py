@@ -1,0 +1,77 @@
+"""ctypes binding of librnnpose_hip.so (C ABI declared in include/rnnpose_hip.h).
+
+The product path has NO fallback: if the library is missing or a call fails, a RuntimeError is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "librnnpose_hip.so")
+
+_p = C.c_void_p
+_i = C.c_int
+_f = C.c_float
+_d = C.c_double
+_z = C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/rnnpose_hip.h one to one
+PROTOTYPES = {
+    "rnnpose_abi_version": (_i, []),
+    "rnnpose_last_error": (C.c_char_p, []),
+    "rnnpose_device_info": (_i, [_i, C.c_char_p, _i, C.POINTER(_i)]),
+    "rnnpose_corr_pyramid_layout": (_i, [_i, _i, _i, _i, C.POINTER(C.c_int64), C.POINTER(_i), C.POINTER(_i)]),
+    "rnnpose_corr_pyramid_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p]),
+    "rnnpose_corr_lookup_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p]),
+    "rnnpose_context_prep_f32": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
+    "rnnpose_flow_to_coords_f32": (_i, [_p, _i, _i, _i, _i, _i, _p, _p]),
+    "rnnpose_convex_upsample_f32": (_i, [_p, _p, _i, _i, _i, _i, _p, _p]),
+    "rnnpose_induced_flow_f32": (_i, [_p, _p, _p, _i, _i, _i, _f, _i, _p, _p, _p]),
+    "rnnpose_induced_coords_lowres_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _f, _p, _p]),
+    "rnnpose_corr_weight_f32": (_i, [_p, _p, _p, _i, _p, _p, _i, _i, _i, _i, _p, _p]),
+    "rnnpose_lm_workspace_bytes": (_z, [_i, _i, _i]),
+    "rnnpose_lm_normal_eq_f64": (_i, [_p, _i, _p, _p, _f, _p, _p, _i, _i, _i, _p, _z, _p, _p, _p]),
+    "rnnpose_lm_solve_update_f32": (_i, [_p, _p, _p, _i, _d, _d, _d, _p, _p, _p, _p]),
+    "rnnpose_lm_step_f32": (_i, [_p, _i, _p, _p, _f, _p, _p, _i, _i, _i, _i, _d, _d, _d, _p, _z, _p, _p, _p, _p, _p]),
+    "rnnpose_se3_exp_f32": (_i, [_p, _i, _p, _p]),
+    "rnnpose_se3_compose_f32": (_i, [_p, _p, _i, _p, _p]),
+    "rnnpose_se3_inverse_f32": (_i, [_p, _i, _p, _p]),
+    "rnnpose_gru_gate_f32": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p]),
+    "rnnpose_gru_update_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _i, _p]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load (once) and type the library.  Raises RuntimeError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: run `python -m rnnpose_amd.build` (hipcc, gfx950). "
+            "rnnpose_amd has no CPU fallback for the refinement hot path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise RuntimeError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.rnnpose_abi_version() != 1:
+        raise RuntimeError("librnnpose_hip.so ABI version mismatch; rebuild it")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, name: str) -> None:
+    if rc != 0:
+        msg = load().rnnpose_last_error().decode(errors="replace")
+        raise RuntimeError(f"{name} failed (code {rc}): {msg}")
+
+
+def call(name: str, *args) -> None:
+    check(getattr(load(), name)(*args), name)

@@ -1,0 +1,89 @@
+"""Builds librnnpose_hip.so (the C-ABI library of include/rnnpose_hip.h) with hipcc for gfx950.
+
+    python -m rnnpose_amd.build [--force] [--verbose]
+
+hipcc cross-compiles without a GPU, so this runs in the build container; the .so is git-ignored but
+travels to the GPU box with the tree.  No torch headers are involved: the library only needs the HIP
+runtime, and Python talks to it through ctypes (rnnpose_amd/_lib.py).
+"""
+from __future__ import annotations
+
+import glob
+import hashlib
+import os
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+LIBDIR = os.path.join(PKG, "lib")
+LIB = os.path.join(LIBDIR, "librnnpose_hip.so")
+STAMP = os.path.join(LIBDIR, "librnnpose_hip.stamp")
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall",
+         "-Wno-unused-function", "-Wno-unused-variable", "-DNDEBUG"]
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def _digest() -> str:
+    h = hashlib.sha256()
+    files = sources() + sorted(glob.glob(os.path.join(CSRC, "*.hpp"))) + sorted(glob.glob(os.path.join(CSRC, "*.cuh")))
+    files.append(os.path.join(ROOT, "include", "rnnpose_hip.h"))
+    for f in files:
+        h.update(f.encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(LIBDIR, exist_ok=True)
+    dig = _digest()
+    if not force and os.path.exists(LIB) and os.path.exists(STAMP) and open(STAMP).read().strip() == dig:
+        return LIB
+    objs = []
+    procs = []
+    for src in sources():
+        obj = os.path.join(LIBDIR, os.path.basename(src) + ".o")
+        cmd = [hipcc(), "-c", "-x", "hip", src, "-o", obj, "-I", os.path.join(ROOT, "include"), "-I", CSRC] + \
+              [f for f in FLAGS if f != "-shared"]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        objs.append(obj)
+    failed = False
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            failed = True
+            sys.stderr.write(f"--- hipcc failed on {src}\n{out}\n")
+        elif verbose and out.strip():
+            print(out)
+    if failed:
+        raise RuntimeError("hipcc compilation failed")
+    cmd = [hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd))
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n" + r.stdout)
+    with open(STAMP, "w") as fh:
+        fh.write(dig)
+    return LIB
+
+
+if __name__ == "__main__":
+    path = build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv)
+    print(path)

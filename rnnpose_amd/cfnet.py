@@ -1,0 +1,127 @@
+"""GRU_CFUpdator / ImageFeaEncoder with the reference's interface (model/CFNet.py:26-173).
+
+GRU_CFUpdator.forward keeps the reference signature
+    forward(fmap1, fmap2, iters=1, flow_init=None, upsample=True, test_mode=False, context_fea=None,
+            update_corr_fn=True) -> [flow_up (B,2,H,W)] * iters
+and its statefulness: the correlation pyramid, the hidden state `net` and the context input `inp` persist
+on the module between calls and are rebuilt only when update_corr_fn is True (CFNet.py:115-133).
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .corr import CorrBlock, coords_grid
+from .extractor import BasicEncoder
+from .update import BasicUpdateBlock
+
+
+class AttrDict(dict):
+    """Minimal stand-in for EasyDict (the reference passes `cfg.raft`, an EasyDict)."""
+    __getattr__ = dict.__getitem__
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+def _as_args(args):
+    if args is None:
+        args = {}
+    if isinstance(args, dict) and not isinstance(args, AttrDict):
+        args = AttrDict(args)
+    return args
+
+
+class ImageFeaEncoder(nn.Module):
+    """model/CFNet.py:26-49.  `pretrained` = path of img_fea_enc.pth (the reference loads
+    <repo>/weights/img_fea_enc.pth unconditionally); None keeps the random initialisation."""
+
+    def __init__(self, input_dim=3, output_dim=256, pretrained=None):
+        super().__init__()
+        self.fnet = BasicEncoder(output_dim=output_dim, norm_fn="instance", dropout=False, input_dim=input_dim)
+        if pretrained is not None:
+            self.load_state_dict(torch.load(pretrained, map_location="cpu"), strict=True)
+
+    def forward(self, image1, image2):
+        # inputs already in [0,1] are normalised AGAIN by the reference (CFNet.py:42-43); reproduced as is
+        image1 = (2 * (image1 / 255.0) - 1.0).contiguous()
+        image2 = (2 * (image2 / 255.0) - 1.0).contiguous()
+        fmap1, fmap2 = self.fnet([image1, image2])
+        return fmap1, fmap2
+
+
+class GRU_CFUpdator(nn.Module):
+    def __init__(self, args=None):
+        super().__init__()
+        self.args = args = _as_args(args)
+        self.hidden_dim = 128
+        self.context_dim = 128
+        args.corr_levels = 4
+        args.corr_radius = 4
+        if "alternate_corr" not in args:
+            args.alternate_corr = False
+        if args.alternate_corr:
+            raise NotImplementedError("alternate_corr needs the external alt_cuda_corr extension; the reference "
+                                      "never enables it (model/CFNet.py:63-64)")
+        self.update_block = BasicUpdateBlock(args, hidden_dim=self.hidden_dim)
+        pre = args.get("pretrained_model", None)
+        if pre is not None:
+            path = pre if isinstance(pre, str) and os.path.exists(pre) else None
+            if path is None:
+                raise FileNotFoundError(f"pretrained_model={pre!r} not found (expected gru_update.pth)")
+            self.load_state_dict(torch.load(path, map_location="cpu"), strict=True)
+        self.corr_fn = None
+        self.net = None
+        self.inp = None
+        self.fmap1 = self.fmap2 = None
+
+    def initialize_flow(self, img, downsample_rate=8):
+        N, _, H, W = img.shape
+        c0 = coords_grid(N, H // downsample_rate, W // downsample_rate, device=img.device)
+        return c0, c0.clone()
+
+    def upsample_flow(self, flow, mask, upsample_scale=8):
+        return ops.convex_upsample(flow, mask, upsample_scale)
+
+    def prepare(self, fmap1, fmap2, context_fea):
+        """The update_corr_fn=True branch (CFNet.py:115-133): volume + pyramid, hidden state, context input."""
+        self.fmap1 = fmap1.float()
+        self.fmap2 = fmap2.float()
+        self.corr_fn = CorrBlock(self.fmap1, self.fmap2, radius=self.args.corr_radius)
+        assert context_fea is not None
+        h, w = self.fmap1.shape[-2:]
+        self.net, self.inp = ops.context_prep(context_fea, h, w, self.hidden_dim)
+
+    def step(self, coords0, coords1):
+        """One GRU iteration given low-res coords (CFNet.py:147-168) -> (coords1_new, flow_up)."""
+        corr = self.corr_fn(coords1)
+        flow = coords1 - coords0
+        self.net, up_mask, delta_flow = self.update_block(self.net, self.inp, corr, flow)
+        coords1 = coords1 + delta_flow
+        flow_up = self.upsample_flow(coords1 - coords0, up_mask)
+        return coords1, flow_up
+
+    @torch.no_grad()
+    def forward(self, fmap1, fmap2, iters=1, flow_init=None, upsample=True, test_mode=False, context_fea=None,
+                update_corr_fn=True):
+        if update_corr_fn:
+            self.prepare(fmap1, fmap2, context_fea)
+        if self.corr_fn is None:
+            raise RuntimeError("GRU_CFUpdator.forward called with update_corr_fn=False before any volume was built")
+        B, _, h, w = self.fmap1.shape
+        coords0 = coords_grid(B, h, w, device=self.fmap1.device)
+        if flow_init is not None:
+            coords1 = ops.flow_to_coords(flow_init, h, w)      # grid + resize(flow_init/ds); input left untouched
+        else:
+            coords1 = coords0.clone()
+        flow_predictions = []
+        flow_up = None
+        for _ in range(iters):
+            coords1, flow_up = self.step(coords0, coords1)
+            flow_predictions.append(flow_up)
+        if test_mode:
+            return coords1 - coords0, flow_up
+        return flow_predictions

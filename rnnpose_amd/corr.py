@@ -1,0 +1,41 @@
+"""CorrBlock with the reference's interface (thirdparty/raft/corr.py:12-67), backed by the HIP kernels
+corr_pyramid (build, once per outer iteration) and corr_lookup (per GRU step)."""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+
+def coords_grid(batch, ht, wd, device=None):
+    """(B,2,ht,wd), channel 0 = x, channel 1 = y   (thirdparty/raft/utils/utils.py:74-77)"""
+    ys, xs = torch.meshgrid(torch.arange(ht, device=device, dtype=torch.float32),
+                            torch.arange(wd, device=device, dtype=torch.float32), indexing="ij")
+    return torch.stack([xs, ys], dim=0)[None].repeat(batch, 1, 1, 1)
+
+
+class CorrBlock:
+    """corr_fn = CorrBlock(fmap1, fmap2, num_levels=4, radius=4); corr = corr_fn(coords)
+
+    `corr_pyramid` is the list of (B*h*w, 1, h_l, w_l) levels like the reference's attribute; they are
+    views into one device buffer (all levels are produced by a single kernel launch)."""
+
+    def __init__(self, fmap1, fmap2, num_levels=4, radius=4, downsample_rate=1):
+        if downsample_rate != 1:
+            # the reference branch is broken (nn.MaxPool2d called with a tensor, corr.py:20-24) and never taken
+            raise NotImplementedError("downsample_rate != 1 is not supported (dead code in the reference)")
+        if radius != 4:
+            raise NotImplementedError("only radius=4 (the reference's value) is implemented")
+        self.num_levels = num_levels
+        self.radius = radius
+        self._buf, self.corr_pyramid = ops.corr_pyramid(fmap1.float(), fmap2.float(), num_levels)
+
+    def __call__(self, coords):
+        return ops.corr_lookup(self._buf, coords, self.num_levels, self.radius)
+
+    @staticmethod
+    def corr(fmap1, fmap2):
+        """Level 0 only, shaped (B,h,w,1,h,w) like CorrBlock.corr (corr.py:59-67)."""
+        B, _, h, w = fmap1.shape
+        _, views = ops.corr_pyramid(fmap1.float(), fmap2.float(), 1)
+        return views[0].view(B, h, w, 1, h, w)

@@ -1,0 +1,129 @@
+// a3: correlation-pyramid window lookup.  Replaces CorrBlock.__call__ + bilinear_sampler
+// (thirdparty/raft/corr.py:36-57, thirdparty/raft/utils/utils.py:57-71).
+//
+// out[b, l*81 + i*9 + j, Y, X] = bilinear_zero_pad( pyr_l[(b,Y,X), :, :], x = cx/2^l + (i-4), y = cy/2^l + (j-4) )
+// (x-major window; align_corners=True so normalise/unnormalise is the identity up to fp32 rounding.)
+//
+// HBM-bound gather.  All 81 taps of a level share one fractional offset, so a pixel needs a 10x10 texel
+// footprint per level (400 B) and produces 81 outputs.
+//   phase 1: the wave walks its 64 pixels; for each one the 64 lanes fetch the 100 footprint texels
+//            (row-contiguous 40-byte runs -> ~10-14 cache lines per instruction instead of 64) into LDS;
+//   phase 2: lane = pixel; each lane slides a two-row register window over its footprint (100 LDS reads,
+//            stride 101 floats -> conflict-free) and writes 81 channels; consecutive lanes are consecutive
+//            pixels, so every channel row is one coalesced 256-byte store.
+// One wave per workgroup (one pyramid level x 64 pixels), 25.9 KB LDS -> 6 workgroups per CU.
+#include "common.hpp"
+
+namespace {
+
+constexpr int R = 4;
+constexpr int WIN = 2 * R + 1;      // 9
+constexpr int FP = WIN + 1;         // 10: footprint side
+constexpr int FS = FP * FP + 1;     // 101: per-pixel LDS stride (odd -> conflict-free lane-per-pixel reads)
+constexpr int PIX = 64;
+
+struct LookupInfo {
+  long long off[RNNPOSE_MAX_LEVELS];
+  int hl[RNNPOSE_MAX_LEVELS];
+  int wl[RNNPOSE_MAX_LEVELS];
+};
+
+__global__ __launch_bounds__(64) void corr_lookup_kernel(const float* __restrict__ pyr, const float* __restrict__ coords,
+                                                         float* __restrict__ out, int B, int h, int w, int levels,
+                                                         LookupInfo info) {
+  __shared__ float foot[PIX * FS];
+  const int N = h * w;
+  const long long total = static_cast<long long>(B) * N;
+  const int lane = threadIdx.x;
+  const int lvl = blockIdx.y;
+  const long long p = static_cast<long long>(blockIdx.x) * PIX + lane;   // flat (b, Y, X)
+  const bool live = p < total;
+  const int hl = info.hl[lvl], wl = info.wl[lvl];
+  const float inv = 1.0f / static_cast<float>(1 << lvl);
+
+  float cx = 0.f, cy = 0.f;
+  int b = 0, pix = 0;
+  if (live) {
+    b = static_cast<int>(p / N);
+    pix = static_cast<int>(p - static_cast<long long>(b) * N);
+    cx = coords[(static_cast<long long>(b) * 2 + 0) * N + pix] * inv;
+    cy = coords[(static_cast<long long>(b) * 2 + 1) * N + pix] * inv;
+  }
+  // integer base of the footprint; non-finite / far-away coordinates sample only padding -> zeros
+  const bool sane = (cx > -1.0e6f) && (cx < 1.0e6f) && (cy > -1.0e6f) && (cy < 1.0e6f);
+  const float fx0 = floorf(cx), fy0 = floorf(cy);
+  const int bx = sane ? static_cast<int>(fx0) - R : -1000000;
+  const int by = sane ? static_cast<int>(fy0) - R : -1000000;
+  const float ax = sane ? cx - fx0 : 0.f;
+  const float ay = sane ? cy - fy0 : 0.f;
+
+  // ---- phase 1: cooperative footprint fetch ----
+  const float* lvl_base = pyr + info.off[lvl];
+  const long long img = static_cast<long long>(hl) * wl;
+  const int t0 = lane, t1 = lane + 64;
+  const int ty0 = t0 / FP, tx0 = t0 - ty0 * FP;
+  const int ty1 = t1 / FP, tx1 = t1 - ty1 * FP;
+  const long long first = static_cast<long long>(blockIdx.x) * PIX;
+  const int npix = static_cast<int>(total - first < PIX ? total - first : PIX);
+#pragma unroll 4
+  for (int q = 0; q < npix; ++q) {
+    const int qbx = __shfl(bx, q), qby = __shfl(by, q);
+    const float* src = lvl_base + (first + q) * img;
+    {
+      const int x = qbx + tx0, y = qby + ty0;
+      float v = 0.f;
+      if (x >= 0 && x < wl && y >= 0 && y < hl) v = src[y * wl + x];
+      foot[q * FS + t0] = v;
+    }
+    if (t1 < FP * FP) {
+      const int x = qbx + tx1, y = qby + ty1;
+      float v = 0.f;
+      if (x >= 0 && x < wl && y >= 0 && y < hl) v = src[y * wl + x];
+      foot[q * FS + t1] = v;
+    }
+  }
+  __syncthreads();
+  if (!live) return;
+
+  // ---- phase 2: lane = pixel ----
+  const float w00 = (1.f - ax) * (1.f - ay), w10 = ax * (1.f - ay), w01 = (1.f - ax) * ay, w11 = ax * ay;
+  const float* f = foot + lane * FS;
+  float* o = out + (static_cast<long long>(b) * levels * (WIN * WIN) + static_cast<long long>(lvl) * (WIN * WIN)) * N + pix;
+  float prev[FP], cur[FP];
+#pragma unroll
+  for (int x = 0; x < FP; ++x) prev[x] = f[x];
+#pragma unroll
+  for (int j = 0; j < WIN; ++j) {          // y offset j-4  -> footprint rows j, j+1
+#pragma unroll
+    for (int x = 0; x < FP; ++x) cur[x] = f[(j + 1) * FP + x];
+#pragma unroll
+    for (int i = 0; i < WIN; ++i) {        // x offset i-4  -> footprint cols i, i+1 ; channel i*9 + j
+      const float v = w00 * prev[i] + w10 * prev[i + 1] + w01 * cur[i] + w11 * cur[i + 1];
+      o[static_cast<long long>(i * WIN + j) * N] = v;
+    }
+#pragma unroll
+    for (int x = 0; x < FP; ++x) prev[x] = cur[x];
+  }
+}
+
+}  // namespace
+
+extern "C" int rnnpose_corr_lookup_f32(const float* pyramid, const float* coords, int B, int h, int w, int levels,
+                                       int radius, float* out, rnnpose_stream_t stream) {
+  const char* fn = "rnnpose_corr_lookup_f32";
+  RP_REQUIRE(pyramid && coords && out, fn, "null pointer");
+  RP_REQUIRE(radius == R, fn, "radius must be 4");
+  int64_t offs[RNNPOSE_MAX_LEVELS + 1];
+  LookupInfo info{};
+  if (int e = rnnpose_corr_pyramid_layout(B, h, w, levels, offs, info.hl, info.wl)) return e;
+  for (int l = 0; l < levels; ++l) {
+    info.off[l] = offs[l];
+    // the reference divides by (W_l - 1): a 1-wide level yields inf/NaN there
+    RP_REQUIRE(info.hl[l] >= 2 && info.wl[l] >= 2, fn, "every pyramid level must be at least 2x2");
+  }
+  const long long total = static_cast<long long>(B) * h * w;
+  dim3 grid(static_cast<unsigned>(rp::cdiv(total, PIX)), static_cast<unsigned>(levels)), block(64);
+  hipLaunchKernelGGL(corr_lookup_kernel, grid, block, 0, rp::as_stream(stream), pyramid, coords, out, B, h, w, levels,
+                     info);
+  return rp::check_launch(fn);
+}

@@ -1,0 +1,365 @@
+// a9-a11: the Levenberg-Marquardt / Gauss-Newton pose step, fully on device.
+//   lm_normal_eq   Hm = sum v w J^T J, bv = sum v w J^T r  (fp64)   geometry/transformation.py:286-297
+//   lm_solve       damping, 6x6 Cholesky, NaN->0, clamp, SE(3) exp, G <- exp(xi) G
+//                  transformation.py:300-306, geometry/cholesky.py:32-50, geometry/se3.py:228-281,303-306
+// The reference materialises J as a (B,1,H,W,2,6) fp64 tensor (29 MB/image at 480x640) and reduces it
+// with two einsums; here every pixel's 2x6 Jacobian lives in registers, each thread accumulates the 21
+// upper-triangle + 6 right-hand-side sums in fp64 over a strided set of pixels, a wave64 shuffle tree and
+// one LDS hop reduce the workgroup, and per-workgroup partials are summed in FIXED order by the solve
+// kernel (deterministic: no atomics).  HBM traffic = target + weight + depth read once (16 B/pixel).
+#include "geometry.cuh"
+
+namespace {
+
+using rp::Intr;
+using rp::Pose;
+
+constexpr int NACC = 27;        // 21 (upper triangle of H, row-major) + 6 (b)
+constexpr int PSTRIDE = 32;     // doubles per partial record
+constexpr int LM_THREADS = 256;
+constexpr int LM_PIX_PER_BLOCK = 4096;
+constexpr int LM_MAX_BLOCKS = 256;
+
+__host__ __device__ inline int lm_blocks_per_image(long long P) {
+  long long n = (P + LM_PIX_PER_BLOCK - 1) / LM_PIX_PER_BLOCK;
+  if (n < 1) n = 1;
+  if (n > LM_MAX_BLOCKS) n = LM_MAX_BLOCKS;
+  return static_cast<int>(n);
+}
+
+__device__ __forceinline__ double shfl_down_f64(double v, int d) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __shfl_down(lo, d);
+  hi = __shfl_down(hi, d);
+  return __hiloint2double(hi, lo);
+}
+
+__global__ __launch_bounds__(LM_THREADS) void lm_normal_eq_kernel(const float* __restrict__ target, int target_mode,
+                                                                  const float* __restrict__ weight,
+                                                                  const float* __restrict__ depth, float eps,
+                                                                  const float* __restrict__ K,
+                                                                  const float* __restrict__ G, int H, int W,
+                                                                  double* __restrict__ partials) {
+  __shared__ double red[LM_THREADS / 64][NACC];
+  const int b = blockIdx.y;
+  const int nblk = gridDim.x;
+  const long long P = static_cast<long long>(H) * W;
+  const Intr k = rp::load_intr(K, b);
+  const Pose g = rp::load_pose(G, b);
+  double acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
+
+  for (long long t = static_cast<long long>(blockIdx.x) * LM_THREADS + threadIdx.x; t < P;
+       t += static_cast<long long>(nblk) * LM_THREADS) {
+    const int x = static_cast<int>(t % W), y = static_cast<int>(t / W);
+    const float wgt = weight[b * P + t];
+    const float Z = depth[b * P + t] + eps;
+    float tx, ty;
+    if (target_mode == 0) {
+      const float2 tt = *reinterpret_cast<const float2*>(target + (b * P + t) * 2);
+      tx = tt.x;
+      ty = tt.y;
+    } else {
+      tx = target[(static_cast<long long>(b) * 2 + 0) * P + t] + static_cast<float>(x);
+      ty = target[(static_cast<long long>(b) * 2 + 1) * P + t] + static_cast<float>(y);
+    }
+    const rp::Reproj r = rp::reproject(Z, static_cast<float>(x), static_cast<float>(y), k, g);
+    const bool valid = (r.Z0 > rp::kMinDepthValid) && (r.Z1 > rp::kMinDepthValid);   // transformation.py:289
+    const double vw = valid ? static_cast<double>(wgt) : 0.0;
+    // J_pi in fp32 (projective_ops.py:118-124): zeros where clamped Z <= 0.02
+    const bool tiny = r.Zc <= rp::kMinDepthProj + 0.01f;
+    const float zi1 = tiny ? 0.f : 1.0f / r.Zc;
+    const float zi2 = tiny ? 0.f : 1.0f / (r.Zc * r.Zc);
+    const double a = static_cast<double>(k.fx * zi1);
+    const double c = static_cast<double>(-k.fx * r.X1 * zi2);
+    const double d = static_cast<double>(k.fy * zi1);
+    const double e = static_cast<double>(-k.fy * r.Y1 * zi2);
+    const double X1 = r.X1, Y1 = r.Y1, Z1 = r.Z1;
+    // J = J_pi * J_T with J_T = [I | -[X']x] built from the TRANSFORMED point (transformation.py:27-46,85-90)
+    double J0[6], J1[6];
+    J0[0] = a;   J0[1] = 0.0; J0[2] = c; J0[3] = c * Y1;            J0[4] = a * Z1 + c * (-X1); J0[5] = a * (-Y1);
+    J1[0] = 0.0; J1[1] = d;   J1[2] = e; J1[3] = d * (-Z1) + e * Y1; J1[4] = e * (-X1);          J1[5] = d * X1;
+    const double r0 = static_cast<double>(tx) - static_cast<double>(r.u);
+    const double r1 = static_cast<double>(ty) - static_cast<double>(r.v);
+    int idx = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const double wi0 = vw * J0[i], wi1 = vw * J1[i];
+#pragma unroll
+      for (int j = i; j < 6; ++j) {
+        acc[idx] += wi0 * J0[j] + wi1 * J1[j];
+        ++idx;
+      }
+      acc[21 + i] += wi0 * r0 + wi1 * r1;
+    }
+  }
+  // wave reduction (64 lanes), then across the 4 waves through LDS
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) {
+    double v = acc[i];
+#pragma unroll
+    for (int dlt = 32; dlt >= 1; dlt >>= 1) v += shfl_down_f64(v, dlt);
+    if (lane == 0) red[wave][i] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < NACC) {
+    double v = red[0][threadIdx.x];
+#pragma unroll
+    for (int wv = 1; wv < LM_THREADS / 64; ++wv) v += red[wv][threadIdx.x];
+    partials[(static_cast<long long>(b) * nblk + blockIdx.x) * PSTRIDE + threadIdx.x] = v;
+  }
+}
+
+// sums the block partials in fixed order and expands to full H (6x6) and b (6)
+__global__ __launch_bounds__(64) void lm_finalize_kernel(const double* __restrict__ partials, int nblk,
+                                                         double* __restrict__ Hm, double* __restrict__ bv) {
+  __shared__ double s[NACC];
+  const int b = blockIdx.x;
+  if (threadIdx.x < NACC) {
+    double v = 0.0;
+    for (int i = 0; i < nblk; ++i) v += partials[(static_cast<long long>(b) * nblk + i) * PSTRIDE + threadIdx.x];
+    s[threadIdx.x] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 36) {
+    const int i = threadIdx.x / 6, j = threadIdx.x % 6;
+    const int r = i < j ? i : j, c = i < j ? j : i;
+    const int idx = r * 6 - r * (r - 1) / 2 + (c - r);     // row-major upper triangle
+    Hm[b * 36 + threadIdx.x] = s[idx];
+  } else if (threadIdx.x < 42) {
+    bv[b * 6 + (threadIdx.x - 36)] = s[21 + (threadIdx.x - 36)];
+  }
+}
+
+// ---- SE(3) exponential, fp32, same branch structure as geometry/se3.py:228-281 ----
+__device__ void se3_exp_dev(const float* xi, float* Gout /*16*/) {
+  const float v0 = xi[0], v1 = xi[1], v2 = xi[2];
+  const float w0 = xi[3], w1 = xi[4], w2 = xi[5];
+  const float th2 = w0 * w0 + w1 * w1 + w2 * w2;
+  const float th = sqrtf(th2);
+  const float th4 = th2 * th2;
+  const float wx[9] = {0.f, -w2, w1, w2, 0.f, -w0, -w1, w0, 0.f};
+  float wx2[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) wx2[i * 3 + j] = wx[i * 3 + 0] * wx[0 * 3 + j] + wx[i * 3 + 1] * wx[1 * 3 + j] + wx[i * 3 + 2] * wx[2 * 3 + j];
+  float A, Bc, Cc;   // R = I + A wx + Bc wx2 ; V = I + Bc' wx + Cc wx2
+  float Bv;
+  const float eps = 1e-12f;
+  if (th < rp::kMinTheta) {
+    A = 1.0f - (1.0f / 6.0f) * th2 + (1.0f / 120.0f) * th4;
+    Bc = 0.5f - (1.0f / 12.0f) * th2 + (1.0f / 720.0f) * th4;
+    Bv = 0.5f - (1.0f / 24.0f) * th2 + (1.0f / 720.0f) * th4;
+    Cc = (1.0f / 6.0f) - (1.0f / 120.0f) * th2 + (1.0f / 5040.0f) * th4;
+  } else {
+    A = sinf(th) / (th + eps);
+    Bc = (1.0f - cosf(th)) / (th2 + eps);
+    Bv = Bc;
+    Cc = (th - sinf(th)) / (th2 * th + eps);
+  }
+  float Rm[9], Vm[9];
+  for (int i = 0; i < 9; ++i) {
+    const float I = (i == 0 || i == 4 || i == 8) ? 1.f : 0.f;
+    Rm[i] = I + A * wx[i] + Bc * wx2[i];
+    Vm[i] = I + Bv * wx[i] + Cc * wx2[i];
+  }
+  for (int i = 0; i < 3; ++i) {
+    Gout[i * 4 + 0] = Rm[i * 3 + 0];
+    Gout[i * 4 + 1] = Rm[i * 3 + 1];
+    Gout[i * 4 + 2] = Rm[i * 3 + 2];
+    Gout[i * 4 + 3] = Vm[i * 3 + 0] * v0 + Vm[i * 3 + 1] * v1 + Vm[i * 3 + 2] * v2;
+  }
+  Gout[12] = 0.f; Gout[13] = 0.f; Gout[14] = 0.f; Gout[15] = 1.f;
+}
+
+__device__ void mat4_mul(const float* A, const float* Bm, float* C) {
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      float s = 0.f;
+      for (int k = 0; k < 4; ++k) s += A[i * 4 + k] * Bm[k * 4 + j];
+      C[i * 4 + j] = s;
+    }
+}
+
+// one thread per image: damping, Cholesky, substitutions, guards, exp, left increment
+__global__ __launch_bounds__(64) void lm_solve_update_kernel(const double* __restrict__ Hm, const double* __restrict__ bv,
+                                                             const float* G, int B, double ep, double lm,
+                                                             double max_update, float* G_new /* may alias G */,
+                                                             float* __restrict__ xi_out, int* __restrict__ info) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  double A[6][6], L[6][6], rhs[6], yv[6], xv[6];
+  for (int i = 0; i < 6; ++i) {
+    for (int j = 0; j < 6; ++j) {
+      A[i][j] = Hm[b * 36 + i * 6 + j];
+      L[i][j] = 0.0;
+    }
+    rhs[i] = bv[b * 6 + i];
+  }
+  for (int i = 0; i < 6; ++i) A[i][i] = A[i][i] + ep + lm * A[i][i];   // H += ep*I + lm*H*I  (transformation.py:300)
+  int bad = 0;
+  const double nan = __longlong_as_double(0x7ff8000000000000LL);
+  for (int j = 0; j < 6; ++j) {
+    double s = A[j][j];
+    for (int k = 0; k < j; ++k) s -= L[j][k] * L[j][k];
+    if (!(s > 0.0)) {
+      if (!bad) bad = j + 1;
+      L[j][j] = nan;
+    } else {
+      L[j][j] = sqrt(s);
+    }
+    for (int i = j + 1; i < 6; ++i) {
+      double t = A[i][j];
+      for (int k = 0; k < j; ++k) t -= L[i][k] * L[j][k];
+      L[i][j] = t / L[j][j];
+    }
+  }
+  for (int i = 0; i < 6; ++i) {
+    double t = rhs[i];
+    for (int k = 0; k < i; ++k) t -= L[i][k] * yv[k];
+    yv[i] = t / L[i][i];
+  }
+  for (int i = 5; i >= 0; --i) {
+    double t = yv[i];
+    for (int k = i + 1; k < 6; ++k) t -= L[k][i] * xv[k];
+    xv[i] = t / L[i][i];
+  }
+  float xi[6];
+  for (int i = 0; i < 6; ++i) {
+    double v = xv[i];
+    if (v != v) v = 0.0;                                   // NaN -> 0      (cholesky.py:43-44)
+    v = v < -max_update ? -max_update : (v > max_update ? max_update : v);   // clamp (cholesky.py:45)
+    xi[i] = static_cast<float>(v);
+    xi_out[b * 6 + i] = xi[i];
+  }
+  if (info) info[b] = bad;
+  float dG[16], Gin[16], Gout[16];
+  se3_exp_dev(xi, dG);
+  for (int i = 0; i < 16; ++i) Gin[i] = G[b * 16 + i];
+  mat4_mul(dG, Gin, Gout);                                 // se3.py:303-306
+  for (int i = 0; i < 16; ++i) G_new[b * 16 + i] = Gout[i];
+}
+
+__global__ void se3_exp_kernel(const float* __restrict__ xi, int B, float* __restrict__ out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float x[6], Gm[16];
+  for (int i = 0; i < 6; ++i) x[i] = xi[b * 6 + i];
+  se3_exp_dev(x, Gm);
+  for (int i = 0; i < 16; ++i) out[b * 16 + i] = Gm[i];
+}
+
+__global__ void se3_compose_kernel(const float* __restrict__ A, const float* __restrict__ Bm, int B, float* __restrict__ out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float a[16], c[16], o[16];
+  for (int i = 0; i < 16; ++i) {
+    a[i] = A[b * 16 + i];
+    c[i] = Bm[b * 16 + i];
+  }
+  mat4_mul(a, c, o);
+  for (int i = 0; i < 16; ++i) out[b * 16 + i] = o[i];
+}
+
+// [R t; 0 1]^-1 = [R^T  -R^T t; 0 1]   (geometry/se3.py:194-209)
+__global__ void se3_inverse_kernel(const float* __restrict__ A, int B, float* __restrict__ out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float a[16], o[16];
+  for (int i = 0; i < 16; ++i) a[i] = A[b * 16 + i];
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) o[i * 4 + j] = a[j * 4 + i];
+    float s = 0.f;
+    for (int k = 0; k < 3; ++k) s += a[k * 4 + i] * a[k * 4 + 3];
+    o[i * 4 + 3] = -s;
+  }
+  o[12] = 0.f; o[13] = 0.f; o[14] = 0.f; o[15] = 1.f;
+  for (int i = 0; i < 16; ++i) out[b * 16 + i] = o[i];
+}
+
+int launch_normal_eq(const float* target, int target_mode, const float* weight, const float* depth, float eps,
+                     const float* K, const float* G, int B, int H, int W, void* workspace, double* Hm, double* bv,
+                     hipStream_t st) {
+  const long long P = static_cast<long long>(H) * W;
+  const int nblk = lm_blocks_per_image(P);
+  double* partials = static_cast<double*>(workspace);
+  hipLaunchKernelGGL(lm_normal_eq_kernel, dim3(nblk, B), dim3(LM_THREADS), 0, st, target, target_mode, weight, depth, eps,
+                     K, G, H, W, partials);
+  hipLaunchKernelGGL(lm_finalize_kernel, dim3(B), dim3(64), 0, st, partials, nblk, Hm, bv);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t rnnpose_lm_workspace_bytes(int B, int H, int W) {
+  if (B <= 0 || H <= 0 || W <= 0) return 0;
+  return static_cast<size_t>(B) * lm_blocks_per_image(static_cast<long long>(H) * W) * PSTRIDE * sizeof(double);
+}
+
+int rnnpose_lm_normal_eq_f64(const float* target, int target_mode, const float* weight, const float* depth,
+                             float depth_eps, const float* K, const float* G, int B, int H, int W, void* workspace,
+                             size_t workspace_bytes, double* Hm, double* bv, rnnpose_stream_t stream) {
+  const char* fn = "rnnpose_lm_normal_eq_f64";
+  RP_REQUIRE(target && weight && depth && K && G && workspace && Hm && bv, fn, "null pointer");
+  RP_REQUIRE(target_mode == 0 || target_mode == 1, fn, "target_mode must be 0 or 1");
+  RP_REQUIRE(B > 0 && B < 65536 && H > 0 && W > 0, fn, "bad size");
+  RP_REQUIRE(workspace_bytes >= rnnpose_lm_workspace_bytes(B, H, W), fn, "workspace too small");
+  launch_normal_eq(target, target_mode, weight, depth, depth_eps, K, G, B, H, W, workspace, Hm, bv, rp::as_stream(stream));
+  return rp::check_launch(fn);
+}
+
+int rnnpose_lm_solve_update_f32(const double* Hm, const double* bv, const float* G, int B, double ep_lambda,
+                                double lm_lambda, double max_update, float* G_new, float* xi, int* info,
+                                rnnpose_stream_t stream) {
+  const char* fn = "rnnpose_lm_solve_update_f32";
+  RP_REQUIRE(Hm && bv && G && G_new && xi, fn, "null pointer");
+  RP_REQUIRE(B > 0, fn, "bad size");
+  hipLaunchKernelGGL(lm_solve_update_kernel, dim3(rp::cdiv(B, 64)), dim3(64), 0, rp::as_stream(stream), Hm, bv, G, B,
+                     ep_lambda, lm_lambda, max_update, G_new, xi, info);
+  return rp::check_launch(fn);
+}
+
+int rnnpose_lm_step_f32(const float* target, int target_mode, const float* weight, const float* depth, float depth_eps,
+                        const float* K, float* G, int B, int H, int W, int num_iters, double ep_lambda, double lm_lambda,
+                        double max_update, void* workspace, size_t workspace_bytes, double* Hm, double* bv, float* xi,
+                        int* info, rnnpose_stream_t stream) {
+  const char* fn = "rnnpose_lm_step_f32";
+  RP_REQUIRE(target && weight && depth && K && G && workspace && Hm && bv && xi, fn, "null pointer");
+  RP_REQUIRE(target_mode == 0 || target_mode == 1, fn, "target_mode must be 0 or 1");
+  RP_REQUIRE(B > 0 && B < 65536 && H > 0 && W > 0 && num_iters >= 0, fn, "bad size");
+  RP_REQUIRE(workspace_bytes >= rnnpose_lm_workspace_bytes(B, H, W), fn, "workspace too small");
+  hipStream_t st = rp::as_stream(stream);
+  for (int it = 0; it < num_iters; ++it) {
+    launch_normal_eq(target, target_mode, weight, depth, depth_eps, K, G, B, H, W, workspace, Hm, bv, st);
+    // in place: each thread reads its whole G before writing it
+    hipLaunchKernelGGL(lm_solve_update_kernel, dim3(rp::cdiv(B, 64)), dim3(64), 0, st, Hm, bv, G, B, ep_lambda,
+                       lm_lambda, max_update, G, xi, info);
+  }
+  return rp::check_launch(fn);
+}
+
+int rnnpose_se3_exp_f32(const float* xi, int B, float* out, rnnpose_stream_t stream) {
+  const char* fn = "rnnpose_se3_exp_f32";
+  RP_REQUIRE(xi && out && B > 0, fn, "bad argument");
+  hipLaunchKernelGGL(se3_exp_kernel, dim3(rp::cdiv(B, 64)), dim3(64), 0, rp::as_stream(stream), xi, B, out);
+  return rp::check_launch(fn);
+}
+
+int rnnpose_se3_compose_f32(const float* A, const float* Bm, int B, float* out, rnnpose_stream_t stream) {
+  const char* fn = "rnnpose_se3_compose_f32";
+  RP_REQUIRE(A && Bm && out && B > 0, fn, "bad argument");
+  hipLaunchKernelGGL(se3_compose_kernel, dim3(rp::cdiv(B, 64)), dim3(64), 0, rp::as_stream(stream), A, Bm, B, out);
+  return rp::check_launch(fn);
+}
+
+int rnnpose_se3_inverse_f32(const float* A, int B, float* out, rnnpose_stream_t stream) {
+  const char* fn = "rnnpose_se3_inverse_f32";
+  RP_REQUIRE(A && out && B > 0, fn, "bad argument");
+  hipLaunchKernelGGL(se3_inverse_kernel, dim3(rp::cdiv(B, 64)), dim3(64), 0, rp::as_stream(stream), A, B, out);
+  return rp::check_launch(fn);
+}
+
+}  // extern "C"

@@ -1,0 +1,379 @@
+// HBM-bound per-pixel stages of the refinement loop:
+//   a5  context_prep / flow_to_coords            model/CFNet.py:124-144
+//   a6  convex_upsample                          model/CFNet.py:95-106
+//   a7  induced_flow / induced_coords_lowres     geometry/transformation.py:184-198, model/PoseRefiner.py:324-328
+//   a8  corr_weight                              model/PoseRefiner.py:342-345
+//   a4  SepConvGRU gate / state update           thirdparty/raft/update.py:45-60
+// Every kernel reads each input byte once with lane-contiguous addresses and writes coalesced rows.
+#include "geometry.cuh"
+
+namespace {
+
+using rp::Intr;
+using rp::Pose;
+
+// ------------------------------------------------------------------------------------------------
+// bilinear resize, align_corners=True: src = dst * (in-1)/(out-1)   (F.interpolate semantics)
+struct AcTap {
+  int i0, i1;
+  float f;
+};
+__device__ __forceinline__ AcTap ac_tap(int dst, int in, int out) {
+  const float scale = out > 1 ? static_cast<float>(in - 1) / static_cast<float>(out - 1) : 0.f;
+  const float s = scale * static_cast<float>(dst);
+  int i0 = static_cast<int>(s);            // s >= 0
+  if (i0 > in - 1) i0 = in - 1;
+  const int i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  return AcTap{i0, i1, s - static_cast<float>(i0)};
+}
+
+// a5: ctx (B,C,H,W) -> net = tanh(first hdim ch), inp = relu(rest) at (h,w)
+__global__ __launch_bounds__(256) void context_prep_kernel(const float* __restrict__ ctx, float* __restrict__ net,
+                                                           float* __restrict__ inp, int B, int C, int H, int W, int h,
+                                                           int w, int hdim) {
+  const long long n = static_cast<long long>(B) * C * h * w;
+  for (long long t = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; t < n;
+       t += static_cast<long long>(gridDim.x) * blockDim.x) {
+    const int X = static_cast<int>(t % w);
+    const int Y = static_cast<int>((t / w) % h);
+    const int c = static_cast<int>((t / (static_cast<long long>(w) * h)) % C);
+    const int b = static_cast<int>(t / (static_cast<long long>(w) * h * C));
+    const AcTap ty = ac_tap(Y, H, h), tx = ac_tap(X, W, w);
+    const float* p = ctx + (static_cast<long long>(b) * C + c) * H * W;
+    const float v00 = p[static_cast<long long>(ty.i0) * W + tx.i0], v01 = p[static_cast<long long>(ty.i0) * W + tx.i1];
+    const float v10 = p[static_cast<long long>(ty.i1) * W + tx.i0], v11 = p[static_cast<long long>(ty.i1) * W + tx.i1];
+    const float top = v00 * (1.f - tx.f) + v01 * tx.f;
+    const float bot = v10 * (1.f - tx.f) + v11 * tx.f;
+    const float v = top * (1.f - ty.f) + bot * ty.f;
+    const long long hw = static_cast<long long>(h) * w;
+    if (c < hdim) {
+      net[(static_cast<long long>(b) * hdim + c) * hw + Y * w + X] = tanhf(v);
+    } else {
+      inp[(static_cast<long long>(b) * (C - hdim) + (c - hdim)) * hw + Y * w + X] = fmaxf(v, 0.f);
+    }
+  }
+}
+
+// a5: coords1 = grid + resize(flow_init / ds)
+__global__ __launch_bounds__(256) void flow_to_coords_kernel(const float* __restrict__ flow, float* __restrict__ coords1,
+                                                             int B, int H, int W, int h, int w) {
+  const long long n = static_cast<long long>(B) * 2 * h * w;
+  const long long t = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const int X = static_cast<int>(t % w);
+  const int Y = static_cast<int>((t / w) % h);
+  const int c = static_cast<int>((t / (static_cast<long long>(w) * h)) % 2);
+  const int b = static_cast<int>(t / (static_cast<long long>(w) * h * 2));
+  const float ds = static_cast<float>(W / w);
+  const AcTap ty = ac_tap(Y, H, h), tx = ac_tap(X, W, w);
+  const float* p = flow + (static_cast<long long>(b) * 2 + c) * H * W;
+  const float v00 = p[static_cast<long long>(ty.i0) * W + tx.i0] / ds, v01 = p[static_cast<long long>(ty.i0) * W + tx.i1] / ds;
+  const float v10 = p[static_cast<long long>(ty.i1) * W + tx.i0] / ds, v11 = p[static_cast<long long>(ty.i1) * W + tx.i1] / ds;
+  const float top = v00 * (1.f - tx.f) + v01 * tx.f;
+  const float bot = v10 * (1.f - tx.f) + v11 * tx.f;
+  const float g = c == 0 ? static_cast<float>(X) : static_cast<float>(Y);
+  coords1[t] = g + (top * (1.f - ty.f) + bot * ty.f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// a7: full-resolution induced flow (API parity with SE3Sequence.transform + PoseRefiner.py:327)
+__global__ __launch_bounds__(256) void induced_flow_kernel(const float* __restrict__ depth, const float* __restrict__ K,
+                                                           const float* __restrict__ G, float* __restrict__ flow,
+                                                           float* __restrict__ vmask, int H, int W, float eps, int mode) {
+  const int b = blockIdx.y;
+  const long long P = static_cast<long long>(H) * W;
+  const long long t = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= P) return;
+  const int x = static_cast<int>(t % W), y = static_cast<int>(t / W);
+  const Intr k = rp::load_intr(K, b);
+  const Pose g = rp::load_pose(G, b);
+  const float Z = depth[b * P + t] + eps;
+  const rp::Reproj r = rp::reproject(Z, static_cast<float>(x), static_cast<float>(y), k, g);
+  const float fg = Z > eps ? 1.f : 0.f;
+  flow[(static_cast<long long>(b) * 2 + 0) * P + t] = mode == 0 ? (r.u - static_cast<float>(x)) * fg : r.u;
+  flow[(static_cast<long long>(b) * 2 + 1) * P + t] = mode == 0 ? (r.v - static_cast<float>(y)) * fg : r.v;
+  if (vmask) vmask[b * P + t] = (r.Z0 > rp::kMinDepthValid && r.Z1 > rp::kMinDepthValid) ? 1.f : 0.f;
+}
+
+__device__ __forceinline__ float2 flow_at(const float* __restrict__ depth_b, int x, int y, int W, float eps, const Intr& k,
+                                          const Pose& g) {
+  const float Z = depth_b[static_cast<long long>(y) * W + x] + eps;
+  const rp::Reproj r = rp::reproject(Z, static_cast<float>(x), static_cast<float>(y), k, g);
+  const float fg = Z > eps ? 1.f : 0.f;
+  return make_float2((r.u - static_cast<float>(x)) * fg, (r.v - static_cast<float>(y)) * fg);
+}
+
+// a7+a5 fused: only the 4 taps each 1/8-res pixel needs are re-projected (P/16 evaluations, no full-res pass)
+__global__ __launch_bounds__(256) void induced_coords_lowres_kernel(const float* __restrict__ depth,
+                                                                    const float* __restrict__ K,
+                                                                    const float* __restrict__ G,
+                                                                    float* __restrict__ coords1, int H, int W, int h,
+                                                                    int w, float eps) {
+  const int b = blockIdx.y;
+  const int n = h * w;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const int X = t % w, Y = t / w;
+  const Intr k = rp::load_intr(K, b);
+  const Pose g = rp::load_pose(G, b);
+  const float ds = static_cast<float>(W / w);
+  const AcTap ty = ac_tap(Y, H, h), tx = ac_tap(X, W, w);
+  const float* d = depth + static_cast<long long>(b) * H * W;
+  const float2 f00 = flow_at(d, tx.i0, ty.i0, W, eps, k, g), f01 = flow_at(d, tx.i1, ty.i0, W, eps, k, g);
+  const float2 f10 = flow_at(d, tx.i0, ty.i1, W, eps, k, g), f11 = flow_at(d, tx.i1, ty.i1, W, eps, k, g);
+  const float topx = (f00.x / ds) * (1.f - tx.f) + (f01.x / ds) * tx.f, botx = (f10.x / ds) * (1.f - tx.f) + (f11.x / ds) * tx.f;
+  const float topy = (f00.y / ds) * (1.f - tx.f) + (f01.y / ds) * tx.f, boty = (f10.y / ds) * (1.f - tx.f) + (f11.y / ds) * tx.f;
+  coords1[(static_cast<long long>(b) * 2 + 0) * n + t] = static_cast<float>(X) + (topx * (1.f - ty.f) + botx * ty.f);
+  coords1[(static_cast<long long>(b) * 2 + 1) * n + t] = static_cast<float>(Y) + (topy * (1.f - ty.f) + boty * ty.f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// a6: convex upsampling, scale 8.  Workgroup = (b, Y, sub-row i, 64-wide X tile): the 72 mask channels
+// (9 taps x 8 sub-columns) of that sub-row are read as coalesced 256-byte rows into LDS (transposed to
+// [tap][X*9 + j], stride 9 -> conflict-free), then each thread produces output pixels of row 8Y+i in x
+// order, so both flow channels leave as contiguous 2-KB row segments.
+constexpr int UX = 64;
+__global__ __launch_bounds__(256) void convex_upsample_kernel(const float* __restrict__ flow,
+                                                              const float* __restrict__ mask,
+                                                              float* __restrict__ up, int h, int w) {
+  __shared__ float ms[9 * (UX * 9 + 1)];
+  __shared__ float fl[2 * 3 * (UX + 2)];
+  const int X0 = blockIdx.x * UX;
+  const int Y = blockIdx.y >> 3, si = blockIdx.y & 7;
+  const int b = blockIdx.z;
+  const int n = h * w;
+  const int tid = threadIdx.x;
+  const float* mb = mask + static_cast<long long>(b) * 576 * n + static_cast<long long>(Y) * w;
+  // mask rows: channel = k*64 + si*8 + j
+  for (int e = tid; e < 72 * UX; e += 256) {
+    const int X = e & (UX - 1);
+    const int cj = e >> 6;            // 0..71 = k*8 + j
+    const int k = cj >> 3, j = cj & 7;
+    float v = 0.f;
+    if (X0 + X < w) v = mb[static_cast<long long>(k * 64 + si * 8 + j) * n + X0 + X];
+    ms[k * (UX * 9 + 1) + X * 9 + j] = v;
+  }
+  // 3x3 flow neighbourhood rows Y-1..Y+1, cols X0-1..X0+UX, zero padded, pre-scaled by 8
+  for (int e = tid; e < 2 * 3 * (UX + 2); e += 256) {
+    const int xx = e % (UX + 2);
+    const int ry = (e / (UX + 2)) % 3;
+    const int c = e / (3 * (UX + 2));
+    const int yy = Y + ry - 1, x = X0 + xx - 1;
+    float v = 0.f;
+    if (yy >= 0 && yy < h && x >= 0 && x < w) v = 8.f * flow[(static_cast<long long>(b) * 2 + c) * n + yy * w + x];
+    fl[e] = v;
+  }
+  __syncthreads();
+  const int Wf = 8 * w;
+  const long long Pf = static_cast<long long>(8 * h) * Wf;
+  const int row = 8 * Y + si;
+#pragma unroll
+  for (int rep = 0; rep < 2; ++rep) {
+    const int px = tid + rep * 256;           // 0..511 within the tile's row segment
+    const int X = px >> 3, j = px & 7;
+    if (X0 + X >= w) continue;
+    float m[9];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      m[k] = ms[k * (UX * 9 + 1) + X * 9 + j];
+      mx = fmaxf(mx, m[k]);
+    }
+    float den = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      m[k] = expf(m[k] - mx);
+      den += m[k];
+    }
+    float ax = 0.f, ay = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int ky = k / 3, kx = k % 3;
+      const float wk = m[k] / den;                                  // softmax weight, as torch.softmax
+      ax += wk * fl[(0 * 3 + ky) * (UX + 2) + X + kx];
+      ay += wk * fl[(1 * 3 + ky) * (UX + 2) + X + kx];
+    }
+    const long long o = static_cast<long long>(row) * Wf + 8 * X0 + px;
+    up[(static_cast<long long>(b) * 2 + 0) * Pf + o] = ax;
+    up[(static_cast<long long>(b) * 2 + 1) * Pf + o] = ay;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// a8: reliability weight.  One thread per pixel; g1 rows are coalesced, the four g2 taps of neighbouring
+// lanes are neighbouring addresses because the flow is smooth (coalesced in practice).
+__global__ __launch_bounds__(256) void corr_weight_kernel(const float* __restrict__ g1, const float* __restrict__ g2,
+                                                          const float* __restrict__ target, int target_mode,
+                                                          const float* __restrict__ depth,
+                                                          const float* __restrict__ sigma, float* __restrict__ weight,
+                                                          int D, int H, int W) {
+  const int b = blockIdx.y;
+  const long long P = static_cast<long long>(H) * W;
+  const long long t = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= P) return;
+  const int x = static_cast<int>(t % W), y = static_cast<int>(t / W);
+  float tx, ty;
+  if (target_mode == 0) {
+    const float2 tt = *reinterpret_cast<const float2*>(target + (b * P + t) * 2);
+    tx = tt.x;
+    ty = tt.y;
+  } else {
+    tx = target[(static_cast<long long>(b) * 2 + 0) * P + t] + static_cast<float>(x);
+    ty = target[(static_cast<long long>(b) * 2 + 1) * P + t] + static_cast<float>(y);
+  }
+  // normalize_coords_grid (align_corners=True formula) then grid_sample's align_corners=False unnormalise
+  const float gx = 2.f * tx / static_cast<float>(W - 1) - 1.f;
+  const float gy = 2.f * ty / static_cast<float>(H - 1) - 1.f;
+  const float px = ((gx + 1.f) * static_cast<float>(W) - 1.f) / 2.f;
+  const float py = ((gy + 1.f) * static_cast<float>(H) - 1.f) / 2.f;
+  const bool sane = (px > -1.0e6f) && (px < 1.0e6f) && (py > -1.0e6f) && (py < 1.0e6f);
+  const float fx0 = floorf(px), fy0 = floorf(py);
+  const int x0 = sane ? static_cast<int>(fx0) : -10, y0 = sane ? static_cast<int>(fy0) : -10;
+  const float ax = px - fx0, ay = py - fy0;
+  const bool vx0 = x0 >= 0 && x0 < W, vx1 = x0 + 1 >= 0 && x0 + 1 < W;
+  const bool vy0 = y0 >= 0 && y0 < H, vy1 = y0 + 1 >= 0 && y0 + 1 < H;
+  const float w00 = (vx0 && vy0) ? (1.f - ax) * (1.f - ay) : 0.f, w10 = (vx1 && vy0) ? ax * (1.f - ay) : 0.f;
+  const float w01 = (vx0 && vy1) ? (1.f - ax) * ay : 0.f, w11 = (vx1 && vy1) ? ax * ay : 0.f;
+  const int cx0 = min(max(x0, 0), W - 1), cx1 = min(max(x0 + 1, 0), W - 1);
+  const int cy0 = min(max(y0, 0), H - 1), cy1 = min(max(y0 + 1, 0), H - 1);
+  const long long o00 = static_cast<long long>(cy0) * W + cx0, o10 = static_cast<long long>(cy0) * W + cx1;
+  const long long o01 = static_cast<long long>(cy1) * W + cx0, o11 = static_cast<long long>(cy1) * W + cx1;
+  const float* a = g1 + static_cast<long long>(b) * D * P + t;
+  const float* q = g2 + static_cast<long long>(b) * D * P;
+  float s = 0.f;
+#pragma unroll 8
+  for (int c = 0; c < D; ++c) {
+    const float* qc = q + c * P;
+    const float wv = ((qc[o00] * w00 + qc[o10] * w10) + qc[o01] * w01) + qc[o11] * w11;
+    s += a[c * P] * wv;
+  }
+  const float fg = depth[b * P + t] > 0.f ? 1.f : 0.f;
+  weight[b * P + t] = expf(-fabsf(1.f - s) / sigma[0]) * fg;
+}
+
+// ------------------------------------------------------------------------------------------------
+// a4: SepConvGRU pointwise stages (update.py:47-52).  hw = h*w; all tensors (B,Cx,hw) channel-major.
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
+
+__global__ __launch_bounds__(256) void gru_gate_kernel(const float* __restrict__ zr, const float* __restrict__ hcat,
+                                                       float* __restrict__ z_out, float* __restrict__ rhx, int C,
+                                                       int Ctot, int hw, long long n) {
+  const long long t = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const long long chw = static_cast<long long>(C) * hw;
+  const long long b = t / chw, r = t - b * chw;          // r = c*hw + p
+  const float zp = zr[b * 2 * chw + r];
+  const float rp_ = zr[b * 2 * chw + chw + r];
+  const float hv = hcat[b * Ctot * hw + r];
+  z_out[t] = sigmoidf_(zp);
+  rhx[b * Ctot * hw + r] = sigmoidf_(rp_) * hv;
+}
+
+__global__ __launch_bounds__(256) void gru_update_kernel(const float* __restrict__ z, const float* __restrict__ q_pre,
+                                                         const float* __restrict__ hcat, float* __restrict__ hout,
+                                                         int C, int Ctot_in, int Ctot_out, int hw, long long n) {
+  const long long t = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const long long chw = static_cast<long long>(C) * hw;
+  const long long b = t / chw, r = t - b * chw;
+  const float zv = z[t];
+  const float hv = hcat[b * Ctot_in * hw + r];
+  hout[b * Ctot_out * hw + r] = (1.f - zv) * hv + zv * tanhf(q_pre[t]);
+}
+
+}  // namespace
+
+extern "C" {
+
+int rnnpose_context_prep_f32(const float* ctx, int B, int C, int H, int W, int h, int w, int hdim, float* net, float* inp,
+                             rnnpose_stream_t stream) {
+  const char* fn = "rnnpose_context_prep_f32";
+  RP_REQUIRE(ctx && net && inp, fn, "null pointer");
+  RP_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && h > 0 && w > 0, fn, "non-positive size");
+  RP_REQUIRE(hdim > 0 && hdim < C, fn, "hdim must be in (0,C)");
+  const long long n = static_cast<long long>(B) * C * h * w;
+  const int blocks = static_cast<int>(n / 256 + 1 < 65536 ? n / 256 + 1 : 65536);
+  hipLaunchKernelGGL(context_prep_kernel, dim3(blocks), dim3(256), 0, rp::as_stream(stream), ctx, net, inp, B, C, H, W, h,
+                     w, hdim);
+  return rp::check_launch(fn);
+}
+
+int rnnpose_flow_to_coords_f32(const float* flow_init, int B, int H, int W, int h, int w, float* coords1,
+                               rnnpose_stream_t stream) {
+  const char* fn = "rnnpose_flow_to_coords_f32";
+  RP_REQUIRE(flow_init && coords1, fn, "null pointer");
+  RP_REQUIRE(B > 0 && H > 0 && W > 0 && h > 0 && w > 0 && W >= w, fn, "bad size");
+  const long long n = static_cast<long long>(B) * 2 * h * w;
+  hipLaunchKernelGGL(flow_to_coords_kernel, dim3(rp::cdiv(n, 256)), dim3(256), 0, rp::as_stream(stream), flow_init,
+                     coords1, B, H, W, h, w);
+  return rp::check_launch(fn);
+}
+
+int rnnpose_induced_flow_f32(const float* depth, const float* K, const float* G, int B, int H, int W, float depth_eps,
+                             int mode, float* flow, float* vmask, rnnpose_stream_t stream) {
+  const char* fn = "rnnpose_induced_flow_f32";
+  RP_REQUIRE(depth && K && G && flow, fn, "null pointer");
+  RP_REQUIRE(B > 0 && B < 65536 && H > 0 && W > 0, fn, "bad size");
+  RP_REQUIRE(mode == 0 || mode == 1, fn, "mode must be 0 or 1");
+  const long long P = static_cast<long long>(H) * W;
+  hipLaunchKernelGGL(induced_flow_kernel, dim3(rp::cdiv(P, 256), B), dim3(256), 0, rp::as_stream(stream), depth, K, G,
+                     flow, vmask, H, W, depth_eps, mode);
+  return rp::check_launch(fn);
+}
+
+int rnnpose_induced_coords_lowres_f32(const float* depth, const float* K, const float* G, int B, int H, int W, int h,
+                                      int w, float depth_eps, float* coords1, rnnpose_stream_t stream) {
+  const char* fn = "rnnpose_induced_coords_lowres_f32";
+  RP_REQUIRE(depth && K && G && coords1, fn, "null pointer");
+  RP_REQUIRE(B > 0 && B < 65536 && H > 0 && W > 0 && h > 0 && w > 0 && W >= w, fn, "bad size");
+  hipLaunchKernelGGL(induced_coords_lowres_kernel, dim3(rp::cdiv(static_cast<long long>(h) * w, 256), B), dim3(256), 0,
+                     rp::as_stream(stream), depth, K, G, coords1, H, W, h, w, depth_eps);
+  return rp::check_launch(fn);
+}
+
+int rnnpose_convex_upsample_f32(const float* flow, const float* mask, int B, int h, int w, int scale, float* flow_up,
+                                rnnpose_stream_t stream) {
+  const char* fn = "rnnpose_convex_upsample_f32";
+  RP_REQUIRE(flow && mask && flow_up, fn, "null pointer");
+  RP_REQUIRE(scale == 8, fn, "scale must be 8");
+  RP_REQUIRE(B > 0 && B < 65536 && h > 0 && w > 0 && h * 8 < 65536, fn, "bad size");
+  hipLaunchKernelGGL(convex_upsample_kernel, dim3(rp::cdiv(w, UX), h * 8, B), dim3(256), 0, rp::as_stream(stream), flow,
+                     mask, flow_up, h, w);
+  return rp::check_launch(fn);
+}
+
+int rnnpose_corr_weight_f32(const float* g1, const float* g2, const float* target, int target_mode, const float* depth,
+                            const float* sigma, int B, int D, int H, int W, float* weight, rnnpose_stream_t stream) {
+  const char* fn = "rnnpose_corr_weight_f32";
+  RP_REQUIRE(g1 && g2 && target && depth && sigma && weight, fn, "null pointer");
+  RP_REQUIRE(target_mode == 0 || target_mode == 1, fn, "target_mode must be 0 or 1");
+  RP_REQUIRE(B > 0 && B < 65536 && D > 0 && H > 1 && W > 1, fn, "bad size");
+  const long long P = static_cast<long long>(H) * W;
+  hipLaunchKernelGGL(corr_weight_kernel, dim3(rp::cdiv(P, 256), B), dim3(256), 0, rp::as_stream(stream), g1, g2, target,
+                     target_mode, depth, sigma, weight, D, H, W);
+  return rp::check_launch(fn);
+}
+
+int rnnpose_gru_gate_f32(const float* zr, const float* hcat, int B, int C, int Ctot, int hw, float* z_out, float* rhx,
+                         rnnpose_stream_t stream) {
+  const char* fn = "rnnpose_gru_gate_f32";
+  RP_REQUIRE(zr && hcat && z_out && rhx, fn, "null pointer");
+  RP_REQUIRE(B > 0 && C > 0 && Ctot >= C && hw > 0, fn, "bad size");
+  const long long n = static_cast<long long>(B) * C * hw;
+  hipLaunchKernelGGL(gru_gate_kernel, dim3(rp::cdiv(n, 256)), dim3(256), 0, rp::as_stream(stream), zr, hcat, z_out, rhx,
+                     C, Ctot, hw, n);
+  return rp::check_launch(fn);
+}
+
+int rnnpose_gru_update_f32(const float* z, const float* q_pre, const float* hcat, int B, int C, int Ctot_in, int hw,
+                           float* hout, int Ctot_out, rnnpose_stream_t stream) {
+  const char* fn = "rnnpose_gru_update_f32";
+  RP_REQUIRE(z && q_pre && hcat && hout, fn, "null pointer");
+  RP_REQUIRE(B > 0 && C > 0 && Ctot_in >= C && Ctot_out >= C && hw > 0, fn, "bad size");
+  const long long n = static_cast<long long>(B) * C * hw;
+  hipLaunchKernelGGL(gru_update_kernel, dim3(rp::cdiv(n, 256)), dim3(256), 0, rp::as_stream(stream), z, q_pre, hcat,
+                     hout, C, Ctot_in, Ctot_out, hw, n);
+  return rp::check_launch(fn);
+}
+
+}  // extern "C"

@@ -1,0 +1,102 @@
+"""One process per GPU; images shard embarrassingly; ONE collective at the end of an evaluation epoch.
+
+Reference behaviour being replaced (SURVEY.md sections 2 row 27-28, 8e):
+  * `DistributedSequatialSampler` gives rank r the indices r, r+n, r+2n, ... of the evaluation set, padded by
+    wrap-around to a multiple of n (utils/distributed_utils.py:150-169, used at tools/eval.py:471);
+  * tools/eval.py performs NO cross-rank reduction (each rank prints its own means, :560-562); tools/train.py
+    all-gathers (mean*count, count) scalars per class and metric (:725-741).
+Here: the same rank-strided shard, but wrap-around duplicates are masked out of the statistics, and the
+per-class sums travel in ONE all_reduce(SUM) of a packed fp64 vector (<= 1 KB: latency-bound on xGMI, the
+ring/tree choice is irrelevant).  backend "nccl" is RCCL on ROCm; CPU tests use "gloo".
+"""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass, field
+
+import torch
+import torch.distributed as dist
+
+METRICS = ("add", "add2", "add5", "proj2d", "cmd5")      # utils/eval_metric.py:261-302
+
+
+def init_from_env(backend: str | None = None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun's contract).
+    Returns (rank, world_size, local_rank).  No-op (0,1,0) when WORLD_SIZE is unset or 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world <= 1:
+        return 0, 1, 0
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local % torch.cuda.device_count())
+    if not dist.is_initialized():
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_indices(n_items: int, rank: int, world: int):
+    """Rank-strided shard with wrap-around padding -> (indices, is_unique mask).
+    indices follow utils/distributed_utils.py:150-169; is_unique is False for the padded duplicates."""
+    if n_items <= 0:
+        return [], []
+    total = ((n_items + world - 1) // world) * world
+    order = list(range(n_items)) + list(range(total - n_items))
+    mine = order[rank:total:world]
+    positions = list(range(rank, total, world))
+    uniq = [p < n_items for p in positions]
+    return mine, uniq
+
+
+@dataclass
+class MetricAccumulator:
+    """Per-class running sums of the LINEMOD metrics + sample count; reduce() is the epoch-end collective."""
+    classes: tuple
+    sums: torch.Tensor = field(init=False)
+
+    def __post_init__(self):
+        self.sums = torch.zeros(len(self.classes), len(METRICS) + 1, dtype=torch.float64)
+
+    def update(self, cls: str, values: dict, unique: bool = True):
+        if not unique:
+            return
+        r = self.classes.index(cls)
+        for k, name in enumerate(METRICS):
+            self.sums[r, k] += float(values.get(name, 0.0))
+        self.sums[r, -1] += 1.0
+
+    def reduce(self, device=None):
+        """ONE all_reduce(SUM) of the packed (n_classes x 6) fp64 vector; returns {cls: {metric: mean, n}}."""
+        buf = self.sums.clone()
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            if device is None:
+                device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else "cpu"
+            buf = buf.to(device)
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+            buf = buf.cpu()
+        out = {}
+        for r, cls in enumerate(self.classes):
+            n = float(buf[r, -1])
+            out[cls] = {m: (float(buf[r, k]) / n if n > 0 else float("nan")) for k, m in enumerate(METRICS)}
+            out[cls]["n"] = int(n)
+        return out
+
+
+def max_over_ranks(seconds: float, device=None) -> float:
+    """all_reduce(MAX) of one double -- the throughput clock of bench.py."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return seconds
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()

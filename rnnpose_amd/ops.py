@@ -1,0 +1,283 @@
+"""Torch-tensor front end of the C ABI (include/rnnpose_hip.h): device memory and streams come from
+PyTorch-ROCm, every computation is a hand-written HIP kernel in librnnpose_hip.so.
+
+All ops take CUDA(=HIP) tensors, enqueue on torch's current stream, never synchronise and never fall back
+to a CPU or ATen implementation: a non-GPU tensor or a missing library raises RuntimeError.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from contextlib import contextmanager
+
+import torch
+
+from . import _lib
+
+F32 = torch.float32
+F64 = torch.float64
+
+# ---- optional per-op HIP-event timing (used by bench.py for the roofline object) -------------------------
+_prof = None   # None or dict name -> list[(start_evt, end_evt)]
+
+
+@contextmanager
+def profile(names=None):
+    """Record HIP events around every op call (or only the ops in `names`) on the current stream.
+    Yields a dict; after the context exits and the device is synchronised, call summarize()."""
+    global _prof
+    prev = _prof
+    rec = {"_only": set(names) if names else None}
+    _prof = rec
+    try:
+        yield rec
+    finally:
+        _prof = prev
+
+
+def summarize(rec) -> dict:
+    """-> {name: (n_calls, mean_ms, total_ms)} (synchronises)."""
+    torch.cuda.synchronize()
+    out = {}
+    for k, evs in rec.items():
+        if k == "_only":
+            continue
+        ms = [a.elapsed_time(b) for a, b in evs]
+        out[k] = (len(ms), sum(ms) / max(len(ms), 1), sum(ms))
+    return out
+
+
+def _launch(name, *args):
+    rec = _prof
+    if rec is not None and (rec["_only"] is None or name in rec["_only"]):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        _lib.call(name, *args)
+        b.record()
+        rec.setdefault(name, []).append((a, b))
+    else:
+        _lib.call(name, *args)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t: torch.Tensor, name: str, dtype=F32) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on the GPU (got {t.device}); rnnpose_amd has no CPU path")
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    return t.contiguous()
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+# ---- a1+a2 ---------------------------------------------------------------------------------------------
+def pyramid_layout(B, h, w, levels=4):
+    offs = (C.c_int64 * (levels + 1))()
+    hl = (C.c_int * levels)()
+    wl = (C.c_int * levels)()
+    _lib.call("rnnpose_corr_pyramid_layout", B, h, w, levels, offs, hl, wl)
+    return list(offs), list(hl), list(wl)
+
+
+def corr_pyramid(fmap1, fmap2, levels: int = 4):
+    """fmap1,fmap2 (B,C,h,w) -> (flat buffer, [views (B*h*w,1,h_l,w_l)])   thirdparty/raft/corr.py:13-34"""
+    fmap1, fmap2 = _chk(fmap1, "fmap1"), _chk(fmap2, "fmap2")
+    if fmap1.shape != fmap2.shape or fmap1.dim() != 4:
+        raise ValueError("fmap1/fmap2 must both be (B,C,h,w)")
+    B, Cc, h, w = fmap1.shape
+    offs, hl, wl = pyramid_layout(B, h, w, levels)
+    buf = torch.empty(offs[-1], device=fmap1.device, dtype=F32)
+    _launch("rnnpose_corr_pyramid_f32", _ptr(fmap1), _ptr(fmap2), B, Cc, h, w, levels, _ptr(buf), _stream())
+    views = [buf[offs[l]:offs[l + 1]].view(B * h * w, 1, hl[l], wl[l]) for l in range(levels)]
+    return buf, views
+
+
+# ---- a3 ------------------------------------------------------------------------------------------------
+def corr_lookup(pyramid_buf, coords, levels: int = 4, radius: int = 4):
+    """coords (B,2,h,w) -> (B, levels*81, h, w)                       thirdparty/raft/corr.py:36-57"""
+    coords = _chk(coords, "coords")
+    pyramid_buf = _chk(pyramid_buf, "pyramid")
+    B, two, h, w = coords.shape
+    if two != 2:
+        raise ValueError("coords must be (B,2,h,w)")
+    offs, _, _ = pyramid_layout(B, h, w, levels)
+    if pyramid_buf.numel() != offs[-1]:
+        raise ValueError("pyramid buffer does not match coords shape")
+    out = torch.empty(B, levels * (2 * radius + 1) ** 2, h, w, device=coords.device, dtype=F32)
+    _launch("rnnpose_corr_lookup_f32", _ptr(pyramid_buf), _ptr(coords), B, h, w, levels, radius, _ptr(out), _stream())
+    return out
+
+
+# ---- a5 ------------------------------------------------------------------------------------------------
+def context_prep(ctx, h, w, hdim: int = 128):
+    ctx = _chk(ctx, "context_fea")
+    B, Cc, H, W = ctx.shape
+    net = torch.empty(B, hdim, h, w, device=ctx.device, dtype=F32)
+    inp = torch.empty(B, Cc - hdim, h, w, device=ctx.device, dtype=F32)
+    _launch("rnnpose_context_prep_f32", _ptr(ctx), B, Cc, H, W, h, w, hdim, _ptr(net), _ptr(inp), _stream())
+    return net, inp
+
+
+def flow_to_coords(flow_init, h, w):
+    flow_init = _chk(flow_init, "flow_init")
+    B, two, H, W = flow_init.shape
+    out = torch.empty(B, 2, h, w, device=flow_init.device, dtype=F32)
+    _launch("rnnpose_flow_to_coords_f32", _ptr(flow_init), B, H, W, h, w, _ptr(out), _stream())
+    return out
+
+
+# ---- a6 ------------------------------------------------------------------------------------------------
+def convex_upsample(flow, mask, scale: int = 8):
+    flow, mask = _chk(flow, "flow"), _chk(mask, "mask")
+    B, _, h, w = flow.shape
+    if mask.shape != (B, 9 * scale * scale, h, w):
+        raise ValueError(f"mask must be (B,{9*scale*scale},h,w)")
+    out = torch.empty(B, 2, scale * h, scale * w, device=flow.device, dtype=F32)
+    _launch("rnnpose_convex_upsample_f32", _ptr(flow), _ptr(mask), B, h, w, scale, _ptr(out), _stream())
+    return out
+
+
+# ---- a7 ------------------------------------------------------------------------------------------------
+def induced_flow(depth, K, G, eps: float = 1e-5, want_vmask: bool = True, absolute: bool = False):
+    """depth (B,1,H,W) raw, K (B,3,3), G (B,[1,]4,4) -> flow (B,2,H,W), vmask (B,H,W) or None.
+    absolute=True returns the raw re-projected coordinates (SE3.transform) instead of the masked flow."""
+    depth, K, G = _chk(depth, "depth"), _chk(K, "intrinsics"), _chk(G, "G")
+    B, H, W = depth.shape[0], depth.shape[-2], depth.shape[-1]
+    flow = torch.empty(B, 2, H, W, device=depth.device, dtype=F32)
+    vmask = torch.empty(B, H, W, device=depth.device, dtype=F32) if want_vmask else None
+    _launch("rnnpose_induced_flow_f32", _ptr(depth), _ptr(K), _ptr(G), B, H, W, eps, int(absolute), _ptr(flow), _ptr(vmask),
+            _stream())
+    return flow, vmask
+
+
+def induced_coords_lowres(depth, K, G, h, w, eps: float = 1e-5):
+    depth, K, G = _chk(depth, "depth"), _chk(K, "intrinsics"), _chk(G, "G")
+    B, H, W = depth.shape[0], depth.shape[-2], depth.shape[-1]
+    out = torch.empty(B, 2, h, w, device=depth.device, dtype=F32)
+    _launch("rnnpose_induced_coords_lowres_f32", _ptr(depth), _ptr(K), _ptr(G), B, H, W, h, w, eps, _ptr(out), _stream())
+    return out
+
+
+# ---- a8 ------------------------------------------------------------------------------------------------
+def _target_mode(target, H, W):
+    if target.dim() >= 3 and target.shape[-1] == 2 and target.shape[-3:-1] == (H, W):
+        return 0      # (B,[K,]H,W,2) absolute coordinates
+    if target.dim() == 4 and target.shape[1] == 2 and target.shape[-2:] == (H, W):
+        return 1      # (B,2,H,W) planar flow, grid added in-kernel
+    raise ValueError(f"target has shape {tuple(target.shape)}; expected (B,H,W,2) or (B,2,H,W)")
+
+
+def corr_weight(g1, g2, target, depth, sigma):
+    g1, g2, target, depth = _chk(g1, "g1"), _chk(g2, "g2"), _chk(target, "target"), _chk(depth, "depth")
+    sigma = _chk(sigma.reshape(-1)[:1], "sigma")
+    B, D, H, W = g1.shape
+    mode = _target_mode(target, H, W)
+    out = torch.empty(B, H, W, device=g1.device, dtype=F32)
+    _launch("rnnpose_corr_weight_f32", _ptr(g1), _ptr(g2), _ptr(target), mode, _ptr(depth), _ptr(sigma), B, D, H, W,
+            _ptr(out), _stream())
+    return out
+
+
+# ---- a9-a11 --------------------------------------------------------------------------------------------
+_ws_cache = {}
+
+
+def _workspace(B, H, W, device):
+    n = int(_lib.load().rnnpose_lm_workspace_bytes(B, H, W))
+    key = (device, n)
+    ws = _ws_cache.get(key)
+    if ws is None:
+        ws = torch.empty(n // 8, device=device, dtype=F64)
+        _ws_cache[key] = ws
+    return ws, n
+
+
+def lm_normal_eq(target, weight, depth, K, G, eps: float = 1e-5):
+    """-> Hm (B,6,6) fp64 (undamped), bv (B,6) fp64             geometry/transformation.py:286-297"""
+    target, weight, depth = _chk(target, "target"), _chk(weight, "weight"), _chk(depth, "depth")
+    K, G = _chk(K, "intrinsics"), _chk(G, "G")
+    B, H, W = depth.shape[0], depth.shape[-2], depth.shape[-1]
+    mode = _target_mode(target, H, W)
+    ws, n = _workspace(B, H, W, depth.device)
+    Hm = torch.empty(B, 6, 6, device=depth.device, dtype=F64)
+    bv = torch.empty(B, 6, device=depth.device, dtype=F64)
+    _launch("rnnpose_lm_normal_eq_f64", _ptr(target), mode, _ptr(weight), _ptr(depth), eps, _ptr(K), _ptr(G), B, H, W,
+            _ptr(ws), n, _ptr(Hm), _ptr(bv), _stream())
+    return Hm, bv
+
+
+def lm_solve_update(Hm, bv, G, ep_lambda=100.0, lm_lambda=1e-4, max_update=1.0):
+    """-> G_new (B,4,4), xi (B,6) fp32, info (B,) int32"""
+    Hm, bv, G = _chk(Hm, "H", F64), _chk(bv, "b", F64), _chk(G, "G")
+    B = Hm.shape[0]
+    G_new = torch.empty(B, 4, 4, device=G.device, dtype=F32)
+    xi = torch.empty(B, 6, device=G.device, dtype=F32)
+    info = torch.empty(B, device=G.device, dtype=torch.int32)
+    _launch("rnnpose_lm_solve_update_f32", _ptr(Hm), _ptr(bv), _ptr(G), B, float(ep_lambda), float(lm_lambda),
+            float(max_update), _ptr(G_new), _ptr(xi), _ptr(info), _stream())
+    return G_new, xi, info
+
+
+def lm_step(target, weight, depth, K, G, num_iters=1, ep_lambda=100.0, lm_lambda=1e-4, max_update=1.0, eps=1e-5):
+    """num_iters fused GN steps; returns (G_new (B,4,4), Hm, bv, xi, info) of the last iteration."""
+    target, weight, depth = _chk(target, "target"), _chk(weight, "weight"), _chk(depth, "depth")
+    K = _chk(K, "intrinsics")
+    G = _chk(G, "G").reshape(-1, 4, 4).clone()
+    B, H, W = depth.shape[0], depth.shape[-2], depth.shape[-1]
+    mode = _target_mode(target, H, W)
+    ws, n = _workspace(B, H, W, depth.device)
+    Hm = torch.empty(B, 6, 6, device=depth.device, dtype=F64)
+    bv = torch.empty(B, 6, device=depth.device, dtype=F64)
+    xi = torch.zeros(B, 6, device=depth.device, dtype=F32)
+    info = torch.zeros(B, device=depth.device, dtype=torch.int32)
+    _launch("rnnpose_lm_step_f32", _ptr(target), mode, _ptr(weight), _ptr(depth), eps, _ptr(K), _ptr(G), B, H, W,
+            int(num_iters), float(ep_lambda), float(lm_lambda), float(max_update), _ptr(ws), n, _ptr(Hm), _ptr(bv),
+            _ptr(xi), _ptr(info), _stream())
+    return G, Hm, bv, xi, info
+
+
+def se3_exp(xi):
+    xi = _chk(xi, "xi")
+    sh = xi.shape[:-1]
+    x = xi.reshape(-1, 6)
+    out = torch.empty(x.shape[0], 4, 4, device=xi.device, dtype=F32)
+    _launch("rnnpose_se3_exp_f32", _ptr(x), x.shape[0], _ptr(out), _stream())
+    return out.reshape(*sh, 4, 4)
+
+
+def se3_compose(A, Bm):
+    A, Bm = _chk(A, "A"), _chk(Bm, "B")
+    if A.shape != Bm.shape:
+        raise ValueError("se3_compose needs equal shapes")
+    out = torch.empty_like(A)
+    _launch("rnnpose_se3_compose_f32", _ptr(A), _ptr(Bm), A.numel() // 16, _ptr(out), _stream())
+    return out
+
+
+def se3_inverse(A):
+    A = _chk(A, "A")
+    out = torch.empty_like(A)
+    _launch("rnnpose_se3_inverse_f32", _ptr(A), A.numel() // 16, _ptr(out), _stream())
+    return out
+
+
+# ---- a4 pointwise ---------------------------------------------------------------------------------------
+def gru_gate(zr, hcat, z_out, rhx, C: int = 128):
+    """zr (B,2C,h,w) pre-activations; hcat (B,Ctot,h,w) with h in [:C]; writes z_out (B,C,h,w), rhx[:, :C]."""
+    B, Ctot = hcat.shape[0], hcat.shape[1]
+    hw = hcat.shape[2] * hcat.shape[3]
+    _launch("rnnpose_gru_gate_f32", _ptr(zr), _ptr(hcat), B, C, Ctot, hw, _ptr(z_out), _ptr(rhx), _stream())
+
+
+def gru_update(z, q_pre, hcat, hout, C: int = 128):
+    """hout[:, :C] = (1-z)*hcat[:, :C] + z*tanh(q_pre)  (hout may be hcat itself)."""
+    B = hcat.shape[0]
+    hw = hcat.shape[2] * hcat.shape[3]
+    _launch("rnnpose_gru_update_f32", _ptr(z), _ptr(q_pre), _ptr(hcat), B, C, hcat.shape[1], hw, _ptr(hout), hout.shape[1],
+            _stream())

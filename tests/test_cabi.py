@@ -1,0 +1,83 @@
+"""The C-ABI library builds for gfx950, loads, and exports every symbol include/rnnpose_hip.h declares.
+No GPU needed: only host-side entry points (layout, workspace size, argument validation) are called."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from rnnpose_amd import build, _lib
+    build.build()
+    return _lib.load()
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "rnnpose_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(rnnpose_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported_and_typed(lib):
+    from rnnpose_amd import _lib
+    names = declared_symbols()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in the header but not exported"
+        assert n in _lib.PROTOTYPES, f"{n} has no ctypes prototype"
+    assert sorted(_lib.PROTOTYPES) == names
+    assert lib.rnnpose_abi_version() == 1
+
+
+def test_gfx950_code_object_present():
+    """The fat binary must carry a gfx950 code object (and nothing else: no portability layer)."""
+    from rnnpose_amd import _lib
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"amdgcn-amd-amdhsa--gfx950" in blob
+    for other in (b"gfx90a", b"gfx942", b"sm_"):
+        assert b"amdgcn-amd-amdhsa--" + other not in blob
+
+
+def test_pyramid_layout(lib):
+    offs = (C.c_int64 * 5)()
+    hl = (C.c_int * 4)()
+    wl = (C.c_int * 4)()
+    assert lib.rnnpose_corr_pyramid_layout(8, 60, 80, 4, offs, hl, wl) == 0
+    assert list(hl) == [60, 30, 15, 7] and list(wl) == [80, 40, 20, 10]
+    n = 8 * 4800
+    assert list(offs) == [0, n * 4800, n * 6000, n * 6300, n * 6370]
+    assert lib.rnnpose_corr_pyramid_layout(1, 30, 30, 4, offs, hl, wl) == 0
+    assert list(hl) == [30, 15, 7, 3]
+    assert lib.rnnpose_corr_pyramid_layout(1, 4, 4, 4, offs, hl, wl) == 1        # level 3 would be empty
+    assert b"too small" in lib.rnnpose_last_error()
+    assert lib.rnnpose_corr_pyramid_layout(1, 16, 16, 5, offs, hl, wl) == 1
+
+
+def test_workspace_and_argument_validation(lib):
+    assert lib.rnnpose_lm_workspace_bytes(8, 480, 640) == 8 * 75 * 32 * 8
+    assert lib.rnnpose_lm_workspace_bytes(1, 16, 16) == 32 * 8
+    assert lib.rnnpose_lm_workspace_bytes(0, 16, 16) == 0
+    null = C.c_void_p(0)
+    assert lib.rnnpose_corr_pyramid_f32(null, null, 1, 256, 16, 16, 4, null, null) == 1
+    assert b"null pointer" in lib.rnnpose_last_error()
+    assert lib.rnnpose_corr_lookup_f32(null, null, 1, 16, 16, 4, 4, null, null) == 1
+    one = C.c_void_p(16)    # non-null dummy, never dereferenced on the host
+    assert lib.rnnpose_corr_lookup_f32(one, one, 1, 16, 16, 4, 3, one, null) == 1
+    assert b"radius" in lib.rnnpose_last_error()
+    assert lib.rnnpose_corr_lookup_f32(one, one, 1, 8, 8, 4, 4, one, null) == 1     # 1x1 top level
+    assert lib.rnnpose_convex_upsample_f32(one, one, 1, 8, 8, 4, one, null) == 1
+    assert lib.rnnpose_corr_weight_f32(one, one, one, 2, one, one, 1, 32, 8, 8, one, null) == 1
+    assert lib.rnnpose_corr_pyramid_f32(one, one, 1, 250, 16, 16, 4, one, null) == 1
+    assert b"multiple of 16" in lib.rnnpose_last_error()
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from rnnpose_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.load()

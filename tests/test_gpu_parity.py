@@ -1,0 +1,446 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every HIP kernel, through the C ABI, against the CPU
+oracle on the same seeded inputs and against the committed reference-generated golden vectors.
+
+Tolerances (north_star): 1e-4 absolute on correlation / flow quantities, 1e-5 on the pose, 1e-7 relative on
+the fp64 normal equations (their inputs are fp32).  Re-projections of near-zero depths reach thousands of
+pixels, so coordinate comparisons add an fp32-relative term (see `close`).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import rnnpose_oracle as orc
+from rnnpose_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from rnnpose_amd import build, ops as _ops
+    build.build()
+    return _ops
+
+
+def D(x, dtype=torch.float32):
+    if isinstance(x, np.ndarray):
+        x = torch.from_numpy(np.ascontiguousarray(x))
+    return x.to(device="cuda", dtype=dtype)
+
+
+def N(x):
+    return x.detach().cpu().numpy() if torch.is_tensor(x) else np.asarray(x)
+
+
+def close(got, want, atol, rtol=0.0, what=""):
+    g, w = N(got).astype(np.float64), N(want).astype(np.float64)
+    assert g.shape == w.shape, f"{what}: shape {g.shape} vs {w.shape}"
+    err = np.abs(g - w) - atol - rtol * np.abs(w)
+    bad = ~(err <= 0)          # catches NaN too
+    if bad.any():
+        i = np.unravel_index(np.argmax(np.where(np.isnan(err), np.inf, err)), err.shape)
+        raise AssertionError(f"{what}: {int(bad.sum())}/{bad.size} elements out of tolerance; worst at {i}: "
+                             f"got {g[i]!r} want {w[i]!r} (|d|={abs(g[i]-w[i]):.3e}, atol={atol}, rtol={rtol})")
+
+
+def T(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+def upd_weights(seed=0):
+    return syn.make_module_weights(orc.UPDATE_BLOCK_SHAPES, seed=seed)
+
+
+# ------------------------------------------------------------------------------------------------ a1/a2
+@pytest.mark.parametrize("B,C,h,w,levels", [(2, 256, 16, 24, 4), (1, 256, 30, 30, 4), (2, 64, 17, 19, 4),
+                                            (1, 256, 16, 16, 2), (1, 32, 40, 23, 3)])
+def test_corr_pyramid_vs_oracle(ops, B, C, h, w, levels):
+    f1 = syn.normal("fmap1", (B, C, h, w), 11)
+    f2 = syn.normal("fmap2", (B, C, h, w), 11)
+    want = orc.corr_pyramid(f1, f2, levels)
+    buf, views = ops.corr_pyramid(D(f1), D(f2), levels)
+    assert len(views) == levels
+    for l in range(levels):
+        assert tuple(views[l].shape) == (B * h * w, 1) + tuple(want[l].shape[1:])
+        close(views[l][:, 0], want[l], 1e-5, what=f"level {l}")
+
+
+def test_corr_pyramid_golden(ops, golden):
+    g = golden("corr")
+    B, C, h, w = 2, 256, 16, 24
+    f1 = syn.normal("fmap1", (B, C, h, w), 11)
+    f2 = syn.normal("fmap2", (B, C, h, w), 11)
+    _, views = ops.corr_pyramid(D(f1), D(f2), 4)
+    close(views[0].reshape(B * h * w, h * w)[::5], g["level0_rows"], 1e-5, what="level0 rows")
+    for l in (1, 2, 3):
+        close(views[l], g[f"level{l}"], 1e-5, what=f"level{l}")
+    assert abs(float(views[0].double().sum()) - float(g["level0_sum"])) < 1e-2
+
+
+def test_corr_pyramid_full_size_properties(ops):
+    """BASELINE config-2 size (B=8, 60x80x256): size-independent properties instead of a CPU replay.
+    (1) level 0 rows == direct dot products; (2) pooled volume == volume of pooled features (avg-pool is
+    linear); (3) bilinearity: corr(a*f1, f2 + f2') == a*corr(f1,f2) + a*corr(f1,f2')."""
+    B, C, h, w = 8, 256, 60, 80
+    f1 = D(syn.normal("fmap1", (B, C, h, w), 0))
+    f2 = D(syn.normal("fmap2", (B, C, h, w), 0))
+    buf, v = ops.corr_pyramid(f1, f2, 4)
+    Np = h * w
+    rows = torch.tensor([0, 1, 79, 80, 2399, 4799], device="cuda")
+    for b in (0, 3, 7):
+        a = f1[b].reshape(C, Np)[:, rows].double()
+        want0 = (a.t() @ f2[b].reshape(C, Np).double() / 16).float()
+        close(v[0].view(B, Np, Np)[b, rows], want0, 2e-5, what=f"level0 b={b}")
+        for l in (1, 2, 3):
+            k = 2 ** l
+            hl, wl = h // k, w // k
+            pooled = torch.nn.functional.avg_pool2d(f2[b].double()[None], k)[0].reshape(C, hl * wl)
+            wantl = (a.t() @ pooled / 16).float()
+            close(v[l].view(B, Np, hl * wl)[b, rows], wantl, 2e-5, what=f"level{l} b={b}")
+    f2b = D(syn.normal("fmap2b", (B, C, h, w), 1))
+    _, v2 = ops.corr_pyramid(f1 * 0.5, f2 + f2b, 4)
+    _, v3 = ops.corr_pyramid(f1, f2b, 4)
+    for l in range(4):
+        close(v2[l], 0.5 * (v[l] + v3[l]), 5e-5, what=f"bilinearity level {l}")
+
+
+# ------------------------------------------------------------------------------------------------ a3
+def _lookup_cases(B, h, w):
+    grid = orc.coords_grid_lowres(B, h, w)
+    return {
+        "int": grid.clone(),
+        "sub": grid + T(syn.uniform("lk_sub", (B, 2, h, w), 11, -3.0, 3.0)),
+        "oob": grid + T(syn.uniform("lk_oob", (B, 2, h, w), 11, -30.0, 30.0)),
+    }
+
+
+def test_corr_lookup_vs_oracle_and_golden(ops, golden):
+    g = golden("corr")
+    B, C, h, w = 2, 256, 16, 24
+    f1 = syn.normal("fmap1", (B, C, h, w), 11)
+    f2 = syn.normal("fmap2", (B, C, h, w), 11)
+    pyr = orc.corr_pyramid(f1, f2)
+    buf, _ = ops.corr_pyramid(D(f1), D(f2), 4)
+    for k, c in _lookup_cases(B, h, w).items():
+        out = ops.corr_lookup(buf, D(c))
+        assert out.shape == (B, 324, h, w) and out.is_contiguous()
+        close(out, orc.corr_lookup(pyr, c), 1e-4, what=f"lookup {k} vs oracle")
+        close(out[:, :, ::2, ::3], g[f"lookup_{k}"], 1e-4, what=f"lookup {k} vs golden")
+
+
+@pytest.mark.parametrize("B,h,w", [(1, 30, 30), (3, 17, 19)])
+def test_corr_lookup_odd_sizes(ops, B, h, w):
+    f1 = syn.normal("fmap1", (B, 64, h, w), 4)
+    f2 = syn.normal("fmap2", (B, 64, h, w), 4)
+    c = orc.coords_grid_lowres(B, h, w) + T(syn.uniform("lk", (B, 2, h, w), 4, -6.0, 6.0))
+    buf, _ = ops.corr_pyramid(D(f1), D(f2), 4)
+    close(ops.corr_lookup(buf, D(c)), orc.corr_lookup(orc.corr_pyramid(f1, f2), c), 1e-4, what="lookup odd")
+
+
+def test_corr_lookup_full_size_integer_coords_and_nan(ops):
+    """At integer coords the level-0 window is the raw volume (x-major order); NaN/inf coords sample zeros."""
+    B, C, h, w = 8, 256, 60, 80
+    f1 = D(syn.normal("fmap1", (B, C, h, w), 0))
+    f2 = D(syn.normal("fmap2", (B, C, h, w), 0))
+    buf, v = ops.corr_pyramid(f1, f2, 4)
+    from rnnpose_amd.corr import coords_grid
+    coords = coords_grid(B, h, w, device="cuda")
+    out = ops.corr_lookup(buf, coords)
+    vol = v[0].view(B, h, w, h, w)
+    for (b, Y, X) in ((0, 10, 10), (5, 59, 79), (7, 0, 0), (2, 31, 47)):
+        for i, j in ((4, 4), (0, 8), (8, 0), (3, 6)):
+            x2, y2 = X + i - 4, Y + j - 4
+            want = float(vol[b, Y, X, y2, x2]) if (0 <= x2 < w and 0 <= y2 < h) else 0.0
+            assert abs(float(out[b, i * 9 + j, Y, X]) - want) < 1e-6, (b, Y, X, i, j)
+    # sortedness-like invariant: a lookup of all-zero pyramid is zero, of a constant pyramid is constant inside
+    bad = coords.clone()
+    bad[0, 0, 5, 5] = float("nan")
+    bad[1, 1, 6, 6] = float("inf")
+    bad[2, 0, 7, 7] = -1e30
+    o2 = ops.corr_lookup(buf, bad)
+    assert torch.isfinite(o2).all()
+    assert float(o2[0, :, 5, 5].abs().max()) == 0 and float(o2[1, :, 6, 6].abs().max()) == 0
+    assert float(o2[2, :, 7, 7].abs().max()) == 0
+    m = torch.ones_like(o2, dtype=torch.bool)
+    m[0, :, 5, 5] = m[1, :, 6, 6] = m[2, :, 7, 7] = False
+    assert torch.equal(o2[m], out[m])
+
+
+# ------------------------------------------------------------------------------------------------ a5/a6
+def test_context_prep_and_flow_to_coords(ops, golden):
+    g = golden("upsample_ctx")
+    ctx = syn.normal("ctx", (1, 256, 64, 96), 5, std=0.1)
+    net, inp = ops.context_prep(D(ctx), 8, 12)
+    close(net, g["net"], 1e-6, what="net golden")
+    close(inp, g["inp"], 1e-6, what="inp golden")
+    finit = syn.normal("finit", (2, 2, 64, 96), 5, std=4.0)
+    fd = D(finit)
+    c1 = ops.flow_to_coords(fd, 8, 12)
+    close(c1, g["coords1"], 1e-5, what="coords1 golden")
+    assert torch.equal(fd.cpu(), T(finit)), "flow_init must not be modified"
+    ctx2 = syn.normal("ctx2", (2, 256, 128, 160), 6, std=0.1)
+    n2, i2 = ops.context_prep(D(ctx2), 16, 20)
+    wn, wi = orc.context_prep(ctx2)
+    close(n2, wn, 1e-6, what="net oracle")
+    close(i2, wi, 1e-6, what="inp oracle")
+
+
+@pytest.mark.parametrize("B,h,w", [(2, 16, 12), (1, 30, 30), (2, 9, 80), (1, 5, 130)])
+def test_convex_upsample(ops, golden, B, h, w):
+    flow = syn.normal("up_flow", (B, 2, h, w), 5, std=3.0)
+    mask = syn.normal("up_mask", (B, 576, h, w), 5, std=2.0)
+    out = ops.convex_upsample(D(flow), D(mask))
+    close(out, orc.convex_upsample(flow, mask), 1e-4, what="upsample vs oracle")
+    if (B, h, w) == (2, 16, 12):
+        close(out, golden("upsample_ctx")["flow_up"], 1e-4, what="upsample vs golden")
+
+
+# ------------------------------------------------------------------------------------------------ a7/a8
+def test_induced_flow(ops, golden):
+    g = golden("geometry")
+    d = syn.make_inputs(2, 64, 96, seed=7, pose_sigma=0.03)
+    depth, K, G = D(g["depth"]), D(d["K"]), D(g["G"])
+    flow, vmask = ops.induced_flow(depth, K, G, eps=1e-5)
+    close(flow[:, None], g["flow_init"], 1e-4, 1e-6, what="flow_init golden")
+    assert np.array_equal(N(vmask)[:, None, :, :, None], g["vmask"])
+    wf, wv = orc.induced_flow(g["depth"], d["K"], g["G"])
+    close(flow, wf, 1e-4, 1e-6, what="flow_init oracle")
+    # SE3.transform semantics: depth already +EPS, raw coordinates
+    uv, _ = ops.induced_flow(depth + 1e-5, K, G, eps=0.0, absolute=True)
+    close(uv.permute(0, 2, 3, 1)[:, None], g["reproj"], 1e-4, 1e-6, what="reproj golden")
+    # fused low-res path == full-res flow then CFNet down-sampling
+    c1 = ops.induced_coords_lowres(depth, K, G, 8, 12, 1e-5)
+    close(c1, orc.flow_init_to_coords1(wf), 1e-4, 1e-6, what="coords lowres")
+    close(c1, ops.flow_to_coords(flow, 8, 12), 1e-5, 1e-6, what="coords lowres vs two-kernel path")
+
+
+def test_corr_weight(ops, golden):
+    g = golden("geometry")
+    d = syn.make_inputs(2, 64, 96, seed=7, pose_sigma=0.03)
+    tgt = D(g["target"])[:, 0]
+    w0 = ops.corr_weight(D(d["g1"]), D(d["g2"]), tgt, D(g["depth"]), D(g["sigma"]))
+    close(w0[:, None, :, :, None], g["weight"], 1e-4, what="weight golden")
+    close(w0, orc.corr_weight(d["g1"], d["g2"], T(g["target"])[:, 0], g["depth"], g["sigma"]), 1e-4, what="weight oracle")
+    # planar-flow target mode adds the grid in-kernel
+    from rnnpose_amd.transformation import coords_grid
+    grid = coords_grid(D(g["depth"]), homogeneous=False)[:, 0]
+    flow = (tgt - grid).permute(0, 3, 1, 2).contiguous()
+    w1 = ops.corr_weight(D(d["g1"]), D(d["g2"]), flow, D(g["depth"]), D(g["sigma"]))
+    close(w1, w0, 2e-5, what="weight planar mode")
+    # far out-of-image targets sample zero padding -> exp(-1/sigma) on foreground
+    far = tgt.clone()
+    far[..., 0] += 1e5
+    wf = ops.corr_weight(D(d["g1"]), D(d["g2"]), far, D(g["depth"]), D(g["sigma"]))
+    fg = D(g["depth"])[:, 0] > 0
+    close(wf[fg], torch.full_like(wf[fg], float(np.exp(-1 / 0.7))), 1e-6, what="oob weight")
+    assert float(wf[~fg].abs().max()) == 0
+
+
+# ------------------------------------------------------------------------------------------------ a9-a11
+def _wpat(g, pat, B, H, W):
+    return {
+        "desc": T(g["weight"])[:, 0, :, :, 0],
+        "ones": torch.ones(B, H, W),
+        "sparse": (T(syn.uniform("wsp", (B, 1, H, W, 1), 7)) > 0.97).float()[:, 0, :, :, 0] * 2.5,
+        "zero": torch.zeros(B, H, W),
+    }[pat]
+
+
+@pytest.mark.parametrize("pat", ["desc", "ones", "sparse", "zero"])
+def test_lm(ops, golden, pat):
+    g = golden("geometry")
+    d = syn.make_inputs(2, 64, 96, seed=7, pose_sigma=0.03)
+    B, H, W = 2, 64, 96
+    wgt = _wpat(g, pat, B, H, W)
+    tgt = T(g["target"])[:, 0]
+    depth, K, G = D(g["depth"]), D(d["K"]), D(g["G"])
+    Hm, bv = ops.lm_normal_eq(D(tgt), D(wgt), depth, K, G, eps=1e-5)
+    oH, ob = orc.lm_normal_eq(tgt, wgt, g["depth"], d["K"], g["G"])
+    sH, sb = max(1.0, float(oH.abs().max())), max(1.0, float(ob.abs().max()))
+    close(Hm, oH, 1e-7 * sH, what="H oracle")
+    close(bv, ob, 1e-7 * sb, what="b oracle")
+    assert torch.equal(Hm, Hm.transpose(1, 2))
+    eye = torch.eye(6, dtype=torch.float64, device="cuda")
+    Hd = Hm + 100.0 * eye + 1e-4 * Hm * eye
+    close(Hd, g[f"lm_{pat}_Hd0"][:, 0], 1e-7 * sH, what="damped H golden")
+    close(bv, g[f"lm_{pat}_b0"][:, 0], 1e-7 * sb, what="b golden")
+    G1, xi, info = ops.lm_solve_update(Hm, bv, G.reshape(B, 4, 4))
+    close(G1[:, None], g[f"lm_{pat}_G1"], 1e-5, what="G after 1 step")
+    assert int(info.abs().sum()) == 0
+    close(xi, orc.lm_solve(N(oH), N(ob)), 1e-6, what="xi oracle")
+    G2, _, _, _, _ = ops.lm_step(D(tgt), D(wgt), depth, K, G, num_iters=2)
+    close(G2[:, None], g[f"lm_{pat}_G"], 1e-5, what="G after 2 fused steps")
+    if pat == "zero":
+        close(G1[:, None], g["G"], 1e-7, what="zero weight leaves the pose unchanged")
+    # determinism: two launches give bit-identical sums (fixed-order reduction, no atomics)
+    Hm2, bv2 = ops.lm_normal_eq(D(tgt), D(wgt), depth, K, G, eps=1e-5)
+    assert torch.equal(Hm, Hm2) and torch.equal(bv, bv2)
+
+
+def test_lm_exact_target_recovery_and_facade(ops, golden):
+    from rnnpose_amd.transformation import SE3Sequence
+    g = golden("geometry")
+    d = syn.make_inputs(2, 64, 96, seed=7)
+    depths = D(g["depth"]) + 1e-5
+    Tk = SE3Sequence(matrix=torch.eye(4, device="cuda").repeat(2, 1, 1, 1))
+    ones = torch.ones(2, 1, 64, 96, 1, device="cuda")
+    errs = []
+    for k in range(4):
+        Tk = Tk.reprojction_optim(D(g["rec_target"]), ones, depths, D(d["K"]), num_iters=1)
+        close(Tk.G, g["rec_G"][k], 1e-5, what=f"recovery step {k}")
+        errs.append(float((Tk.G.cpu() - T(g["rec_Gstar"])).abs().max()))
+    assert errs[-1] < 1e-5 and errs[0] > errs[1] > errs[2]
+    # transform round trip through the facade
+    coords, vm = SE3Sequence(matrix=D(g["G"])).transform(depths, D(d["K"]), valid_mask=True)
+    close(coords, g["reproj"], 1e-4, 1e-6, what="facade transform")
+    assert np.array_equal(N(vm), g["vmask"])
+
+
+def test_solve_exp_compose_inverse(ops, golden):
+    from rnnpose_amd import transformation as tr
+    g = golden("geometry")
+    x = tr.solve(D(g["solve_H"], torch.float64)[:, None], D(g["solve_b"], torch.float64)[:, None])
+    close(x, g["solve_x"], 1e-6, what="cholesky.solve golden")
+    assert float(x.abs().max()) == 1.0                               # clamp exercised
+    close(tr.se3_matrix_expm(D(g["exp_xi"])), g["exp_G"], 1e-6, what="expm golden")
+    G0 = D(g["G"])[:1, 0].repeat(len(g["exp_xi"]), 1, 1)
+    close(tr.se3_matrix_increment(G0, D(g["exp_xi"])), g["inc_G"], 1e-6, what="increment golden")
+    close(tr.se3_matrix_inverse(D(g["G"])), g["inv_G"], 1e-6, what="inverse golden")
+    # non-SPD system: NaN -> 0 update, pose unchanged, info flags the failing minor
+    bad = -torch.eye(6, dtype=torch.float64, device="cuda")[None]
+    Gn, xi, info = ops.lm_solve_update(bad, torch.ones(1, 6, dtype=torch.float64, device="cuda"),
+                                       torch.eye(4, device="cuda")[None], 0.0, 0.0, 1.0)
+    assert float(xi.abs().max()) == 0 and int(info[0]) == 1
+    close(Gn, torch.eye(4)[None], 0.0, what="pose unchanged on failure")
+
+
+# ------------------------------------------------------------------------------------------------ a4
+def _load_update_block(seed=0):
+    from rnnpose_amd.cfnet import GRU_CFUpdator
+    net = GRU_CFUpdator(dict(pretrained_model=None, mixed_precision=False, fea_net="default")).cuda().eval()
+    net.update_block.load_state_dict({k: T(v) for k, v in upd_weights(seed).items()}, strict=True)
+    return net
+
+
+def test_gru_pointwise_kernels(ops):
+    B, C, h, w = 2, 128, 9, 13
+    zr = D(syn.normal("zr", (B, 2 * C, h, w), 1, std=2.0))
+    hcat = D(syn.normal("hc", (B, 384, h, w), 1))
+    z = torch.empty(B, C, h, w, device="cuda")
+    rhx = torch.full((B, 384, h, w), 7.0, device="cuda")
+    ops.gru_gate(zr, hcat, z, rhx, C)
+    close(z, torch.sigmoid(zr[:, :C].cpu()), 1e-6, what="z")
+    close(rhx[:, :C], torch.sigmoid(zr[:, C:].cpu()) * hcat[:, :C].cpu(), 1e-6, what="r*h")
+    assert float((rhx[:, C:] - 7.0).abs().max()) == 0
+    q = D(syn.normal("q", (B, C, h, w), 2, std=2.0))
+    want = (1 - z.cpu()) * hcat[:, :C].cpu() + z.cpu() * torch.tanh(q.cpu())
+    keep = hcat[:, C:].clone()
+    ops.gru_update(z, q, hcat, hcat, C)
+    close(hcat[:, :C], want, 1e-6, what="h update in place")
+    assert torch.equal(hcat[:, C:], keep)
+
+
+def test_update_block(ops, golden):
+    g = golden("update_block")
+    B, h, w = 1, 16, 20
+    hid = np.tanh(syn.normal("u_net", (B, 128, h, w), 3))
+    inp = np.maximum(syn.normal("u_inp", (B, 128, h, w), 3), 0)
+    corr = syn.normal("u_corr", (B, 324, h, w), 3)
+    flow = syn.normal("u_flow", (B, 2, h, w), 3, std=2.0)
+    net = _load_update_block()
+    with torch.no_grad():
+        n2, mask, df = net.update_block(D(hid), D(inp), D(corr), D(flow))
+    close(n2, g["net"], 1e-5, what="net golden")
+    close(mask, g["mask"], 1e-4, what="mask golden")
+    close(df, g["dflow"], 1e-4, what="dflow golden")
+
+
+def test_encoder(ops, golden):
+    from rnnpose_amd.cfnet import ImageFeaEncoder
+    g = golden("encoder")
+    enc = ImageFeaEncoder().cuda().eval()
+    W = syn.make_module_weights(orc.encoder_shapes(), seed=2)
+    enc.fnet.load_state_dict({k: T(v) for k, v in W.items()}, strict=True)
+    with torch.no_grad():
+        f1, f2 = enc(D(syn.uniform("img_render", (2, 3, 64, 96), 2)), D(syn.uniform("img_target", (2, 3, 64, 96), 2)))
+    close(f1, g["fmap1"], 1e-4, what="fmap1 golden")
+    close(f2, g["fmap2"], 1e-4, what="fmap2 golden")
+
+
+# ------------------------------------------------------------------------------------------------ a5/a12
+def _renderer(d):
+    from rnnpose_amd.pose_refiner import SyntheticRenderer
+    z3 = torch.zeros(d["depth"].shape[0], 3, *d["depth"].shape[-2:], device="cuda")
+    return SyntheticRenderer(syn_img=z3, image_crop=z3, cfea=D(d["ctx"]), geofea1=D(d["g1"]), geofea2_crop=D(d["g2"]),
+                             syn_depth=D(d["depth"]), intrinsics_crop=D(d["K"]), fmap1=D(d["fmap1"]), fmap2=D(d["fmap2"]))
+
+
+def _refiner(d, outer, inner, opt, fused):
+    from rnnpose_amd.pose_refiner import PoseRefiner, default_config
+    ref = PoseRefiner(default_config(RENDER_ITER_COUNT=outer, ITER_COUNT=inner, OPTIM_ITER_COUNT=opt),
+                      renderer=_renderer(d), fused=fused).cuda().eval()
+    ref.cf_net.update_block.load_state_dict({k: T(v) for k, v in upd_weights().items()}, strict=True)
+    return ref
+
+
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("name,shape,outer,inner,opt", [("loop_128", (2, 128, 128, 21), 1, 3, 1),
+                                                         ("loop_2x2", (2, 128, 160, 22), 2, 2, 2),
+                                                         ("loop_S1", (1, 240, 240, 23), 1, 3, 1)])
+def test_refinement_loop_golden(ops, golden, name, shape, outer, inner, opt, fused):
+    from rnnpose_amd.transformation import SE3Sequence
+    g = golden(name)
+    B, H, W, seed = shape
+    d = syn.make_inputs(B, H, W, seed=seed)
+    ref = _refiner(d, outer, inner, opt, fused)
+    out = ref(None, SE3Sequence(matrix=D(d["G0"])), D(d["K"]))
+    Gi = torch.stack([t.G for t in ref.residual_pose_history])
+    close(Gi, g["G_iters"], 1e-5, what="per-iteration relative poses")
+    close(out["Ti_pred"].G, g["G_final"], 1e-5, what="final pose")
+    fl = out["flow_last"]
+    if name == "loop_128":
+        close(fl, g["flow_last"], 1e-4, what="last flow")
+        close(out["flow"][-1], g["flow_first"], 1e-4, what="first flow")
+        close(out["weight"][:, 0, 0], g["w_last"], 1e-4, what="last weight")
+    elif name == "loop_2x2":
+        close(fl[:, :, ::2, ::2], g["flow_last"], 1e-4, what="last flow")
+    else:
+        close(fl[:, :, ::3, ::3], g["flow_last"], 1e-4, what="last flow")
+        close(out["weight"][:, 0, 0, ::3, ::3], g["w_last"], 1e-4, what="last weight")
+    assert set(out) >= {"Tij", "Ti_pred", "intrinsics", "flow", "vmask", "weight", "syn_depth", "syn_img", "Tij_gt"}
+
+
+def test_cfupdator_facade_stateful(ops):
+    """GRU_CFUpdator keeps volume + hidden state between calls (update_corr_fn=False) like the reference."""
+    d = syn.make_inputs(2, 128, 160, seed=31)
+    net = _load_update_block()
+    W = {"upd": upd_weights()}
+    fi = syn.normal("fi", (2, 2, 128, 160), 31, std=2.0)
+    with torch.no_grad():
+        a = net(D(d["fmap1"]), D(d["fmap2"]), flow_init=D(fi), context_fea=D(d["ctx"]), update_corr_fn=True)
+        b = net(D(d["fmap1"]), D(d["fmap2"]), flow_init=D(fi), context_fea=D(d["ctx"]), update_corr_fn=False)
+    # oracle replay of the same two calls
+    pyr = orc.corr_pyramid(d["fmap1"], d["fmap2"])
+    hid, cinp = orc.context_prep(d["ctx"])
+    c0 = orc.coords_grid_lowres(2, 16, 20)
+    outs = []
+    for _ in range(2):
+        c1 = orc.flow_init_to_coords1(fi)
+        hid, mask, df = orc.update_block(W["upd"], hid, cinp, orc.corr_lookup(pyr, c1), c1 - c0)
+        outs.append(orc.convex_upsample(c1 + df - c0, mask))
+    close(a[0], outs[0], 1e-4, what="first call")
+    close(b[0], outs[1], 1e-4, what="second call (state carried)")
+
+
+def test_s2_shape_short_horizon_vs_oracle(ops):
+    """BASELINE config-2 shape (480x640, 3 images of the batch), 1 outer x 2 inner, against the CPU oracle."""
+    from rnnpose_amd.transformation import SE3Sequence
+    B, H, W = 3, 480, 640
+    d = syn.make_inputs(B, H, W, seed=0)
+    want = orc.refine(d, {"upd": upd_weights()}, outer=1, inner=2, optim_iters=1)
+    ref = _refiner(d, 1, 2, 1, True)
+    out = ref(None, SE3Sequence(matrix=D(d["G0"])), D(d["K"]))
+    close(out["Ti_pred"].G, want["G"], 1e-5, what="pose")
+    close(out["flow_last"], want["flow_up"], 1e-4, what="flow")
+    close(out["weight"][:, 0, 0], want["weight"], 1e-4, what="weight")

@@ -1,0 +1,109 @@
+"""Host-side logic that needs no GPU: module trees / state_dict keys, synthetic generator determinism,
+sharding rule, refusal to run on CPU tensors (there is no CPU product path)."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import rnnpose_oracle as orc
+from rnnpose_amd import synthetic as syn
+
+
+def test_update_block_state_dict_matches_reference_shapes():
+    from rnnpose_amd.cfnet import GRU_CFUpdator
+    net = GRU_CFUpdator(dict(pretrained_model=None, mixed_precision=True, fea_net="default"))
+    sd = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    want = {"update_block." + k: v for k, v in orc.UPDATE_BLOCK_SHAPES.items()}
+    assert sd == want                                             # 30 tensors
+    assert sum(int(np.prod(s)) for s in sd.values()) == 3_120_960
+
+
+def test_encoder_and_refiner_state_dict_keys():
+    from rnnpose_amd.cfnet import ImageFeaEncoder
+    from rnnpose_amd.pose_refiner import PoseRefiner
+    enc = ImageFeaEncoder()
+    sd = {k: tuple(v.shape) for k, v in enc.state_dict().items()}
+    assert sd == {"fnet." + k: v for k, v in orc.encoder_shapes().items()}
+    ref = PoseRefiner()
+    keys = list(ref.state_dict())
+    assert keys[0] == "sigma.0"
+    assert sum(k.startswith("image_fea_enc.fnet.") for k in keys) == len(sd)
+    assert sum(k.startswith("cf_net.update_block.") for k in keys) == 30
+    # reference weights load by name
+    w = syn.make_module_weights(orc.UPDATE_BLOCK_SHAPES, seed=0)
+    ref.cf_net.update_block.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}, strict=True)
+
+
+def test_zr_weight_fusion_cache_tracks_updates():
+    from rnnpose_amd.update import SepConvGRU
+    g = SepConvGRU(hidden_dim=128, input_dim=128 + 128)          # as built by BasicUpdateBlock (update.py:169)
+    w1, b1 = g._zr("1")
+    assert w1.shape == (256, 384, 1, 5) and b1.shape == (256,)
+    assert torch.equal(w1[:128], g.convz1.weight) and torch.equal(w1[128:], g.convr1.weight)
+    assert g._zr("1")[0] is w1                                    # cached
+    with torch.no_grad():
+        g.convr1.weight.add_(1.0)
+    w2, _ = g._zr("1")
+    assert w2 is not w1 and torch.equal(w2[128:], g.convr1.weight)
+
+
+def test_synthetic_inputs_are_bit_reproducible():
+    d = syn.make_inputs(2, 32, 48, seed=5)
+    h = hashlib.sha256()
+    for k in sorted(d):
+        h.update(np.ascontiguousarray(d[k]).tobytes())
+    assert h.hexdigest() == syn_digest()
+    assert d["depth"][:, :, :8].max() == 0 and d["depth"][:, :, 8:].min() >= 0.9
+    n = np.sqrt((d["g1"].astype(np.float64) ** 2).sum(1))
+    assert np.allclose(n, 1.0, atol=1e-6)
+    u = syn.uniform("u", (100000,), 1)
+    assert 0.0 <= u.min() and u.max() < 1.0 and abs(u.mean() - 0.5) < 5e-3
+    g = syn.normal("n", (100000,), 1)
+    assert abs(g.mean()) < 1e-2 and abs(g.std() - 1.0) < 1e-2
+
+
+def syn_digest():
+    # recorded from the build container; any change of the generator invalidates tests/golden/*.npz
+    return "0baa51015be23deba3ab0ca1b76b004dced002a7442ceb5c7affcb82cb54795b"
+
+
+def test_ops_refuse_cpu_tensors():
+    from rnnpose_amd import ops
+    x = torch.zeros(1, 256, 16, 16)
+    with pytest.raises(RuntimeError, match="GPU"):
+        ops.corr_pyramid(x, x)
+    with pytest.raises(RuntimeError, match="GPU"):
+        ops.lm_solve_update(torch.eye(6, dtype=torch.float64)[None], torch.zeros(1, 6, dtype=torch.float64),
+                            torch.eye(4)[None])
+    from rnnpose_amd.update import BasicUpdateBlock
+    from rnnpose_amd.cfnet import AttrDict
+    blk = BasicUpdateBlock(AttrDict(corr_levels=4, corr_radius=4))
+    with pytest.raises(RuntimeError, match="GPU only"):
+        blk(torch.zeros(1, 128, 16, 16), torch.zeros(1, 128, 16, 16), torch.zeros(1, 324, 16, 16),
+            torch.zeros(1, 2, 16, 16))
+
+
+def test_shard_indices_match_reference_rule():
+    from rnnpose_amd.distributed import shard_indices
+    # utils/distributed_utils.py:150-169: rank-strided, wrap-around padded
+    for n, world in ((10, 4), (8, 4), (1, 2), (13, 8)):
+        seen = []
+        for r in range(world):
+            idx, uniq = shard_indices(n, r, world)
+            total = -(-n // world) * world
+            ref = (list(range(n)) + list(range(total - n)))[r:total:world]
+            assert idx == ref
+            seen += [i for i, u in zip(idx, uniq) if u]
+        assert sorted(seen) == list(range(n))                   # duplicates are masked exactly once each
+
+
+def test_metric_accumulator_single_process():
+    from rnnpose_amd.distributed import MetricAccumulator
+    acc = MetricAccumulator(("cat", "ape"))
+    acc.update("cat", dict(add=1.0, proj2d=1.0))
+    acc.update("cat", dict(add=0.0, proj2d=1.0))
+    acc.update("cat", dict(add=1.0), unique=False)              # padded duplicate: ignored
+    out = acc.reduce()
+    assert out["cat"]["n"] == 2 and out["cat"]["add"] == 0.5 and out["cat"]["proj2d"] == 1.0
+    assert out["ape"]["n"] == 0 and np.isnan(out["ape"]["add"])
