@@ -53,6 +53,14 @@ def load() -> C.CDLL:
         raise RuntimeError(
             f"{LIB_PATH} is missing: run `python -m rnnpose_amd.build` (hipcc, gfx950). "
             "rnnpose_amd has no CPU fallback for the refinement hot path.")
+    # PyTorch-ROCm ships its own libamdhip64 (same SONAME as the system one).  Load torch's FIRST so that this
+    # library binds to the runtime that owns torch's device context and streams; loading ours first would pull
+    # in /opt/rocm's copy and leave the process with two HIP runtimes (kernel launches then fail with
+    # hipErrorNoDevice on streams created by the other one).
+    import torch  # noqa: F401
+    tl = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(tl):
+        C.CDLL(tl, mode=C.RTLD_GLOBAL)
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in PROTOTYPES.items():
         try:

@@ -97,7 +97,10 @@ class PoseRefiner(nn.Module):
         views = None
         for ren_iter in range(cfg.RENDER_ITER_COUNT):
             Ti = Tij * Ti                                               # accumulate (PoseRefiner.py:241)
-            Tij.identity_()
+            # the reference calls Tij.identity_() here, which also resets the object it stored in
+            # residual_pose_history one line of bookkeeping earlier (same Python object); a fresh object keeps
+            # the history intact
+            Tij = Tij.identity()
             if self.legacy:
                 Tij = Ti * Ti.inv()                                     # identity up to rounding (:243-244)
             views = self.renderer.render_views(Ti.matrix().squeeze(1), intrinsics, obj_cls=obj_cls, image=image,

@@ -398,17 +398,51 @@ def test_refinement_loop_golden(ops, golden, name, shape, outer, inner, opt, fus
     Gi = torch.stack([t.G for t in ref.residual_pose_history])
     close(Gi, g["G_iters"], 1e-5, what="per-iteration relative poses")
     close(out["Ti_pred"].G, g["G_final"], 1e-5, what="final pose")
+    # FREE-RUNNING flow: the first iteration sees identical inputs -> 1e-4.  Later iterations see the pose fed
+    # back through the projection (d flow / d pose ~ fx/Z ~ 600 px per unit), so a pose that agrees to 3e-7 --
+    # far inside its 1e-5 tolerance, and at the fp32 resolution of G itself -- already moves the flow by 2e-4 px.
+    # The strict 1e-4 check per iteration is test_refinement_teacher_forced; here the drift is bounded by 1e-3.
     fl = out["flow_last"]
     if name == "loop_128":
-        close(fl, g["flow_last"], 1e-4, what="last flow")
-        close(out["flow"][-1], g["flow_first"], 1e-4, what="first flow")
-        close(out["weight"][:, 0, 0], g["w_last"], 1e-4, what="last weight")
+        close(out["flow"][-1], g["flow_first"], 1e-4, what="first flow (identical inputs)")
+        close(fl, g["flow_last"], 1e-3, what="last flow (free-running drift bound)")
+        close(out["weight"][:, 0, 0], g["w_last"], 1e-3, what="last weight (free-running drift bound)")
     elif name == "loop_2x2":
-        close(fl[:, :, ::2, ::2], g["flow_last"], 1e-4, what="last flow")
+        close(fl[:, :, ::2, ::2], g["flow_last"], 1e-3, what="last flow (free-running drift bound)")
     else:
-        close(fl[:, :, ::3, ::3], g["flow_last"], 1e-4, what="last flow")
-        close(out["weight"][:, 0, 0, ::3, ::3], g["w_last"], 1e-4, what="last weight")
+        close(fl[:, :, ::3, ::3], g["flow_last"], 1e-3, what="last flow (free-running drift bound)")
+        close(out["weight"][:, 0, 0, ::3, ::3], g["w_last"], 1e-3, what="last weight (free-running drift bound)")
     assert set(out) >= {"Tij", "Ti_pred", "intrinsics", "flow", "vmask", "weight", "syn_depth", "syn_img", "Tij_gt"}
+
+
+@pytest.mark.parametrize("shape,inner,opt", [((2, 128, 128, 21), 3, 1), ((2, 128, 160, 22), 3, 2), ((1, 240, 240, 23), 4, 1)])
+def test_refinement_teacher_forced(ops, shape, inner, opt):
+    """Per-iteration parity on IDENTICAL inputs (north_star: 1e-4 on the correspondence field, 1e-5 on the pose):
+    every inner iteration starts from the oracle's pose of the previous iteration (the oracle itself is pinned to
+    the reference's poses in tests/test_oracle_golden.py); the GPU hidden state and correlation volume run free."""
+    from rnnpose_amd.corr import coords_grid
+    B, H, W, seed = shape
+    d = syn.make_inputs(B, H, W, seed=seed)
+    Wt = upd_weights()
+    trace = orc.refine(d, {"upd": Wt}, outer=1, inner=inner, optim_iters=opt, capture=True)["trace"]
+    net = _load_update_block()
+    h, w = H // 8, W // 8
+    depth, K, g1, g2, sig = D(d["depth"]), D(d["K"]), D(d["g1"]), D(d["g2"]), D(d["sigma"])
+    c0 = coords_grid(B, h, w, device="cuda")
+    with torch.no_grad():
+        net.prepare(D(d["fmap1"]), D(d["fmap2"]), D(d["ctx"]))
+        G_prev = torch.eye(4).repeat(B, 1, 1, 1)
+        for it, tr in enumerate(trace):
+            c1 = ops.induced_coords_lowres(depth, K, D(G_prev), h, w, 1e-5)
+            _, flow_up = net.step(c0, c1)
+            close(flow_up, tr["flow_up"], 1e-4, what=f"it{it} flow_up")
+            close(net.net, tr["net"], 1e-5, what=f"it{it} hidden state")
+            wmap = ops.corr_weight(g1, g2, flow_up, depth, sig)
+            close(wmap, tr["weight"], 1e-4, what=f"it{it} weight")
+            Gn, Hm, bv, xi, info = ops.lm_step(flow_up, wmap, depth, K, D(G_prev), num_iters=opt)
+            close(Gn[:, None], tr["Tij"], 1e-5, what=f"it{it} pose")
+            close(xi, tr["xi"], 1e-5, what=f"it{it} pose delta xi")
+            G_prev = tr["Tij"]
 
 
 def test_cfupdator_facade_stateful(ops):

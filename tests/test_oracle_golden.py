@@ -165,6 +165,21 @@ def test_solve_and_exp(golden):
     assert np.all(orc.lm_solve(bad, np.ones((1, 6)), 0.0, 0.0) == 0)
 
 
+def test_fast_variants_equal_explicit_restatement():
+    """The library-call variants used ONLY by bench.py's cpu_baseline leg equal the explicit restatements."""
+    B, C, h, w = 2, 64, 16, 24
+    f1, f2 = syn.normal("fmap1", (B, C, h, w), 9), syn.normal("fmap2", (B, C, h, w), 9)
+    pyr = orc.corr_pyramid(f1, f2)
+    c = orc.coords_grid_lowres(B, h, w) + T(syn.uniform("c", (B, 2, h, w), 9, -20.0, 20.0))
+    assert maxdiff(orc.corr_lookup_fast(pyr, c), orc.corr_lookup(pyr, c)) < 1e-5
+    flow, mask = syn.normal("f", (B, 2, h, w), 9, std=3.0), syn.normal("m", (B, 576, h, w), 9, std=2.0)
+    assert maxdiff(orc.convex_upsample_fast(flow, mask), orc.convex_upsample(flow, mask)) < 1e-5
+    d = syn.make_inputs(2, 64, 96, seed=9)
+    tgt = torch.stack(orc._pix_grid(64, 96), -1)[None] + T(syn.normal("t", (2, 64, 96, 2), 9, std=5.0))
+    a = orc.corr_weight_fast(d["g1"], d["g2"], tgt, d["depth"], d["sigma"])
+    assert maxdiff(a, orc.corr_weight(d["g1"], d["g2"], tgt, d["depth"], d["sigma"])) < 1e-5
+
+
 def test_encoder(golden):
     g = golden("encoder")
     W = syn.make_module_weights(orc.encoder_shapes(), seed=2)
