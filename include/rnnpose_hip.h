@@ -134,6 +134,75 @@ int rnnpose_gru_gate_f32(const float* zr, const float* hcat, int B, int C, int C
 int rnnpose_gru_update_f32(const float* z, const float* q_pre, const float* hcat, int B, int C, int Ctot_in,
                            int hw, float* hout, int Ctot_out, rnnpose_stream_t stream);
 
+/* ---- a4: dense convolutions of the update block, NHWC, fp16x3-split MFMA (fp32-class accuracy) ----------
+ *      thirdparty/raft/update.py:6-14 (FlowHead), :33-60 (SepConvGRU), :79-97 (BasicMotionEncoder), :172-187
+ * Stride 1, zero "same" padding, odd kernel sizes up to 7 (1x1, 3x3, 1x5, 5x1 are what the update block uses).
+ * Input = virtual concat of up to 4 NHWC tensors (B,H,W,c_stride), using channels [c_offset, c_offset+c_count).
+ * Weights are packed once by rnnpose_conv_pack_weights_f16x3 from the PyTorch layout (c_out, c_in, kh, kw),
+ * with the SAME segment channel counts; w_scale (a power of two) must be the one given to the packer.
+ * Output y = conv(x) + bias goes through `epilogue`:
+ *   0 linear / 1 ReLU            -> dst[pixel, dst_c_offset + n]
+ *   2 GRU z|r (c_out = 2*gru_c)  -> n <  gru_c: dst  = sigmoid(y)                     (z)
+ *                                   n >= gru_c: dst2 = sigmoid(y) * aux0[pixel, n-gru_c]   (r*h, aux0 = h)
+ *   3 GRU state update           -> dst = (1 - aux1) * aux0 + aux1 * tanh(y)          (aux1 = z, aux0 = h)
+ * All destination / aux tensors are NHWC with their own channel stride and offset (so results land directly
+ * in a slice of a wider tensor).  dst must not alias a source of the same launch.                      */
+typedef struct {
+  const float* ptr;
+  int c_stride, c_offset, c_count;
+} rnnpose_conv_src_t;
+
+typedef struct {
+  rnnpose_conv_src_t src[4];
+  int n_src;
+  int B, H, W;
+  int kh, kw;
+  const void* w_hi;
+  const void* w_lo;
+  const float* bias;
+  int c_out;
+  float a_scale, w_scale;
+  int epilogue;
+  float* dst;
+  int dst_c_stride, dst_c_offset;
+  const float* aux0;
+  int aux0_c_stride, aux0_c_offset;
+  const float* aux1;
+  int aux1_c_stride, aux1_c_offset;
+  float* dst2;
+  int dst2_c_stride, dst2_c_offset;
+  int gru_c;
+} rnnpose_conv_desc_t;
+
+/* number of fp16 elements of EACH of the two packed arrays (hi, lo); -1 on bad arguments */
+long long rnnpose_conv_packed_halfs(int c_out, int kh, int kw, const int* h_seg_counts, int n_seg);
+int rnnpose_conv_pack_weights_f16x3(const float* w_oihw, int c_out, int c_in, int kh, int kw, const int* h_seg_counts,
+                                    int n_seg, float w_scale, void* w_hi, void* w_lo, rnnpose_stream_t stream);
+int rnnpose_conv2d_nhwc_f16x3(const rnnpose_conv_desc_t* h_desc, rnnpose_stream_t stream);
+
+/* ---- NHWC companions of the fused update-block engine ----------------------------------------------------
+ * corr_lookup_nhwc: a3 with the output laid out (B,h,w,levels*81) (thirdparty/raft/corr.py:36-57).
+ * nchw_to_nhwc / nhwc_to_nchw: (B,C,HW) <-> channel window [c_offset, c_offset+C) of a (B,HW,c_stride) tensor.
+ * flow_prep: flow = coords1 - grid (model/CFNet.py:150) written as (B,h,w,4) [fx,fy,0,0] (input of the 7x7 flow
+ *   convolution, update.py:84) and into channels [motion_c_offset, +2) of the motion-feature tensor (update.py:97).
+ * flow_head_out: FlowHead.conv2 (3x3, c_in -> 2, update.py:10,14) on channels [x_c_offset, +c_in) of x, fused with
+ *   coords1 += delta (CFNet.py:157): delta (B,h,w,2), coords1_out (B,2,h,w) (may be NULL), flow_lr (B,h,w,2) =
+ *   coords1_out - grid.  w_oihw is the PyTorch (2,c_in,3,3) weight.
+ * convex_upsample_nhwc: a6 (model/CFNet.py:95-106) with mask (B,h,w,576) and flow_lr (B,h,w,2) -> (B,2,8h,8w). */
+int rnnpose_corr_lookup_nhwc_f32(const float* pyramid, const float* coords, int B, int h, int w, int levels, int radius,
+                                 float* out, rnnpose_stream_t stream);
+int rnnpose_nchw_to_nhwc_f32(const float* src, int B, int C, int HW, float* dst, int dst_c_stride, int dst_c_offset,
+                             rnnpose_stream_t stream);
+int rnnpose_nhwc_to_nchw_f32(const float* src, int B, int C, int HW, int src_c_stride, int src_c_offset, float* dst,
+                             rnnpose_stream_t stream);
+int rnnpose_flow_prep_f32(const float* coords1, int B, int h, int w, float* flow4, float* motion, int motion_c_stride,
+                          int motion_c_offset, rnnpose_stream_t stream);
+int rnnpose_flow_head_out_f32(const float* x, int x_c_stride, int x_c_offset, int c_in, const float* w_oihw,
+                              const float* bias, const float* coords1, int B, int h, int w, float* delta,
+                              float* coords1_out, float* flow_lr, rnnpose_stream_t stream);
+int rnnpose_convex_upsample_nhwc_f32(const float* flow_lr, const float* mask, int B, int h, int w, float* flow_up,
+                                     rnnpose_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

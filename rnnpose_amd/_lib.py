@@ -16,6 +16,20 @@ _f = C.c_float
 _d = C.c_double
 _z = C.c_size_t
 
+class ConvSrc(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("c_stride", C.c_int), ("c_offset", C.c_int), ("c_count", C.c_int)]
+
+
+class ConvDesc(C.Structure):       # rnnpose_conv_desc_t
+    _fields_ = [("src", ConvSrc * 4), ("n_src", C.c_int), ("B", C.c_int), ("H", C.c_int), ("W", C.c_int),
+                ("kh", C.c_int), ("kw", C.c_int), ("w_hi", C.c_void_p), ("w_lo", C.c_void_p), ("bias", C.c_void_p),
+                ("c_out", C.c_int), ("a_scale", C.c_float), ("w_scale", C.c_float), ("epilogue", C.c_int),
+                ("dst", C.c_void_p), ("dst_c_stride", C.c_int), ("dst_c_offset", C.c_int),
+                ("aux0", C.c_void_p), ("aux0_c_stride", C.c_int), ("aux0_c_offset", C.c_int),
+                ("aux1", C.c_void_p), ("aux1_c_stride", C.c_int), ("aux1_c_offset", C.c_int),
+                ("dst2", C.c_void_p), ("dst2_c_stride", C.c_int), ("dst2_c_offset", C.c_int), ("gru_c", C.c_int)]
+
+
 # name -> (restype, argtypes); mirrors include/rnnpose_hip.h one to one
 PROTOTYPES = {
     "rnnpose_abi_version": (_i, []),
@@ -39,6 +53,15 @@ PROTOTYPES = {
     "rnnpose_se3_inverse_f32": (_i, [_p, _i, _p, _p]),
     "rnnpose_gru_gate_f32": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p]),
     "rnnpose_gru_update_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _i, _p]),
+    "rnnpose_conv_packed_halfs": (C.c_longlong, [_i, _i, _i, C.POINTER(_i), _i]),
+    "rnnpose_conv_pack_weights_f16x3": (_i, [_p, _i, _i, _i, _i, C.POINTER(_i), _i, _f, _p, _p, _p]),
+    "rnnpose_conv2d_nhwc_f16x3": (_i, [C.POINTER(ConvDesc), _p]),
+    "rnnpose_corr_lookup_nhwc_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p]),
+    "rnnpose_nchw_to_nhwc_f32": (_i, [_p, _i, _i, _i, _p, _i, _i, _p]),
+    "rnnpose_nhwc_to_nchw_f32": (_i, [_p, _i, _i, _i, _i, _i, _p, _p]),
+    "rnnpose_flow_prep_f32": (_i, [_p, _i, _i, _i, _p, _p, _i, _i, _p]),
+    "rnnpose_flow_head_out_f32": (_i, [_p, _i, _i, _i, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p]),
+    "rnnpose_convex_upsample_nhwc_f32": (_i, [_p, _p, _i, _i, _i, _p, _p]),
 }
 
 _lib = None

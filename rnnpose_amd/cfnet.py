@@ -74,9 +74,32 @@ class GRU_CFUpdator(nn.Module):
                 raise FileNotFoundError(f"pretrained_model={pre!r} not found (expected gru_update.pth)")
             self.load_state_dict(torch.load(path, map_location="cpu"), strict=True)
         self.corr_fn = None
-        self.net = None
+        self._net = None
         self.inp = None
         self.fmap1 = self.fmap2 = None
+        # "hip": every convolution in the hand-written NHWC implicit-GEMM kernel (rnnpose_amd/engine.py);
+        # "miopen": the literal reference call sequence, convolutions through torch/MIOpen (update.py facade)
+        self.conv_backend = args.get("conv_backend", "hip")
+        self._engine = None
+        self._net_in_engine = False
+
+    @property
+    def net(self):
+        """Hidden state (B,128,h,w); converted from the engine's NHWC buffer on demand."""
+        if self._net_in_engine:
+            return self._engine.hidden_nchw()
+        return self._net
+
+    @net.setter
+    def net(self, v):
+        self._net = v
+        self._net_in_engine = False
+
+    def engine(self):
+        if self._engine is None:
+            from .engine import UpdateEngine
+            self._engine = UpdateEngine(self.update_block)
+        return self._engine
 
     def initialize_flow(self, img, downsample_rate=8):
         N, _, H, W = img.shape
@@ -94,9 +117,18 @@ class GRU_CFUpdator(nn.Module):
         assert context_fea is not None
         h, w = self.fmap1.shape[-2:]
         self.net, self.inp = ops.context_prep(context_fea, h, w, self.hidden_dim)
+        if self.conv_backend == "hip":
+            self.engine().load_state(self._net, self.inp)
+            self._net_in_engine = True
 
     def step(self, coords0, coords1):
         """One GRU iteration given low-res coords (CFNet.py:147-168) -> (coords1_new, flow_up)."""
+        if self.conv_backend == "hip":
+            if not self._net_in_engine:                  # hidden state was assigned from outside
+                self.engine().load_state(self._net, self.inp)
+                self._net_in_engine = True
+            coords1_new, flow_up = self.engine().step(self.corr_fn, coords1)
+            return coords1_new.clone(), flow_up
         corr = self.corr_fn(coords1)
         flow = coords1 - coords0
         self.net, up_mask, delta_flow = self.update_block(self.net, self.inp, corr, flow)

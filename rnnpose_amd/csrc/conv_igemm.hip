@@ -1,0 +1,451 @@
+// a4: the update block's dense convolutions as ONE hand-written implicit-GEMM kernel family for CDNA4
+// (thirdparty/raft/update.py:6-14,33-60,79-97,164-188).
+//
+// Numerics -- "fp16x3 split" fp32 emulation on the fp16 matrix cores.  gfx950 has no TF32/xf32, and its exact
+// fp32 MFMA runs at 1/16 of the fp16 rate.  Every fp32 operand x is split as x*S = hi + lo with
+// hi = fp16(x*S), lo = fp16(x*S - hi) (S a power of two keeping lo out of the subnormal range), and
+//     a*b  ~=  a_hi*b_hi + a_hi*b_lo + a_lo*b_hi          (3 MFMAs, fp32 accumulation)
+// The neglected terms are O(2^-22) relative per product -- fp32 round-off class (measured against an fp64
+// reference in tests/test_gpu_conv.py), at 16/3 = 5.3x the fp32-MFMA rate.  Weights are split once on the
+// host side (rnnpose_conv_pack_weights_f16x3); activations are split on the fly while staging to LDS.
+//
+// Structure (per 128x128 output tile, 4 waves as 2x2, each 64x64 = 2x2 MFMA tiles of 32x32x16):
+//   * activations are NHWC, so the GEMM K axis (channels) is contiguous: one 128-byte row per pixel per 32-ch
+//     block.  Up to 4 source tensors are read as a VIRTUAL CONCAT (hidden state | context | motion features
+//     never get copied into one buffer).
+//   * taps that differ along the tile's fast axis share ONE staged activation tile: the tile is loaded with a
+//     halo (BM + 8 rows) and tap dv just reads LDS rows shifted by dv; rows whose neighbour falls outside the
+//     image line are masked to zero in registers.  A 1x5 conv therefore reads its input once, not 5 times.
+//     (5x1 convs tile the image column-major so the same trick applies; 3x3 = 3 groups of 3 taps.)
+//   * weights: pre-packed [group][tap][32-ch block][n][32] fp16 hi/lo -> each (tap, block) tile is one contiguous
+//     8-KB burst per half; double-buffered in LDS, prefetched into registers one tap ahead.
+//   * LDS rows are padded to 80 bytes: ds_read_b128 of 32 consecutive rows is bank-conflict free.
+//   * fused epilogues: bias + {linear, ReLU, GRU z|r gate (sigmoid, r*h), GRU state update (tanh, (1-z)h+zq)},
+//     writing straight into a channel slice of the destination NHWC tensor (no cat / clone / relu kernels).
+#include "common.hpp"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 32, NT = 256;
+constexpr int HALO = 4;                 // rows of halo on each side (taps up to +-3 along the fast axis)
+constexpr int AROWS = BM + 2 * HALO;    // 136
+constexpr int RS = 40;                  // LDS row stride in halfs: 32 + 8 pad = 80 bytes
+constexpr int MAX_CB = 24;
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct Seg {
+  const float* ptr;
+  int cstride, coff, ccount;
+};
+
+struct KParams {
+  Seg seg0, seg1, seg2, seg3;       // separate members: a dynamically indexed by-value array would be copied to LDS
+  int cb1, cb2, cb3;                // first channel block of segments 1..3 (ncb if absent)
+  int ncb;
+  int B, U, V, su, sv;              // slow / fast axis extents and pixel strides
+  int G, T, du0, dv0;               // groups (slow-axis taps) x taps per group (fast axis)
+  const _Float16* whi;
+  const _Float16* wlo;
+  int Npad;
+  const float* bias;
+  int Cout;
+  float a_scale, out_scale;
+  int epi;
+  float* dst;
+  int dst_cs, dst_co;
+  const float* aux0;
+  int aux0_cs, aux0_co;
+  const float* aux1;
+  int aux1_cs, aux1_co;
+  float* dst2;
+  int dst2_cs, dst2_co;
+  int gru_c;
+  int n_mt, n_nt;
+};
+
+struct ARegs {
+  float4 v[5];
+};
+
+__device__ __forceinline__ void split4(const float4 v, float s, h4& hi, h4& lo) {
+  const float x[4] = {v.x * s, v.y * s, v.z * s, v.w * s};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float c = fminf(fmaxf(x[i], -65504.f), 65504.f);   // saturate instead of producing inf
+    const _Float16 h = static_cast<_Float16>(c);
+    hi[i] = h;
+    lo[i] = static_cast<_Float16>(c - static_cast<float>(h));
+  }
+}
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
+
+__global__ __launch_bounds__(NT, 2) void conv_igemm_f16x3_kernel(const KParams p) {
+  __shared__ __attribute__((aligned(16))) _Float16 sA[2][AROWS * RS];      // hi, lo            21.8 KB
+  __shared__ __attribute__((aligned(16))) _Float16 sB[2][2][BN * RS];      // [buf][hi,lo]      40.0 KB
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  // ---- tile id: XCD-contiguous chunks, n fastest (the n tiles of one m tile share the activation tile) ----
+  const int ntiles = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int per = ntiles >> 3, rem = ntiles & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    bid = xcd * per + (xcd < rem ? xcd : rem) + idx;
+  }
+  const int nt_i = bid % p.n_nt, mt_i = bid / p.n_nt;
+  const long long Mtot = static_cast<long long>(p.B) * p.U * p.V;
+  const long long m0 = static_cast<long long>(mt_i) * BM;
+  const int n0 = nt_i * BN;
+  const int UV = p.U * p.V;
+
+  // ---- per-thread activation rows (global -> LDS staging): rows j = (tid>>3) + 32 r, 16-byte column c4 ----
+  const int c4 = tid & 7;
+  int a_pix[5], a_u[5];
+  bool a_ok[5];
+#pragma unroll
+  for (int r = 0; r < 5; ++r) {
+    const int j = (tid >> 3) + 32 * r;
+    const long long m = m0 - HALO + j;
+    a_ok[r] = (j < AROWS) && m >= 0 && m < Mtot;
+    const long long mm = a_ok[r] ? m : 0;
+    const int q = static_cast<int>(mm / p.V), v = static_cast<int>(mm - static_cast<long long>(q) * p.V);
+    const int b = q / p.U, u = q - b * p.U;
+    a_u[r] = u;
+    a_pix[r] = b * UV + u * p.su + v * p.sv;
+  }
+  // ---- per-lane fragment rows: fast-axis coordinate for the tap masks ----
+  int fv[2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const long long m = m0 + wm * 64 + mi * 32 + l31;
+    fv[mi] = (m < Mtot) ? static_cast<int>(m % p.V) : -1000;
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  auto load_A = [&](ARegs& a, int g, int cb) {
+    Seg s = p.seg0;
+    int cb0 = 0;
+    if (cb >= p.cb1) { s = p.seg1; cb0 = p.cb1; }
+    if (cb >= p.cb2) { s = p.seg2; cb0 = p.cb2; }
+    if (cb >= p.cb3) { s = p.seg3; cb0 = p.cb3; }
+    const int c = (cb - cb0) * BK + c4 * 4;
+    const int du = p.du0 + g;
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int uu = a_u[r] + du;
+      if (a_ok[r] && uu >= 0 && uu < p.U && c < s.ccount) {
+        const float* q = s.ptr + static_cast<long long>(a_pix[r] + du * p.su) * s.cstride + s.coff + c;
+        if (c + 3 < s.ccount) {
+          v = *reinterpret_cast<const float4*>(q);
+        } else {
+          v.x = q[0];
+          if (c + 1 < s.ccount) v.y = q[1];
+          if (c + 2 < s.ccount) v.z = q[2];
+        }
+      }
+      a.v[r] = v;
+    }
+  };
+  auto store_A = [&](const ARegs& a) {
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+      const int j = (tid >> 3) + 32 * r;
+      if (j < AROWS) {
+        h4 hi, lo;
+        split4(a.v[r], p.a_scale, hi, lo);
+        *reinterpret_cast<h4*>(&sA[0][j * RS + c4 * 4]) = hi;
+        *reinterpret_cast<h4*>(&sA[1][j * RS + c4 * 4]) = lo;
+      }
+    }
+  };
+  // weight tile registers: plain named locals + macros (a struct handed to a lambda by reference ends up as a
+  // per-thread LDS slot: +16 KB/block and an LDS round trip per tap)
+  uint4 bh0, bh1, bl0, bl1;
+#define RP_LOAD_B(G_, T_, CB_)                                                                              \
+  do {                                                                                                      \
+    const long long tile_ = ((static_cast<long long>(G_) * p.T + (T_)) * p.ncb + (CB_)) * p.Npad + n0;     \
+    const uint4* hs_ = reinterpret_cast<const uint4*>(p.whi + tile_ * BK);                                  \
+    const uint4* ls_ = reinterpret_cast<const uint4*>(p.wlo + tile_ * BK);                                  \
+    bh0 = hs_[tid];                                                                                         \
+    bh1 = hs_[tid + NT];                                                                                    \
+    bl0 = ls_[tid];                                                                                         \
+    bl1 = ls_[tid + NT];                                                                                    \
+  } while (0)
+#define RP_STORE_B(BUF_)                                                                                    \
+  do {                                                                                                      \
+    const int row0_ = tid >> 2, qd_ = tid & 3; /* second chunk: index tid + 256 -> row0 + 64 */            \
+    *reinterpret_cast<uint4*>(&sB[BUF_][0][row0_ * RS + qd_ * 8]) = bh0;                                    \
+    *reinterpret_cast<uint4*>(&sB[BUF_][1][row0_ * RS + qd_ * 8]) = bl0;                                    \
+    *reinterpret_cast<uint4*>(&sB[BUF_][0][(row0_ + 64) * RS + qd_ * 8]) = bh1;                             \
+    *reinterpret_cast<uint4*>(&sB[BUF_][1][(row0_ + 64) * RS + qd_ * 8]) = bl1;                             \
+  } while (0)
+
+  ARegs areg;
+  load_A(areg, 0, 0);
+  RP_LOAD_B(0, 0, 0);
+  int buf = 0;
+  const int nsteps_cb = p.G * p.ncb;
+  for (int s = 0; s < nsteps_cb; ++s) {
+    const int g = s / p.ncb, cb = s - g * p.ncb;
+    store_A(areg);
+    if (s + 1 < nsteps_cb) {
+      const int g2 = (s + 1) / p.ncb;
+      load_A(areg, g2, (s + 1) - g2 * p.ncb);
+    }
+    for (int t = 0; t < p.T; ++t) {
+      RP_STORE_B(buf);
+      {  // prefetch the next weight tile (next tap, or first tap of the next (g, cb))
+        int t2 = t + 1, s2 = s;
+        if (t2 == p.T) {
+          t2 = 0;
+          s2 = s + 1;
+        }
+        if (s2 < nsteps_cb) {
+          const int g2 = s2 / p.ncb;
+          RP_LOAD_B(g2, t2, s2 - g2 * p.ncb);
+        }
+      }
+      __syncthreads();
+      const int dv = p.dv0 + t;
+      const bool ok0 = static_cast<unsigned>(fv[0] + dv) < static_cast<unsigned>(p.V);
+      const bool ok1 = static_cast<unsigned>(fv[1] + dv) < static_cast<unsigned>(p.V);
+      const h8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int ko = kk * 16 + lh * 8;
+        h8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          const int row = wm * 64 + mi * 32 + l31 + HALO + dv;
+          ah[mi] = *reinterpret_cast<const h8*>(&sA[0][row * RS + ko]);
+          al[mi] = *reinterpret_cast<const h8*>(&sA[1][row * RS + ko]);
+        }
+        if (!ok0) { ah[0] = zero; al[0] = zero; }
+        if (!ok1) { ah[1] = zero; al[1] = zero; }
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const int row = wn * 64 + ni * 32 + l31;
+          bh[ni] = *reinterpret_cast<const h8*>(&sB[buf][0][row * RS + ko]);
+          bl[ni] = *reinterpret_cast<const h8*>(&sB[buf][1][row * RS + ko]);
+        }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) {
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+          }
+      }
+      buf ^= 1;
+    }
+    __syncthreads();   // every wave is done with this activation tile before it is overwritten
+  }
+
+  // ------------------------------------------- epilogue -------------------------------------------
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const long long m = m0 + row;
+      if (m >= Mtot) continue;
+      long long pix = m;
+      if (p.sv != 1) {
+        const int q = static_cast<int>(m / p.V), v = static_cast<int>(m - static_cast<long long>(q) * p.V);
+        const int b = q / p.U, u = q - b * p.U;
+        pix = static_cast<long long>(b) * UV + u * p.su + v * p.sv;
+      }
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int col = n0 + wn * 64 + ni * 32 + l31;
+        if (col >= p.Cout) continue;
+        const float y = acc[mi][ni][r] * p.out_scale + p.bias[col];
+        if (p.epi == 0) {
+          p.dst[pix * p.dst_cs + p.dst_co + col] = y;
+        } else if (p.epi == 1) {
+          p.dst[pix * p.dst_cs + p.dst_co + col] = fmaxf(y, 0.f);
+        } else if (p.epi == 2) {
+          if (col < p.gru_c) {
+            p.dst[pix * p.dst_cs + p.dst_co + col] = sigmoidf_(y);                       // z
+          } else {
+            const int c2 = col - p.gru_c;
+            const float hv = p.aux0[pix * p.aux0_cs + p.aux0_co + c2];
+            p.dst2[pix * p.dst2_cs + p.dst2_co + c2] = sigmoidf_(y) * hv;                // r * h
+          }
+        } else {
+          const float z = p.aux1[pix * p.aux1_cs + p.aux1_co + col];
+          const float hv = p.aux0[pix * p.aux0_cs + p.aux0_co + col];
+          p.dst[pix * p.dst_cs + p.dst_co + col] = (1.f - z) * hv + z * tanhf(y);        // h' = (1-z)h + z q
+        }
+      }
+    }
+  }
+}
+
+// ---- weight packing: (Cout, Cin, kh, kw) fp32 -> [g][t][cb][Npad][32] fp16 hi / lo -------------------------
+struct PackParams {
+  int Cout, Cin, kh, kw, G, T, ncb, Npad, vertical;
+  unsigned char cb_seg[MAX_CB];
+  short cb_c0[MAX_CB];
+  short seg_start[4];     // first input channel (in the concatenated Cin order) of each segment
+  short seg_count[4];
+  float w_scale;
+};
+
+__global__ void pack_weights_kernel(const float* __restrict__ w, _Float16* __restrict__ hi, _Float16* __restrict__ lo,
+                                    const PackParams q) {
+  const long long total = static_cast<long long>(q.G) * q.T * q.ncb * q.Npad * BK;
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int k = static_cast<int>(i % BK);
+  const int n = static_cast<int>((i / BK) % q.Npad);
+  const int cb = static_cast<int>((i / (static_cast<long long>(BK) * q.Npad)) % q.ncb);
+  const int t = static_cast<int>((i / (static_cast<long long>(BK) * q.Npad * q.ncb)) % q.T);
+  const int g = static_cast<int>(i / (static_cast<long long>(BK) * q.Npad * q.ncb * q.T));
+  const int s = q.cb_seg[cb];
+  const int cl = q.cb_c0[cb] + k;
+  float v = 0.f;
+  if (n < q.Cout && cl < q.seg_count[s]) {
+    const int ci = q.seg_start[s] + cl;
+    // vertical (kw == 1, kh > 1): one group, taps along y.  otherwise groups = ky, taps = kx.
+    const int ky = q.vertical ? t : g, kx = q.vertical ? 0 : t;
+    v = w[((static_cast<long long>(n) * q.Cin + ci) * q.kh + ky) * q.kw + kx] * q.w_scale;
+  }
+  const _Float16 h = static_cast<_Float16>(v);
+  hi[i] = h;
+  lo[i] = static_cast<_Float16>(v - static_cast<float>(h));
+}
+
+int fill_cb_tables(const int* counts, int n, unsigned char* cb_seg, short* cb_c0) {
+  int ncb = 0;
+  for (int s = 0; s < n; ++s)
+    for (int c = 0; c < counts[s]; c += BK) {
+      if (ncb >= MAX_CB) return -1;
+      cb_seg[ncb] = static_cast<unsigned char>(s);
+      cb_c0[ncb] = static_cast<short>(c);
+      ++ncb;
+    }
+  return ncb;
+}
+
+}  // namespace
+
+extern "C" {
+
+long long rnnpose_conv_packed_halfs(int c_out, int kh, int kw, const int* h_seg_counts, int n_seg) {
+  if (c_out <= 0 || kh <= 0 || kw <= 0 || !h_seg_counts || n_seg < 1 || n_seg > 4) return -1;
+  unsigned char cs[MAX_CB];
+  short c0[MAX_CB];
+  const int ncb = fill_cb_tables(h_seg_counts, n_seg, cs, c0);
+  if (ncb < 0) return -1;
+  const long long Npad = static_cast<long long>(rp::cdiv(c_out, BN)) * BN;
+  return static_cast<long long>(kh) * kw * ncb * Npad * BK;
+}
+
+int rnnpose_conv_pack_weights_f16x3(const float* w_oihw, int c_out, int c_in, int kh, int kw, const int* h_seg_counts,
+                                    int n_seg, float w_scale, void* w_hi, void* w_lo, rnnpose_stream_t stream) {
+  const char* fn = "rnnpose_conv_pack_weights_f16x3";
+  RP_REQUIRE(w_oihw && w_hi && w_lo && h_seg_counts, fn, "null pointer");
+  RP_REQUIRE(n_seg >= 1 && n_seg <= 4, fn, "1..4 source segments");
+  RP_REQUIRE((kh & 1) && (kw & 1) && kh <= 7 && kw <= 7, fn, "odd kernel sizes up to 7");
+  PackParams q{};
+  int tot = 0;
+  for (int s = 0; s < n_seg; ++s) {
+    RP_REQUIRE(h_seg_counts[s] > 0 && h_seg_counts[s] % 4 == 0, fn, "segment channel counts must be positive multiples of 4");
+    q.seg_start[s] = static_cast<short>(tot);
+    q.seg_count[s] = static_cast<short>(h_seg_counts[s]);
+    tot += h_seg_counts[s];
+  }
+  RP_REQUIRE(tot == c_in, fn, "segment channel counts must sum to c_in");
+  q.ncb = fill_cb_tables(h_seg_counts, n_seg, q.cb_seg, q.cb_c0);
+  RP_REQUIRE(q.ncb > 0, fn, "too many channel blocks");
+  q.Cout = c_out; q.Cin = c_in; q.kh = kh; q.kw = kw;
+  q.vertical = (kw == 1 && kh > 1) ? 1 : 0;
+  q.G = q.vertical ? 1 : kh;
+  q.T = q.vertical ? kh : kw;
+  q.Npad = rp::cdiv(c_out, BN) * BN;
+  q.w_scale = w_scale;
+  const long long total = static_cast<long long>(q.G) * q.T * q.ncb * q.Npad * BK;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(rp::cdiv(total, 256)), dim3(256), 0, rp::as_stream(stream), w_oihw,
+                     static_cast<_Float16*>(w_hi), static_cast<_Float16*>(w_lo), q);
+  return rp::check_launch(fn);
+}
+
+int rnnpose_conv2d_nhwc_f16x3(const rnnpose_conv_desc_t* d, rnnpose_stream_t stream) {
+  const char* fn = "rnnpose_conv2d_nhwc_f16x3";
+  RP_REQUIRE(d, fn, "null descriptor");
+  RP_REQUIRE(d->n_src >= 1 && d->n_src <= 4, fn, "1..4 sources");
+  RP_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->c_out > 0, fn, "bad size");
+  RP_REQUIRE((d->kh & 1) && (d->kw & 1) && d->kh <= 7 && d->kw <= 7, fn, "odd kernel sizes up to 7");
+  RP_REQUIRE(d->w_hi && d->w_lo && d->bias && d->dst, fn, "null pointer");
+  RP_REQUIRE(d->epilogue >= 0 && d->epilogue <= 3, fn, "epilogue must be 0..3");
+  RP_REQUIRE(d->a_scale > 0.f && d->w_scale > 0.f, fn, "scales must be positive");
+  if (d->epilogue == 2) RP_REQUIRE(d->aux0 && d->dst2 && d->gru_c > 0 && d->c_out == 2 * d->gru_c, fn, "gru_zr needs aux0 (h), dst2 (r*h), c_out == 2*gru_c");
+  if (d->epilogue == 3) RP_REQUIRE(d->aux0 && d->aux1, fn, "gru_q needs aux0 (h) and aux1 (z)");
+  KParams p{};
+  int counts[4];
+  for (int s = 0; s < d->n_src; ++s) {
+    const rnnpose_conv_src_t& sr = d->src[s];
+    RP_REQUIRE(sr.ptr && sr.c_count > 0 && sr.c_count % 4 == 0 && sr.c_stride % 4 == 0 && sr.c_offset % 4 == 0 &&
+                   sr.c_offset + sr.c_count <= sr.c_stride && reinterpret_cast<uintptr_t>(sr.ptr) % 16 == 0,
+               fn, "source: 16-byte aligned pointer, channel stride/offset/count multiples of 4");
+    const Seg sg{sr.ptr, sr.c_stride, sr.c_offset, sr.c_count};
+    (s == 0 ? p.seg0 : s == 1 ? p.seg1 : s == 2 ? p.seg2 : p.seg3) = sg;
+    counts[s] = sr.c_count;
+  }
+  {
+    unsigned char cs[MAX_CB];
+    short c0[MAX_CB];
+    p.ncb = fill_cb_tables(counts, d->n_src, cs, c0);
+    RP_REQUIRE(p.ncb > 0, fn, "too many channel blocks");
+    int st[5] = {0, p.ncb, p.ncb, p.ncb, p.ncb};
+    for (int s = 1; s < d->n_src; ++s) st[s] = st[s - 1] + rp::cdiv(counts[s - 1], BK);
+    p.cb1 = st[1]; p.cb2 = st[2]; p.cb3 = st[3];
+  }
+  const bool vertical = (d->kw == 1 && d->kh > 1);
+  p.B = d->B;
+  if (vertical) {           // column-major tiling: fast axis = y
+    p.U = d->W; p.V = d->H; p.su = 1; p.sv = d->W;
+    p.G = 1; p.T = d->kh; p.du0 = 0; p.dv0 = -(d->kh / 2);
+  } else {
+    p.U = d->H; p.V = d->W; p.su = d->W; p.sv = 1;
+    p.G = d->kh; p.T = d->kw; p.du0 = -(d->kh / 2); p.dv0 = -(d->kw / 2);
+  }
+  RP_REQUIRE(p.T / 2 <= HALO, fn, "kernel too wide for the staged halo");
+  p.whi = static_cast<const _Float16*>(d->w_hi);
+  p.wlo = static_cast<const _Float16*>(d->w_lo);
+  p.Npad = rp::cdiv(d->c_out, BN) * BN;
+  p.bias = d->bias; p.Cout = d->c_out;
+  p.a_scale = d->a_scale;
+  p.out_scale = 1.0f / (d->a_scale * d->w_scale);
+  p.epi = d->epilogue;
+  p.dst = d->dst; p.dst_cs = d->dst_c_stride; p.dst_co = d->dst_c_offset;
+  p.aux0 = d->aux0; p.aux0_cs = d->aux0_c_stride; p.aux0_co = d->aux0_c_offset;
+  p.aux1 = d->aux1; p.aux1_cs = d->aux1_c_stride; p.aux1_co = d->aux1_c_offset;
+  p.dst2 = d->dst2; p.dst2_cs = d->dst2_c_stride; p.dst2_co = d->dst2_c_offset;
+  p.gru_c = d->gru_c;
+  const long long Mtot = static_cast<long long>(d->B) * d->H * d->W;
+  RP_REQUIRE(Mtot < (1LL << 31) - 256, fn, "too many pixels");
+  p.n_mt = rp::cdiv(Mtot, BM);
+  p.n_nt = p.Npad / BN;
+  hipLaunchKernelGGL(conv_igemm_f16x3_kernel, dim3(static_cast<unsigned>(p.n_mt) * p.n_nt), dim3(NT), 0,
+                     rp::as_stream(stream), p);
+  return rp::check_launch(fn);
+}
+
+}  // extern "C"

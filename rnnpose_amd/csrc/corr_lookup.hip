@@ -30,7 +30,7 @@ struct LookupInfo {
 
 __global__ __launch_bounds__(64) void corr_lookup_kernel(const float* __restrict__ pyr, const float* __restrict__ coords,
                                                          float* __restrict__ out, int B, int h, int w, int levels,
-                                                         LookupInfo info) {
+                                                         LookupInfo info, int nhwc) {
   __shared__ float foot[PIX * FS];
   const int N = h * w;
   const long long total = static_cast<long long>(B) * N;
@@ -83,12 +83,10 @@ __global__ __launch_bounds__(64) void corr_lookup_kernel(const float* __restrict
     }
   }
   __syncthreads();
-  if (!live) return;
-
   // ---- phase 2: lane = pixel ----
   const float w00 = (1.f - ax) * (1.f - ay), w10 = ax * (1.f - ay), w01 = (1.f - ax) * ay, w11 = ax * ay;
   const float* f = foot + lane * FS;
-  float* o = out + (static_cast<long long>(b) * levels * (WIN * WIN) + static_cast<long long>(lvl) * (WIN * WIN)) * N + pix;
+  float res[WIN * WIN];
   float prev[FP], cur[FP];
 #pragma unroll
   for (int x = 0; x < FP; ++x) prev[x] = f[x];
@@ -97,20 +95,38 @@ __global__ __launch_bounds__(64) void corr_lookup_kernel(const float* __restrict
 #pragma unroll
     for (int x = 0; x < FP; ++x) cur[x] = f[(j + 1) * FP + x];
 #pragma unroll
-    for (int i = 0; i < WIN; ++i) {        // x offset i-4  -> footprint cols i, i+1 ; channel i*9 + j
-      const float v = w00 * prev[i] + w10 * prev[i + 1] + w01 * cur[i] + w11 * cur[i + 1];
-      o[static_cast<long long>(i * WIN + j) * N] = v;
-    }
+    for (int i = 0; i < WIN; ++i)          // x offset i-4  -> footprint cols i, i+1 ; channel i*9 + j
+      res[i * WIN + j] = w00 * prev[i] + w10 * prev[i + 1] + w01 * cur[i] + w11 * cur[i + 1];
 #pragma unroll
     for (int x = 0; x < FP; ++x) prev[x] = cur[x];
+  }
+  if (!nhwc) {
+    // (B, L*81, h, w): consecutive lanes are consecutive pixels -> one coalesced 256-byte row per channel
+    if (live) {
+      float* o = out + (static_cast<long long>(b) * levels * (WIN * WIN) + static_cast<long long>(lvl) * (WIN * WIN)) * N + pix;
+#pragma unroll
+      for (int c = 0; c < WIN * WIN; ++c) o[static_cast<long long>(c) * N] = res[c];
+    }
+  } else {
+    // (B, h, w, L*81): transpose through LDS (aliasing the footprints) so that every pixel's 81 values of this
+    // level leave as one contiguous 324-byte run
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < WIN * WIN; ++c) foot[lane * (WIN * WIN) + c] = res[c];
+    __syncthreads();
+    const int ctot = levels * WIN * WIN;
+    float* o = out + first * ctot + lvl * (WIN * WIN);
+    for (int q = 0; q < npix; ++q) {
+      o[static_cast<long long>(q) * ctot + lane] = foot[q * (WIN * WIN) + lane];
+      if (lane < WIN * WIN - 64) o[static_cast<long long>(q) * ctot + 64 + lane] = foot[q * (WIN * WIN) + 64 + lane];
+    }
   }
 }
 
 }  // namespace
 
-extern "C" int rnnpose_corr_lookup_f32(const float* pyramid, const float* coords, int B, int h, int w, int levels,
-                                       int radius, float* out, rnnpose_stream_t stream) {
-  const char* fn = "rnnpose_corr_lookup_f32";
+static int launch_lookup(const char* fn, const float* pyramid, const float* coords, int B, int h, int w, int levels,
+                         int radius, float* out, int nhwc, rnnpose_stream_t stream) {
   RP_REQUIRE(pyramid && coords && out, fn, "null pointer");
   RP_REQUIRE(radius == R, fn, "radius must be 4");
   int64_t offs[RNNPOSE_MAX_LEVELS + 1];
@@ -124,6 +140,17 @@ extern "C" int rnnpose_corr_lookup_f32(const float* pyramid, const float* coords
   const long long total = static_cast<long long>(B) * h * w;
   dim3 grid(static_cast<unsigned>(rp::cdiv(total, PIX)), static_cast<unsigned>(levels)), block(64);
   hipLaunchKernelGGL(corr_lookup_kernel, grid, block, 0, rp::as_stream(stream), pyramid, coords, out, B, h, w, levels,
-                     info);
+                     info, nhwc);
   return rp::check_launch(fn);
+}
+
+extern "C" int rnnpose_corr_lookup_f32(const float* pyramid, const float* coords, int B, int h, int w, int levels,
+                                       int radius, float* out, rnnpose_stream_t stream) {
+  return launch_lookup("rnnpose_corr_lookup_f32", pyramid, coords, B, h, w, levels, radius, out, 0, stream);
+}
+
+// same lookup, output laid out (B, h, w, levels*81) for the NHWC update-block engine
+extern "C" int rnnpose_corr_lookup_nhwc_f32(const float* pyramid, const float* coords, int B, int h, int w, int levels,
+                                            int radius, float* out, rnnpose_stream_t stream) {
+  return launch_lookup("rnnpose_corr_lookup_nhwc_f32", pyramid, coords, B, h, w, levels, radius, out, 1, stream);
 }

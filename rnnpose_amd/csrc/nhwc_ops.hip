@@ -1,0 +1,221 @@
+// NHWC companions of the fused update-block engine (a4/a5/a6): layout conversion, flow bookkeeping, the two
+// degenerate convolutions of the update block (Cin = 2 is handled by padding in the igemm; Cout = 2 is this
+// file's bandwidth kernel) and the convex upsampling that reads the mask in NHWC.
+#include "common.hpp"
+
+namespace {
+
+// ---- (B,C,HW) <-> (B,HW,Cs) tiled transposes through LDS ------------------------------------------------
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int C,
+                                                           int HW, int dst_cs, int dst_co) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z;
+  const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int c = c0 + ty + 8 * r, pp = p0 + tx;
+    tile[ty + 8 * r][tx] = (c < C && pp < HW) ? src[(static_cast<long long>(b) * C + c) * HW + pp] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int pp = p0 + ty + 8 * r, c = c0 + tx;
+    if (c < C && pp < HW) dst[(static_cast<long long>(b) * HW + pp) * dst_cs + dst_co + c] = tile[tx][ty + 8 * r];
+  }
+}
+
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst, int C,
+                                                           int HW, int src_cs, int src_co) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z;
+  const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int pp = p0 + ty + 8 * r, c = c0 + tx;
+    tile[ty + 8 * r][tx] = (c < C && pp < HW) ? src[(static_cast<long long>(b) * HW + pp) * src_cs + src_co + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int c = c0 + ty + 8 * r, pp = p0 + tx;
+    if (c < C && pp < HW) dst[(static_cast<long long>(b) * C + c) * HW + pp] = tile[tx][ty + 8 * r];
+  }
+}
+
+// ---- flow bookkeeping of one GRU step (model/CFNet.py:147-157, update.py:97) -----------------------------
+// coords1 (B,2,h,w) planar -> flow = coords1 - grid written (a) as a 4-channel zero-padded NHWC tensor (input of the
+// 7x7 flow convolution) and (b) into channels [co, co+2) of the NHWC motion-feature tensor.
+__global__ __launch_bounds__(256) void flow_prep_kernel(const float* __restrict__ coords1, float* __restrict__ flow4,
+                                                        float* __restrict__ motion, int motion_cs, int motion_co, int h,
+                                                        int w, long long total) {
+  const long long t = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int n = h * w;
+  const int b = static_cast<int>(t / n), pix = static_cast<int>(t - static_cast<long long>(b) * n);
+  const int X = pix % w, Y = pix / w;
+  const float fx = coords1[(static_cast<long long>(b) * 2 + 0) * n + pix] - static_cast<float>(X);
+  const float fy = coords1[(static_cast<long long>(b) * 2 + 1) * n + pix] - static_cast<float>(Y);
+  *reinterpret_cast<float4*>(flow4 + t * 4) = make_float4(fx, fy, 0.f, 0.f);
+  *reinterpret_cast<float2*>(motion + t * motion_cs + motion_co) = make_float2(fx, fy);
+}
+
+// ---- FlowHead.conv2: 3x3, Cin -> 2 (update.py:10,14) fused with coords1 += delta (CFNet.py:157) -------------
+// Bandwidth kernel: one wave per output pixel, lanes split the Cin channels (float4 each), 9 taps x 2 outputs
+// accumulated per lane, wave64 shuffle reduction.  x: NHWC (B,h,w,cs) using channels [co, co+Cin), Cin = 256.
+// w: (2, Cin, 3, 3) PyTorch layout.  Outputs: delta (B,h,w,2) NHWC, coords1_out (B,2,h,w) planar = coords1 + delta,
+// flow_lr (B,h,w,2) NHWC = coords1_out - grid.
+__global__ __launch_bounds__(256) void conv3x3_cout2_kernel(const float* __restrict__ x, int cs, int co, int Cin,
+                                                            const float* __restrict__ wgt, const float* __restrict__ bias,
+                                                            const float* __restrict__ coords1, float* __restrict__ delta,
+                                                            float* __restrict__ coords1_out, float* __restrict__ flow_lr,
+                                                            int B, int h, int w) {
+  extern __shared__ float wl[];                 // [o][tap][Cin]
+  const int tid = threadIdx.x;
+  for (int e = tid; e < 2 * 9 * Cin; e += 256) {
+    const int c = e % Cin, tap = (e / Cin) % 9, o = e / (9 * Cin);
+    wl[e] = wgt[(static_cast<long long>(o) * Cin + c) * 9 + tap];
+  }
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6;
+  const int n = h * w;
+  const long long total = static_cast<long long>(B) * n;
+  for (long long p = static_cast<long long>(blockIdx.x) * 4 + wave; p < total; p += static_cast<long long>(gridDim.x) * 4) {
+    const int b = static_cast<int>(p / n), pix = static_cast<int>(p - static_cast<long long>(b) * n);
+    const int X = pix % w, Y = pix / w;
+    float a0 = 0.f, a1 = 0.f;
+    for (int c = lane * 4; c < Cin; c += 256) {
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int yy = Y + tap / 3 - 1, xx = X + tap % 3 - 1;
+        if (yy < 0 || yy >= h || xx < 0 || xx >= w) continue;
+        const float4 v = *reinterpret_cast<const float4*>(x + (static_cast<long long>(b) * n + yy * w + xx) * cs + co + c);
+        const float4 w0 = *reinterpret_cast<const float4*>(wl + (0 * 9 + tap) * Cin + c);
+        const float4 w1 = *reinterpret_cast<const float4*>(wl + (1 * 9 + tap) * Cin + c);
+        a0 += v.x * w0.x + v.y * w0.y + v.z * w0.z + v.w * w0.w;
+        a1 += v.x * w1.x + v.y * w1.y + v.z * w1.z + v.w * w1.w;
+      }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      a0 += __shfl_down(a0, d);
+      a1 += __shfl_down(a1, d);
+    }
+    if (lane == 0) {
+      const float dx = a0 + bias[0], dy = a1 + bias[1];
+      *reinterpret_cast<float2*>(delta + p * 2) = make_float2(dx, dy);
+      const float cx = coords1[(static_cast<long long>(b) * 2 + 0) * n + pix] + dx;
+      const float cy = coords1[(static_cast<long long>(b) * 2 + 1) * n + pix] + dy;
+      if (coords1_out) {
+        coords1_out[(static_cast<long long>(b) * 2 + 0) * n + pix] = cx;
+        coords1_out[(static_cast<long long>(b) * 2 + 1) * n + pix] = cy;
+      }
+      *reinterpret_cast<float2*>(flow_lr + p * 2) = make_float2(cx - static_cast<float>(X), cy - static_cast<float>(Y));
+    }
+  }
+}
+
+// ---- a6 with NHWC inputs: mask (B,h,w,576) [channel k*64 + i*8 + j], flow (B,h,w,2) -> flow_up (B,2,8h,8w) planar
+// Workgroup = 4 consecutive low-res pixels x 64 sub-pixels: every mask read is a coalesced 256-byte run, every
+// output row segment is 4 x 8 contiguous floats.
+__global__ __launch_bounds__(256) void convex_upsample_nhwc_kernel(const float* __restrict__ flow,
+                                                                   const float* __restrict__ mask,
+                                                                   float* __restrict__ up, int h, int w) {
+  const int b = blockIdx.z, Y = blockIdx.y;
+  const int X = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int t = threadIdx.x & 63;     // sub-pixel i*8 + j
+  if (X >= w) return;
+  const int n = h * w;
+  const float* m = mask + (static_cast<long long>(b) * n + Y * w + X) * 576 + t;
+  float mv[9], mx = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    mv[k] = m[k * 64];
+    mx = fmaxf(mx, mv[k]);
+  }
+  float den = 0.f;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    mv[k] = expf(mv[k] - mx);
+    den += mv[k];
+  }
+  float ax = 0.f, ay = 0.f;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const int yy = Y + k / 3 - 1, xx = X + k % 3 - 1;
+    float2 f = make_float2(0.f, 0.f);
+    if (yy >= 0 && yy < h && xx >= 0 && xx < w) f = *reinterpret_cast<const float2*>(flow + (static_cast<long long>(b) * n + yy * w + xx) * 2);
+    const float wk = mv[k] / den;
+    ax += wk * (8.f * f.x);
+    ay += wk * (8.f * f.y);
+  }
+  const int i = t >> 3, j = t & 7;
+  const long long Wf = 8LL * w, Pf = 64LL * n;
+  const long long o = (8LL * Y + i) * Wf + 8 * X + j;
+  up[(static_cast<long long>(b) * 2 + 0) * Pf + o] = ax;
+  up[(static_cast<long long>(b) * 2 + 1) * Pf + o] = ay;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rnnpose_nchw_to_nhwc_f32(const float* src, int B, int C, int HW, float* dst, int dst_c_stride, int dst_c_offset,
+                             rnnpose_stream_t stream) {
+  const char* fn = "rnnpose_nchw_to_nhwc_f32";
+  RP_REQUIRE(src && dst, fn, "null pointer");
+  RP_REQUIRE(B > 0 && B < 65536 && C > 0 && HW > 0 && dst_c_offset >= 0 && dst_c_offset + C <= dst_c_stride, fn, "bad size");
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(rp::cdiv(HW, 32), rp::cdiv(C, 32), B), dim3(256), 0, rp::as_stream(stream),
+                     src, dst, C, HW, dst_c_stride, dst_c_offset);
+  return rp::check_launch(fn);
+}
+
+int rnnpose_nhwc_to_nchw_f32(const float* src, int B, int C, int HW, int src_c_stride, int src_c_offset, float* dst,
+                             rnnpose_stream_t stream) {
+  const char* fn = "rnnpose_nhwc_to_nchw_f32";
+  RP_REQUIRE(src && dst, fn, "null pointer");
+  RP_REQUIRE(B > 0 && B < 65536 && C > 0 && HW > 0 && src_c_offset >= 0 && src_c_offset + C <= src_c_stride, fn, "bad size");
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(rp::cdiv(HW, 32), rp::cdiv(C, 32), B), dim3(256), 0, rp::as_stream(stream),
+                     src, dst, C, HW, src_c_stride, src_c_offset);
+  return rp::check_launch(fn);
+}
+
+int rnnpose_flow_prep_f32(const float* coords1, int B, int h, int w, float* flow4, float* motion, int motion_c_stride,
+                          int motion_c_offset, rnnpose_stream_t stream) {
+  const char* fn = "rnnpose_flow_prep_f32";
+  RP_REQUIRE(coords1 && flow4 && motion, fn, "null pointer");
+  RP_REQUIRE(B > 0 && h > 0 && w > 0 && motion_c_offset % 2 == 0 && motion_c_stride % 2 == 0 &&
+                 motion_c_offset + 2 <= motion_c_stride, fn, "bad size");
+  const long long total = static_cast<long long>(B) * h * w;
+  hipLaunchKernelGGL(flow_prep_kernel, dim3(rp::cdiv(total, 256)), dim3(256), 0, rp::as_stream(stream), coords1, flow4,
+                     motion, motion_c_stride, motion_c_offset, h, w, total);
+  return rp::check_launch(fn);
+}
+
+int rnnpose_flow_head_out_f32(const float* x, int x_c_stride, int x_c_offset, int c_in, const float* w_oihw,
+                              const float* bias, const float* coords1, int B, int h, int w, float* delta,
+                              float* coords1_out, float* flow_lr, rnnpose_stream_t stream) {
+  const char* fn = "rnnpose_flow_head_out_f32";
+  RP_REQUIRE(x && w_oihw && bias && coords1 && delta && flow_lr, fn, "null pointer");
+  RP_REQUIRE(B > 0 && h > 0 && w > 0 && c_in > 0 && c_in % 4 == 0 && c_in <= 1024, fn, "bad size");
+  RP_REQUIRE(x_c_stride % 4 == 0 && x_c_offset % 4 == 0 && x_c_offset + c_in <= x_c_stride, fn, "bad channel window");
+  const long long total = static_cast<long long>(B) * h * w;
+  const int blocks = static_cast<int>(total / 4 + 1 < 4096 ? total / 4 + 1 : 4096);
+  const size_t lds = static_cast<size_t>(2) * 9 * c_in * sizeof(float);
+  hipLaunchKernelGGL(conv3x3_cout2_kernel, dim3(blocks), dim3(256), lds, rp::as_stream(stream), x, x_c_stride, x_c_offset,
+                     c_in, w_oihw, bias, coords1, delta, coords1_out, flow_lr, B, h, w);
+  return rp::check_launch(fn);
+}
+
+int rnnpose_convex_upsample_nhwc_f32(const float* flow_lr, const float* mask, int B, int h, int w, float* flow_up,
+                                     rnnpose_stream_t stream) {
+  const char* fn = "rnnpose_convex_upsample_nhwc_f32";
+  RP_REQUIRE(flow_lr && mask && flow_up, fn, "null pointer");
+  RP_REQUIRE(B > 0 && B < 65536 && h > 0 && h < 65536 && w > 0, fn, "bad size");
+  hipLaunchKernelGGL(convex_upsample_nhwc_kernel, dim3(rp::cdiv(w, 4), h, B), dim3(256), 0, rp::as_stream(stream), flow_lr,
+                     mask, flow_up, h, w);
+  return rp::check_launch(fn);
+}
+
+}  // extern "C"

@@ -1,0 +1,104 @@
+"""Fused NHWC execution of one GRU correspondence update (model/CFNet.py:147-168 around
+thirdparty/raft/update.py:178-188): every convolution of BasicUpdateBlock runs in the hand-written implicit-GEMM
+kernel (csrc/conv_igemm.hip) with bias / ReLU / GRU gates fused into its epilogue, reading the concatenations
+[h | inp | motion] and [cor | flo] as virtual concats and writing straight into channel slices.
+
+Per step: lookup (NHWC) -> convc1 -> convc2 | convf1 -> convf2 -> conv -> z|r (1x5) -> q (1x5) -> z|r (5x1) -> q (5x1)
+-> flow/mask heads (one 128->512 conv) -> flow_head.conv2 + coords update -> mask.2 (x0.25 folded) -> convex upsample:
+16 launches, no ATen elementwise / cat / clone kernels.  The module's parameters stay the single source of truth:
+packed fp16 hi/lo copies are rebuilt whenever a parameter's version or storage changes.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+
+class UpdateEngine:
+    def __init__(self, update_block):
+        self.blk = update_block
+        self._key = None
+        self._w = None
+        self._buf_key = None
+        self._b = None
+
+    # ---- weights ---------------------------------------------------------------------------------------------
+    def _params(self):
+        b = self.blk
+        e, g = b.encoder, b.gru
+        return [e.convc1, e.convc2, e.convf1, e.convf2, e.conv, g.convz1, g.convr1, g.convq1, g.convz2, g.convr2,
+                g.convq2, b.flow_head.conv1, b.flow_head.conv2, b.mask[0], b.mask[2]]
+
+    def _weights(self):
+        key = tuple((m.weight._version, m.weight.data_ptr(), m.bias._version, m.bias.data_ptr()) for m in self._params())
+        if key == self._key:
+            return self._w
+        b = self.blk
+        e, g = b.encoder, b.gru
+        cat = lambda *t: torch.cat([x.detach() for x in t], 0)
+        P = ops.PackedConv
+        wf1 = torch.cat([e.convf1.weight.detach(), torch.zeros_like(e.convf1.weight.detach())], 1)   # Cin 2 -> 4 (zeros)
+        w = dict(
+            convc1=P(e.convc1.weight, e.convc1.bias, [e.convc1.weight.shape[1]]),
+            convc2=P(e.convc2.weight, e.convc2.bias, [256]),
+            convf1=P(wf1, e.convf1.bias, [4]),
+            convf2=P(e.convf2.weight, e.convf2.bias, [128]),
+            conv=P(e.conv.weight, e.conv.bias, [256]),
+            zr1=P(cat(g.convz1.weight, g.convr1.weight), cat(g.convz1.bias, g.convr1.bias), [128, 128, 128]),
+            q1=P(g.convq1.weight, g.convq1.bias, [128, 128, 128]),
+            zr2=P(cat(g.convz2.weight, g.convr2.weight), cat(g.convz2.bias, g.convr2.bias), [128, 128, 128]),
+            q2=P(g.convq2.weight, g.convq2.bias, [128, 128, 128]),
+            heads=P(cat(b.flow_head.conv1.weight, b.mask[0].weight), cat(b.flow_head.conv1.bias, b.mask[0].bias), [128]),
+            mask2=P(b.mask[2].weight, b.mask[2].bias, [256], post_scale=0.25),            # update.py:187
+            flow2_w=b.flow_head.conv2.weight.detach().float().contiguous(),
+            flow2_b=b.flow_head.conv2.bias.detach().float().contiguous(),
+        )
+        self._key, self._w = key, w
+        return w
+
+    # ---- activations -----------------------------------------------------------------------------------------
+    def _buffers(self, B, h, w, device):
+        key = (B, h, w, str(device))
+        if key != self._buf_key:
+            z = lambda c: torch.zeros(B, h, w, c, device=device, dtype=torch.float32)
+            self._b = dict(corr=z(324), cor1=z(256), corflo=z(256), flow4=z(4), flo1=z(128), motion=z(128), hA=z(128),
+                           hB=z(128), inp=z(128), z=z(128), rh=z(128), heads=z(512), delta=z(2), flow_lr=z(2),
+                           mask=z(576), coords1=torch.zeros(B, 2, h, w, device=device))
+            self._buf_key = key
+        return self._b
+
+    def load_state(self, net, inp):
+        """net, inp: (B,128,h,w) NCHW (tanh / relu of the context features, model/CFNet.py:131-133)."""
+        B, _, h, w = net.shape
+        b = self._buffers(B, h, w, net.device)
+        ops.nchw_to_nhwc(net, b["hA"])
+        ops.nchw_to_nhwc(inp, b["inp"])
+
+    def hidden_nchw(self):
+        return ops.nhwc_to_nchw(self._b["hA"])
+
+    def step(self, corr_fn, coords1):
+        """coords1 (B,2,h,w) -> (coords1 + delta_flow (B,2,h,w), flow_up (B,2,8h,8w))."""
+        W = self._weights()
+        B, _, h, w = coords1.shape
+        b = self._b
+        c = ops.conv2d_nhwc
+        R = ops.EPI_RELU
+        ops.flow_prep(coords1, b["flow4"], b["motion"], 126)                       # flow -> convf1 input, motion[126:128]
+        ops.corr_lookup_nhwc(corr_fn._buf, coords1, b["corr"], corr_fn.num_levels, corr_fn.radius)
+        c(W["convc1"], [(b["corr"], 0)], (b["cor1"], 0), R)                         # update.py:89
+        c(W["convc2"], [(b["cor1"], 0)], (b["corflo"], 0), R)                       # :90
+        c(W["convf1"], [(b["flow4"], 0)], (b["flo1"], 0), R)                        # :91
+        c(W["convf2"], [(b["flo1"], 0)], (b["corflo"], 192), R)                     # :92
+        c(W["conv"], [(b["corflo"], 0)], (b["motion"], 0), R)                       # :95-96 (126 ch; flow already at 126)
+        hx = lambda hbuf: [(hbuf, 0), (b["inp"], 0), (b["motion"], 0)]              # [h | inp | motion]  (:181, :47)
+        c(W["zr1"], hx(b["hA"]), (b["z"], 0), ops.EPI_GRU_ZR, aux0=(b["hA"], 0), dst2=(b["rh"], 0), gru_c=128)
+        c(W["q1"], hx(b["rh"]), (b["hB"], 0), ops.EPI_GRU_Q, aux0=(b["hA"], 0), aux1=(b["z"], 0))
+        c(W["zr2"], hx(b["hB"]), (b["z"], 0), ops.EPI_GRU_ZR, aux0=(b["hB"], 0), dst2=(b["rh"], 0), gru_c=128)
+        c(W["q2"], hx(b["rh"]), (b["hA"], 0), ops.EPI_GRU_Q, aux0=(b["hB"], 0), aux1=(b["z"], 0))
+        c(W["heads"], [(b["hA"], 0)], (b["heads"], 0), R)                           # flow_head.conv1 | mask.0
+        ops.flow_head_out(b["heads"], 0, 256, W["flow2_w"], W["flow2_b"], coords1, b["delta"], b["coords1"], b["flow_lr"])
+        c(W["mask2"], [(b["heads"], 256)], (b["mask"], 0), ops.EPI_LINEAR)          # 0.25 * mask.2(relu(mask.0(h)))
+        flow_up = ops.convex_upsample_nhwc(b["flow_lr"], b["mask"])
+        return b["coords1"], flow_up

@@ -281,3 +281,124 @@ def gru_update(z, q_pre, hcat, hout, C: int = 128):
     hw = hcat.shape[2] * hcat.shape[3]
     _launch("rnnpose_gru_update_f32", _ptr(z), _ptr(q_pre), _ptr(hcat), B, C, hcat.shape[1], hw, _ptr(hout), hout.shape[1],
             _stream())
+
+
+# ---- a4 dense convolutions: NHWC implicit GEMM on the fp16 matrix cores with fp16x3 split (fp32-class accuracy) ----
+EPI_LINEAR, EPI_RELU, EPI_GRU_ZR, EPI_GRU_Q = 0, 1, 2, 3
+
+
+class PackedConv:
+    """Weights of one convolution, split into fp16 hi/lo and laid out for csrc/conv_igemm.hip.
+    weight (Cout,Cin,kh,kw), bias (Cout,), seg_counts = channel counts of the virtual-concat sources (sum = Cin).
+    post_scale is folded into weight and bias (the 0.25 of the mask head, update.py:187)."""
+
+    def __init__(self, weight, bias, seg_counts=None, post_scale: float = 1.0, a_scale: float = 64.0):
+        import math
+        w = _chk(weight.detach(), "weight") * post_scale
+        b = _chk(bias.detach(), "bias") * post_scale
+        self.c_out, self.c_in, self.kh, self.kw = w.shape
+        self.seg_counts = [int(c) for c in (seg_counts or [self.c_in])]
+        if sum(self.seg_counts) != self.c_in:
+            raise ValueError("seg_counts must sum to the input channels")
+        wmax = float(w.abs().max())
+        self.w_scale = float(2.0 ** math.floor(math.log2(1024.0 / wmax))) if wmax > 0 else 1.0
+        self.a_scale = float(a_scale)
+        segs = (C.c_int * len(self.seg_counts))(*self.seg_counts)
+        n = int(_lib.load().rnnpose_conv_packed_halfs(self.c_out, self.kh, self.kw, segs, len(self.seg_counts)))
+        if n <= 0:
+            raise ValueError("unsupported convolution shape")
+        self.w_hi = torch.empty(n, device=w.device, dtype=torch.float16)
+        self.w_lo = torch.empty(n, device=w.device, dtype=torch.float16)
+        self.bias = b.contiguous()
+        _lib.call("rnnpose_conv_pack_weights_f16x3", _ptr(w), self.c_out, self.c_in, self.kh, self.kw, segs,
+                  len(self.seg_counts), self.w_scale, _ptr(self.w_hi), _ptr(self.w_lo), _stream())
+
+
+def _nhwc(t, name):
+    if not (t.is_cuda and t.dtype == F32 and t.is_contiguous() and t.dim() == 4):
+        raise ValueError(f"{name} must be a contiguous fp32 CUDA tensor shaped (B,H,W,C)")
+    return t
+
+
+def conv2d_nhwc(pc: PackedConv, srcs, dst, epilogue: int = EPI_LINEAR, aux0=None, aux1=None, dst2=None, gru_c: int = 0):
+    """srcs: list of (tensor (B,H,W,C), c_offset) matched with pc.seg_counts; dst/aux0/aux1/dst2: (tensor, c_offset).
+    Writes in place into dst (and dst2); returns nothing."""
+    d = _lib.ConvDesc()
+    if len(srcs) != len(pc.seg_counts):
+        raise ValueError("number of sources differs from the packed segment list")
+    B, H, W, _ = srcs[0][0].shape
+    for i, ((t, off), cnt) in enumerate(zip(srcs, pc.seg_counts)):
+        _nhwc(t, f"src{i}")
+        if t.shape[:3] != (B, H, W):
+            raise ValueError("sources must share (B,H,W)")
+        d.src[i] = _lib.ConvSrc(t.data_ptr(), t.shape[3], off, cnt)
+    d.n_src = len(srcs)
+    d.B, d.H, d.W, d.kh, d.kw = B, H, W, pc.kh, pc.kw
+    d.w_hi, d.w_lo, d.bias = pc.w_hi.data_ptr(), pc.w_lo.data_ptr(), pc.bias.data_ptr()
+    d.c_out, d.a_scale, d.w_scale, d.epilogue = pc.c_out, pc.a_scale, pc.w_scale, epilogue
+
+    def put(prefix, spec):
+        if spec is None:
+            return
+        t, off = spec
+        _nhwc(t, prefix)
+        setattr(d, prefix, t.data_ptr())
+        setattr(d, prefix + "_c_stride", t.shape[3])
+        setattr(d, prefix + "_c_offset", off)
+
+    put("dst", dst)
+    put("aux0", aux0)
+    put("aux1", aux1)
+    put("dst2", dst2)
+    d.gru_c = gru_c
+    _launch("rnnpose_conv2d_nhwc_f16x3", C.byref(d), _stream())
+
+
+# ---- NHWC companions ------------------------------------------------------------------------------------------
+def corr_lookup_nhwc(pyramid_buf, coords, out=None, levels: int = 4, radius: int = 4):
+    """coords (B,2,h,w) -> (B,h,w,levels*81)"""
+    coords = _chk(coords, "coords")
+    B, _, h, w = coords.shape
+    if out is None:
+        out = torch.empty(B, h, w, levels * (2 * radius + 1) ** 2, device=coords.device, dtype=F32)
+    _launch("rnnpose_corr_lookup_nhwc_f32", _ptr(pyramid_buf), _ptr(coords), B, h, w, levels, radius, _ptr(out), _stream())
+    return out
+
+
+def nchw_to_nhwc(src, dst=None, c_offset: int = 0):
+    """src (B,C,H,W) -> channels [c_offset, c_offset+C) of dst (B,H,W,Cs) (allocated (B,H,W,C) if None)."""
+    src = _chk(src, "src")
+    B, Cc, H, W = src.shape
+    if dst is None:
+        dst = torch.empty(B, H, W, Cc, device=src.device, dtype=F32)
+    _launch("rnnpose_nchw_to_nhwc_f32", _ptr(src), B, Cc, H * W, _ptr(dst), dst.shape[3], c_offset, _stream())
+    return dst
+
+
+def nhwc_to_nchw(src, c_offset: int = 0, c_count: int | None = None):
+    """channels [c_offset, c_offset+c_count) of src (B,H,W,Cs) -> (B,c_count,H,W)"""
+    B, H, W, Cs = src.shape
+    c_count = Cs - c_offset if c_count is None else c_count
+    dst = torch.empty(B, c_count, H, W, device=src.device, dtype=F32)
+    _launch("rnnpose_nhwc_to_nchw_f32", _ptr(src), B, c_count, H * W, Cs, c_offset, _ptr(dst), _stream())
+    return dst
+
+
+def flow_prep(coords1, flow4, motion, motion_c_offset):
+    B, _, h, w = coords1.shape
+    _launch("rnnpose_flow_prep_f32", _ptr(coords1), B, h, w, _ptr(flow4), _ptr(motion), motion.shape[3], motion_c_offset,
+            _stream())
+
+
+def flow_head_out(x, x_c_offset, c_in, weight, bias, coords1, delta, coords1_out, flow_lr):
+    B, h, w, cs = x.shape
+    _launch("rnnpose_flow_head_out_f32", _ptr(x), cs, x_c_offset, c_in, _ptr(weight), _ptr(bias), _ptr(coords1), B, h, w,
+            _ptr(delta), _ptr(coords1_out), _ptr(flow_lr), _stream())
+
+
+def convex_upsample_nhwc(flow_lr, mask, out=None):
+    B, h, w, _ = mask.shape
+    if out is None:
+        out = torch.empty(B, 2, 8 * h, 8 * w, device=mask.device, dtype=F32)
+    _launch("rnnpose_convex_upsample_nhwc_f32", _ptr(flow_lr), _ptr(mask), B, h, w, _ptr(out), _stream())
+    return out

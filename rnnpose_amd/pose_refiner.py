@@ -34,7 +34,7 @@ def default_config(**over):
     """Iteration counts of config/linemod/template_fw0.5.yml:76-81,92 unless overridden."""
     cfg = AttrDict(RENDER_ITER_COUNT=3, ITER_COUNT=4, OPTIM_ITER_COUNT=1, FLOW_NET="raft", ONLINE_CROP=True,
                    IS_CALIBRATED=True, RESCALE_IMAGES=False, with_corr_weight=True,
-                   raft=AttrDict(pretrained_model=None, mixed_precision=False, fea_net="default"),
+                   raft=AttrDict(pretrained_model=None, mixed_precision=False, fea_net="default", conv_backend="hip"),
                    LM_LMBDA=LM_LMBDA, EP_LMBDA=EP_LMBDA)
     cfg.update(over)
     return cfg

@@ -1,0 +1,107 @@
+"""GPU tests of the hand-written NHWC implicit-GEMM convolution (csrc/conv_igemm.hip): fp16x3-split MFMA must be
+fp32-class accurate.  Reference = torch conv2d in fp64; the fp32 MIOpen result gives the error scale to beat."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from rnnpose_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available()
+    from rnnpose_amd import build, ops as _ops
+    build.build()
+    return _ops
+
+
+def D(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+def check(y, y64, y32, what):
+    err = float((y.double() - y64).abs().max())
+    e32 = float((y32.double() - y64).abs().max())
+    scale = float(y64.abs().max())
+    print(f"{what}: split err {err:.3e}, fp32(MIOpen) err {e32:.3e}, max|y| {scale:.2f}")
+    assert err <= max(10 * e32, 3e-6 * scale), f"{what}: fp16x3 error {err:.3e} vs fp32 error {e32:.3e} (max|y|={scale:.2f})"
+
+
+@pytest.mark.parametrize("B,H,W,segs,cout,kh,kw", [
+    (2, 9, 13, [324], 256, 1, 1),          # 1x1, K tail (324 = 10*32 + 4), M tail (234 rows)
+    (2, 12, 20, [192, 64], 126, 3, 3),     # 3x3, two sources, Cout not a multiple of 128
+    (1, 16, 16, [128, 128, 128], 256, 1, 5),
+    (3, 7, 11, [128, 128, 128], 128, 5, 1),
+    (1, 20, 24, [128], 512, 3, 3),
+    (1, 8, 8, [256], 576, 1, 1),
+])
+def test_conv_linear_relu(ops, B, H, W, segs, cout, kh, kw):
+    cin = sum(segs)
+    x = syn.normal("x", (B, cin, H, W), 1, std=1.5)
+    w = syn.normal("w", (cout, cin, kh, kw), 1, std=float(np.sqrt(2.0 / (cin * kh * kw))))
+    b = syn.uniform("b", (cout,), 1, -0.5, 0.5)
+    xd, wd, bd = D(x), D(w), D(b)
+    y64 = F.conv2d(xd.double(), wd.double(), bd.double(), padding=(kh // 2, kw // 2))
+    y32 = F.conv2d(xd, wd, bd, padding=(kh // 2, kw // 2))
+    pc = ops.PackedConv(wd, bd, segs)
+    xs, off = [], 0
+    for c in segs:                       # sources live inside wider tensors at a channel offset
+        t = torch.zeros(B, H, W, c + 8, device="cuda")
+        t[..., 4:4 + c] = nhwc(xd[:, off:off + c])
+        xs.append((t, 4))
+        off += c
+    out = torch.full((B, H, W, cout + 12), 7.0, device="cuda")
+    ops.conv2d_nhwc(pc, xs, (out, 8), ops.EPI_LINEAR)
+    check(nchw(out[..., 8:8 + cout]), y64, y32, f"{kh}x{kw} linear")
+    assert float((out[..., :8] - 7).abs().max()) == 0 and float((out[..., 8 + cout:] - 7).abs().max()) == 0
+    ops.conv2d_nhwc(pc, xs, (out, 8), ops.EPI_RELU)
+    check(nchw(out[..., 8:8 + cout]), y64.clamp(min=0), y32.clamp(min=0), f"{kh}x{kw} relu")
+
+
+@pytest.mark.parametrize("kh,kw", [(1, 5), (5, 1)])
+def test_conv_gru_epilogues(ops, kh, kw):
+    B, H, W, C = 2, 10, 14, 128
+    h = np.tanh(syn.normal("h", (B, C, H, W), 2))
+    x = syn.normal("x", (B, 2 * C, H, W), 2)
+    wz, wr, wq = (syn.normal(n, (C, 3 * C, kh, kw), 2, std=0.03) for n in ("wz", "wr", "wq"))
+    bz, br, bq = (syn.uniform(n, (C,), 2, -0.2, 0.2) for n in ("bz", "br", "bq"))
+    hd, xd = D(h), D(x)
+    pad = (kh // 2, kw // 2)
+    hx = torch.cat([hd, xd], 1).double()
+    z64 = torch.sigmoid(F.conv2d(hx, D(wz).double(), D(bz).double(), padding=pad))
+    r64 = torch.sigmoid(F.conv2d(hx, D(wr).double(), D(br).double(), padding=pad))
+    q64 = torch.tanh(F.conv2d(torch.cat([r64 * hd.double(), xd.double()], 1), D(wq).double(), D(bq).double(), padding=pad))
+    h64 = (1 - z64) * hd.double() + z64 * q64
+    pzr = ops.PackedConv(torch.cat([D(wz), D(wr)], 0), torch.cat([D(bz), D(br)], 0), [C, C, C])
+    pq = ops.PackedConv(D(wq), D(bq), [C, C, C])
+    hN, xN = nhwc(hd), nhwc(xd)
+    z = torch.empty(B, H, W, C, device="cuda")
+    rh = torch.empty(B, H, W, C, device="cuda")
+    hnew = torch.empty(B, H, W, C, device="cuda")
+    ops.conv2d_nhwc(pzr, [(hN, 0), (xN, 0), (xN, C)], (z, 0), ops.EPI_GRU_ZR, aux0=(hN, 0), dst2=(rh, 0), gru_c=C)
+    assert float((nchw(z).double() - z64).abs().max()) < 2e-6
+    assert float((nchw(rh).double() - r64 * hd.double()).abs().max()) < 2e-6
+    ops.conv2d_nhwc(pq, [(rh, 0), (xN, 0), (xN, C)], (hnew, 0), ops.EPI_GRU_Q, aux0=(hN, 0), aux1=(z, 0))
+    assert float((nchw(hnew).double() - h64).abs().max()) < 3e-6
+
+
+def test_conv_large_activations_saturate_not_nan(ops):
+    """|x|*a_scale beyond the fp16 range saturates (finite output), it does not poison the tile with inf/NaN."""
+    B, H, W = 1, 8, 8
+    x = torch.full((B, H, W, 32), 2000.0, device="cuda")
+    w = torch.full((128, 32, 1, 1), 0.01, device="cuda")
+    pc = ops.PackedConv(w, torch.zeros(128, device="cuda"), [32])
+    out = torch.empty(B, H, W, 128, device="cuda")
+    ops.conv2d_nhwc(pc, [(x, 0)], (out, 0))
+    assert torch.isfinite(out).all()

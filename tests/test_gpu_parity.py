@@ -316,9 +316,10 @@ def test_solve_exp_compose_inverse(ops, golden):
 
 
 # ------------------------------------------------------------------------------------------------ a4
-def _load_update_block(seed=0):
+def _load_update_block(seed=0, backend="hip"):
     from rnnpose_amd.cfnet import GRU_CFUpdator
-    net = GRU_CFUpdator(dict(pretrained_model=None, mixed_precision=False, fea_net="default")).cuda().eval()
+    net = GRU_CFUpdator(dict(pretrained_model=None, mixed_precision=False, fea_net="default",
+                             conv_backend=backend)).cuda().eval()
     net.update_block.load_state_dict({k: T(v) for k, v in upd_weights(seed).items()}, strict=True)
     return net
 
@@ -356,6 +357,54 @@ def test_update_block(ops, golden):
     close(df, g["dflow"], 1e-4, what="dflow golden")
 
 
+def test_update_engine_one_step(ops, golden):
+    """The fused NHWC engine (hand-written fp16x3 implicit-GEMM convs + fused epilogues) against the golden
+    BasicUpdateBlock outputs and the oracle, teacher forced: hidden state, mask, delta flow, upsampled flow."""
+    from rnnpose_amd.corr import coords_grid
+    from rnnpose_amd.engine import UpdateEngine
+    g = golden("update_block")
+    B, h, w = 1, 16, 20
+    hid = np.tanh(syn.normal("u_net", (B, 128, h, w), 3))
+    inp = np.maximum(syn.normal("u_inp", (B, 128, h, w), 3), 0)
+    flow = syn.normal("u_flow", (B, 2, h, w), 3, std=2.0)
+    f1, f2 = syn.normal("e_f1", (B, 256, h, w), 3), syn.normal("e_f2", (B, 256, h, w), 3)
+    net = _load_update_block()
+    eng = UpdateEngine(net.update_block)
+    from rnnpose_amd.corr import CorrBlock
+    cb = CorrBlock(D(f1), D(f2))
+    c0 = coords_grid(B, h, w, device="cuda")
+    c1 = c0 + D(flow)
+    eng.load_state(D(hid), D(inp))
+    c1n, flow_up = eng.step(cb, c1)
+    corr = orc.corr_lookup(orc.corr_pyramid(f1, f2), c1.cpu())
+    wn, wm, wd = orc.update_block(upd_weights(), hid, inp, corr, flow)
+    close(eng.hidden_nchw(), wn, 1e-5, what="engine hidden state")
+    close(ops.nhwc_to_nchw(eng._b["mask"]), wm, 2e-5, what="engine mask")
+    close(ops.nhwc_to_nchw(eng._b["delta"]), wd, 1e-5, what="engine delta flow")
+    close(c1n, c1.cpu() + wd, 2e-5, what="engine coords1")
+    close(flow_up, orc.convex_upsample(T(flow) + wd, wm), 1e-4, what="engine flow_up")
+
+
+def test_nhwc_helpers(ops):
+    x = D(syn.normal("x", (2, 37, 9, 11), 1))
+    y = ops.nchw_to_nhwc(x)
+    assert torch.equal(y, x.permute(0, 2, 3, 1).contiguous())
+    wide = torch.zeros(2, 9, 11, 48, device="cuda")
+    ops.nchw_to_nhwc(x, wide, 8)
+    assert torch.equal(wide[..., 8:45], y) and float(wide[..., :8].abs().max()) == 0
+    assert torch.equal(ops.nhwc_to_nchw(wide, 8, 37), x)
+    # NHWC lookup == NCHW lookup
+    f1, f2 = D(syn.normal("a", (2, 64, 16, 20), 1)), D(syn.normal("b", (2, 64, 16, 20), 1))
+    buf, _ = ops.corr_pyramid(f1, f2)
+    c = D(orc.coords_grid_lowres(2, 16, 20) + T(syn.uniform("c", (2, 2, 16, 20), 1, -5.0, 5.0)))
+    assert torch.equal(ops.corr_lookup_nhwc(buf, c), ops.corr_lookup(buf, c).permute(0, 2, 3, 1).contiguous())
+    # NHWC convex upsample == NCHW one
+    flow, mask = D(syn.normal("f", (2, 2, 16, 20), 1, std=3.0)), D(syn.normal("m", (2, 576, 16, 20), 1, std=2.0))
+    a = ops.convex_upsample(flow, mask)
+    b = ops.convex_upsample_nhwc(ops.nchw_to_nhwc(flow), ops.nchw_to_nhwc(mask))
+    close(b, a, 1e-6, 1e-6, what="nhwc upsample")      # same math, different multiplication order
+
+
 def test_encoder(ops, golden):
     from rnnpose_amd.cfnet import ImageFeaEncoder
     g = golden("encoder")
@@ -376,24 +425,25 @@ def _renderer(d):
                              syn_depth=D(d["depth"]), intrinsics_crop=D(d["K"]), fmap1=D(d["fmap1"]), fmap2=D(d["fmap2"]))
 
 
-def _refiner(d, outer, inner, opt, fused):
+def _refiner(d, outer, inner, opt, fused, backend="hip"):
     from rnnpose_amd.pose_refiner import PoseRefiner, default_config
-    ref = PoseRefiner(default_config(RENDER_ITER_COUNT=outer, ITER_COUNT=inner, OPTIM_ITER_COUNT=opt),
-                      renderer=_renderer(d), fused=fused).cuda().eval()
+    cfg = default_config(RENDER_ITER_COUNT=outer, ITER_COUNT=inner, OPTIM_ITER_COUNT=opt)
+    cfg.raft.conv_backend = backend
+    ref = PoseRefiner(cfg, renderer=_renderer(d), fused=fused).cuda().eval()
     ref.cf_net.update_block.load_state_dict({k: T(v) for k, v in upd_weights().items()}, strict=True)
     return ref
 
 
-@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("fused,backend", [(True, "hip"), (False, "hip"), (True, "miopen")])
 @pytest.mark.parametrize("name,shape,outer,inner,opt", [("loop_128", (2, 128, 128, 21), 1, 3, 1),
                                                          ("loop_2x2", (2, 128, 160, 22), 2, 2, 2),
                                                          ("loop_S1", (1, 240, 240, 23), 1, 3, 1)])
-def test_refinement_loop_golden(ops, golden, name, shape, outer, inner, opt, fused):
+def test_refinement_loop_golden(ops, golden, name, shape, outer, inner, opt, fused, backend):
     from rnnpose_amd.transformation import SE3Sequence
     g = golden(name)
     B, H, W, seed = shape
     d = syn.make_inputs(B, H, W, seed=seed)
-    ref = _refiner(d, outer, inner, opt, fused)
+    ref = _refiner(d, outer, inner, opt, fused, backend)
     out = ref(None, SE3Sequence(matrix=D(d["G0"])), D(d["K"]))
     Gi = torch.stack([t.G for t in ref.residual_pose_history])
     close(Gi, g["G_iters"], 1e-5, what="per-iteration relative poses")
@@ -415,8 +465,9 @@ def test_refinement_loop_golden(ops, golden, name, shape, outer, inner, opt, fus
     assert set(out) >= {"Tij", "Ti_pred", "intrinsics", "flow", "vmask", "weight", "syn_depth", "syn_img", "Tij_gt"}
 
 
+@pytest.mark.parametrize("backend", ["hip", "miopen"])
 @pytest.mark.parametrize("shape,inner,opt", [((2, 128, 128, 21), 3, 1), ((2, 128, 160, 22), 3, 2), ((1, 240, 240, 23), 4, 1)])
-def test_refinement_teacher_forced(ops, shape, inner, opt):
+def test_refinement_teacher_forced(ops, shape, inner, opt, backend):
     """Per-iteration parity on IDENTICAL inputs (north_star: 1e-4 on the correspondence field, 1e-5 on the pose):
     every inner iteration starts from the oracle's pose of the previous iteration (the oracle itself is pinned to
     the reference's poses in tests/test_oracle_golden.py); the GPU hidden state and correlation volume run free."""
@@ -425,7 +476,7 @@ def test_refinement_teacher_forced(ops, shape, inner, opt):
     d = syn.make_inputs(B, H, W, seed=seed)
     Wt = upd_weights()
     trace = orc.refine(d, {"upd": Wt}, outer=1, inner=inner, optim_iters=opt, capture=True)["trace"]
-    net = _load_update_block()
+    net = _load_update_block(backend=backend)
     h, w = H // 8, W // 8
     depth, K, g1, g2, sig = D(d["depth"]), D(d["K"]), D(d["g1"]), D(d["g2"]), D(d["sigma"])
     c0 = coords_grid(B, h, w, device="cuda")
@@ -445,10 +496,11 @@ def test_refinement_teacher_forced(ops, shape, inner, opt):
             G_prev = tr["Tij"]
 
 
-def test_cfupdator_facade_stateful(ops):
+@pytest.mark.parametrize("backend", ["hip", "miopen"])
+def test_cfupdator_facade_stateful(ops, backend):
     """GRU_CFUpdator keeps volume + hidden state between calls (update_corr_fn=False) like the reference."""
     d = syn.make_inputs(2, 128, 160, seed=31)
-    net = _load_update_block()
+    net = _load_update_block(backend=backend)
     W = {"upd": upd_weights()}
     fi = syn.normal("fi", (2, 2, 128, 160), 31, std=2.0)
     with torch.no_grad():
