@@ -203,6 +203,15 @@ int rnnpose_flow_head_out_f32(const float* x, int x_c_stride, int x_c_offset, in
 int rnnpose_convex_upsample_nhwc_f32(const float* flow_lr, const float* mask, int B, int h, int w, float* flow_up,
                                      rnnpose_stream_t stream);
 
+/* ---- f1 (adjacent): instance norm of the RAFT encoder on NHWC tensors ---- thirdparty/raft/extractor.py:28-31,48-58
+ * x (B,HW,C) -> out = act((x - mean_bc) * rsqrt(var_bc + eps)) (biased variance, no affine, as nn.InstanceNorm2d);
+ * relu != 0 applies ReLU; if residual != NULL: out = relu(residual + out) (ResidualBlock tail, extractor.py:58).
+ * mean_rstd (B,C,2) receives the statistics.  Deterministic (fixed-order fp64 partial sums in `workspace`). */
+size_t rnnpose_instnorm_workspace_bytes(int B, int HW, int C);
+int rnnpose_instnorm_nhwc_f32(const float* x, int B, int HW, int C, float eps, int relu, const float* residual,
+                              void* workspace, size_t workspace_bytes, float* mean_rstd, float* out,
+                              rnnpose_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -39,16 +39,25 @@ class ImageFeaEncoder(nn.Module):
     """model/CFNet.py:26-49.  `pretrained` = path of img_fea_enc.pth (the reference loads
     <repo>/weights/img_fea_enc.pth unconditionally); None keeps the random initialisation."""
 
-    def __init__(self, input_dim=3, output_dim=256, pretrained=None):
+    def __init__(self, input_dim=3, output_dim=256, pretrained=None, conv_backend="hip"):
         super().__init__()
         self.fnet = BasicEncoder(output_dim=output_dim, norm_fn="instance", dropout=False, input_dim=input_dim)
         if pretrained is not None:
             self.load_state_dict(torch.load(pretrained, map_location="cpu"), strict=True)
+        self.conv_backend = conv_backend      # "hip": NHWC engine (rnnpose_amd/engine.py); "miopen": nn.Module forward
+        self._engine = None
 
     def forward(self, image1, image2):
         # inputs already in [0,1] are normalised AGAIN by the reference (CFNet.py:42-43); reproduced as is
         image1 = (2 * (image1 / 255.0) - 1.0).contiguous()
         image2 = (2 * (image2 / 255.0) - 1.0).contiguous()
+        if self.conv_backend == "hip" and image1.is_cuda:
+            if self._engine is None:
+                from .engine import EncoderEngine
+                self._engine = EncoderEngine(self.fnet)
+            B = image1.shape[0]
+            f = self._engine(torch.cat([image1, image2], 0))
+            return f[:B], f[B:]
         fmap1, fmap2 = self.fnet([image1, image2])
         return fmap1, fmap2
 

@@ -66,9 +66,6 @@ struct KParams {
   int n_mt, n_nt;
 };
 
-struct ARegs {
-  float4 v[5];
-};
 
 __device__ __forceinline__ void split4(const float4 v, float s, h4& hi, h4& lo) {
   const float x[4] = {v.x * s, v.y * s, v.z * s, v.w * s};
@@ -83,9 +80,13 @@ __device__ __forceinline__ void split4(const float4 v, float s, h4& hi, h4& lo) 
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
 
+// NI = MFMA column tiles per wave: output tile = 128 x (64*NI).  NI=2 (128x128) for wide layers, NI=1 (128x64) when
+// the 128-wide tiling would leave the 256 CUs short of workgroups (Cout <= 128 at 300 row tiles) or pad Cout.
+template <int NI>
 __global__ __launch_bounds__(NT, 2) void conv_igemm_f16x3_kernel(const KParams p) {
+  constexpr int BNT = 64 * NI;
   __shared__ __attribute__((aligned(16))) _Float16 sA[2][AROWS * RS];      // hi, lo            21.8 KB
-  __shared__ __attribute__((aligned(16))) _Float16 sB[2][2][BN * RS];      // [buf][hi,lo]      40.0 KB
+  __shared__ __attribute__((aligned(16))) _Float16 sB[2][2][BNT * RS];     // [buf][hi,lo]      40 / 20 KB
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, lh = lane >> 5;
@@ -99,161 +100,172 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_f16x3_kernel(const KParams p
     bid = xcd * per + (xcd < rem ? xcd : rem) + idx;
   }
   const int nt_i = bid % p.n_nt, mt_i = bid / p.n_nt;
-  const long long Mtot = static_cast<long long>(p.B) * p.U * p.V;
-  const long long m0 = static_cast<long long>(mt_i) * BM;
-  const int n0 = nt_i * BN;
+  const int Mtot = p.B * p.U * p.V;          // < 2^31 - 256 (checked on the host): 32-bit index math throughout
+  const int m0 = mt_i * BM;
+  const int n0 = nt_i * BNT;
   const int UV = p.U * p.V;
 
   // ---- per-thread activation rows (global -> LDS staging): rows j = (tid>>3) + 32 r, 16-byte column c4 ----
+  // (named scalars + macros on purpose: arrays / structs captured by lambdas end up in scratch or LDS here)
   const int c4 = tid & 7;
-  int a_pix[5], a_u[5];
-  bool a_ok[5];
-#pragma unroll
-  for (int r = 0; r < 5; ++r) {
-    const int j = (tid >> 3) + 32 * r;
-    const long long m = m0 - HALO + j;
-    a_ok[r] = (j < AROWS) && m >= 0 && m < Mtot;
-    const long long mm = a_ok[r] ? m : 0;
-    const int q = static_cast<int>(mm / p.V), v = static_cast<int>(mm - static_cast<long long>(q) * p.V);
-    const int b = q / p.U, u = q - b * p.U;
-    a_u[r] = u;
-    a_pix[r] = b * UV + u * p.su + v * p.sv;
+#define RP_ROW_INIT(R_)                                                                                     \
+  int a_pix##R_, a_u##R_;                                                                                   \
+  bool a_ok##R_;                                                                                            \
+  {                                                                                                         \
+    const int j_ = (tid >> 3) + 32 * R_;                                                                    \
+    const int m_ = m0 - HALO + j_;                                                                          \
+    a_ok##R_ = (j_ < AROWS) && m_ >= 0 && m_ < Mtot;                                                        \
+    const int mm_ = a_ok##R_ ? m_ : 0;                                                                      \
+    const int q_ = mm_ / p.V, v_ = mm_ - q_ * p.V;                                                          \
+    const int b_ = q_ / p.U, u_ = q_ - b_ * p.U;                                                            \
+    a_u##R_ = u_;                                                                                           \
+    a_pix##R_ = b_ * UV + u_ * p.su + v_ * p.sv;                                                            \
   }
+  RP_ROW_INIT(0) RP_ROW_INIT(1) RP_ROW_INIT(2) RP_ROW_INIT(3) RP_ROW_INIT(4)
   // ---- per-lane fragment rows: fast-axis coordinate for the tap masks ----
   int fv[2];
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi) {
-    const long long m = m0 + wm * 64 + mi * 32 + l31;
-    fv[mi] = (m < Mtot) ? static_cast<int>(m % p.V) : -1000;
+    const int m = m0 + wm * 64 + mi * 32 + l31;
+    fv[mi] = (m < Mtot) ? m % p.V : -1000;
   }
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][NI];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NI; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  auto load_A = [&](ARegs& a, int g, int cb) {
-    Seg s = p.seg0;
-    int cb0 = 0;
-    if (cb >= p.cb1) { s = p.seg1; cb0 = p.cb1; }
-    if (cb >= p.cb2) { s = p.seg2; cb0 = p.cb2; }
-    if (cb >= p.cb3) { s = p.seg3; cb0 = p.cb3; }
-    const int c = (cb - cb0) * BK + c4 * 4;
-    const int du = p.du0 + g;
-#pragma unroll
-    for (int r = 0; r < 5; ++r) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      const int uu = a_u[r] + du;
-      if (a_ok[r] && uu >= 0 && uu < p.U && c < s.ccount) {
-        const float* q = s.ptr + static_cast<long long>(a_pix[r] + du * p.su) * s.cstride + s.coff + c;
-        if (c + 3 < s.ccount) {
-          v = *reinterpret_cast<const float4*>(q);
-        } else {
-          v.x = q[0];
-          if (c + 1 < s.ccount) v.y = q[1];
-          if (c + 2 < s.ccount) v.z = q[2];
-        }
-      }
-      a.v[r] = v;
-    }
-  };
-  auto store_A = [&](const ARegs& a) {
-#pragma unroll
-    for (int r = 0; r < 5; ++r) {
-      const int j = (tid >> 3) + 32 * r;
-      if (j < AROWS) {
-        h4 hi, lo;
-        split4(a.v[r], p.a_scale, hi, lo);
-        *reinterpret_cast<h4*>(&sA[0][j * RS + c4 * 4]) = hi;
-        *reinterpret_cast<h4*>(&sA[1][j * RS + c4 * 4]) = lo;
-      }
-    }
-  };
+  float4 av0, av1, av2, av3, av4;
+#define RP_LOAD_A_ROW(R_)                                                                                   \
+  {                                                                                                         \
+    float4 v_ = make_float4(0.f, 0.f, 0.f, 0.f);                                                            \
+    const int uu_ = a_u##R_ + du_;                                                                          \
+    if (a_ok##R_ && uu_ >= 0 && uu_ < p.U && c_ < sg_.ccount) {                                             \
+      const float* q_ = sg_.ptr + static_cast<long long>(a_pix##R_ + du_ * p.su) * sg_.cstride + sg_.coff + c_; \
+      if (c_ + 3 < sg_.ccount) {                                                                            \
+        v_ = *reinterpret_cast<const float4*>(q_);                                                          \
+      } else {                                                                                              \
+        v_.x = q_[0];                                                                                       \
+        if (c_ + 1 < sg_.ccount) v_.y = q_[1];                                                              \
+        if (c_ + 2 < sg_.ccount) v_.z = q_[2];                                                              \
+      }                                                                                                     \
+    }                                                                                                       \
+    av##R_ = v_;                                                                                            \
+  }
+#define RP_LOAD_A(G_, CB_)                                                                                  \
+  do {                                                                                                      \
+    Seg sg_ = p.seg0;                                                                                       \
+    int cb0_ = 0;                                                                                           \
+    if ((CB_) >= p.cb1) { sg_ = p.seg1; cb0_ = p.cb1; }                                                     \
+    if ((CB_) >= p.cb2) { sg_ = p.seg2; cb0_ = p.cb2; }                                                     \
+    if ((CB_) >= p.cb3) { sg_ = p.seg3; cb0_ = p.cb3; }                                                     \
+    const int c_ = ((CB_) - cb0_) * BK + c4 * 4;                                                            \
+    const int du_ = p.du0 + (G_);                                                                           \
+    RP_LOAD_A_ROW(0) RP_LOAD_A_ROW(1) RP_LOAD_A_ROW(2) RP_LOAD_A_ROW(3) RP_LOAD_A_ROW(4)                    \
+  } while (0)
+#define RP_STORE_A_ROW(R_)                                                                                  \
+  {                                                                                                         \
+    const int j_ = (tid >> 3) + 32 * R_;                                                                    \
+    if (j_ < AROWS) {                                                                                       \
+      h4 hi_, lo_;                                                                                          \
+      split4(av##R_, p.a_scale, hi_, lo_);                                                                  \
+      *reinterpret_cast<h4*>(&sA[0][j_ * RS + c4 * 4]) = hi_;                                               \
+      *reinterpret_cast<h4*>(&sA[1][j_ * RS + c4 * 4]) = lo_;                                               \
+    }                                                                                                       \
+  }
+#define RP_STORE_A() do { RP_STORE_A_ROW(0) RP_STORE_A_ROW(1) RP_STORE_A_ROW(2) RP_STORE_A_ROW(3) RP_STORE_A_ROW(4) } while (0)
   // weight tile registers: plain named locals + macros (a struct handed to a lambda by reference ends up as a
-  // per-thread LDS slot: +16 KB/block and an LDS round trip per tap)
-  uint4 bh0, bh1, bl0, bl1;
-#define RP_LOAD_B(G_, T_, CB_)                                                                              \
+  // per-thread LDS slot: +16 KB/block and an LDS round trip per tap).  TWO sets: tile i+2 is requested while tile
+  // i is consumed, so an L2/HBM round trip has two MFMA phases (>= 1500 cycles) to complete.
+  uint4 b0h0, b0h1, b0l0, b0l1, b1h0, b1h1, b1l0, b1l1;
+#define RP_LOAD_B(S_, G_, T_, CB_)                                                                          \
   do {                                                                                                      \
     const long long tile_ = ((static_cast<long long>(G_) * p.T + (T_)) * p.ncb + (CB_)) * p.Npad + n0;     \
     const uint4* hs_ = reinterpret_cast<const uint4*>(p.whi + tile_ * BK);                                  \
     const uint4* ls_ = reinterpret_cast<const uint4*>(p.wlo + tile_ * BK);                                  \
-    bh0 = hs_[tid];                                                                                         \
-    bh1 = hs_[tid + NT];                                                                                    \
-    bl0 = ls_[tid];                                                                                         \
-    bl1 = ls_[tid + NT];                                                                                    \
+    b##S_##h0 = hs_[tid];                                                                                   \
+    b##S_##l0 = ls_[tid];                                                                                   \
+    if (NI == 2) {                                                                                          \
+      b##S_##h1 = hs_[tid + NT];                                                                            \
+      b##S_##l1 = ls_[tid + NT];                                                                            \
+    }                                                                                                       \
   } while (0)
-#define RP_STORE_B(BUF_)                                                                                    \
+#define RP_STORE_B(S_)                                                                                      \
   do {                                                                                                      \
     const int row0_ = tid >> 2, qd_ = tid & 3; /* second chunk: index tid + 256 -> row0 + 64 */            \
-    *reinterpret_cast<uint4*>(&sB[BUF_][0][row0_ * RS + qd_ * 8]) = bh0;                                    \
-    *reinterpret_cast<uint4*>(&sB[BUF_][1][row0_ * RS + qd_ * 8]) = bl0;                                    \
-    *reinterpret_cast<uint4*>(&sB[BUF_][0][(row0_ + 64) * RS + qd_ * 8]) = bh1;                             \
-    *reinterpret_cast<uint4*>(&sB[BUF_][1][(row0_ + 64) * RS + qd_ * 8]) = bl1;                             \
+    *reinterpret_cast<uint4*>(&sB[S_][0][row0_ * RS + qd_ * 8]) = b##S_##h0;                                \
+    *reinterpret_cast<uint4*>(&sB[S_][1][row0_ * RS + qd_ * 8]) = b##S_##l0;                                \
+    if (NI == 2) {                                                                                          \
+      *reinterpret_cast<uint4*>(&sB[S_][0][(row0_ + 64) * RS + qd_ * 8]) = b##S_##h1;                       \
+      *reinterpret_cast<uint4*>(&sB[S_][1][(row0_ + 64) * RS + qd_ * 8]) = b##S_##l1;                       \
+    }                                                                                                       \
+  } while (0)
+#define RP_MMA(S_, DV_)                                                                                     \
+  do {                                                                                                      \
+    const int dv_ = (DV_);                                                                                  \
+    const bool ok0_ = static_cast<unsigned>(fv[0] + dv_) < static_cast<unsigned>(p.V);                      \
+    const bool ok1_ = static_cast<unsigned>(fv[1] + dv_) < static_cast<unsigned>(p.V);                      \
+    const h8 zero_ = {0, 0, 0, 0, 0, 0, 0, 0};                                                              \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                                      \
+      const int ko = kk * 16 + lh * 8;                                                                      \
+      h8 ah[2], al[2], bh[NI], bl[NI];                                                                      \
+      _Pragma("unroll") for (int mi = 0; mi < 2; ++mi) {                                                    \
+        const int row = wm * 64 + mi * 32 + l31 + HALO + dv_;                                               \
+        ah[mi] = *reinterpret_cast<const h8*>(&sA[0][row * RS + ko]);                                       \
+        al[mi] = *reinterpret_cast<const h8*>(&sA[1][row * RS + ko]);                                       \
+      }                                                                                                     \
+      if (!ok0_) { ah[0] = zero_; al[0] = zero_; }                                                          \
+      if (!ok1_) { ah[1] = zero_; al[1] = zero_; }                                                          \
+      _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) {                                                   \
+        const int row = wn * (32 * NI) + ni * 32 + l31;                                                     \
+        bh[ni] = *reinterpret_cast<const h8*>(&sB[S_][0][row * RS + ko]);                                   \
+        bl[ni] = *reinterpret_cast<const h8*>(&sB[S_][1][row * RS + ko]);                                   \
+      }                                                                                                     \
+      /* term-major: the 4 accumulator tiles are independent, consecutive MFMAs never wait on each other */ \
+      _Pragma("unroll") for (int mi = 0; mi < 2; ++mi) _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)    \
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);      \
+      _Pragma("unroll") for (int mi = 0; mi < 2; ++mi) _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)    \
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);      \
+      _Pragma("unroll") for (int mi = 0; mi < 2; ++mi) _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)    \
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);      \
+    }                                                                                                       \
+  } while (0)
+  // one pipeline stage: (activation tile on the first tap of a (group, block)) -> stage weight tile i in LDS buffer
+  // S_ -> request tile i+2 into the same registers -> barrier -> MFMAs of tile i
+#define RP_STAGE(S_)                                                                                        \
+  do {                                                                                                      \
+    if (ct == 0) {                                                                                          \
+      RP_STORE_A();                                                                                         \
+      int ncb_ = ccb + 1, ng_ = cg;                                                                         \
+      if (ncb_ == p.ncb) { ncb_ = 0; ++ng_; }                                                               \
+      if (ng_ < p.G) RP_LOAD_A(ng_, ncb_);                                                                  \
+    }                                                                                                       \
+    RP_STORE_B(S_);                                                                                         \
+    if (pg < p.G) RP_LOAD_B(S_, pg, pt, pcb);                                                               \
+    if (++pt == p.T) { pt = 0; if (++pcb == p.ncb) { pcb = 0; ++pg; } }                                     \
+    __syncthreads();                                                                                        \
+    RP_MMA(S_, p.dv0 + ct);                                                                                 \
+    if (++ct == p.T) {                                                                                      \
+      ct = 0;                                                                                               \
+      if (++ccb == p.ncb) { ccb = 0; ++cg; }                                                                \
+      __syncthreads(); /* every wave is done with this activation tile before it is overwritten */         \
+    }                                                                                                       \
   } while (0)
 
-  ARegs areg;
-  load_A(areg, 0, 0);
-  RP_LOAD_B(0, 0, 0);
-  int buf = 0;
-  const int nsteps_cb = p.G * p.ncb;
-  for (int s = 0; s < nsteps_cb; ++s) {
-    const int g = s / p.ncb, cb = s - g * p.ncb;
-    store_A(areg);
-    if (s + 1 < nsteps_cb) {
-      const int g2 = (s + 1) / p.ncb;
-      load_A(areg, g2, (s + 1) - g2 * p.ncb);
-    }
-    for (int t = 0; t < p.T; ++t) {
-      RP_STORE_B(buf);
-      {  // prefetch the next weight tile (next tap, or first tap of the next (g, cb))
-        int t2 = t + 1, s2 = s;
-        if (t2 == p.T) {
-          t2 = 0;
-          s2 = s + 1;
-        }
-        if (s2 < nsteps_cb) {
-          const int g2 = s2 / p.ncb;
-          RP_LOAD_B(g2, t2, s2 - g2 * p.ncb);
-        }
-      }
-      __syncthreads();
-      const int dv = p.dv0 + t;
-      const bool ok0 = static_cast<unsigned>(fv[0] + dv) < static_cast<unsigned>(p.V);
-      const bool ok1 = static_cast<unsigned>(fv[1] + dv) < static_cast<unsigned>(p.V);
-      const h8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const int ko = kk * 16 + lh * 8;
-        h8 ah[2], al[2], bh[2], bl[2];
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-          const int row = wm * 64 + mi * 32 + l31 + HALO + dv;
-          ah[mi] = *reinterpret_cast<const h8*>(&sA[0][row * RS + ko]);
-          al[mi] = *reinterpret_cast<const h8*>(&sA[1][row * RS + ko]);
-        }
-        if (!ok0) { ah[0] = zero; al[0] = zero; }
-        if (!ok1) { ah[1] = zero; al[1] = zero; }
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-          const int row = wn * 64 + ni * 32 + l31;
-          bh[ni] = *reinterpret_cast<const h8*>(&sB[buf][0][row * RS + ko]);
-          bl[ni] = *reinterpret_cast<const h8*>(&sB[buf][1][row * RS + ko]);
-        }
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < 2; ++ni) {
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
-          }
-      }
-      buf ^= 1;
-    }
-    __syncthreads();   // every wave is done with this activation tile before it is overwritten
+  RP_LOAD_A(0, 0);
+  int cg = 0, ccb = 0, ct = 0;     // coordinates of the tile being consumed
+  int pg = 0, pcb = 0, pt = 0;     // coordinates of the next tile to request
+  const int total = p.G * p.ncb * p.T;
+  RP_LOAD_B(0, pg, pt, pcb);
+  if (++pt == p.T) { pt = 0; if (++pcb == p.ncb) { pcb = 0; ++pg; } }
+  if (pg < p.G) RP_LOAD_B(1, pg, pt, pcb);
+  if (++pt == p.T) { pt = 0; if (++pcb == p.ncb) { pcb = 0; ++pg; } }
+  for (int i = 0; i < total; i += 2) {
+    RP_STAGE(0);
+    if (i + 1 < total) RP_STAGE(1);
   }
 
   // ------------------------------------------- epilogue -------------------------------------------
@@ -262,17 +274,17 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_f16x3_kernel(const KParams p
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const long long m = m0 + row;
+      const int m = m0 + row;
       if (m >= Mtot) continue;
       long long pix = m;
       if (p.sv != 1) {
-        const int q = static_cast<int>(m / p.V), v = static_cast<int>(m - static_cast<long long>(q) * p.V);
+        const int q = m / p.V, v = m - q * p.V;
         const int b = q / p.U, u = q - b * p.U;
         pix = static_cast<long long>(b) * UV + u * p.su + v * p.sv;
       }
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-        const int col = n0 + wn * 64 + ni * 32 + l31;
+      for (int ni = 0; ni < NI; ++ni) {
+        const int col = n0 + wn * (32 * NI) + ni * 32 + l31;
         if (col >= p.Cout) continue;
         const float y = acc[mi][ni][r] * p.out_scale + p.bias[col];
         if (p.epi == 0) {
@@ -442,9 +454,17 @@ int rnnpose_conv2d_nhwc_f16x3(const rnnpose_conv_desc_t* d, rnnpose_stream_t str
   const long long Mtot = static_cast<long long>(d->B) * d->H * d->W;
   RP_REQUIRE(Mtot < (1LL << 31) - 256, fn, "too many pixels");
   p.n_mt = rp::cdiv(Mtot, BM);
-  p.n_nt = p.Npad / BN;
-  hipLaunchKernelGGL(conv_igemm_f16x3_kernel, dim3(static_cast<unsigned>(p.n_mt) * p.n_nt), dim3(NT), 0,
-                     rp::as_stream(stream), p);
+  // tile width: 128 when Cout fills it and there are enough workgroups for 2 per CU, else 64
+  const bool wide = (d->c_out % 128 == 0) && (static_cast<long long>(p.n_mt) * (d->c_out / 128) >= 512);
+  if (wide) {
+    p.n_nt = p.Npad / 128;
+    hipLaunchKernelGGL(conv_igemm_f16x3_kernel<2>, dim3(static_cast<unsigned>(p.n_mt) * p.n_nt), dim3(NT), 0,
+                       rp::as_stream(stream), p);
+  } else {
+    p.n_nt = rp::cdiv(d->c_out, 64);
+    hipLaunchKernelGGL(conv_igemm_f16x3_kernel<1>, dim3(static_cast<unsigned>(p.n_mt) * p.n_nt), dim3(NT), 0,
+                       rp::as_stream(stream), p);
+  }
   return rp::check_launch(fn);
 }
 

@@ -157,6 +157,86 @@ __global__ __launch_bounds__(256) void convex_upsample_nhwc_kernel(const float* 
   up[(static_cast<long long>(b) * 2 + 1) * Pf + o] = ay;
 }
 
+
+// ---- instance norm (no affine, eps inside the sqrt) on NHWC tensors: thirdparty/raft/extractor.py:28-31,129-130 ------
+// pass 1: per (image, row chunk) partial sums in fp64, fixed order; pass 2: mean / rstd; pass 3: apply (+ReLU,
+// + residual add + ReLU), float4 wide.  x viewed as (B, HW, C), C % 4 == 0, C <= 256.
+constexpr int IN_ROWS = 512;     // rows per partial
+__global__ __launch_bounds__(256) void instnorm_partial_kernel(const float* __restrict__ x, double* __restrict__ part,
+                                                               int HW, int C) {
+  __shared__ double s1[256], s2[256];
+  const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
+  const int tid = threadIdx.x;
+  const int lanes_per_row = C >> 2;                 // float4 lanes covering one row
+  const int rows_per_iter = 256 / lanes_per_row;    // C in {32..256} -> 32..4 rows per sweep (C divides 1024)
+  const int c4 = tid % lanes_per_row, r0 = tid / lanes_per_row;
+  const int row_beg = chunk * IN_ROWS, row_end = min(HW, row_beg + IN_ROWS);
+  double a[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+  if (r0 < rows_per_iter) {
+    for (int r = row_beg + r0; r < row_end; r += rows_per_iter) {
+      const float4 v = *reinterpret_cast<const float4*>(x + (static_cast<long long>(b) * HW + r) * C + c4 * 4);
+      a[0] += v.x; a[1] += v.y; a[2] += v.z; a[3] += v.w;
+      q[0] += static_cast<double>(v.x) * v.x; q[1] += static_cast<double>(v.y) * v.y;
+      q[2] += static_cast<double>(v.z) * v.z; q[3] += static_cast<double>(v.w) * v.w;
+    }
+  }
+  // reduce the rows_per_iter row groups of each channel quad through LDS (fixed order)
+  for (int k = 0; k < 4; ++k) {
+    s1[tid] = a[k];
+    s2[tid] = q[k];
+    __syncthreads();
+    if (tid < lanes_per_row) {
+      double t1 = 0, t2 = 0;
+      for (int g = 0; g < rows_per_iter; ++g) {
+        t1 += s1[g * lanes_per_row + tid];
+        t2 += s2[g * lanes_per_row + tid];
+      }
+      const int c = tid * 4 + k;
+      part[((static_cast<long long>(b) * nchunk + chunk) * C + c) * 2 + 0] = t1;
+      part[((static_cast<long long>(b) * nchunk + chunk) * C + c) * 2 + 1] = t2;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void instnorm_finalize_kernel(const double* __restrict__ part, float* __restrict__ mean_rstd, int nchunk, int C,
+                                         int HW, float eps) {
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    double t1 = 0, t2 = 0;
+    for (int k = 0; k < nchunk; ++k) {
+      t1 += part[((static_cast<long long>(b) * nchunk + k) * C + c) * 2 + 0];
+      t2 += part[((static_cast<long long>(b) * nchunk + k) * C + c) * 2 + 1];
+    }
+    const double m = t1 / HW;
+    double var = t2 / HW - m * m;                   // biased variance, as F.instance_norm
+    if (var < 0) var = 0;
+    mean_rstd[(static_cast<long long>(b) * C + c) * 2 + 0] = static_cast<float>(m);
+    mean_rstd[(static_cast<long long>(b) * C + c) * 2 + 1] = static_cast<float>(1.0 / sqrt(var + static_cast<double>(eps)));
+  }
+}
+
+// out = act1((x - mean) * rstd); if residual: out = relu(residual + out)
+__global__ __launch_bounds__(256) void instnorm_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean_rstd,
+                                                             const float* __restrict__ residual, float* __restrict__ out,
+                                                             int HW, int C, int relu, long long total4) {
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= total4) return;
+  const int c4 = static_cast<int>(i % (C >> 2));
+  const long long row = i / (C >> 2);
+  const int b = static_cast<int>(row / HW);
+  const float4 v = reinterpret_cast<const float4*>(x)[i];
+  const float4 m01 = *reinterpret_cast<const float4*>(mean_rstd + (static_cast<long long>(b) * C + c4 * 4) * 2);
+  const float4 m23 = *reinterpret_cast<const float4*>(mean_rstd + (static_cast<long long>(b) * C + c4 * 4 + 2) * 2);
+  float4 y = make_float4((v.x - m01.x) * m01.y, (v.y - m01.z) * m01.w, (v.z - m23.x) * m23.y, (v.w - m23.z) * m23.w);
+  if (relu) y = make_float4(fmaxf(y.x, 0.f), fmaxf(y.y, 0.f), fmaxf(y.z, 0.f), fmaxf(y.w, 0.f));
+  if (residual) {
+    const float4 r = reinterpret_cast<const float4*>(residual)[i];
+    y = make_float4(fmaxf(r.x + y.x, 0.f), fmaxf(r.y + y.y, 0.f), fmaxf(r.z + y.z, 0.f), fmaxf(r.w + y.w, 0.f));
+  }
+  reinterpret_cast<float4*>(out)[i] = y;
+}
+
 }  // namespace
 
 extern "C" {
@@ -215,6 +295,31 @@ int rnnpose_convex_upsample_nhwc_f32(const float* flow_lr, const float* mask, in
   RP_REQUIRE(B > 0 && B < 65536 && h > 0 && h < 65536 && w > 0, fn, "bad size");
   hipLaunchKernelGGL(convex_upsample_nhwc_kernel, dim3(rp::cdiv(w, 4), h, B), dim3(256), 0, rp::as_stream(stream), flow_lr,
                      mask, flow_up, h, w);
+  return rp::check_launch(fn);
+}
+
+
+size_t rnnpose_instnorm_workspace_bytes(int B, int HW, int C) {
+  if (B <= 0 || HW <= 0 || C <= 0) return 0;
+  return static_cast<size_t>(B) * rp::cdiv(HW, IN_ROWS) * C * 2 * sizeof(double);
+}
+
+int rnnpose_instnorm_nhwc_f32(const float* x, int B, int HW, int C, float eps, int relu, const float* residual,
+                              void* workspace, size_t workspace_bytes, float* mean_rstd, float* out,
+                              rnnpose_stream_t stream) {
+  const char* fn = "rnnpose_instnorm_nhwc_f32";
+  RP_REQUIRE(x && workspace && mean_rstd && out, fn, "null pointer");
+  RP_REQUIRE(B > 0 && B < 65536 && HW > 0 && C >= 32 && C <= 256 && 1024 % C == 0 || C == 96 || C == 192, fn,
+             "C must be 32, 64, 96, 128, 192 or 256");
+  RP_REQUIRE(workspace_bytes >= rnnpose_instnorm_workspace_bytes(B, HW, C), fn, "workspace too small");
+  const int nchunk = rp::cdiv(HW, IN_ROWS);
+  hipStream_t st = rp::as_stream(stream);
+  hipLaunchKernelGGL(instnorm_partial_kernel, dim3(nchunk, B), dim3(256), 0, st, x, static_cast<double*>(workspace), HW, C);
+  hipLaunchKernelGGL(instnorm_finalize_kernel, dim3(B), dim3(256), 0, st, static_cast<const double*>(workspace), mean_rstd,
+                     nchunk, C, HW, eps);
+  const long long total4 = static_cast<long long>(B) * HW * (C >> 2);
+  hipLaunchKernelGGL(instnorm_apply_kernel, dim3(rp::cdiv(total4, 256)), dim3(256), 0, st, x, mean_rstd, residual, out, HW,
+                     C, relu, total4);
   return rp::check_launch(fn);
 }
 

@@ -102,3 +102,71 @@ class UpdateEngine:
         c(W["mask2"], [(b["heads"], 256)], (b["mask"], 0), ops.EPI_LINEAR)          # 0.25 * mask.2(relu(mask.0(h)))
         flow_up = ops.convex_upsample_nhwc(b["flow_lr"], b["mask"])
         return b["coords1"], flow_up
+
+
+class EncoderEngine:
+    """RAFT BasicEncoder (instance-norm variant, thirdparty/raft/extractor.py:118-232) executed NHWC: all stride-1
+    3x3 convolutions and the 1x1 output convolution run in the hand-written implicit-GEMM kernel, instance norm /
+    ReLU / residual adds in one fused HIP pass each.  The 7x7 stride-2 stem and the three stride-2 convolutions
+    (8 % of the FLOPs) stay on MIOpen in channels_last layout (their outputs are NHWC already)."""
+
+    def __init__(self, fnet):
+        self.fnet = fnet
+        self._key = None
+        self._w = None
+
+    def _mine(self):
+        f = self.fnet
+        convs = {}
+        for li, layer in enumerate((f.layer1, f.layer2, f.layer3), start=1):
+            for bi, blk in enumerate(layer):
+                if blk.downsample is None:
+                    convs[f"l{li}.{bi}.c1"] = blk.conv1
+                convs[f"l{li}.{bi}.c2"] = blk.conv2
+        convs["out"] = f.conv2
+        return convs
+
+    def _weights(self):
+        convs = self._mine()
+        key = tuple((m.weight._version, m.weight.data_ptr(), m.bias._version, m.bias.data_ptr()) for m in convs.values())
+        if key != self._key:
+            self._w = {k: ops.PackedConv(m.weight, m.bias, [m.weight.shape[1]]) for k, m in convs.items()}
+            self._key = key
+        return self._w
+
+    @staticmethod
+    def _torch_conv(x_nhwc, conv):
+        import torch.nn.functional as F
+        x = x_nhwc.permute(0, 3, 1, 2)                       # NCHW view of NHWC memory == channels_last
+        y = F.conv2d(x, conv.weight, conv.bias, stride=conv.stride, padding=conv.padding)
+        return y.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
+
+    @staticmethod
+    def _conv(pc, x):
+        B, H, W, _ = x.shape
+        out = torch.empty(B, H, W, pc.c_out, device=x.device, dtype=torch.float32)
+        ops.conv2d_nhwc(pc, [(x, 0)], (out, 0), ops.EPI_LINEAR)
+        return out
+
+    def _block(self, W, name, blk, x):
+        if blk.downsample is None:
+            y = ops.instnorm_nhwc(self._conv(W[name + ".c1"], x), relu=True)
+            res = x
+        else:
+            y = ops.instnorm_nhwc(self._torch_conv(x, blk.conv1), relu=True)
+            res = ops.instnorm_nhwc(self._torch_conv(x, blk.downsample[0]), relu=False)      # norm3, no ReLU
+        y = self._conv(W[name + ".c2"], y)
+        return ops.instnorm_nhwc(y, relu=True, residual=res)                                  # relu(x + relu(IN(.)))
+
+    @torch.no_grad()
+    def __call__(self, x_nchw):
+        """x (N,3,H,W) already normalised -> (N,256,H/8,W/8) NCHW."""
+        W = self._weights()
+        f = self.fnet
+        x = x_nchw.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
+        y = ops.instnorm_nhwc(self._torch_conv(x, f.conv1).contiguous(), relu=True)
+        for li, layer in enumerate((f.layer1, f.layer2, f.layer3), start=1):
+            for bi, blk in enumerate(layer):
+                y = self._block(W, f"l{li}.{bi}", blk, y.contiguous())
+        out = self._conv(W["out"], y)
+        return ops.nhwc_to_nchw(out)

@@ -402,3 +402,24 @@ def convex_upsample_nhwc(flow_lr, mask, out=None):
         out = torch.empty(B, 2, 8 * h, 8 * w, device=mask.device, dtype=F32)
     _launch("rnnpose_convex_upsample_nhwc_f32", _ptr(flow_lr), _ptr(mask), B, h, w, _ptr(out), _stream())
     return out
+
+
+# ---- f1: instance norm on NHWC --------------------------------------------------------------------------------
+_in_ws = {}
+
+
+def instnorm_nhwc(x, relu=True, residual=None, out=None, eps: float = 1e-5):
+    """x (B,H,W,C) -> act((x-mean)*rstd) [then relu(residual + .)], nn.InstanceNorm2d semantics (no affine)."""
+    _nhwc(x, "x")
+    B, H, W, Cc = x.shape
+    n = int(_lib.load().rnnpose_instnorm_workspace_bytes(B, H * W, Cc))
+    key = (x.device, n)
+    ws = _in_ws.get(key)
+    if ws is None:
+        ws = _in_ws[key] = torch.empty(n // 8, device=x.device, dtype=F64)
+    if out is None:
+        out = torch.empty_like(x)
+    stats = torch.empty(B, Cc, 2, device=x.device, dtype=F32)
+    _launch("rnnpose_instnorm_nhwc_f32", _ptr(x), B, H * W, Cc, eps, int(bool(relu)), _ptr(residual), _ptr(ws), n,
+            _ptr(stats), _ptr(out), _stream())
+    return out

@@ -69,7 +69,8 @@ class PoseRefiner(nn.Module):
         self.use_regressor = use_regressor
         if cfg.get("FLOW_NET", "raft") != "raft":
             raise NotImplementedError
-        self.image_fea_enc = ImageFeaEncoder(pretrained=img_fea_enc_weights)
+        self.image_fea_enc = ImageFeaEncoder(pretrained=img_fea_enc_weights,
+                                             conv_backend=cfg.get("raft", {}).get("conv_backend", "hip"))
         self.cf_net = GRU_CFUpdator(cfg.get("raft", None))
         self.renderer = renderer
         self.fused = fused
