@@ -136,7 +136,7 @@ int rnnpose_gru_update_f32(const float* z, const float* q_pre, const float* hcat
 
 /* ---- a4: dense convolutions of the update block, NHWC, fp16x3-split MFMA (fp32-class accuracy) ----------
  *      thirdparty/raft/update.py:6-14 (FlowHead), :33-60 (SepConvGRU), :79-97 (BasicMotionEncoder), :172-187
- * Stride 1, zero "same" padding, odd kernel sizes up to 7 (1x1, 3x3, 1x5, 5x1 are what the update block uses).
+ * Zero padding kh/2 x kw/2, odd kernel sizes up to 7 (1x1, 3x3, 1x5, 5x1 are what the update block uses), stride 1 or 2.
  * Input = virtual concat of up to 4 NHWC tensors (B,H,W,c_stride), using channels [c_offset, c_offset+c_count).
  * Weights are packed once by rnnpose_conv_pack_weights_f16x3 from the PyTorch layout (c_out, c_in, kh, kw),
  * with the SAME segment channel counts; w_scale (a power of two) must be the one given to the packer.
@@ -155,8 +155,9 @@ typedef struct {
 typedef struct {
   rnnpose_conv_src_t src[4];
   int n_src;
-  int B, H, W;
+  int B, H, W;                 /* INPUT spatial size */
   int kh, kw;
+  int stride;                  /* 1, or 2 (output = ceil(H/2) x ceil(W/2), padding kh/2, kw/2: the encoder's strided convs) */
   const void* w_hi;
   const void* w_lo;
   const float* bias;

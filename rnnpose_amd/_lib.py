@@ -22,7 +22,7 @@ class ConvSrc(C.Structure):
 
 class ConvDesc(C.Structure):       # rnnpose_conv_desc_t
     _fields_ = [("src", ConvSrc * 4), ("n_src", C.c_int), ("B", C.c_int), ("H", C.c_int), ("W", C.c_int),
-                ("kh", C.c_int), ("kw", C.c_int), ("w_hi", C.c_void_p), ("w_lo", C.c_void_p), ("bias", C.c_void_p),
+                ("kh", C.c_int), ("kw", C.c_int), ("stride", C.c_int), ("w_hi", C.c_void_p), ("w_lo", C.c_void_p), ("bias", C.c_void_p),
                 ("c_out", C.c_int), ("a_scale", C.c_float), ("w_scale", C.c_float), ("epilogue", C.c_int),
                 ("dst", C.c_void_p), ("dst_c_stride", C.c_int), ("dst_c_offset", C.c_int),
                 ("aux0", C.c_void_p), ("aux0_c_stride", C.c_int), ("aux0_c_offset", C.c_int),

@@ -24,6 +24,8 @@
 //     writing straight into a channel slice of the destination NHWC tensor (no cat / clone / relu kernels).
 #include "common.hpp"
 
+#include <cstdlib>
+
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 32, NT = 256;
@@ -47,6 +49,7 @@ struct KParams {
   int ncb;
   int B, U, V, su, sv;              // slow / fast axis extents and pixel strides
   int G, T, du0, dv0;               // groups (slow-axis taps) x taps per group (fast axis)
+  int stride, Uin, Vin, gkw, dvg0;  // strided mode (stride 2): no tap sharing, G = kh*kw groups decoded as (g / gkw, g % gkw)
   const _Float16* whi;
   const _Float16* wlo;
   int Npad;
@@ -64,6 +67,7 @@ struct KParams {
   int dst2_cs, dst2_co;
   int gru_c;
   int n_mt, n_nt;
+  int dbg;   // ablation switches for tools/conv_ablate.py (RNNPOSE_CONV_DBG); 0 in production
 };
 
 
@@ -82,7 +86,9 @@ __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-
 
 // NI = MFMA column tiles per wave: output tile = 128 x (64*NI).  NI=2 (128x128) for wide layers, NI=1 (128x64) when
 // the 128-wide tiling would leave the 256 CUs short of workgroups (Cout <= 128 at 300 row tiles) or pad Cout.
-template <int NI>
+// STRIDED = stride-2 mode (every tap is its own group, general input addressing); a template flag so that the
+// stride-1 instantiations keep their register budget (the 64-wide variant must stay <= 128 VGPRs for 4 waves/SIMD).
+template <int NI, bool STRIDED>
 __global__ __launch_bounds__(NT, 2) void conv_igemm_f16x3_kernel(const KParams p) {
   constexpr int BNT = 64 * NI;
   __shared__ __attribute__((aligned(16))) _Float16 sA[2][AROWS * RS];      // hi, lo            21.8 KB
@@ -109,7 +115,7 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_f16x3_kernel(const KParams p
   // (named scalars + macros on purpose: arrays / structs captured by lambdas end up in scratch or LDS here)
   const int c4 = tid & 7;
 #define RP_ROW_INIT(R_)                                                                                     \
-  int a_pix##R_, a_u##R_;                                                                                   \
+  int a_pix##R_, a_u##R_, a_v##R_;                                                                          \
   bool a_ok##R_;                                                                                            \
   {                                                                                                         \
     const int j_ = (tid >> 3) + 32 * R_;                                                                    \
@@ -118,8 +124,9 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_f16x3_kernel(const KParams p
     const int mm_ = a_ok##R_ ? m_ : 0;                                                                      \
     const int q_ = mm_ / p.V, v_ = mm_ - q_ * p.V;                                                          \
     const int b_ = q_ / p.U, u_ = q_ - b_ * p.U;                                                            \
-    a_u##R_ = u_;                                                                                           \
-    a_pix##R_ = b_ * UV + u_ * p.su + v_ * p.sv;                                                            \
+    a_u##R_ = STRIDED ? u_ * 2 : u_;                                                                        \
+    a_v##R_ = STRIDED ? v_ * 2 : 0;                                                                         \
+    a_pix##R_ = STRIDED ? b_ * (p.Uin * p.Vin) : b_ * UV + u_ * p.su + v_ * p.sv;                           \
   }
   RP_ROW_INIT(0) RP_ROW_INIT(1) RP_ROW_INIT(2) RP_ROW_INIT(3) RP_ROW_INIT(4)
   // ---- per-lane fragment rows: fast-axis coordinate for the tap masks ----
@@ -142,9 +149,11 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_f16x3_kernel(const KParams p
 #define RP_LOAD_A_ROW(R_)                                                                                   \
   {                                                                                                         \
     float4 v_ = make_float4(0.f, 0.f, 0.f, 0.f);                                                            \
-    const int uu_ = a_u##R_ + du_;                                                                          \
-    if (a_ok##R_ && uu_ >= 0 && uu_ < p.U && c_ < sg_.ccount) {                                             \
-      const float* q_ = sg_.ptr + static_cast<long long>(a_pix##R_ + du_ * p.su) * sg_.cstride + sg_.coff + c_; \
+    const int uu_ = a_u##R_ + du_, vv_ = a_v##R_ + dvg_;                                                    \
+    const bool in_ = STRIDED ? (uu_ >= 0 && uu_ < p.Uin && vv_ >= 0 && vv_ < p.Vin) : (uu_ >= 0 && uu_ < p.U); \
+    if (a_ok##R_ && in_ && c_ < sg_.ccount) {                                                               \
+      const long long px_ = STRIDED ? a_pix##R_ + uu_ * p.su + vv_ * p.sv : a_pix##R_ + du_ * p.su;         \
+      const float* q_ = sg_.ptr + px_ * sg_.cstride + sg_.coff + c_;                                        \
       if (c_ + 3 < sg_.ccount) {                                                                            \
         v_ = *reinterpret_cast<const float4*>(q_);                                                          \
       } else {                                                                                              \
@@ -163,7 +172,8 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_f16x3_kernel(const KParams p
     if ((CB_) >= p.cb2) { sg_ = p.seg2; cb0_ = p.cb2; }                                                     \
     if ((CB_) >= p.cb3) { sg_ = p.seg3; cb0_ = p.cb3; }                                                     \
     const int c_ = ((CB_) - cb0_) * BK + c4 * 4;                                                            \
-    const int du_ = p.du0 + (G_);                                                                           \
+    const int du_ = p.du0 + (STRIDED ? (G_) / p.gkw : (G_));                                                \
+    const int dvg_ = STRIDED ? p.dvg0 + (G_) % p.gkw : 0;                                                   \
     RP_LOAD_A_ROW(0) RP_LOAD_A_ROW(1) RP_LOAD_A_ROW(2) RP_LOAD_A_ROW(3) RP_LOAD_A_ROW(4)                    \
   } while (0)
 #define RP_STORE_A_ROW(R_)                                                                                  \
@@ -238,20 +248,20 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_f16x3_kernel(const KParams p
 #define RP_STAGE(S_)                                                                                        \
   do {                                                                                                      \
     if (ct == 0) {                                                                                          \
-      RP_STORE_A();                                                                                         \
+      if (!(p.dbg & 8)) RP_STORE_A();                                                                       \
       int ncb_ = ccb + 1, ng_ = cg;                                                                         \
       if (ncb_ == p.ncb) { ncb_ = 0; ++ng_; }                                                               \
       if (ng_ < p.G) RP_LOAD_A(ng_, ncb_);                                                                  \
     }                                                                                                       \
-    RP_STORE_B(S_);                                                                                         \
-    if (pg < p.G) RP_LOAD_B(S_, pg, pt, pcb);                                                               \
+    if (!(p.dbg & 2)) RP_STORE_B(S_);                                                                       \
+    if (pg < p.G && !(p.dbg & 1)) RP_LOAD_B(S_, pg, pt, pcb);                                               \
     if (++pt == p.T) { pt = 0; if (++pcb == p.ncb) { pcb = 0; ++pg; } }                                     \
-    __syncthreads();                                                                                        \
-    RP_MMA(S_, p.dv0 + ct);                                                                                 \
+    if (!(p.dbg & 16)) __syncthreads();                                                                     \
+    if (!(p.dbg & 4)) RP_MMA(S_, p.dv0 + ct);                                                               \
     if (++ct == p.T) {                                                                                      \
       ct = 0;                                                                                               \
       if (++ccb == p.ncb) { ccb = 0; ++cg; }                                                                \
-      __syncthreads(); /* every wave is done with this activation tile before it is overwritten */         \
+      if (!(p.dbg & 16)) __syncthreads(); /* every wave is done with this activation tile before it is overwritten */ \
     }                                                                                                       \
   } while (0)
 
@@ -269,41 +279,65 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_f16x3_kernel(const KParams p
   }
 
   // ------------------------------------------- epilogue -------------------------------------------
+  // accumulators -> wave-private LDS tile (aliasing the weight staging buffers) -> 16-byte row-contiguous stores:
+  // 16 lanes cover 256 contiguous bytes of one output pixel (the MFMA C layout would give 4-byte stores spread
+  // over 2 rows per instruction: measured 0.86 TB/s, the epilogue was 35-45 % of the kernel).
+  __syncthreads();
+  constexpr int ES = 32 * NI + 4;                       // row stride (floats) of the staging tile
+  constexpr int F4 = 8 * NI;                            // float4 per tile row
+  float* S = reinterpret_cast<float*>(&sB[0][0][0]) + wave * (32 * ES);
+  const int colw = n0 + wn * (32 * NI);
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const int m = m0 + row;
-      if (m >= Mtot) continue;
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) S[((r & 3) + 8 * (r >> 2) + 4 * lh) * ES + ni * 32 + l31] = acc[mi][ni][r] * p.out_scale;
+#pragma unroll
+    for (int k = 0; k < 4 * NI; ++k) {
+      const int idx = lane + 64 * k;
+      const int rl = idx / F4, c = (idx % F4) * 4;
+      const int m = m0 + wm * 64 + mi * 32 + rl;
+      const int col = colw + c;
+      if (m >= Mtot || col >= p.Cout) continue;
       long long pix = m;
       if (p.sv != 1) {
         const int q = m / p.V, v = m - q * p.V;
         const int b = q / p.U, u = q - b * p.U;
         pix = static_cast<long long>(b) * UV + u * p.su + v * p.sv;
       }
+      const float4 a4 = *reinterpret_cast<const float4*>(S + rl * ES + c);
+      float y[4] = {a4.x, a4.y, a4.z, a4.w};
+      const int nv = p.Cout - col < 4 ? p.Cout - col : 4;      // valid columns of this quad (Cout = 126 -> tail of 2)
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        const int col = n0 + wn * (32 * NI) + ni * 32 + l31;
-        if (col >= p.Cout) continue;
-        const float y = acc[mi][ni][r] * p.out_scale + p.bias[col];
-        if (p.epi == 0) {
-          p.dst[pix * p.dst_cs + p.dst_co + col] = y;
-        } else if (p.epi == 1) {
-          p.dst[pix * p.dst_cs + p.dst_co + col] = fmaxf(y, 0.f);
-        } else if (p.epi == 2) {
-          if (col < p.gru_c) {
-            p.dst[pix * p.dst_cs + p.dst_co + col] = sigmoidf_(y);                       // z
-          } else {
-            const int c2 = col - p.gru_c;
-            const float hv = p.aux0[pix * p.aux0_cs + p.aux0_co + c2];
-            p.dst2[pix * p.dst2_cs + p.dst2_co + c2] = sigmoidf_(y) * hv;                // r * h
-          }
+      for (int e = 0; e < 4; ++e) y[e] += (e < nv) ? p.bias[col + e] : 0.f;
+      float* dptr = p.dst + pix * p.dst_cs + p.dst_co + col;
+      if (p.epi == 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = fmaxf(y[e], 0.f);
+      } else if (p.epi == 2) {
+        if (col < p.gru_c) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) y[e] = sigmoidf_(y[e]);                             // z
         } else {
-          const float z = p.aux1[pix * p.aux1_cs + p.aux1_co + col];
-          const float hv = p.aux0[pix * p.aux0_cs + p.aux0_co + col];
-          p.dst[pix * p.dst_cs + p.dst_co + col] = (1.f - z) * hv + z * tanhf(y);        // h' = (1-z)h + z q
+          const int c2 = col - p.gru_c;
+          const float4 hv = *reinterpret_cast<const float4*>(p.aux0 + pix * p.aux0_cs + p.aux0_co + c2);
+          y[0] = sigmoidf_(y[0]) * hv.x; y[1] = sigmoidf_(y[1]) * hv.y;                   // r * h
+          y[2] = sigmoidf_(y[2]) * hv.z; y[3] = sigmoidf_(y[3]) * hv.w;
+          dptr = p.dst2 + pix * p.dst2_cs + p.dst2_co + c2;
         }
+      } else if (p.epi == 3) {
+        const float4 z = *reinterpret_cast<const float4*>(p.aux1 + pix * p.aux1_cs + p.aux1_co + col);
+        const float4 hv = *reinterpret_cast<const float4*>(p.aux0 + pix * p.aux0_cs + p.aux0_co + col);
+        y[0] = (1.f - z.x) * hv.x + z.x * tanhf(y[0]); y[1] = (1.f - z.y) * hv.y + z.y * tanhf(y[1]);   // h' = (1-z)h + z q
+        y[2] = (1.f - z.z) * hv.z + z.z * tanhf(y[2]); y[3] = (1.f - z.w) * hv.w + z.w * tanhf(y[3]);
+      }
+      if (nv == 4) {
+        *reinterpret_cast<float4*>(dptr) = make_float4(y[0], y[1], y[2], y[3]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 3; ++e)
+          if (e < nv) dptr[e] = y[e];
       }
     }
   }
@@ -406,9 +440,19 @@ int rnnpose_conv2d_nhwc_f16x3(const rnnpose_conv_desc_t* d, rnnpose_stream_t str
   RP_REQUIRE((d->kh & 1) && (d->kw & 1) && d->kh <= 7 && d->kw <= 7, fn, "odd kernel sizes up to 7");
   RP_REQUIRE(d->w_hi && d->w_lo && d->bias && d->dst, fn, "null pointer");
   RP_REQUIRE(d->epilogue >= 0 && d->epilogue <= 3, fn, "epilogue must be 0..3");
+  RP_REQUIRE(d->stride == 1 || d->stride == 2, fn, "stride must be 1 or 2");
   RP_REQUIRE(d->a_scale > 0.f && d->w_scale > 0.f, fn, "scales must be positive");
   if (d->epilogue == 2) RP_REQUIRE(d->aux0 && d->dst2 && d->gru_c > 0 && d->c_out == 2 * d->gru_c, fn, "gru_zr needs aux0 (h), dst2 (r*h), c_out == 2*gru_c");
   if (d->epilogue == 3) RP_REQUIRE(d->aux0 && d->aux1, fn, "gru_q needs aux0 (h) and aux1 (z)");
+  RP_REQUIRE(d->dst_c_stride % 4 == 0 && d->dst_c_offset % 4 == 0 && reinterpret_cast<uintptr_t>(d->dst) % 16 == 0, fn,
+             "dst: 16-byte aligned, channel stride/offset multiples of 4");
+  if (d->epilogue >= 2) {
+    RP_REQUIRE(d->c_out % 4 == 0 && d->gru_c % 4 == 0, fn, "GRU epilogues need c_out % 4 == 0");
+    RP_REQUIRE(d->aux0_c_stride % 4 == 0 && d->aux0_c_offset % 4 == 0 && reinterpret_cast<uintptr_t>(d->aux0) % 16 == 0, fn,
+               "aux0: 16-byte aligned, channel stride/offset multiples of 4");
+  }
+  if (d->epilogue == 2) RP_REQUIRE(d->dst2_c_stride % 4 == 0 && d->dst2_c_offset % 4 == 0 && reinterpret_cast<uintptr_t>(d->dst2) % 16 == 0, fn, "dst2 alignment");
+  if (d->epilogue == 3) RP_REQUIRE(d->aux1_c_stride % 4 == 0 && d->aux1_c_offset % 4 == 0 && reinterpret_cast<uintptr_t>(d->aux1) % 16 == 0, fn, "aux1 alignment");
   KParams p{};
   int counts[4];
   for (int s = 0; s < d->n_src; ++s) {
@@ -438,6 +482,14 @@ int rnnpose_conv2d_nhwc_f16x3(const rnnpose_conv_desc_t* d, rnnpose_stream_t str
     p.U = d->H; p.V = d->W; p.su = d->W; p.sv = 1;
     p.G = d->kh; p.T = d->kw; p.du0 = -(d->kh / 2); p.dv0 = -(d->kw / 2);
   }
+  p.stride = 1; p.Uin = p.U; p.Vin = p.V; p.gkw = 0; p.dvg0 = 0;
+  int Ho = d->H, Wo = d->W;
+  if (d->stride == 2) {      // strided: every tap is its own group (no tap sharing), row-major tiling over the OUTPUT
+    Ho = (d->H + 1) / 2; Wo = (d->W + 1) / 2;
+    p.stride = 2; p.Uin = d->H; p.Vin = d->W; p.su = d->W; p.sv = 1;
+    p.U = Ho; p.V = Wo;
+    p.G = d->kh * d->kw; p.T = 1; p.gkw = d->kw; p.du0 = -(d->kh / 2); p.dvg0 = -(d->kw / 2); p.dv0 = 0;
+  }
   RP_REQUIRE(p.T / 2 <= HALO, fn, "kernel too wide for the staged halo");
   p.whi = static_cast<const _Float16*>(d->w_hi);
   p.wlo = static_cast<const _Float16*>(d->w_lo);
@@ -451,19 +503,33 @@ int rnnpose_conv2d_nhwc_f16x3(const rnnpose_conv_desc_t* d, rnnpose_stream_t str
   p.aux1 = d->aux1; p.aux1_cs = d->aux1_c_stride; p.aux1_co = d->aux1_c_offset;
   p.dst2 = d->dst2; p.dst2_cs = d->dst2_c_stride; p.dst2_co = d->dst2_c_offset;
   p.gru_c = d->gru_c;
-  const long long Mtot = static_cast<long long>(d->B) * d->H * d->W;
-  RP_REQUIRE(Mtot < (1LL << 31) - 256, fn, "too many pixels");
+  const long long Mtot = static_cast<long long>(d->B) * Ho * Wo;
+  RP_REQUIRE(Mtot < (1LL << 31) - 256 && static_cast<long long>(d->B) * d->H * d->W < (1LL << 31) - 256, fn, "too many pixels");
   p.n_mt = rp::cdiv(Mtot, BM);
+  {
+    const char* e = getenv("RNNPOSE_CONV_DBG");
+    p.dbg = e ? atoi(e) : 0;
+  }
   // tile width: 128 when Cout fills it and there are enough workgroups for 2 per CU, else 64
-  const bool wide = (d->c_out % 128 == 0) && (static_cast<long long>(p.n_mt) * (d->c_out / 128) >= 512);
+  bool wide = (d->c_out % 128 == 0) && (static_cast<long long>(p.n_mt) * (d->c_out / 128) >= 512);
+  if (p.dbg & 32) wide = false;
+  if (p.dbg & 64) wide = (d->c_out % 128 == 0);
   if (wide) {
     p.n_nt = p.Npad / 128;
-    hipLaunchKernelGGL(conv_igemm_f16x3_kernel<2>, dim3(static_cast<unsigned>(p.n_mt) * p.n_nt), dim3(NT), 0,
-                       rp::as_stream(stream), p);
+    if (p.stride == 2)
+      hipLaunchKernelGGL((conv_igemm_f16x3_kernel<2, true>), dim3(static_cast<unsigned>(p.n_mt) * p.n_nt), dim3(NT), 0,
+                         rp::as_stream(stream), p);
+    else
+      hipLaunchKernelGGL((conv_igemm_f16x3_kernel<2, false>), dim3(static_cast<unsigned>(p.n_mt) * p.n_nt), dim3(NT), 0,
+                         rp::as_stream(stream), p);
   } else {
     p.n_nt = rp::cdiv(d->c_out, 64);
-    hipLaunchKernelGGL(conv_igemm_f16x3_kernel<1>, dim3(static_cast<unsigned>(p.n_mt) * p.n_nt), dim3(NT), 0,
-                       rp::as_stream(stream), p);
+    if (p.stride == 2)
+      hipLaunchKernelGGL((conv_igemm_f16x3_kernel<1, true>), dim3(static_cast<unsigned>(p.n_mt) * p.n_nt), dim3(NT), 0,
+                         rp::as_stream(stream), p);
+    else
+      hipLaunchKernelGGL((conv_igemm_f16x3_kernel<1, false>), dim3(static_cast<unsigned>(p.n_mt) * p.n_nt), dim3(NT), 0,
+                         rp::as_stream(stream), p);
   }
   return rp::check_launch(fn);
 }

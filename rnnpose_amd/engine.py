@@ -42,7 +42,7 @@ class UpdateEngine:
         w = dict(
             convc1=P(e.convc1.weight, e.convc1.bias, [e.convc1.weight.shape[1]]),
             convc2=P(e.convc2.weight, e.convc2.bias, [256]),
-            convf1=P(wf1, e.convf1.bias, [4]),
+            convf1=P(wf1, e.convf1.bias, [4]),                      # (algorithmic flops counted on the 2 real channels)
             convf2=P(e.convf2.weight, e.convf2.bias, [128]),
             conv=P(e.conv.weight, e.conv.bias, [256]),
             zr1=P(cat(g.convz1.weight, g.convr1.weight), cat(g.convz1.bias, g.convr1.bias), [128, 128, 128]),
@@ -54,6 +54,7 @@ class UpdateEngine:
             flow2_w=b.flow_head.conv2.weight.detach().float().contiguous(),
             flow2_b=b.flow_head.conv2.bias.detach().float().contiguous(),
         )
+        w["convf1"].c_in_real = 2
         self._key, self._w = key, w
         return w
 
@@ -105,10 +106,10 @@ class UpdateEngine:
 
 
 class EncoderEngine:
-    """RAFT BasicEncoder (instance-norm variant, thirdparty/raft/extractor.py:118-232) executed NHWC: all stride-1
-    3x3 convolutions and the 1x1 output convolution run in the hand-written implicit-GEMM kernel, instance norm /
-    ReLU / residual adds in one fused HIP pass each.  The 7x7 stride-2 stem and the three stride-2 convolutions
-    (8 % of the FLOPs) stay on MIOpen in channels_last layout (their outputs are NHWC already)."""
+    """RAFT BasicEncoder (instance-norm variant, thirdparty/raft/extractor.py:118-232) executed NHWC: all 3x3
+    convolutions and the 1x1 output convolution run in the hand-written implicit-GEMM kernel, instance norm /
+    ReLU / residual adds in one fused HIP pass each; the stride-2 3x3 / 1x1 convolutions use the kernel's strided mode.
+    Only the 7x7 stride-2 stem on 3 input channels (1.4 of 41 GFLOP/image) stays on MIOpen, channels_last (= NHWC)."""
 
     def __init__(self, fnet):
         self.fnet = fnet
@@ -120,9 +121,10 @@ class EncoderEngine:
         convs = {}
         for li, layer in enumerate((f.layer1, f.layer2, f.layer3), start=1):
             for bi, blk in enumerate(layer):
-                if blk.downsample is None:
-                    convs[f"l{li}.{bi}.c1"] = blk.conv1
+                convs[f"l{li}.{bi}.c1"] = blk.conv1
                 convs[f"l{li}.{bi}.c2"] = blk.conv2
+                if blk.downsample is not None:
+                    convs[f"l{li}.{bi}.down"] = blk.downsample[0]
         convs["out"] = f.conv2
         return convs
 
@@ -142,19 +144,18 @@ class EncoderEngine:
         return y.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
 
     @staticmethod
-    def _conv(pc, x):
+    def _conv(pc, x, stride=1):
         B, H, W, _ = x.shape
-        out = torch.empty(B, H, W, pc.c_out, device=x.device, dtype=torch.float32)
-        ops.conv2d_nhwc(pc, [(x, 0)], (out, 0), ops.EPI_LINEAR)
+        out = torch.empty(B, -(-H // stride), -(-W // stride), pc.c_out, device=x.device, dtype=torch.float32)
+        ops.conv2d_nhwc(pc, [(x, 0)], (out, 0), ops.EPI_LINEAR, stride=stride)
         return out
 
     def _block(self, W, name, blk, x):
-        if blk.downsample is None:
-            y = ops.instnorm_nhwc(self._conv(W[name + ".c1"], x), relu=True)
-            res = x
-        else:
-            y = ops.instnorm_nhwc(self._torch_conv(x, blk.conv1), relu=True)
-            res = ops.instnorm_nhwc(self._torch_conv(x, blk.downsample[0]), relu=False)      # norm3, no ReLU
+        st = blk.conv1.stride[0]
+        y = ops.instnorm_nhwc(self._conv(W[name + ".c1"], x, st), relu=True)
+        res = x
+        if blk.downsample is not None:
+            res = ops.instnorm_nhwc(self._conv(W[name + ".down"], x, st), relu=False)         # norm3, no ReLU
         y = self._conv(W[name + ".c2"], y)
         return ops.instnorm_nhwc(y, relu=True, residual=res)                                  # relu(x + relu(IN(.)))
 

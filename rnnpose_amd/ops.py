@@ -35,25 +35,26 @@ def profile(names=None):
 
 
 def summarize(rec) -> dict:
-    """-> {name: (n_calls, mean_ms, total_ms)} (synchronises)."""
+    """-> {name: (n_calls, mean_ms, total_ms, total_work)} (synchronises).  total_work = sum of the `work` each
+    launch declared (algorithmic flops for the convolution kernel), 0 if none."""
     torch.cuda.synchronize()
     out = {}
     for k, evs in rec.items():
         if k == "_only":
             continue
-        ms = [a.elapsed_time(b) for a, b in evs]
-        out[k] = (len(ms), sum(ms) / max(len(ms), 1), sum(ms))
+        ms = [a.elapsed_time(b) for a, b, _ in evs]
+        out[k] = (len(ms), sum(ms) / max(len(ms), 1), sum(ms), sum(w for _, _, w in evs))
     return out
 
 
-def _launch(name, *args):
+def _launch(name, *args, work=0):
     rec = _prof
     if rec is not None and (rec["_only"] is None or name in rec["_only"]):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         _lib.call(name, *args)
         b.record()
-        rec.setdefault(name, []).append((a, b))
+        rec.setdefault(name, []).append((a, b, work))
     else:
         _lib.call(name, *args)
 
@@ -297,6 +298,7 @@ class PackedConv:
         w = _chk(weight.detach(), "weight") * post_scale
         b = _chk(bias.detach(), "bias") * post_scale
         self.c_out, self.c_in, self.kh, self.kw = w.shape
+        self.c_in_real = self.c_in          # engines that zero-pad input channels overwrite this for flop accounting
         self.seg_counts = [int(c) for c in (seg_counts or [self.c_in])]
         if sum(self.seg_counts) != self.c_in:
             raise ValueError("seg_counts must sum to the input channels")
@@ -320,7 +322,8 @@ def _nhwc(t, name):
     return t
 
 
-def conv2d_nhwc(pc: PackedConv, srcs, dst, epilogue: int = EPI_LINEAR, aux0=None, aux1=None, dst2=None, gru_c: int = 0):
+def conv2d_nhwc(pc: PackedConv, srcs, dst, epilogue: int = EPI_LINEAR, aux0=None, aux1=None, dst2=None, gru_c: int = 0,
+                stride: int = 1):
     """srcs: list of (tensor (B,H,W,C), c_offset) matched with pc.seg_counts; dst/aux0/aux1/dst2: (tensor, c_offset).
     Writes in place into dst (and dst2); returns nothing."""
     d = _lib.ConvDesc()
@@ -333,7 +336,7 @@ def conv2d_nhwc(pc: PackedConv, srcs, dst, epilogue: int = EPI_LINEAR, aux0=None
             raise ValueError("sources must share (B,H,W)")
         d.src[i] = _lib.ConvSrc(t.data_ptr(), t.shape[3], off, cnt)
     d.n_src = len(srcs)
-    d.B, d.H, d.W, d.kh, d.kw = B, H, W, pc.kh, pc.kw
+    d.B, d.H, d.W, d.kh, d.kw, d.stride = B, H, W, pc.kh, pc.kw, stride
     d.w_hi, d.w_lo, d.bias = pc.w_hi.data_ptr(), pc.w_lo.data_ptr(), pc.bias.data_ptr()
     d.c_out, d.a_scale, d.w_scale, d.epilogue = pc.c_out, pc.a_scale, pc.w_scale, epilogue
 
@@ -351,7 +354,8 @@ def conv2d_nhwc(pc: PackedConv, srcs, dst, epilogue: int = EPI_LINEAR, aux0=None
     put("aux1", aux1)
     put("dst2", dst2)
     d.gru_c = gru_c
-    _launch("rnnpose_conv2d_nhwc_f16x3", C.byref(d), _stream())
+    _launch("rnnpose_conv2d_nhwc_f16x3", C.byref(d), _stream(),
+            work=2.0 * B * (-(-H // stride)) * (-(-W // stride)) * pc.c_out * pc.c_in_real * pc.kh * pc.kw)
 
 
 # ---- NHWC companions ------------------------------------------------------------------------------------------

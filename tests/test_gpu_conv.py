@@ -61,12 +61,29 @@ def test_conv_linear_relu(ops, B, H, W, segs, cout, kh, kw):
         t[..., 4:4 + c] = nhwc(xd[:, off:off + c])
         xs.append((t, 4))
         off += c
-    out = torch.full((B, H, W, cout + 12), 7.0, device="cuda")
+    out = torch.full((B, H, W, (cout + 15) // 4 * 4), 7.0, device="cuda")     # channel stride must be a multiple of 4
     ops.conv2d_nhwc(pc, xs, (out, 8), ops.EPI_LINEAR)
     check(nchw(out[..., 8:8 + cout]), y64, y32, f"{kh}x{kw} linear")
     assert float((out[..., :8] - 7).abs().max()) == 0 and float((out[..., 8 + cout:] - 7).abs().max()) == 0
     ops.conv2d_nhwc(pc, xs, (out, 8), ops.EPI_RELU)
     check(nchw(out[..., 8:8 + cout]), y64.clamp(min=0), y32.clamp(min=0), f"{kh}x{kw} relu")
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout,k", [(2, 16, 24, 64, 96, 3), (1, 15, 21, 96, 128, 3), (2, 16, 24, 64, 96, 1),
+                                              (1, 9, 7, 96, 128, 1)])
+def test_conv_stride2(ops, B, H, W, cin, cout, k):
+    """The encoder's strided convolutions (extractor.py:9,44: 3x3 stride 2 pad 1; 1x1 stride 2 pad 0)."""
+    x = syn.normal("x", (B, cin, H, W), 3, std=1.5)
+    w = syn.normal("w", (cout, cin, k, k), 3, std=float(np.sqrt(2.0 / (cin * k * k))))
+    b = syn.uniform("b", (cout,), 3, -0.5, 0.5)
+    xd, wd, bd = D(x), D(w), D(b)
+    y64 = F.conv2d(xd.double(), wd.double(), bd.double(), stride=2, padding=k // 2)
+    y32 = F.conv2d(xd, wd, bd, stride=2, padding=k // 2)
+    pc = ops.PackedConv(wd, bd, [cin])
+    out = torch.empty(B, (H + 1) // 2, (W + 1) // 2, cout, device="cuda")
+    assert tuple(out.shape[1:3]) == tuple(y64.shape[2:])
+    ops.conv2d_nhwc(pc, [(nhwc(xd), 0)], (out, 0), ops.EPI_LINEAR, stride=2)
+    check(nchw(out), y64, y32, f"{k}x{k} stride 2")
 
 
 @pytest.mark.parametrize("kh,kw", [(1, 5), (5, 1)])
