@@ -213,6 +213,25 @@ int rnnpose_instnorm_nhwc_f32(const float* x, int B, int HW, int C, float eps, i
                               void* workspace, size_t workspace_bytes, float* mean_rstd, float* out,
                               rnnpose_stream_t stream);
 
+/* ---- f3 ("next"): brute-force nearest neighbour for ADD-S ------ thirdparty/nn/src/nearest_neighborhood.cu:48-163
+ * idxs[b,q] = argmin_r |ref[b,r,:] - que[b,q,:]|^2, first minimum wins, optional r != q; dim 2 or 3.
+ * rnnpose_nn_search_f32: DEVICE pointers, asynchronous.
+ * findNearestPointIdxLauncher: the reference's own cffi symbol (thirdparty/nn/src/ext.h:1-10): HOST pointers,
+ * synchronous, same argument list -- thirdparty/nn/nn_utils.py binds to this library unchanged.              */
+int rnnpose_nn_search_f32(const float* ref_pts, const float* que_pts, int* idxs, int b, int pn1, int pn2, int dim,
+                          int exclude_self, rnnpose_stream_t stream);
+void findNearestPointIdxLauncher(float* ref_pts, float* que_pts, int* idxs, int b, int pn1, int pn2, int dim,
+                                 int exclude_self);
+
+/* ---- f2 ("next"): LINEMOD pose metrics on device -------------------- utils/eval_metric.py:28-37,102-192
+ * model (P,3), pose_pred / pose_gt (B,3,4), K (3,3) -> out (B,5) fp64 = [mean ADD distance, mean ADD-S distance
+ * (nearest predicted point of every target point; -1 unless symmetric), mean 2-D projection error in px,
+ * translation error in cm, rotation error in degrees].  Thresholding (0.1/0.02/0.05 diameter, 5 px, 5 cm 5 deg)
+ * is host logic (rnnpose_amd/evaluator.py).  workspace is only needed when symmetric != 0.                    */
+size_t rnnpose_pose_metrics_workspace_bytes(int B, int P);
+int rnnpose_pose_metrics_f64(const float* model, int P, const float* pose_pred, const float* pose_gt, const float* K, int B,
+                             int symmetric, void* workspace, size_t workspace_bytes, double* out, rnnpose_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

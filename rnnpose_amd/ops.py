@@ -427,3 +427,27 @@ def instnorm_nhwc(x, relu=True, residual=None, out=None, eps: float = 1e-5):
     _launch("rnnpose_instnorm_nhwc_f32", _ptr(x), B, H * W, Cc, eps, int(bool(relu)), _ptr(residual), _ptr(ws), n,
             _ptr(stats), _ptr(out), _stream())
     return out
+
+
+# ---- f2/f3: evaluator metrics ------------------------------------------------------------------------------------
+def nn_search(ref_pts, que_pts, exclude_self: bool = False):
+    """ref (B,N1,D), que (B,N2,D) fp32 on the GPU, D in {2,3} -> idx (B,N2) int32: first nearest reference point."""
+    ref_pts, que_pts = _chk(ref_pts, "ref_pts"), _chk(que_pts, "que_pts")
+    B, n1, dim = ref_pts.shape
+    n2 = que_pts.shape[1]
+    idx = torch.empty(B, n2, device=ref_pts.device, dtype=torch.int32)
+    _launch("rnnpose_nn_search_f32", _ptr(ref_pts), _ptr(que_pts), _ptr(idx), B, n1, n2, dim, int(exclude_self), _stream())
+    return idx
+
+
+def pose_metrics(model, pose_pred, pose_gt, K, symmetric: bool = False):
+    """model (P,3), pose_pred/pose_gt (B,3,4), K (3,3) -> (B,5) fp64 [ADD, ADD-S (-1 if not symmetric), proj2d px,
+    translation cm, rotation deg]   (utils/eval_metric.py:102-192)."""
+    model, pose_pred, pose_gt, K = _chk(model, "model"), _chk(pose_pred, "pose_pred"), _chk(pose_gt, "pose_gt"), _chk(K, "K")
+    P, B = model.shape[0], pose_pred.shape[0]
+    n = int(_lib.load().rnnpose_pose_metrics_workspace_bytes(B, P)) if symmetric else 0
+    ws = torch.empty(max(n, 4) // 4, device=model.device, dtype=F32)
+    out = torch.empty(B, 5, device=model.device, dtype=F64)
+    _launch("rnnpose_pose_metrics_f64", _ptr(model), P, _ptr(pose_pred), _ptr(pose_gt), _ptr(K), B, int(symmetric),
+            _ptr(ws), n, _ptr(out), _stream())
+    return out

@@ -19,7 +19,7 @@ def lib():
 def declared_symbols():
     src = open(os.path.join(ROOT, "include", "rnnpose_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(rnnpose_[a-z0-9_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(rnnpose_[a-z0-9_]+|findNearestPointIdxLauncher)\s*\(", src)))
 
 
 def test_header_symbols_exported_and_typed(lib):
