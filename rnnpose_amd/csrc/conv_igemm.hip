@@ -91,8 +91,12 @@ __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-
 template <int NI, bool STRIDED>
 __global__ __launch_bounds__(NT, 2) void conv_igemm_f16x3_kernel(const KParams p) {
   constexpr int BNT = 64 * NI;
-  __shared__ __attribute__((aligned(16))) _Float16 sA[2][AROWS * RS];      // hi, lo            21.8 KB
-  __shared__ __attribute__((aligned(16))) _Float16 sB[2][2][BNT * RS];     // [buf][hi,lo]      40 / 20 KB
+  // activation tile only, double-buffered: [buffer][hi, lo][row * RS + k]  (43.5 KB).  Weights never touch LDS: each
+  // wave loads its own MFMA B fragments straight from the fragment-ordered packed array (two waves of a workgroup read
+  // the same lines; the second hits L1).  r01 ablation: staging weights through LDS cost 16 % in ds_write alone, made
+  // the LDS pipe a co-bottleneck with the matrix pipe, and needed a barrier per tap (now: one per 32-channel block).
+  __shared__ __attribute__((aligned(16))) _Float16 sA[2][2][AROWS * RS];
+  _Float16* const sAf = &sA[0][0][0];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, lh = lane >> 5;
@@ -115,16 +119,15 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_f16x3_kernel(const KParams p
   // (named scalars + macros on purpose: arrays / structs captured by lambdas end up in scratch or LDS here)
   const int c4 = tid & 7;
 #define RP_ROW_INIT(R_)                                                                                     \
-  int a_pix##R_, a_u##R_, a_v##R_;                                                                          \
-  bool a_ok##R_;                                                                                            \
+  int a_pix##R_, a_u##R_, a_v##R_;   /* rows outside the problem carry a_u = -2^20: every range test fails */ \
   {                                                                                                         \
     const int j_ = (tid >> 3) + 32 * R_;                                                                    \
     const int m_ = m0 - HALO + j_;                                                                          \
-    a_ok##R_ = (j_ < AROWS) && m_ >= 0 && m_ < Mtot;                                                        \
-    const int mm_ = a_ok##R_ ? m_ : 0;                                                                      \
+    const bool okr_ = (j_ < AROWS) && m_ >= 0 && m_ < Mtot;                                                 \
+    const int mm_ = okr_ ? m_ : 0;                                                                          \
     const int q_ = mm_ / p.V, v_ = mm_ - q_ * p.V;                                                          \
     const int b_ = q_ / p.U, u_ = q_ - b_ * p.U;                                                            \
-    a_u##R_ = STRIDED ? u_ * 2 : u_;                                                                        \
+    a_u##R_ = okr_ ? (STRIDED ? u_ * 2 : u_) : -(1 << 20);                                                  \
     a_v##R_ = STRIDED ? v_ * 2 : 0;                                                                         \
     a_pix##R_ = STRIDED ? b_ * (p.Uin * p.Vin) : b_ * UV + u_ * p.su + v_ * p.sv;                           \
   }
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_f16x3_kernel(const KParams p
     float4 v_ = make_float4(0.f, 0.f, 0.f, 0.f);                                                            \
     const int uu_ = a_u##R_ + du_, vv_ = a_v##R_ + dvg_;                                                    \
     const bool in_ = STRIDED ? (uu_ >= 0 && uu_ < p.Uin && vv_ >= 0 && vv_ < p.Vin) : (uu_ >= 0 && uu_ < p.U); \
-    if (a_ok##R_ && in_ && c_ < sg_.ccount) {                                                               \
+    if (in_ && c_ < sg_.ccount) {                                                                           \
       const long long px_ = STRIDED ? a_pix##R_ + uu_ * p.su + vv_ * p.sv : a_pix##R_ + du_ * p.su;         \
       const float* q_ = sg_.ptr + px_ * sg_.cstride + sg_.coff + c_;                                        \
       if (c_ + 3 < sg_.ccount) {                                                                            \
@@ -176,103 +179,109 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_f16x3_kernel(const KParams p
     const int dvg_ = STRIDED ? p.dvg0 + (G_) % p.gkw : 0;                                                   \
     RP_LOAD_A_ROW(0) RP_LOAD_A_ROW(1) RP_LOAD_A_ROW(2) RP_LOAD_A_ROW(3) RP_LOAD_A_ROW(4)                    \
   } while (0)
-#define RP_STORE_A_ROW(R_)                                                                                  \
+#define RP_STORE_A_ROW(R_, AB_)                                                                             \
   {                                                                                                         \
     const int j_ = (tid >> 3) + 32 * R_;                                                                    \
     if (j_ < AROWS) {                                                                                       \
       h4 hi_, lo_;                                                                                          \
       split4(av##R_, p.a_scale, hi_, lo_);                                                                  \
-      *reinterpret_cast<h4*>(&sA[0][j_ * RS + c4 * 4]) = hi_;                                               \
-      *reinterpret_cast<h4*>(&sA[1][j_ * RS + c4 * 4]) = lo_;                                               \
+      *reinterpret_cast<h4*>(sAf + (AB_) * (2 * AROWS * RS) + j_ * RS + c4 * 4) = hi_;                      \
+      *reinterpret_cast<h4*>(sAf + (AB_) * (2 * AROWS * RS) + AROWS * RS + j_ * RS + c4 * 4) = lo_;         \
     }                                                                                                       \
   }
-#define RP_STORE_A() do { RP_STORE_A_ROW(0) RP_STORE_A_ROW(1) RP_STORE_A_ROW(2) RP_STORE_A_ROW(3) RP_STORE_A_ROW(4) } while (0)
-  // weight tile registers: plain named locals + macros (a struct handed to a lambda by reference ends up as a
-  // per-thread LDS slot: +16 KB/block and an LDS round trip per tap).  TWO sets: tile i+2 is requested while tile
-  // i is consumed, so an L2/HBM round trip has two MFMA phases (>= 1500 cycles) to complete.
-  uint4 b0h0, b0h1, b0l0, b0l1, b1h0, b1h1, b1l0, b1l1;
+#define RP_STORE_A(AB_) do { RP_STORE_A_ROW(0, AB_) RP_STORE_A_ROW(1, AB_) RP_STORE_A_ROW(2, AB_) RP_STORE_A_ROW(3, AB_) RP_STORE_A_ROW(4, AB_) } while (0)
+  // weight fragment registers: two stages (named locals + macros: structs/arrays handed to lambdas end up in LDS or
+  // scratch with this compiler).  Stage S holds, for the tap being consumed, this wave's B fragments
+  // [ni][kk] x (hi, lo): 16 bytes per lane each, already in MFMA operand order.
+  uint4 b0h00, b0h01, b0h10, b0h11, b0l00, b0l01, b0l10, b0l11;
+  uint4 b1h00, b1h01, b1h10, b1h11, b1l00, b1l01, b1l10, b1l11;
+  const int ntile0 = (n0 >> 5) + wn * NI;             // first 32-column tile of this wave
+  const int ntiles32 = p.Npad >> 5;
 #define RP_LOAD_B(S_, G_, T_, CB_)                                                                          \
   do {                                                                                                      \
-    const long long tile_ = ((static_cast<long long>(G_) * p.T + (T_)) * p.ncb + (CB_)) * p.Npad + n0;     \
-    const uint4* hs_ = reinterpret_cast<const uint4*>(p.whi + tile_ * BK);                                  \
-    const uint4* ls_ = reinterpret_cast<const uint4*>(p.wlo + tile_ * BK);                                  \
-    b##S_##h0 = hs_[tid];                                                                                   \
-    b##S_##l0 = ls_[tid];                                                                                   \
+    const long long f_ = (((static_cast<long long>(G_) * p.T + (T_)) * p.ncb + (CB_)) * ntiles32 + ntile0) * 128 + lane; \
+    const uint4* hs_ = reinterpret_cast<const uint4*>(p.whi) + f_;                                          \
+    const uint4* ls_ = reinterpret_cast<const uint4*>(p.wlo) + f_;                                          \
+    b##S_##h00 = hs_[0];                                                                                    \
+    b##S_##h01 = hs_[64];                                                                                   \
+    b##S_##l00 = ls_[0];                                                                                    \
+    b##S_##l01 = ls_[64];                                                                                   \
     if (NI == 2) {                                                                                          \
-      b##S_##h1 = hs_[tid + NT];                                                                            \
-      b##S_##l1 = ls_[tid + NT];                                                                            \
+      b##S_##h10 = hs_[128];                                                                                \
+      b##S_##h11 = hs_[192];                                                                                \
+      b##S_##l10 = ls_[128];                                                                                \
+      b##S_##l11 = ls_[192];                                                                                \
     }                                                                                                       \
   } while (0)
-#define RP_STORE_B(S_)                                                                                      \
-  do {                                                                                                      \
-    const int row0_ = tid >> 2, qd_ = tid & 3; /* second chunk: index tid + 256 -> row0 + 64 */            \
-    *reinterpret_cast<uint4*>(&sB[S_][0][row0_ * RS + qd_ * 8]) = b##S_##h0;                                \
-    *reinterpret_cast<uint4*>(&sB[S_][1][row0_ * RS + qd_ * 8]) = b##S_##l0;                                \
-    if (NI == 2) {                                                                                          \
-      *reinterpret_cast<uint4*>(&sB[S_][0][(row0_ + 64) * RS + qd_ * 8]) = b##S_##h1;                       \
-      *reinterpret_cast<uint4*>(&sB[S_][1][(row0_ + 64) * RS + qd_ * 8]) = b##S_##l1;                       \
+#define RP_MMA_KK(S_, KK_, AB_)                                                                             \
+  {                                                                                                         \
+    const int ko = KK_ * 16 + lh * 8;                                                                       \
+    h8 ah[2], al[2], bh[2], bl[2];                                                                          \
+    _Pragma("unroll") for (int mi = 0; mi < 2; ++mi) {                                                      \
+      const int row = wm * 64 + mi * 32 + l31 + HALO + dv_;                                                 \
+      ah[mi] = *reinterpret_cast<const h8*>(sAf + (AB_) * (2 * AROWS * RS) + row * RS + ko);               \
+      al[mi] = *reinterpret_cast<const h8*>(sAf + (AB_) * (2 * AROWS * RS) + AROWS * RS + row * RS + ko);  \
     }                                                                                                       \
-  } while (0)
-#define RP_MMA(S_, DV_)                                                                                     \
+    if (!ok0_) { ah[0] = zero_; al[0] = zero_; }                                                            \
+    if (!ok1_) { ah[1] = zero_; al[1] = zero_; }                                                            \
+    bh[0] = __builtin_bit_cast(h8, b##S_##h0##KK_);                                                         \
+    bl[0] = __builtin_bit_cast(h8, b##S_##l0##KK_);                                                         \
+    if (NI == 2) {                                                                                          \
+      bh[1] = __builtin_bit_cast(h8, b##S_##h1##KK_);                                                       \
+      bl[1] = __builtin_bit_cast(h8, b##S_##l1##KK_);                                                       \
+    }                                                                                                       \
+    /* term-major: the accumulator tiles are independent, consecutive MFMAs never wait on each other */    \
+    _Pragma("unroll") for (int mi = 0; mi < 2; ++mi) _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)      \
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);        \
+    _Pragma("unroll") for (int mi = 0; mi < 2; ++mi) _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)      \
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);        \
+    _Pragma("unroll") for (int mi = 0; mi < 2; ++mi) _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)      \
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);        \
+  }
+#define RP_MMA(S_, DV_, AB_)                                                                                \
   do {                                                                                                      \
     const int dv_ = (DV_);                                                                                  \
     const bool ok0_ = static_cast<unsigned>(fv[0] + dv_) < static_cast<unsigned>(p.V);                      \
     const bool ok1_ = static_cast<unsigned>(fv[1] + dv_) < static_cast<unsigned>(p.V);                      \
     const h8 zero_ = {0, 0, 0, 0, 0, 0, 0, 0};                                                              \
-    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                                      \
-      const int ko = kk * 16 + lh * 8;                                                                      \
-      h8 ah[2], al[2], bh[NI], bl[NI];                                                                      \
-      _Pragma("unroll") for (int mi = 0; mi < 2; ++mi) {                                                    \
-        const int row = wm * 64 + mi * 32 + l31 + HALO + dv_;                                               \
-        ah[mi] = *reinterpret_cast<const h8*>(&sA[0][row * RS + ko]);                                       \
-        al[mi] = *reinterpret_cast<const h8*>(&sA[1][row * RS + ko]);                                       \
-      }                                                                                                     \
-      if (!ok0_) { ah[0] = zero_; al[0] = zero_; }                                                          \
-      if (!ok1_) { ah[1] = zero_; al[1] = zero_; }                                                          \
-      _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) {                                                   \
-        const int row = wn * (32 * NI) + ni * 32 + l31;                                                     \
-        bh[ni] = *reinterpret_cast<const h8*>(&sB[S_][0][row * RS + ko]);                                   \
-        bl[ni] = *reinterpret_cast<const h8*>(&sB[S_][1][row * RS + ko]);                                   \
-      }                                                                                                     \
-      /* term-major: the 4 accumulator tiles are independent, consecutive MFMAs never wait on each other */ \
-      _Pragma("unroll") for (int mi = 0; mi < 2; ++mi) _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)    \
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);      \
-      _Pragma("unroll") for (int mi = 0; mi < 2; ++mi) _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)    \
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);      \
-      _Pragma("unroll") for (int mi = 0; mi < 2; ++mi) _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)    \
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);      \
-    }                                                                                                       \
+    RP_MMA_KK(S_, 0, AB_)                                                                                   \
+    RP_MMA_KK(S_, 1, AB_)                                                                                   \
   } while (0)
-  // one pipeline stage: (activation tile on the first tap of a (group, block)) -> stage weight tile i in LDS buffer
-  // S_ -> request tile i+2 into the same registers -> barrier -> MFMAs of tile i
+  // one pipeline stage = one tap of one (group, 32-channel block):
+  //   first tap: request the NEXT block's activation rows (consumed T taps later)
+  //   MFMAs of this tap (activations from LDS buffer `ab`, weights from stage-S registers)
+  //   refill stage S with the weights of tap i+2
+  //   last tap: split + store the next activation tile into the other LDS buffer, ONE barrier, swap buffers
 #define RP_STAGE(S_)                                                                                        \
   do {                                                                                                      \
-    if (ct == 0) {                                                                                          \
-      if (!(p.dbg & 8)) RP_STORE_A();                                                                       \
-      int ncb_ = ccb + 1, ng_ = cg;                                                                         \
-      if (ncb_ == p.ncb) { ncb_ = 0; ++ng_; }                                                               \
-      if (ng_ < p.G) RP_LOAD_A(ng_, ncb_);                                                                  \
+    int ncb_ = ccb + 1, ng_ = cg;                                                                           \
+    if (ncb_ == p.ncb) { ncb_ = 0; ++ng_; }                                                                 \
+    if (ct == 0 && ng_ < p.G && !(p.dbg & 512)) RP_LOAD_A(ng_, ncb_);                                       \
+    if (!(p.dbg & 4)) {                                                                                     \
+      RP_MMA(S_, p.dv0 + ct, ab);                                                                           \
     }                                                                                                       \
-    if (!(p.dbg & 2)) RP_STORE_B(S_);                                                                       \
     if (pg < p.G && !(p.dbg & 1)) RP_LOAD_B(S_, pg, pt, pcb);                                               \
     if (++pt == p.T) { pt = 0; if (++pcb == p.ncb) { pcb = 0; ++pg; } }                                     \
-    if (!(p.dbg & 16)) __syncthreads();                                                                     \
-    if (!(p.dbg & 4)) RP_MMA(S_, p.dv0 + ct);                                                               \
     if (++ct == p.T) {                                                                                      \
       ct = 0;                                                                                               \
-      if (++ccb == p.ncb) { ccb = 0; ++cg; }                                                                \
-      if (!(p.dbg & 16)) __syncthreads(); /* every wave is done with this activation tile before it is overwritten */ \
+      ccb = ncb_; cg = ng_;                                                                                 \
+      if (ng_ < p.G && !(p.dbg & 8)) RP_STORE_A(ab ^ 1);                                                    \
+      if (!(p.dbg & 16)) __syncthreads();                                                                   \
+      ab ^= 1;                                                                                              \
     }                                                                                                       \
   } while (0)
 
   RP_LOAD_A(0, 0);
-  int cg = 0, ccb = 0, ct = 0;     // coordinates of the tile being consumed
-  int pg = 0, pcb = 0, pt = 0;     // coordinates of the next tile to request
+  RP_STORE_A(0);
+  int ab = 0;                      // LDS buffer holding the activation tile being consumed
+  int cg = 0, ccb = 0, ct = 0;     // coordinates of the tap being consumed
+  int pg = 0, pcb = 0, pt = 0;     // coordinates of the next weight tile to request
   const int total = p.G * p.ncb * p.T;
   RP_LOAD_B(0, pg, pt, pcb);
   if (++pt == p.T) { pt = 0; if (++pcb == p.ncb) { pcb = 0; ++pg; } }
   if (pg < p.G) RP_LOAD_B(1, pg, pt, pcb);
   if (++pt == p.T) { pt = 0; if (++pcb == p.ncb) { pcb = 0; ++pg; } }
+  __syncthreads();
   for (int i = 0; i < total; i += 2) {
     RP_STAGE(0);
     if (i + 1 < total) RP_STAGE(1);
@@ -283,9 +292,10 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_f16x3_kernel(const KParams p
   // 16 lanes cover 256 contiguous bytes of one output pixel (the MFMA C layout would give 4-byte stores spread
   // over 2 rows per instruction: measured 0.86 TB/s, the epilogue was 35-45 % of the kernel).
   __syncthreads();
+  if (p.dbg & 256) return;
   constexpr int ES = 32 * NI + 4;                       // row stride (floats) of the staging tile
   constexpr int F4 = 8 * NI;                            // float4 per tile row
-  float* S = reinterpret_cast<float*>(&sB[0][0][0]) + wave * (32 * ES);
+  float* S = reinterpret_cast<float*>(&sA[0][0][0]) + wave * (32 * ES);    // 4 x 32 x 68 floats = 34.8 KB <= 43.5 KB
   const int colw = n0 + wn * (32 * NI);
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi) {
@@ -358,8 +368,14 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, _Float16* __res
   const long long total = static_cast<long long>(q.G) * q.T * q.ncb * q.Npad * BK;
   const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= total) return;
-  const int k = static_cast<int>(i % BK);
-  const int n = static_cast<int>((i / BK) % q.Npad);
+  // fragment order: [g][t][cb][n tile of 32][kk][lane][8]: lane l carries column n = 32*tile + (l & 31) and the 8
+  // channels k = 16*kk + 8*(l >> 5) + j  -- exactly one MFMA B operand (16 bytes per lane, 1 KB per wave load)
+  const int j8 = static_cast<int>(i % 8);
+  const int ln = static_cast<int>((i / 8) % 64);
+  const int kk = static_cast<int>((i / 512) % 2);
+  const int ntl = static_cast<int>((i / 1024) % (q.Npad / 32));
+  const int k = kk * 16 + (ln >> 5) * 8 + j8;
+  const int n = ntl * 32 + (ln & 31);
   const int cb = static_cast<int>((i / (static_cast<long long>(BK) * q.Npad)) % q.ncb);
   const int t = static_cast<int>((i / (static_cast<long long>(BK) * q.Npad * q.ncb)) % q.T);
   const int g = static_cast<int>(i / (static_cast<long long>(BK) * q.Npad * q.ncb * q.T));

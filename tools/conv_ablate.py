@@ -1,10 +1,14 @@
 #!/usr/bin/env python3
 """Ablation timing of the conv kernel (results are WRONG for dbg != 0; only the time is meaningful).
-bits: 1 no weight global loads, 2 no weight LDS stores, 4 no MFMA block (incl. LDS reads), 8 no activation LDS store,
-16 no barriers, 32 force 64-wide tiles, 64 force 128-wide tiles"""
+bits: 1 no weight fragment loads, 4 no MFMA block (incl. LDS reads), 8 no activation LDS store, 16 no barriers,
+32 force 64-wide tiles, 64 force 128-wide tiles, 256 no epilogue, 512 no activation global loads.
+NOTE: below ~0.03 ms the Python/ctypes launch path (not the GPU) sets the floor of this loop.
+r01 findings (zr 1x5, 0.17 ms): MFMA phase 0.083 (55 % of the fp16 MFMA rate inside the phase), weight loads 0.025,
+activation split+store 0.017, activation loads 0.011, epilogue 0.019 -- the parts add up (no overlap across the two
+resident workgroups); de-phasing them (s_sleep) or static s_setprio changed nothing."""
 import os, sys, time, subprocess
 if len(sys.argv) == 1:
-    for dbg in (0, 1, 2, 3, 4, 8, 16, 11, 27, 31, 32, 64):
+    for dbg in (0, 1, 4, 8, 16, 256, 512, 4 + 256, 1 + 8 + 256, 31, 31 + 256 + 512, 32, 64):
         out = subprocess.run([sys.executable, __file__, str(dbg)], capture_output=True, text=True,
                              env=dict(os.environ, RNNPOSE_CONV_DBG=str(dbg))).stdout.strip()
         print(f"dbg={dbg:3d}  {out}", flush=True)
