@@ -88,7 +88,7 @@ def cpu_baseline(refiner, rend, K, G0, args):
     ncpu = os.cpu_count() or 1
     cores = int(os.environ.get("RNNPOSE_CPU_THREADS", min(ncpu, 64)))   # torch-CPU stops scaling well before 256 SMT threads
     torch.set_num_threads(cores)
-    nb = min(args.batch, 2)                                             # bounded sample: 2 images of the batch
+    nb = min(args.batch, 4)                                             # bounded sample: 4 images of the batch
     sl = lambda t: t[:nb]
     inp = {"ctx": sl(v["cfea"]), "g1": sl(v["geofea1"]), "g2": sl(v["geofea2_crop"]), "depth": sl(v["syn_depth"]),
            "K": sl(K), "G0": sl(G0), "sigma": refiner.sigma[0].detach()}
@@ -102,15 +102,15 @@ def cpu_baseline(refiner, rend, K, G0, args):
     orc.refine(inp, W, outer=1, inner=1, optim_iters=args.optim_iters, fast=True)          # warm-up (thread pools, oneDNN)
     tm = {}
     t0 = time.perf_counter()
-    orc.refine(inp, W, outer=1, inner=2, optim_iters=args.optim_iters, stage_timer=tm, fast=True)
+    orc.refine(inp, W, outer=1, inner=3, optim_iters=args.optim_iters, stage_timer=tm, fast=True)
     wall = time.perf_counter() - t0
     scale = args.batch / nb                                             # per-image cost is batch-independent
     t_outer = (tm.get("encoder", 0.0) + tm.get("corr_build_ctx", 0.0)) * scale
-    t_inner = (wall * scale - t_outer) / 2.0
+    t_inner = (wall * scale - t_outer) / 3.0
     sched = args.outer * t_outer + args.outer * args.inner * t_inner
     return {
         "value": args.outer * args.inner / sched, "unit": "iters/s", "cores": cores, "kind": "port",
-        "sample": (f"{nb} of the {args.batch} images ({args.height}x{args.width}), 1 outer x 2 inner iterations of the CPU "
+        "sample": (f"{nb} of the {args.batch} images ({args.height}x{args.width}), 1 outer x 3 inner iterations of the CPU "
                    f"oracle in its library-call form (grid_sample/unfold as the reference uses on CPU), {wall:.1f} s wall, "
                    f"torch {torch.__version__} CPU with {cores} threads on {ncpu} logical CPUs; scaled x{scale:g} to the "
                    f"batch: per-outer {t_outer:.2f} s, per-inner {t_inner:.2f} s, extrapolated to {args.outer}x{args.inner}"),

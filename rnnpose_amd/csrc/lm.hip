@@ -17,7 +17,7 @@ using rp::Pose;
 constexpr int NACC = 27;        // 21 (upper triangle of H, row-major) + 6 (b)
 constexpr int PSTRIDE = 32;     // doubles per partial record
 constexpr int LM_THREADS = 256;
-constexpr int LM_PIX_PER_BLOCK = 4096;
+constexpr int LM_PIX_PER_BLOCK = 2048;   // 150 workgroups per 480x640 image: >4 per CU at B=8 (latency hiding for the fp64 chain)
 constexpr int LM_MAX_BLOCKS = 256;
 
 __host__ __device__ inline int lm_blocks_per_image(long long P) {
@@ -113,14 +113,22 @@ __global__ __launch_bounds__(LM_THREADS) void lm_normal_eq_kernel(const float* _
 }
 
 // sums the block partials in fixed order and expands to full H (6x6) and b (6)
-__global__ __launch_bounds__(64) void lm_finalize_kernel(const double* __restrict__ partials, int nblk,
-                                                         double* __restrict__ Hm, double* __restrict__ bv) {
+__global__ __launch_bounds__(256) void lm_finalize_kernel(const double* __restrict__ partials, int nblk,
+                                                          double* __restrict__ Hm, double* __restrict__ bv) {
+  // 8 groups of 32 lanes walk the partial records with stride 8 (each load is one coalesced 256-byte record), then
+  // the 8 group sums are added in fixed order: deterministic, and 8x shorter than one serial chain per value.
+  __shared__ double grp[8][PSTRIDE];
   __shared__ double s[NACC];
   const int b = blockIdx.x;
+  const int k = threadIdx.x & 31, g = threadIdx.x >> 5;
+  double v = 0.0;
+  for (int i = g; i < nblk; i += 8) v += partials[(static_cast<long long>(b) * nblk + i) * PSTRIDE + k];
+  grp[g][k] = v;
+  __syncthreads();
   if (threadIdx.x < NACC) {
-    double v = 0.0;
-    for (int i = 0; i < nblk; ++i) v += partials[(static_cast<long long>(b) * nblk + i) * PSTRIDE + threadIdx.x];
-    s[threadIdx.x] = v;
+    double t = 0.0;
+    for (int q = 0; q < 8; ++q) t += grp[q][threadIdx.x];
+    s[threadIdx.x] = t;
   }
   __syncthreads();
   if (threadIdx.x < 36) {
@@ -286,7 +294,7 @@ int launch_normal_eq(const float* target, int target_mode, const float* weight, 
   double* partials = static_cast<double*>(workspace);
   hipLaunchKernelGGL(lm_normal_eq_kernel, dim3(nblk, B), dim3(LM_THREADS), 0, st, target, target_mode, weight, depth, eps,
                      K, G, H, W, partials);
-  hipLaunchKernelGGL(lm_finalize_kernel, dim3(B), dim3(64), 0, st, partials, nblk, Hm, bv);
+  hipLaunchKernelGGL(lm_finalize_kernel, dim3(B), dim3(256), 0, st, partials, nblk, Hm, bv);
   return 0;
 }
 
