@@ -242,6 +242,8 @@ def main():
                    "outer": args.outer, "inner": args.inner, "optim_iters": args.optim_iters,
                    "encoder_in_timed_region": not args.no_encoder, "fused_schedule": not args.unfused,
                    "conv_backend": args.conv_backend,
+                   "hip_graphs": "encoder+volume build and the inner-iteration body replay as hipGraphs (except in the "
+                                 "event-instrumented first timed step)" if refiner.use_graph and not args.unfused else "off",
                    "weights": "random init", "lm_accumulation": "f64", "sharding": f"dp{world} (independent images, no collective in the path)"},
         "roofline": roofline, "correlation_volume_kernel": corr_vol, "kernels": kernels,
     }

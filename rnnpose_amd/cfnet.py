@@ -122,7 +122,7 @@ class GRU_CFUpdator(nn.Module):
         """The update_corr_fn=True branch (CFNet.py:115-133): volume + pyramid, hidden state, context input."""
         self.fmap1 = fmap1.float()
         self.fmap2 = fmap2.float()
-        self.corr_fn = CorrBlock(self.fmap1, self.fmap2, radius=self.args.corr_radius)
+        self.corr_fn = CorrBlock(self.fmap1, self.fmap2, radius=self.args.corr_radius, reuse=self.corr_fn)
         assert context_fea is not None
         h, w = self.fmap1.shape[-2:]
         self.net, self.inp = ops.context_prep(context_fea, h, w, self.hidden_dim)

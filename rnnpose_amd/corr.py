@@ -20,7 +20,7 @@ class CorrBlock:
     `corr_pyramid` is the list of (B*h*w, 1, h_l, w_l) levels like the reference's attribute; they are
     views into one device buffer (all levels are produced by a single kernel launch)."""
 
-    def __init__(self, fmap1, fmap2, num_levels=4, radius=4, downsample_rate=1):
+    def __init__(self, fmap1, fmap2, num_levels=4, radius=4, downsample_rate=1, reuse=None):
         if downsample_rate != 1:
             # the reference branch is broken (nn.MaxPool2d called with a tensor, corr.py:20-24) and never taken
             raise NotImplementedError("downsample_rate != 1 is not supported (dead code in the reference)")
@@ -28,7 +28,9 @@ class CorrBlock:
             raise NotImplementedError("only radius=4 (the reference's value) is implemented")
         self.num_levels = num_levels
         self.radius = radius
-        self._buf, self.corr_pyramid = ops.corr_pyramid(fmap1.float(), fmap2.float(), num_levels)
+        # reuse: a previous CorrBlock whose device buffer may be overwritten (same shapes) -- keeps addresses stable
+        self._buf, self.corr_pyramid = ops.corr_pyramid(fmap1.float(), fmap2.float(), num_levels,
+                                                        out=None if reuse is None else reuse._buf)
 
     def __call__(self, coords):
         return ops.corr_lookup(self._buf, coords, self.num_levels, self.radius)

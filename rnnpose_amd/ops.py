@@ -34,6 +34,11 @@ def profile(names=None):
         _prof = prev
 
 
+def profiling() -> bool:
+    """True while a profile() context is recording (HIP events cannot be recorded into a captured graph)."""
+    return _prof is not None
+
+
 def summarize(rec) -> dict:
     """-> {name: (n_calls, mean_ms, total_ms, total_work)} (synchronises).  total_work = sum of the `work` each
     launch declared (algorithmic flops for the convolution kernel), 0 if none."""
@@ -86,14 +91,16 @@ def pyramid_layout(B, h, w, levels=4):
     return list(offs), list(hl), list(wl)
 
 
-def corr_pyramid(fmap1, fmap2, levels: int = 4):
-    """fmap1,fmap2 (B,C,h,w) -> (flat buffer, [views (B*h*w,1,h_l,w_l)])   thirdparty/raft/corr.py:13-34"""
+def corr_pyramid(fmap1, fmap2, levels: int = 4, out=None):
+    """fmap1,fmap2 (B,C,h,w) -> (flat buffer, [views (B*h*w,1,h_l,w_l)])   thirdparty/raft/corr.py:13-34.
+    `out`: an existing flat buffer of the right size to overwrite (keeps the address stable for captured graphs)."""
     fmap1, fmap2 = _chk(fmap1, "fmap1"), _chk(fmap2, "fmap2")
     if fmap1.shape != fmap2.shape or fmap1.dim() != 4:
         raise ValueError("fmap1/fmap2 must both be (B,C,h,w)")
     B, Cc, h, w = fmap1.shape
     offs, hl, wl = pyramid_layout(B, h, w, levels)
-    buf = torch.empty(offs[-1], device=fmap1.device, dtype=F32)
+    buf = out if (out is not None and out.numel() == offs[-1] and out.device == fmap1.device) else \
+        torch.empty(offs[-1], device=fmap1.device, dtype=F32)
     _launch("rnnpose_corr_pyramid_f32", _ptr(fmap1), _ptr(fmap2), B, Cc, h, w, levels, _ptr(buf), _stream())
     views = [buf[offs[l]:offs[l + 1]].view(B * h * w, 1, hl[l], wl[l]) for l in range(levels)]
     return buf, views

@@ -57,7 +57,7 @@ class SyntheticRenderer:
 class PoseRefiner(nn.Module):
     def __init__(self, cfg=None, reuse=False, schedule=None, use_regressor=True, is_calibrated=True,
                  bn_is_training=False, is_training=True, renderer=None, fused=True,
-                 img_fea_enc_weights=None):
+                 img_fea_enc_weights=None, use_graph=True):
         super().__init__()
         self.legacy = True
         self.cfg = cfg = cfg if cfg is not None else default_config()
@@ -74,6 +74,12 @@ class PoseRefiner(nn.Module):
         self.cf_net = GRU_CFUpdator(cfg.get("raft", None))
         self.renderer = renderer
         self.fused = fused
+        # hipGraph replay of the inner-iteration body (~25 launches): at the reference's own working size (B=1,
+        # 240x240) the loop is launch-bound, not GPU-bound.  Falls back to eager launches if capture is refused.
+        self.use_graph = use_graph
+        self._graph = None
+        self._outer_graphs = {}
+        self._outer_captures = 0
         self._clear()
 
     def _clear(self):
@@ -84,6 +90,104 @@ class PoseRefiner(nn.Module):
 
     def __len__(self):
         return len(self.residual_pose_history)
+
+    # ---- per-outer-iteration unit: RAFT encoder (PoseRefiner.py:311) + CorrBlock build + context prep (CFNet.py:115-133)
+    def _outer_body(self, views):
+        if views.get("fmap1") is not None:
+            feats1, feats2 = views["fmap1"], views["fmap2"]
+        else:
+            feats1, feats2 = self.image_fea_enc(views["syn_img"], views["image_crop"])
+        self.cf_net.prepare(feats1, feats2, views["cfea"])
+        return feats1, feats2
+
+    def _outer(self, views):
+        if not (self.use_graph and self.cf_net.conv_backend == "hip") or ops.profiling():
+            return self._outer_body(views)
+        ins = [views[k] for k in ("syn_img", "image_crop", "cfea", "fmap1", "fmap2") if views.get(k) is not None]
+        key = tuple((t.data_ptr(), tuple(t.shape)) for t in ins) + (self.cf_net.engine()._key,
+                                                                    getattr(self.image_fea_enc._engine, "_key", None))
+        gr = self._outer_graphs.get(key)
+        if gr is None:
+            if self._outer_captures >= 8:      # views keep moving (a renderer allocating fresh tensors): stay eager
+                return self._outer_body(views)
+            self._outer_captures += 1
+            try:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(2):
+                        self._outer_body(views)
+                torch.cuda.current_stream().wait_stream(side)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    out = self._outer_body(views)
+                gr = dict(graph=graph, out=out, corr_fn=self.cf_net.corr_fn, net=self.cf_net._net, inp=self.cf_net.inp)
+                if len(self._outer_graphs) >= 4:
+                    self._outer_graphs.pop(next(iter(self._outer_graphs)))
+                self._outer_graphs[key] = gr
+            except Exception as e:             # noqa: BLE001
+                import warnings
+                warnings.warn(f"hipGraph capture of encoder+volume build failed ({e!r}); running eager launches")
+                self._outer_captures = 8
+                return self._outer_body(views)
+        gr["graph"].replay()
+        # the Python-side state prepare() sets is the one recorded at capture time (same device buffers)
+        self.cf_net.corr_fn = gr["corr_fn"]
+        self.cf_net._net, self.cf_net.inp = gr["net"], gr["inp"]
+        self.cf_net._net_in_engine = True
+        self.cf_net.fmap1, self.cf_net.fmap2 = gr["out"]
+        return gr["out"]
+
+    # ---- one inner iteration of the fused schedule, eager or as a replayed hipGraph ---------------------------
+    def _body(self, depth, K, g1, g2, G, coords0, h, w, ep_l, lm_l):
+        coords1 = ops.induced_coords_lowres(depth, K, G, h, w, EPS)
+        _, flow_up = self.cf_net.step(coords0, coords1)
+        wmap = ops.corr_weight(g1, g2, flow_up, depth, self.sigma[0])
+        Gn, Hm, bv, xi, info = ops.lm_step(flow_up, wmap, depth, K, G, num_iters=self.cfg.OPTIM_ITER_COUNT,
+                                           ep_lambda=ep_l, lm_lambda=lm_l, max_update=1.0, eps=EPS)
+        return flow_up, wmap, Gn, Hm, bv, xi, info
+
+    def _iteration(self, depth, K, g1, g2, G, coords0, h, w, ep_l, lm_l):
+        if not (self.use_graph and self.cf_net.conv_backend == "hip") or ops.profiling():
+            return self._body(depth, K, g1, g2, G, coords0, h, w, ep_l, lm_l)
+        eng = self.cf_net.engine()
+        # (coords0 is not part of the key: the HIP engine derives the grid in-kernel and never reads it)
+        key = (depth.data_ptr(), K.data_ptr(), g1.data_ptr(), g2.data_ptr(), self.cf_net.corr_fn._buf.data_ptr(),
+               tuple(depth.shape), self.cfg.OPTIM_ITER_COUNT, float(ep_l), float(lm_l), eng._key)
+        gr = self._graph
+        if gr is None or gr["key"] != key:
+            gr = self._capture(key, depth, K, g1, g2, G, coords0, h, w, ep_l, lm_l)
+        if gr is None:                                     # capture refused: eager launches
+            return self._body(depth, K, g1, g2, G, coords0, h, w, ep_l, lm_l)
+        gr["G"].copy_(G.reshape(-1, 4, 4))
+        gr["graph"].replay()
+        flow_up, wmap, Gn, Hm, bv, xi, info = gr["out"]
+        # outputs live in the graph's private pool and are overwritten by the next replay: hand out copies of the
+        # small ones, and of the flow only when a caller keeps it (first and last iteration)
+        return flow_up, wmap, Gn.clone(), Hm, bv, xi, info
+
+    def _capture(self, key, depth, K, g1, g2, G, coords0, h, w, ep_l, lm_l):
+        try:
+            Gs = G.reshape(-1, 4, 4).clone()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                  # warm-up on a side stream: weight packing, allocator, caches
+                hA = self.cf_net.engine()._b["hA"].clone()
+                for _ in range(2):
+                    self._body(depth, K, g1, g2, Gs, coords0, h, w, ep_l, lm_l)
+                self.cf_net.engine()._b["hA"].copy_(hA)    # warm-up advanced the hidden state: restore it
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self._body(depth, K, g1, g2, Gs, coords0, h, w, ep_l, lm_l)
+            self.cf_net.engine()._b["hA"].copy_(hA)        # capture does not execute, but keep the invariant explicit
+            self._graph = dict(key=key, graph=graph, G=Gs, out=out)
+        except Exception as e:                             # noqa: BLE001 -- any capture failure means "run eagerly"
+            import warnings
+            warnings.warn(f"hipGraph capture of the refinement iteration failed ({e!r}); running eager launches")
+            self.use_graph = False
+            self._graph = None
+        return self._graph
 
     @torch.no_grad()
     def forward(self, image, Ts, intrinsics, fea_3d=None, Tj_gt=None, obj_cls=None, geofea_3d=None, geofea_2d=None):
@@ -111,7 +215,9 @@ class PoseRefiner(nn.Module):
             cfea_crop = views["cfea"]
             geofea1_crop, geofea2_crop = views["geofea1"], views["geofea2_crop"]
             syn_imgs += [views["syn_img"], views["image_crop"]]
-            if views.get("fmap1") is not None:
+            if self.fused:       # encoder + volume / pyramid + context prep: one (replayable) unit per outer iteration
+                feats1, feats2 = self._outer(views)
+            elif views.get("fmap1") is not None:
                 feats1, feats2 = views["fmap1"], views["fmap2"]
             else:
                 feats1, feats2 = self.image_fea_enc(views["syn_img"], views["image_crop"])   # (:311)
@@ -127,15 +233,9 @@ class PoseRefiner(nn.Module):
                 syn_depths.append(syn_depth)
                 Tij = Tij.copy(stop_gradients=True)
                 if self.fused:
-                    if i == 0:
-                        self.cf_net.prepare(feats1, feats2, cfea_crop)
-                    coords1 = ops.induced_coords_lowres(syn_depth, intrinsics_crop, Tij.G, h, w, EPS)
-                    _, flow_up = self.cf_net.step(coords0, coords1)
+                    flow_up, wmap, G, Hm, bv, xi, info = self._iteration(
+                        syn_depth, intrinsics_crop, geofea1_crop, geofea2_crop, Tij.G, coords0, h, w, ep_l, lm_l)
                     flow = [flow_up]
-                    wmap = ops.corr_weight(geofea1_crop, geofea2_crop, flow_up, syn_depth, self.sigma[0])
-                    G, Hm, bv, xi, info = ops.lm_step(flow_up, wmap, syn_depth, intrinsics_crop, Tij.G,
-                                                      num_iters=cfg.OPTIM_ITER_COUNT, ep_lambda=ep_l, lm_lambda=lm_l,
-                                                      max_update=1.0, eps=EPS)
                     Tij = SE3Sequence(matrix=G.reshape(B, 1, 4, 4))
                     Tij.last_info, Tij.last_system = info, (Hm, bv, xi)
                     corr_weight = wmap[:, None, :, :, None]
@@ -152,6 +252,8 @@ class PoseRefiner(nn.Module):
                     corr_weight = wmap[:, None, :, :, None]
                     Tij = Tij.reprojction_optim(target, corr_weight, depths, intrinsics_crop,
                                                 num_iters=cfg.OPTIM_ITER_COUNT, lm_lmbda=lm_l, ep_lmbda=ep_l)
+                if self.fused and self.use_graph and self._graph is not None and not self.flow_history:
+                    flow = [flow[0].clone()]               # "flow" of the returned dict = first iteration's flow
                 self.flow_history.append(flow)
                 self.residual_pose_history.append(Tij)
                 self.Ti_history.append(Ti.copy(stop_gradients=True))
