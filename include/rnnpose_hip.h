@@ -186,6 +186,9 @@ int rnnpose_conv2d_nhwc_f16x3(const rnnpose_conv_desc_t* h_desc, rnnpose_stream_
  * nchw_to_nhwc / nhwc_to_nchw: (B,C,HW) <-> channel window [c_offset, c_offset+C) of a (B,HW,c_stride) tensor.
  * flow_prep: flow = coords1 - grid (model/CFNet.py:150) written as (B,h,w,4) [fx,fy,0,0] (input of the 7x7 flow
  *   convolution, update.py:84) and into channels [motion_c_offset, +2) of the motion-feature tensor (update.py:97).
+ * flow_conv7x7_relu: BasicMotionEncoder.convf1 + ReLU (7x7, 2 -> c_out <= 128, update.py:84,91) as a direct fp32
+ *   convolution (K = 98 is too thin for the matrix cores): flow4 from flow_prep, w_t = the (c_out,2,7,7) weight
+ *   transposed to (98, c_out), output into channels [out_c_offset, +c_out) of an NHWC tensor.
  * flow_head_out: FlowHead.conv2 (3x3, c_in -> 2, update.py:10,14) on channels [x_c_offset, +c_in) of x, fused with
  *   coords1 += delta (CFNet.py:157): delta (B,h,w,2), coords1_out (B,2,h,w) (may be NULL), flow_lr (B,h,w,2) =
  *   coords1_out - grid.  w_oihw is the PyTorch (2,c_in,3,3) weight.
@@ -198,6 +201,8 @@ int rnnpose_nhwc_to_nchw_f32(const float* src, int B, int C, int HW, int src_c_s
                              rnnpose_stream_t stream);
 int rnnpose_flow_prep_f32(const float* coords1, int B, int h, int w, float* flow4, float* motion, int motion_c_stride,
                           int motion_c_offset, rnnpose_stream_t stream);
+int rnnpose_flow_conv7x7_relu_f32(const float* flow4, const float* w_t, const float* bias, int B, int h, int w, int c_out,
+                                  float* out, int out_c_stride, int out_c_offset, rnnpose_stream_t stream);
 int rnnpose_flow_head_out_f32(const float* x, int x_c_stride, int x_c_offset, int c_in, const float* w_oihw,
                               const float* bias, const float* coords1, int B, int h, int w, float* delta,
                               float* coords1_out, float* flow_lr, rnnpose_stream_t stream);

@@ -71,6 +71,12 @@ struct KParams {
 };
 
 
+// Every global load of the main loop is UNCONDITIONAL (out-of-range activation rows read this zero quad, weight
+// requests past the end re-read the last tile): with loads under branches the compiler cannot count how many younger
+// loads are in flight and falls back to s_waitcnt vmcnt(0) -- r01 in-kernel timestamps showed two full memory-latency
+// stalls per 32-channel block (the weight prefetch drained before the activation loads and before the LDS store).
+__device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};   // (not const: keeps the select in the global address space, a flat load would tie up lgkmcnt)
+
 __device__ __forceinline__ void split4(const float4 v, float s, h4& hi, h4& lo) {
   const float x[4] = {v.x * s, v.y * s, v.z * s, v.w * s};
 #pragma unroll
@@ -88,6 +94,20 @@ __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-
 // the 128-wide tiling would leave the 256 CUs short of workgroups (Cout <= 128 at 300 row tiles) or pad Cout.
 // STRIDED = stride-2 mode (every tap is its own group, general input addressing); a template flag so that the
 // stride-1 instantiations keep their register budget (the 64-wide variant must stay <= 128 VGPRs for 4 waves/SIMD).
+// -DRP_CONV_TS (diagnostics build only): wave 0 of logical tile 0 records s_memtime at the phase boundaries of its
+// first 64 pipeline stages; tools/conv_ts.py prints the per-phase cycle counts.
+#ifdef RP_CONV_TS
+__device__ long long g_conv_ts[64 * 8];
+#define RP_TS(K_)                                                                      \
+  do {                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    if (ts_on && ts_i < 64) { const long long t_ = clock64(); if (lane == 0) g_conv_ts[ts_i * 8 + (K_)] = t_; } \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+  } while (0)
+#else
+#define RP_TS(K_) do { } while (0)
+#endif
+
 template <int NI, bool STRIDED>
 __global__ __launch_bounds__(NT, 2) void conv_igemm_f16x3_kernel(const KParams p) {
   constexpr int BNT = 64 * NI;
@@ -151,21 +171,13 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_f16x3_kernel(const KParams p
   float4 av0, av1, av2, av3, av4;
 #define RP_LOAD_A_ROW(R_)                                                                                   \
   {                                                                                                         \
-    float4 v_ = make_float4(0.f, 0.f, 0.f, 0.f);                                                            \
     const int uu_ = a_u##R_ + du_, vv_ = a_v##R_ + dvg_;                                                    \
-    const bool in_ = STRIDED ? (uu_ >= 0 && uu_ < p.Uin && vv_ >= 0 && vv_ < p.Vin) : (uu_ >= 0 && uu_ < p.U); \
-    if (in_ && c_ < sg_.ccount) {                                                                           \
-      const long long px_ = STRIDED ? a_pix##R_ + uu_ * p.su + vv_ * p.sv : a_pix##R_ + du_ * p.su;         \
-      const float* q_ = sg_.ptr + px_ * sg_.cstride + sg_.coff + c_;                                        \
-      if (c_ + 3 < sg_.ccount) {                                                                            \
-        v_ = *reinterpret_cast<const float4*>(q_);                                                          \
-      } else {                                                                                              \
-        v_.x = q_[0];                                                                                       \
-        if (c_ + 1 < sg_.ccount) v_.y = q_[1];                                                              \
-        if (c_ + 2 < sg_.ccount) v_.z = q_[2];                                                              \
-      }                                                                                                     \
-    }                                                                                                       \
-    av##R_ = v_;                                                                                            \
+    const bool in_ = (STRIDED ? (uu_ >= 0 && uu_ < p.Uin && vv_ >= 0 && vv_ < p.Vin) : (uu_ >= 0 && uu_ < p.U)) && \
+                     c_ < sg_.ccount;                                                                       \
+    const long long px_ = STRIDED ? a_pix##R_ + static_cast<long long>(uu_) * p.su + vv_ * p.sv             \
+                                  : a_pix##R_ + static_cast<long long>(du_) * p.su;                         \
+    const float* q_ = in_ ? sg_.ptr + px_ * sg_.cstride + sg_.coff + c_ : g_zero16;                         \
+    av##R_ = *reinterpret_cast<const float4*>(q_);                                                          \
   }
 #define RP_LOAD_A(G_, CB_)                                                                                  \
   do {                                                                                                      \
@@ -213,6 +225,11 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_f16x3_kernel(const KParams p
       b##S_##l11 = ls_[192];                                                                                \
     }                                                                                                       \
   } while (0)
+#define RP_LOAD_B_CLAMPED(S_)                                                                               \
+  do {                                                                                                      \
+    const bool v_ = pg < p.G;                                                                               \
+    RP_LOAD_B(S_, v_ ? pg : p.G - 1, v_ ? pt : p.T - 1, v_ ? pcb : p.ncb - 1);                              \
+  } while (0)
 #define RP_MMA_KK(S_, KK_, AB_)                                                                             \
   {                                                                                                         \
     const int ko = KK_ * 16 + lh * 8;                                                                       \
@@ -256,21 +273,33 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_f16x3_kernel(const KParams p
   do {                                                                                                      \
     int ncb_ = ccb + 1, ng_ = cg;                                                                           \
     if (ncb_ == p.ncb) { ncb_ = 0; ++ng_; }                                                                 \
-    if (ct == 0 && ng_ < p.G && !(p.dbg & 512)) RP_LOAD_A(ng_, ncb_);                                       \
-    if (!(p.dbg & 4)) {                                                                                     \
-      RP_MMA(S_, p.dv0 + ct, ab);                                                                           \
-    }                                                                                                       \
-    if (pg < p.G && !(p.dbg & 1)) RP_LOAD_B(S_, pg, pt, pcb);                                               \
+    RP_TS(0);                                                                                               \
+    if (ct == 0) RP_LOAD_A(ng_ < p.G ? ng_ : cg, ng_ < p.G ? ncb_ : ccb);                                   \
+    RP_TS(1);                                                                                               \
+    RP_MMA(S_, p.dv0 + ct, ab);                                                                             \
+    RP_TS(2);                                                                                               \
+    RP_LOAD_B_CLAMPED(S_);                                                                                  \
+    RP_TS(3);                                                                                               \
     if (++pt == p.T) { pt = 0; if (++pcb == p.ncb) { pcb = 0; ++pg; } }                                     \
     if (++ct == p.T) {                                                                                      \
       ct = 0;                                                                                               \
       ccb = ncb_; cg = ng_;                                                                                 \
-      if (ng_ < p.G && !(p.dbg & 8)) RP_STORE_A(ab ^ 1);                                                    \
-      if (!(p.dbg & 16)) __syncthreads();                                                                   \
+      RP_STORE_A(ab ^ 1);                                                                                   \
+      RP_TS(4);                                                                                             \
+      __syncthreads();                                                                                      \
       ab ^= 1;                                                                                              \
     }                                                                                                       \
+    RP_TS(5);                                                                                               \
+    RP_TS_NEXT;                                                                                             \
   } while (0)
 
+#ifdef RP_CONV_TS
+  const bool ts_on = (bid == p.n_nt * (p.n_mt / 2)) && wave == 0;     // a tile in the middle of the problem
+  int ts_i = 0;
+#define RP_TS_NEXT ++ts_i
+#else
+#define RP_TS_NEXT do { } while (0)
+#endif
   RP_LOAD_A(0, 0);
   RP_STORE_A(0);
   int ab = 0;                      // LDS buffer holding the activation tile being consumed
@@ -279,20 +308,28 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_f16x3_kernel(const KParams p
   const int total = p.G * p.ncb * p.T;
   RP_LOAD_B(0, pg, pt, pcb);
   if (++pt == p.T) { pt = 0; if (++pcb == p.ncb) { pcb = 0; ++pg; } }
-  if (pg < p.G) RP_LOAD_B(1, pg, pt, pcb);
+  RP_LOAD_B_CLAMPED(1);
   if (++pt == p.T) { pt = 0; if (++pcb == p.ncb) { pcb = 0; ++pg; } }
   __syncthreads();
-  for (int i = 0; i < total; i += 2) {
-    RP_STAGE(0);
-    if (i + 1 < total) RP_STAGE(1);
+  // (stage pairs in a branch-free loop body + an odd tail: with "if (i + 1 < total) stage 1" inside the loop the compiler
+  //  sees a path stage 0 -> latch -> stage 0 on which the stage-0 weight loads are the youngest in flight, and drains
+  //  the stage-1 prefetch with vmcnt(0) in every stage 0)
+  const int total_even = total & ~1;
+  if (total_even) {
+    int i = 0;
+    do {
+      RP_STAGE(0);
+      RP_STAGE(1);
+      i += 2;
+    } while (i < total_even);
   }
+  if (total & 1) RP_STAGE(0);
 
   // ------------------------------------------- epilogue -------------------------------------------
   // accumulators -> wave-private LDS tile (aliasing the weight staging buffers) -> 16-byte row-contiguous stores:
   // 16 lanes cover 256 contiguous bytes of one output pixel (the MFMA C layout would give 4-byte stores spread
   // over 2 rows per instruction: measured 0.86 TB/s, the epilogue was 35-45 % of the kernel).
   __syncthreads();
-  if (p.dbg & 256) return;
   constexpr int ES = 32 * NI + 4;                       // row stride (floats) of the staging tile
   constexpr int F4 = 8 * NI;                            // float4 per tile row
   float* S = reinterpret_cast<float*>(&sA[0][0][0]) + wave * (32 * ES);    // 4 x 32 x 68 floats = 34.8 KB <= 43.5 KB
@@ -549,5 +586,11 @@ int rnnpose_conv2d_nhwc_f16x3(const rnnpose_conv_desc_t* d, rnnpose_stream_t str
   }
   return rp::check_launch(fn);
 }
+
+#ifdef RP_CONV_TS
+int rnnpose_conv_dbg_timestamps(long long* h_out) {     // 64 x 8 cycle counters of the last launch (diagnostics build)
+  return hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_conv_ts), sizeof(long long) * 64 * 8) == hipSuccess ? 0 : 1;
+}
+#endif
 
 }  // extern "C"

@@ -237,6 +237,52 @@ __global__ __launch_bounds__(256) void instnorm_apply_kernel(const float* __rest
   reinterpret_cast<float4*>(out)[i] = y;
 }
 
+// ---- BasicMotionEncoder.convf1: 7x7, 2 -> Cout (=128), ReLU (update.py:84,91) ------------------------------------
+// K = 98: far too thin for the matrix cores (the implicit-GEMM kernel pads the 2 channels to 32: 16x wasted MFMA work).
+// Direct form: thread = output channel with its 98 weights in registers; a workgroup walks a 20-pixel row segment
+// whose 7 x 26 x 2 flow patch sits in LDS (wave-uniform broadcast reads); each pixel's Cout outputs leave as one
+// contiguous NHWC row.  flow4: (B,h,w,4) [fx,fy,0,0]; wt: weights transposed to (98, Cout) = [(ci*7+ky)*7+kx][c].
+constexpr int F1_TX = 20;
+__global__ __launch_bounds__(128) void conv7x7_cin2_kernel(const float* __restrict__ flow4, const float* __restrict__ wt,
+                                                           const float* __restrict__ bias, float* __restrict__ out,
+                                                           int out_cs, int out_co, int Cout, int h, int w) {
+  __shared__ float patch[2][7][F1_TX + 6];
+  const int b = blockIdx.z, Y = blockIdx.y, X0 = blockIdx.x * F1_TX;
+  const int c = threadIdx.x;
+  const int n = h * w;
+  for (int e = threadIdx.x; e < 7 * (F1_TX + 6); e += 128) {
+    const int ky = e / (F1_TX + 6), xx = e % (F1_TX + 6);
+    const int yy = Y + ky - 3, x = X0 + xx - 3;
+    float2 v = make_float2(0.f, 0.f);
+    if (yy >= 0 && yy < h && x >= 0 && x < w) {
+      const float4 f = *reinterpret_cast<const float4*>(flow4 + (static_cast<long long>(b) * n + yy * w + x) * 4);
+      v = make_float2(f.x, f.y);
+    }
+    patch[0][ky][xx] = v.x;
+    patch[1][ky][xx] = v.y;
+  }
+  float wreg[98];
+  if (c < Cout) {
+#pragma unroll
+    for (int k = 0; k < 98; ++k) wreg[k] = wt[k * Cout + c];
+  }
+  const float bs = c < Cout ? bias[c] : 0.f;
+  __syncthreads();
+  if (c >= Cout) return;
+#pragma unroll 4
+  for (int x = 0; x < F1_TX; ++x) {
+    if (X0 + x >= w) break;
+    float acc = bs;
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+      for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 7; ++kx) acc += wreg[(ci * 7 + ky) * 7 + kx] * patch[ci][ky][x + kx];
+    out[(static_cast<long long>(b) * n + Y * w + X0 + x) * out_cs + out_co + c] = fmaxf(acc, 0.f);
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -320,6 +366,19 @@ int rnnpose_instnorm_nhwc_f32(const float* x, int B, int HW, int C, float eps, i
   const long long total4 = static_cast<long long>(B) * HW * (C >> 2);
   hipLaunchKernelGGL(instnorm_apply_kernel, dim3(rp::cdiv(total4, 256)), dim3(256), 0, st, x, mean_rstd, residual, out, HW,
                      C, relu, total4);
+  return rp::check_launch(fn);
+}
+
+
+int rnnpose_flow_conv7x7_relu_f32(const float* flow4, const float* w_t, const float* bias, int B, int h, int w, int c_out,
+                                  float* out, int out_c_stride, int out_c_offset, rnnpose_stream_t stream) {
+  const char* fn = "rnnpose_flow_conv7x7_relu_f32";
+  RP_REQUIRE(flow4 && w_t && bias && out, fn, "null pointer");
+  RP_REQUIRE(B > 0 && B < 65536 && h > 0 && h < 65536 && w > 0 && c_out > 0 && c_out <= 128, fn, "bad size (c_out <= 128)");
+  RP_REQUIRE(out_c_offset >= 0 && out_c_offset + c_out <= out_c_stride && reinterpret_cast<uintptr_t>(flow4) % 16 == 0, fn,
+             "bad output window / flow4 alignment");
+  hipLaunchKernelGGL(conv7x7_cin2_kernel, dim3(rp::cdiv(w, F1_TX), h, B), dim3(128), 0, rp::as_stream(stream), flow4, w_t,
+                     bias, out, out_c_stride, out_c_offset, c_out, h, w);
   return rp::check_launch(fn);
 }
 

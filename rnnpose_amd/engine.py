@@ -38,11 +38,11 @@ class UpdateEngine:
         e, g = b.encoder, b.gru
         cat = lambda *t: torch.cat([x.detach() for x in t], 0)
         P = ops.PackedConv
-        wf1 = torch.cat([e.convf1.weight.detach(), torch.zeros_like(e.convf1.weight.detach())], 1)   # Cin 2 -> 4 (zeros)
         w = dict(
             convc1=P(e.convc1.weight, e.convc1.bias, [e.convc1.weight.shape[1]]),
             convc2=P(e.convc2.weight, e.convc2.bias, [256]),
-            convf1=P(wf1, e.convf1.bias, [4]),                      # (algorithmic flops counted on the 2 real channels)
+            convf1_wt=e.convf1.weight.detach().float().reshape(e.convf1.weight.shape[0], 98).t().contiguous(),   # (98, 128)
+            convf1_b=e.convf1.bias.detach().float().contiguous(),
             convf2=P(e.convf2.weight, e.convf2.bias, [128]),
             conv=P(e.conv.weight, e.conv.bias, [256]),
             zr1=P(cat(g.convz1.weight, g.convr1.weight), cat(g.convz1.bias, g.convr1.bias), [128, 128, 128]),
@@ -54,7 +54,6 @@ class UpdateEngine:
             flow2_w=b.flow_head.conv2.weight.detach().float().contiguous(),
             flow2_b=b.flow_head.conv2.bias.detach().float().contiguous(),
         )
-        w["convf1"].c_in_real = 2
         self._key, self._w = key, w
         return w
 
@@ -90,7 +89,7 @@ class UpdateEngine:
         ops.corr_lookup_nhwc(corr_fn._buf, coords1, b["corr"], corr_fn.num_levels, corr_fn.radius)
         c(W["convc1"], [(b["corr"], 0)], (b["cor1"], 0), R)                         # update.py:89
         c(W["convc2"], [(b["cor1"], 0)], (b["corflo"], 0), R)                       # :90
-        c(W["convf1"], [(b["flow4"], 0)], (b["flo1"], 0), R)                        # :91
+        ops.flow_conv7x7_relu(b["flow4"], W["convf1_wt"], W["convf1_b"], b["flo1"])  # :91 (direct fp32, K = 98)
         c(W["convf2"], [(b["flo1"], 0)], (b["corflo"], 192), R)                     # :92
         c(W["conv"], [(b["corflo"], 0)], (b["motion"], 0), R)                       # :95-96 (126 ch; flow already at 126)
         hx = lambda hbuf: [(hbuf, 0), (b["inp"], 0), (b["motion"], 0)]              # [h | inp | motion]  (:181, :47)

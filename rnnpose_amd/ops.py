@@ -401,6 +401,15 @@ def flow_prep(coords1, flow4, motion, motion_c_offset):
             _stream())
 
 
+def flow_conv7x7_relu(flow4, w_t, bias, out, out_c_offset=0):
+    """relu(convf1(flow)) (update.py:84,91): flow4 (B,h,w,4), w_t (98,c_out) -> channels of NHWC `out`."""
+    B, h, w, _ = flow4.shape
+    c_out = w_t.shape[1]
+    _launch("rnnpose_flow_conv7x7_relu_f32", _ptr(flow4), _ptr(w_t), _ptr(bias), B, h, w, c_out, _ptr(out), out.shape[-1],
+            out_c_offset, _stream(), work=2.0 * 98 * c_out * B * h * w)
+    return out
+
+
 def flow_head_out(x, x_c_offset, c_in, weight, bias, coords1, delta, coords1_out, flow_lr):
     B, h, w, cs = x.shape
     _launch("rnnpose_flow_head_out_f32", _ptr(x), cs, x_c_offset, c_in, _ptr(weight), _ptr(bias), _ptr(coords1), B, h, w,

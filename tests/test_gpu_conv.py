@@ -122,3 +122,21 @@ def test_conv_large_activations_saturate_not_nan(ops):
     out = torch.empty(B, H, W, 128, device="cuda")
     ops.conv2d_nhwc(pc, [(x, 0)], (out, 0))
     assert torch.isfinite(out).all()
+
+
+@pytest.mark.parametrize("B,h,w,cout", [(2, 9, 23, 128), (1, 30, 40, 128), (1, 5, 3, 96)])
+def test_flow_conv7x7_direct(ops, B, h, w, cout):
+    """BasicMotionEncoder.convf1 + ReLU as the direct fp32 kernel (update.py:84,91): borders, ragged row tiles."""
+    wt = D(syn.normal("f1.w", (cout, 2, 7, 7), 5, std=0.2))
+    bias = D(syn.normal("f1.b", (cout,), 5, std=0.1))
+    flow = D(syn.normal("f1.x", (B, 2, h, w), 5, std=3.0))
+    flow4 = torch.zeros(B, h, w, 4, device="cuda")
+    flow4[..., :2] = flow.permute(0, 2, 3, 1)
+    out = torch.full((B, h, w, cout + 4), -7.0, device="cuda")
+    ops.flow_conv7x7_relu(flow4, wt.reshape(cout, 98).t().contiguous(), bias, out, out_c_offset=4)
+    ref = F.relu(F.conv2d(flow.double(), wt.double(), bias.double(), padding=3))
+    y = nchw(out[..., 4:])
+    err = float((y.double() - ref).abs().max())
+    print(f"flow conv7x7 err {err:.3e} (max {float(ref.max()):.2f})")
+    assert err <= 2e-5 * max(1.0, float(ref.abs().max()))
+    assert float(out[..., :4].min()) == -7.0 and float(out[..., :4].max()) == -7.0      # channel window respected

@@ -1,0 +1,37 @@
+"""Micro-benchmarks of the small per-iteration kernels at the S2 shape (B=8, 60x80): lookup, 7x7 flow conv, flow head."""
+import sys
+import torch
+from rnnpose_amd import build, ops, synthetic as syn
+
+build.build()
+B, h, w = 8, 60, 80
+dev = "cuda"
+g = torch.Generator(device=dev).manual_seed(0)
+f1 = torch.randn(B, 256, h, w, device=dev, generator=g) * 0.5
+f2 = torch.randn(B, 256, h, w, device=dev, generator=g) * 0.5
+buf, _ = ops.corr_pyramid(f1, f2, 4)
+from rnnpose_amd.corr import coords_grid
+coords = coords_grid(B, h, w, dev) + torch.randn(B, 2, h, w, device=dev, generator=g) * 4.0
+out = torch.empty(B, h, w, 324, device=dev)
+
+
+def timeit(fn, n=50):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+print("lookup nhwc  %.4f ms" % timeit(lambda: ops.corr_lookup_nhwc(buf, coords, out, 4, 4)))
+print("lookup nchw  %.4f ms" % timeit(lambda: ops.corr_lookup(buf, coords, 4, 4)))
+flow4 = torch.randn(B, h, w, 4, device=dev, generator=g)
+wt = torch.randn(98, 128, device=dev, generator=g) * 0.1
+bias = torch.randn(128, device=dev, generator=g)
+flo1 = torch.empty(B, h, w, 128, device=dev)
+print("flow conv7x7 %.4f ms" % timeit(lambda: ops.flow_conv7x7_relu(flow4, wt, bias, flo1)))
