@@ -143,6 +143,12 @@ def main():
     def step():
         return refiner(rend.views["image_crop"], SE3Sequence(matrix=G0.clone()), K)
 
+    # setup (not a warm-up step): one eager pass under the event recorder -- the event-instrumented timed step below runs
+    # eagerly too and would otherwise pay first-use allocations (1 GB volume buffer, ...) inside the timed region --
+    # and one pass that captures the hipGraphs the remaining steps replay.
+    with ops.profile(None):
+        step()
+    step()
     for _ in range(args.warmup):
         step()
     hip_ops = None          # HIP events around EVERY C-ABI launch (~25 per iteration; <1 % of the step)

@@ -71,12 +71,11 @@ struct KParams {
 };
 
 
-// Every global load of the main loop is UNCONDITIONAL (out-of-range activation rows read this zero quad, weight
-// requests past the end re-read the last tile): with loads under branches the compiler cannot count how many younger
-// loads are in flight and falls back to s_waitcnt vmcnt(0) -- r01 in-kernel timestamps showed two full memory-latency
-// stalls per 32-channel block (the weight prefetch drained before the activation loads and before the LDS store).
-__device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};   // (not const: keeps the select in the global address space, a flat load would tie up lgkmcnt)
-
+// Every global load of the main loop is UNCONDITIONAL (out-of-range activation rows read element 0 of their tensor and
+// are zeroed when they are split into LDS, weight requests past the end re-read the last tile): with loads under
+// branches the compiler cannot count how many younger loads are in flight and falls back to s_waitcnt vmcnt(0) -- r01
+// in-kernel timestamps showed two full memory-latency stalls per 32-channel block (the weight prefetch drained
+// before the activation loads and again before the LDS store).
 __device__ __forceinline__ void split4(const float4 v, float s, h4& hi, h4& lo) {
   const float x[4] = {v.x * s, v.y * s, v.z * s, v.w * s};
 #pragma unroll
@@ -101,7 +100,7 @@ __device__ long long g_conv_ts[64 * 8];
 #define RP_TS(K_)                                                                      \
   do {                                                                                 \
     __builtin_amdgcn_sched_barrier(0);                                                 \
-    if (ts_on && ts_i < 64) { const long long t_ = clock64(); if (lane == 0) g_conv_ts[ts_i * 8 + (K_)] = t_; } \
+    if (ts_on && ts_i < 64) { const long long t_ = clock64(); if (lane == 0) ts_lds[ts_i * 8 + (K_)] = t_; } /* LDS: a global store would count in vmcnt */ \
     __builtin_amdgcn_sched_barrier(0);                                                 \
   } while (0)
 #else
@@ -169,15 +168,18 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_f16x3_kernel(const KParams p
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   float4 av0, av1, av2, av3, av4;
+  unsigned amask_n = 0u;            // bit r: staged row r of the tile in flight is inside the image (else: zeros)
 #define RP_LOAD_A_ROW(R_)                                                                                   \
   {                                                                                                         \
     const int uu_ = a_u##R_ + du_, vv_ = a_v##R_ + dvg_;                                                    \
-    const bool in_ = (STRIDED ? (uu_ >= 0 && uu_ < p.Uin && vv_ >= 0 && vv_ < p.Vin) : (uu_ >= 0 && uu_ < p.U)) && \
-                     c_ < sg_.ccount;                                                                       \
-    const long long px_ = STRIDED ? a_pix##R_ + static_cast<long long>(uu_) * p.su + vv_ * p.sv             \
-                                  : a_pix##R_ + static_cast<long long>(du_) * p.su;                         \
-    const float* q_ = in_ ? sg_.ptr + px_ * sg_.cstride + sg_.coff + c_ : g_zero16;                         \
-    av##R_ = *reinterpret_cast<const float4*>(q_);                                                          \
+    const bool in_ = cok_ && (STRIDED ? (static_cast<unsigned>(uu_) < static_cast<unsigned>(p.Uin) &&       \
+                                         static_cast<unsigned>(vv_) < static_cast<unsigned>(p.Vin))         \
+                                      : static_cast<unsigned>(uu_) < static_cast<unsigned>(p.U));           \
+    const unsigned px_ = STRIDED ? static_cast<unsigned>(a_pix##R_) + static_cast<unsigned>(uu_) * p.su + static_cast<unsigned>(vv_) * p.sv \
+                                 : static_cast<unsigned>(a_pix##R_ + dpix_);   /* (unsigned: rows outside wrap harmlessly) */ \
+    const unsigned off_ = in_ ? px_ * static_cast<unsigned>(sg_.cstride) + cc_ : 0u;   /* < 2^31 (host check) */ \
+    av##R_ = *reinterpret_cast<const float4*>(sg_.ptr + off_);                                              \
+    amask_n |= in_ ? (1u << R_) : 0u;                                                                       \
   }
 #define RP_LOAD_A(G_, CB_)                                                                                  \
   do {                                                                                                      \
@@ -187,8 +189,12 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_f16x3_kernel(const KParams p
     if ((CB_) >= p.cb2) { sg_ = p.seg2; cb0_ = p.cb2; }                                                     \
     if ((CB_) >= p.cb3) { sg_ = p.seg3; cb0_ = p.cb3; }                                                     \
     const int c_ = ((CB_) - cb0_) * BK + c4 * 4;                                                            \
+    const bool cok_ = c_ < sg_.ccount;                                                                      \
+    const int cc_ = sg_.coff + c_;                                                                          \
     const int du_ = p.du0 + (STRIDED ? (G_) / p.gkw : (G_));                                                \
     const int dvg_ = STRIDED ? p.dvg0 + (G_) % p.gkw : 0;                                                   \
+    const int dpix_ = du_ * p.su;                                                                           \
+    amask_n = 0u;                                                                                           \
     RP_LOAD_A_ROW(0) RP_LOAD_A_ROW(1) RP_LOAD_A_ROW(2) RP_LOAD_A_ROW(3) RP_LOAD_A_ROW(4)                    \
   } while (0)
 #define RP_STORE_A_ROW(R_, AB_)                                                                             \
@@ -196,7 +202,8 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_f16x3_kernel(const KParams p
     const int j_ = (tid >> 3) + 32 * R_;                                                                    \
     if (j_ < AROWS) {                                                                                       \
       h4 hi_, lo_;                                                                                          \
-      split4(av##R_, p.a_scale, hi_, lo_);                                                                  \
+      const float4 z4_ = make_float4(0.f, 0.f, 0.f, 0.f);                                                   \
+      split4((amask_n >> R_) & 1u ? av##R_ : z4_, p.a_scale, hi_, lo_);   /* padding / out-of-range rows: zeros */ \
       *reinterpret_cast<h4*>(sAf + (AB_) * (2 * AROWS * RS) + j_ * RS + c4 * 4) = hi_;                      \
       *reinterpret_cast<h4*>(sAf + (AB_) * (2 * AROWS * RS) + AROWS * RS + j_ * RS + c4 * 4) = lo_;         \
     }                                                                                                       \
@@ -294,6 +301,7 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_f16x3_kernel(const KParams p
   } while (0)
 
 #ifdef RP_CONV_TS
+  __shared__ long long ts_lds[64 * 8];
   const bool ts_on = (bid == p.n_nt * (p.n_mt / 2)) && wave == 0;     // a tile in the middle of the problem
   int ts_i = 0;
 #define RP_TS_NEXT ++ts_i
@@ -325,6 +333,9 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_f16x3_kernel(const KParams p
   }
   if (total & 1) RP_STAGE(0);
 
+#ifdef RP_CONV_TS
+  if (ts_on) for (int e = lane; e < 64 * 8; e += 64) g_conv_ts[e] = ts_lds[e];
+#endif
   // ------------------------------------------- epilogue -------------------------------------------
   // accumulators -> wave-private LDS tile (aliasing the weight staging buffers) -> 16-byte row-contiguous stores:
   // 16 lanes cover 256 contiguous bytes of one output pixel (the MFMA C layout would give 4-byte stores spread
@@ -513,6 +524,8 @@ int rnnpose_conv2d_nhwc_f16x3(const rnnpose_conv_desc_t* d, rnnpose_stream_t str
     RP_REQUIRE(sr.ptr && sr.c_count > 0 && sr.c_count % 4 == 0 && sr.c_stride % 4 == 0 && sr.c_offset % 4 == 0 &&
                    sr.c_offset + sr.c_count <= sr.c_stride && reinterpret_cast<uintptr_t>(sr.ptr) % 16 == 0,
                fn, "source: 16-byte aligned pointer, channel stride/offset/count multiples of 4");
+    RP_REQUIRE(static_cast<long long>(d->B) * d->H * d->W * sr.c_stride < (1LL << 31), fn,
+               "source tensor too large for 32-bit element offsets (B*H*W*c_stride must be < 2^31)");
     const Seg sg{sr.ptr, sr.c_stride, sr.c_offset, sr.c_count};
     (s == 0 ? p.seg0 : s == 1 ? p.seg1 : s == 2 ? p.seg2 : p.seg3) = sg;
     counts[s] = sr.c_count;
