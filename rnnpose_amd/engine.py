@@ -22,6 +22,7 @@ class UpdateEngine:
         self._w = None
         self._buf_key = None
         self._b = None
+        self._side = None         # side stream of step(): the flow-feature chain / flow head run next to the main chain
 
     # ---- weights ---------------------------------------------------------------------------------------------
     def _params(self):
@@ -68,6 +69,11 @@ class UpdateEngine:
             self._buf_key = key
         return self._b
 
+    def _side_stream(self, device):
+        if self._side is None or self._side.device != device:
+            self._side = torch.cuda.Stream(device=device)
+        return self._side
+
     def load_state(self, net, inp):
         """net, inp: (B,128,h,w) NCHW (tanh / relu of the context features, model/CFNet.py:131-133)."""
         B, _, h, w = net.shape
@@ -85,12 +91,25 @@ class UpdateEngine:
         b = self._b
         c = ops.conv2d_nhwc
         R = ops.EPI_RELU
-        ops.flow_prep(coords1, b["flow4"], b["motion"], 126)                       # flow -> convf1 input, motion[126:128]
+        # Two independent chains feed the motion encoder's last convolution (update.py:89-92): correlation features
+        # (lookup -> convc1 -> convc2) and flow features (flow_prep -> convf1 -> convf2).  The second one runs on a side
+        # stream (a parallel branch when the step is captured into a hipGraph): its small kernels fill the CUs the
+        # first chain's ragged last wave of workgroups leaves idle.  Same for flow_head.conv2 next to mask.2.
+        main = torch.cuda.current_stream()
+        side = self._side_stream(coords1.device)
+        fork = torch.cuda.Event()
+        fork.record(main)
+        side.wait_event(fork)
+        with torch.cuda.stream(side):
+            ops.flow_prep(coords1, b["flow4"], b["motion"], 126)                   # flow -> convf1 input, motion[126:128]
+            ops.flow_conv7x7_relu(b["flow4"], W["convf1_wt"], W["convf1_b"], b["flo1"])  # :91 (direct fp32, K = 98)
+            c(W["convf2"], [(b["flo1"], 0)], (b["corflo"], 192), R)                 # :92
+            join = torch.cuda.Event()
+            join.record(side)
         ops.corr_lookup_nhwc(corr_fn._buf, coords1, b["corr"], corr_fn.num_levels, corr_fn.radius)
         c(W["convc1"], [(b["corr"], 0)], (b["cor1"], 0), R)                         # update.py:89
         c(W["convc2"], [(b["cor1"], 0)], (b["corflo"], 0), R)                       # :90
-        ops.flow_conv7x7_relu(b["flow4"], W["convf1_wt"], W["convf1_b"], b["flo1"])  # :91 (direct fp32, K = 98)
-        c(W["convf2"], [(b["flo1"], 0)], (b["corflo"], 192), R)                     # :92
+        main.wait_event(join)
         c(W["conv"], [(b["corflo"], 0)], (b["motion"], 0), R)                       # :95-96 (126 ch; flow already at 126)
         hx = lambda hbuf: [(hbuf, 0), (b["inp"], 0), (b["motion"], 0)]              # [h | inp | motion]  (:181, :47)
         c(W["zr1"], hx(b["hA"]), (b["z"], 0), ops.EPI_GRU_ZR, aux0=(b["hA"], 0), dst2=(b["rh"], 0), gru_c=128)
@@ -98,8 +117,15 @@ class UpdateEngine:
         c(W["zr2"], hx(b["hB"]), (b["z"], 0), ops.EPI_GRU_ZR, aux0=(b["hB"], 0), dst2=(b["rh"], 0), gru_c=128)
         c(W["q2"], hx(b["rh"]), (b["hA"], 0), ops.EPI_GRU_Q, aux0=(b["hB"], 0), aux1=(b["z"], 0))
         c(W["heads"], [(b["hA"], 0)], (b["heads"], 0), R)                           # flow_head.conv1 | mask.0
-        ops.flow_head_out(b["heads"], 0, 256, W["flow2_w"], W["flow2_b"], coords1, b["delta"], b["coords1"], b["flow_lr"])
+        fork2 = torch.cuda.Event()
+        fork2.record(main)
+        side.wait_event(fork2)
+        with torch.cuda.stream(side):
+            ops.flow_head_out(b["heads"], 0, 256, W["flow2_w"], W["flow2_b"], coords1, b["delta"], b["coords1"], b["flow_lr"])
+            join2 = torch.cuda.Event()
+            join2.record(side)
         c(W["mask2"], [(b["heads"], 256)], (b["mask"], 0), ops.EPI_LINEAR)          # 0.25 * mask.2(relu(mask.0(h)))
+        main.wait_event(join2)
         flow_up = ops.convex_upsample_nhwc(b["flow_lr"], b["mask"])
         return b["coords1"], flow_up
 
