@@ -237,6 +237,18 @@ size_t rnnpose_pose_metrics_workspace_bytes(int B, int P);
 int rnnpose_pose_metrics_f64(const float* model, int P, const float* pose_pred, const float* pose_gt, const float* K, int B,
                              int symmetric, void* workspace, size_t workspace_bytes, double* out, rnnpose_stream_t stream);
 
+/* ---- f4 ("next"): zoom-crop of every outer iteration on device ------- model/PoseRefiner.py:145-218,286-291
+ * mask_bbox: bbox (B,4) int32 = [xmin, ymin, xmax, ymax] of depth (B,1,H,W) > 0 ([INT_MAX,INT_MAX,-1,-1] if empty).
+ * zoom_crop_params: get_affine_transformation + gen_zoom_crop_grids without the host round trip: K (B,3,3), T (B,4,4)
+ *   -> theta (B,2,3) (the F.affine_grid matrices) and K_crop (B,3,3) = inverse(window transform) @ K.
+ * zoom_crop: out (B,C,crop_h,crop_w) = F.grid_sample(in (B,C,H,W), F.affine_grid(theta)) (bilinear, zero padding,
+ *   align_corners=False); grid_out (B,crop_h,crop_w,2) optionally receives the sampling grid; out may be NULL.  */
+int rnnpose_mask_bbox_f32(const float* depth, int B, int H, int W, int* bbox, rnnpose_stream_t stream);
+int rnnpose_zoom_crop_params_f32(const int* bbox, const float* K, const float* T, int B, int H, int W, int crop_h, int crop_w,
+                                 float margin_ratio, float* theta, float* K_crop, rnnpose_stream_t stream);
+int rnnpose_zoom_crop_f32(const float* in, const float* theta, int B, int C, int H, int W, int crop_h, int crop_w, float* out,
+                          float* grid_out, rnnpose_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -467,3 +467,43 @@ def pose_metrics(model, pose_pred, pose_gt, K, symmetric: bool = False):
     _launch("rnnpose_pose_metrics_f64", _ptr(model), P, _ptr(pose_pred), _ptr(pose_gt), _ptr(K), B, int(symmetric),
             _ptr(ws), n, _ptr(out), _stream())
     return out
+
+
+# ---- f4: zoom-crop on device ---------------------------------------------------------------------------------------
+def mask_bbox(depth):
+    """depth (B,1,H,W) -> (B,4) int32 [xmin, ymin, xmax, ymax] of depth > 0 (model/PoseRefiner.py:154-158,259)."""
+    depth = _chk(depth, "depth")
+    B, _, H, W = depth.shape
+    bbox = torch.empty(B, 4, device=depth.device, dtype=torch.int32)
+    _launch("rnnpose_mask_bbox_f32", _ptr(depth), B, H, W, _ptr(bbox), _stream())
+    return bbox
+
+
+def zoom_crop_params(bbox, K, T, image_size, crop_size, margin_ratio=0.4):
+    """-> theta (B,2,3) for F.affine_grid and K_crop (B,3,3)   (model/PoseRefiner.py:145-218, no host round trip)."""
+    K, T = _chk(K, "K"), _chk(T, "T")
+    if not (bbox.is_cuda and bbox.dtype == torch.int32 and bbox.is_contiguous()):
+        raise RuntimeError("bbox must be a contiguous int32 GPU tensor (from mask_bbox)")
+    B = K.shape[0]
+    theta = torch.empty(B, 2, 3, device=K.device, dtype=F32)
+    K_crop = torch.empty(B, 3, 3, device=K.device, dtype=F32)
+    _launch("rnnpose_zoom_crop_params_f32", _ptr(bbox), _ptr(K), _ptr(T), B, int(image_size[0]), int(image_size[1]),
+            int(crop_size[0]), int(crop_size[1]), float(margin_ratio), _ptr(theta), _ptr(K_crop), _stream())
+    return theta, K_crop
+
+
+def zoom_crop(x, theta, crop_size, want_grid=False):
+    """F.grid_sample(x, F.affine_grid(theta, (B,C,*crop_size))) fused (bilinear, zeros, align_corners=False).
+    x (B,C,H,W) or None (grid only) -> out (B,C,hc,wc) [, grid (B,hc,wc,2)]."""
+    theta = _chk(theta, "theta")
+    B = theta.shape[0]
+    hc, wc = int(crop_size[0]), int(crop_size[1])
+    out = None
+    C_, H, W = 0, 1, 1
+    if x is not None:
+        x = _chk(x, "x")
+        _, C_, H, W = x.shape
+        out = torch.empty(B, C_, hc, wc, device=theta.device, dtype=F32)
+    grid = torch.empty(B, hc, wc, 2, device=theta.device, dtype=F32) if want_grid else None
+    _launch("rnnpose_zoom_crop_f32", _ptr(x), _ptr(theta), B, C_, H, W, hc, wc, _ptr(out), _ptr(grid), _stream())
+    return (out, grid) if want_grid else out
