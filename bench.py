@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-encoder", action="store_true", help="feed synthetic feature maps (kernel-only runs)")
     ap.add_argument("--unfused", action="store_true", help="literal reference call sequence through the facade")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches only (no hipGraph replay; for counter passes)")
     ap.add_argument("--conv-backend", choices=["hip", "miopen"], default="hip",
                     help="update-block convolutions: hand-written fp16x3 implicit GEMM (default) or torch/MIOpen fp32")
     return ap.parse_args()
@@ -138,7 +139,7 @@ def main():
     rend, K, G0 = synth_views(B, H, W, device, seed=rank, with_encoder=not args.no_encoder)
     cfg = default_config(RENDER_ITER_COUNT=args.outer, ITER_COUNT=args.inner, OPTIM_ITER_COUNT=args.optim_iters)
     cfg.raft.conv_backend = args.conv_backend
-    refiner = PoseRefiner(cfg, renderer=rend, fused=not args.unfused).to(device).eval()
+    refiner = PoseRefiner(cfg, renderer=rend, fused=not args.unfused, use_graph=not args.no_graph).to(device).eval()
 
     def step():
         return refiner(rend.views["image_crop"], SE3Sequence(matrix=G0.clone()), K)
