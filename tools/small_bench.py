@@ -35,3 +35,13 @@ wt = torch.randn(98, 128, device=dev, generator=g) * 0.1
 bias = torch.randn(128, device=dev, generator=g)
 flo1 = torch.empty(B, h, w, 128, device=dev)
 print("flow conv7x7 %.4f ms" % timeit(lambda: ops.flow_conv7x7_relu(flow4, wt, bias, flo1)))
+
+# corr_weight at full resolution with a smooth flow field (B=8, 480x640, 32-ch descriptors)
+H, W = 480, 640
+g1 = torch.randn(B, 32, H, W, device=dev, generator=g)
+g2 = torch.randn(B, 32, H, W, device=dev, generator=g)
+yy, xx = torch.meshgrid(torch.arange(H, device=dev, dtype=torch.float32), torch.arange(W, device=dev, dtype=torch.float32), indexing="ij")
+flow = torch.stack([3.3 + 0.01 * yy, -2.7 + 0.005 * xx], 0)[None].repeat(B, 1, 1, 1).contiguous()
+depth = torch.ones(B, 1, H, W, device=dev)
+sigma = torch.ones(1, device=dev)
+print("corr_weight  %.4f ms" % timeit(lambda: ops.corr_weight(g1, g2, flow, depth, sigma)))
