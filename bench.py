@@ -184,6 +184,7 @@ def main():
         "rnnpose_corr_weight_f32": dict(bytes=(4 * 32 * 2 + 8 + 4 + 4) * H * W * B),
         "rnnpose_lm_step_f32": dict(bytes=16 * H * W * B * args.optim_iters),
     }
+    alg["rnnpose_corr_pyramid_f16x3"] = alg["rnnpose_corr_pyramid_f32"]
     alg["rnnpose_corr_lookup_nhwc_f32"] = alg["rnnpose_corr_lookup_f32"]
     alg["rnnpose_convex_upsample_nhwc_f32"] = alg["rnnpose_convex_upsample_f32"]
     kernels = {}
@@ -229,7 +230,18 @@ def main():
                     "launches_timed": cp[0], "mean_ms": round(cp[1], 4)}
     # north_star's named kernel is always reported beside it
     corr_vol = None
-    if "rnnpose_corr_pyramid_f32" in prof:
+    if "rnnpose_corr_pyramid_f16x3" in prof:
+        cp = prof["rnnpose_corr_pyramid_f16x3"]
+        a = alg["rnnpose_corr_pyramid_f16x3"]
+        gbs = a["bytes"] / (cp[1] * 1e-3) / 1e9
+        corr_vol = {"kernel": "corr_pyramid_h3_kernel (+ 2 split_features_kernel pre-passes inside the same C-ABI call)",
+                    "bound": "hbm (volume + pooled levels written once; fp16x3-split MFMA: 3 fp16 products per multiply-add)",
+                    "achieved_GBps": round(gbs, 1), "peak_GBps": PEAK_HBM_GBS, "frac": round(gbs / PEAK_HBM_GBS, 4),
+                    "executed_fp16_TFLOPps": round(3 * a["flops"] / (cp[1] * 1e-3) / 1e12, 1),
+                    "fp32_equivalent_TFLOPps": round(a["flops"] / (cp[1] * 1e-3) / 1e12, 1),
+                    "algorithmic_bytes_per_launch": a["bytes"], "traffic": traffic.get("corr_pyramid_h3_bytes_per_launch"),
+                    "mean_ms": round(cp[1], 4)}
+    elif "rnnpose_corr_pyramid_f32" in prof:
         cp = prof["rnnpose_corr_pyramid_f32"]
         ach = alg["rnnpose_corr_pyramid_f32"]["flops"] / (cp[1] * 1e-3) / 1e12
         corr_vol = {"kernel": "corr_pyramid_kernel", "bound": "mfma (fp32, 96 flop/B)", "achieved_TFLOPps": round(ach, 2),

@@ -43,6 +43,15 @@ int rnnpose_corr_pyramid_layout(int B, int h, int w, int levels, int64_t* h_offs
                                 int* h_hl /*[levels]*/, int* h_wl /*[levels]*/);
 int rnnpose_corr_pyramid_f32(const float* fmap1, const float* fmap2, int B, int C, int h, int w,
                              int levels, float* pyramid, rnnpose_stream_t stream);
+/* Same volume + pyramid with the operands split into fp16 hi/lo halves and multiplied on the fp16 matrix cores with
+ * fp32 accumulation (3 MFMAs per k-slab; the dropped lo*lo term is 2^-22 relative: fp32-class accuracy).  A pre-pass
+ * writes the scaled, split, pixel-major operands into `workspace`.  layout 0: fmaps are (B,C,h,w) as above; layout 1:
+ * (B,h,w,C) (what the encoder engine produces).  a_scale (a power of two, 64 in the host code) scales both operands
+ * before the split; |x| * a_scale beyond 65504 saturates.  C % 32 == 0. */
+size_t rnnpose_corr_pyramid_f16x3_workspace_bytes(int B, int C, int h, int w);
+int rnnpose_corr_pyramid_f16x3(const float* fmap1, const float* fmap2, int layout, int B, int C, int h, int w, int levels,
+                               float a_scale, void* workspace, size_t workspace_bytes, float* pyramid,
+                               rnnpose_stream_t stream);
 
 /* ---- a3: pyramid lookup -------- thirdparty/raft/corr.py:36-57, thirdparty/raft/utils/utils.py:57-71
  * coords (B,2,h,w) (ch0 = x, ch1 = y) -> out (B, levels*(2r+1)^2, h, w); channel

@@ -37,6 +37,8 @@ PROTOTYPES = {
     "rnnpose_device_info": (_i, [_i, C.c_char_p, _i, C.POINTER(_i)]),
     "rnnpose_corr_pyramid_layout": (_i, [_i, _i, _i, _i, C.POINTER(C.c_int64), C.POINTER(_i), C.POINTER(_i)]),
     "rnnpose_corr_pyramid_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p]),
+    "rnnpose_corr_pyramid_f16x3_workspace_bytes": (_z, [_i, _i, _i, _i]),
+    "rnnpose_corr_pyramid_f16x3": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _f, _p, _z, _p, _p]),
     "rnnpose_corr_lookup_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p]),
     "rnnpose_context_prep_f32": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
     "rnnpose_flow_to_coords_f32": (_i, [_p, _i, _i, _i, _i, _i, _p, _p]),

@@ -89,6 +89,9 @@ class GRU_CFUpdator(nn.Module):
         # "hip": every convolution in the hand-written NHWC implicit-GEMM kernel (rnnpose_amd/engine.py);
         # "miopen": the literal reference call sequence, convolutions through torch/MIOpen (update.py facade)
         self.conv_backend = args.get("conv_backend", "hip")
+        # volume build: "f16x3" = fp16 hi/lo split on the fp16 matrix cores (fp32-class accuracy, default with the hip
+        # backend); "f32" = fp32 MFMA kernel
+        self.corr_precision = args.get("corr_precision", "f16x3" if self.conv_backend == "hip" else "f32")
         self._engine = None
         self._net_in_engine = False
 
@@ -122,7 +125,8 @@ class GRU_CFUpdator(nn.Module):
         """The update_corr_fn=True branch (CFNet.py:115-133): volume + pyramid, hidden state, context input."""
         self.fmap1 = fmap1.float()
         self.fmap2 = fmap2.float()
-        self.corr_fn = CorrBlock(self.fmap1, self.fmap2, radius=self.args.corr_radius, reuse=self.corr_fn)
+        self.corr_fn = CorrBlock(self.fmap1, self.fmap2, radius=self.args.corr_radius, reuse=self.corr_fn,
+                                 precision=self.corr_precision)
         assert context_fea is not None
         h, w = self.fmap1.shape[-2:]
         self.net, self.inp = ops.context_prep(context_fea, h, w, self.hidden_dim)

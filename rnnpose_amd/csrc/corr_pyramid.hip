@@ -101,6 +101,97 @@ __device__ __forceinline__ void store_tile(const TileRegs& t, float* As, float* 
   }
 }
 
+// accumulators (4 sub-tiles of 32 i x 32 j per wave, C layout of the 32x32 MFMAs) -> level 0 + pooled levels.
+// Shared by the fp32 and the fp16x3 kernels; `smem` is the (re-used) staging LDS, all 256 threads must call it.
+template <bool ALIGNED>
+__device__ __forceinline__ void pyramid_epilogue(const f32x16& acc0, const f32x16& acc1, const f32x16& acc2,
+                                                 const f32x16& acc3, float* smem, float* __restrict__ pyr,
+                                                 const PyrInfo& info, int b, int N, int h, int w, int i0, int y0, int x0,
+                                                 float scale, int wave, int lane) {
+  const int kh = lane >> 5, l31 = lane & 31;
+  const f32x16 acc[4] = {acc0, acc1, acc2, acc3};
+  float* S = smem + wave * 2304;    // [32 i][32 j]   j = yy*16 + xx within sub-tile s (patch rows 2s, 2s+1)
+  float* L1 = S + 1024;             // [32 i][4 Y1][8 X1]
+  float* L2 = S + 2048;             // [32 i][2 Y2][4 X2]
+  const int iw = i0 + wave * 32;    // first i row of this wave
+  float* p0 = pyr + info.off[0] + static_cast<long long>(b) * N * N;
+  const int h1 = info.hl[1], w1 = info.wl[1];
+  float* p1 = info.levels > 1 ? pyr + info.off[1] + static_cast<long long>(b) * N * h1 * w1 : nullptr;
+
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    // accumulators -> LDS (C layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
+      S[row * 32 + l31] = acc[s][r] * scale;
+    }
+    __builtin_amdgcn_wave_barrier();   // S / L1 / L2 are wave-private: LDS ops of one wave execute in order
+    // level 0: 32 rows x 2 segments of 16 floats
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int f = lane + 64 * p;
+      const int row = f >> 3;
+      const int c = (f & 7) << 2;
+      const int yy = c >> 4, xx = c & 15;
+      const int i = iw + row, y = y0 + 2 * s + yy, x = x0 + xx;
+      if (i < N && y < h) {
+        const float4 v = *reinterpret_cast<const float4*>(S + row * 32 + c);
+        float* dst = p0 + static_cast<long long>(i) * N + static_cast<long long>(y) * w + x;
+        if (ALIGNED && x + 3 < w) {
+          *reinterpret_cast<float4*>(dst) = v;
+        } else {
+          if (x + 0 < w) dst[0] = v.x;
+          if (x + 1 < w) dst[1] = v.y;
+          if (x + 2 < w) dst[2] = v.z;
+          if (x + 3 < w) dst[3] = v.w;
+        }
+      }
+    }
+    // level 1: 32 rows x 8 cells (2x2 means), kept in LDS for level 2
+    if (info.levels > 1) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int f = lane + 64 * p;
+        const int row = f >> 3;
+        const int X = f & 7;
+        const float2 top = *reinterpret_cast<const float2*>(S + row * 32 + 2 * X);
+        const float2 bot = *reinterpret_cast<const float2*>(S + row * 32 + 16 + 2 * X);
+        const float v = (((top.x + top.y) + bot.x) + bot.y) * 0.25f;
+        L1[row * 32 + s * 8 + X] = v;
+        const int i = iw + row, Y1 = (y0 >> 1) + s, X1 = (x0 >> 1) + X;
+        if (i < N && Y1 < h1 && X1 < w1) p1[(static_cast<long long>(i) * h1 + Y1) * w1 + X1] = v;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();   // S / L1 / L2 are wave-private: LDS ops of one wave execute in order
+  }
+  if (info.levels > 2) {
+    const int h2 = info.hl[2], w2 = info.wl[2];
+    float* p2 = pyr + info.off[2] + static_cast<long long>(b) * N * h2 * w2;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int f = lane + 64 * p;
+      const int row = f >> 3;
+      const int Y = (f & 7) >> 2, X = f & 3;
+      const float* q = L1 + row * 32 + (2 * Y) * 8 + 2 * X;
+      const float v = (((q[0] + q[1]) + q[8]) + q[9]) * 0.25f;
+      L2[row * 8 + Y * 4 + X] = v;
+      const int i = iw + row, Y2 = (y0 >> 2) + Y, X2 = (x0 >> 2) + X;
+      if (i < N && Y2 < h2 && X2 < w2) p2[(static_cast<long long>(i) * h2 + Y2) * w2 + X2] = v;
+    }
+    __builtin_amdgcn_wave_barrier();   // S / L1 / L2 are wave-private: LDS ops of one wave execute in order
+    if (info.levels > 3) {
+      const int h3 = info.hl[3], w3 = info.wl[3];
+      float* p3 = pyr + info.off[3] + static_cast<long long>(b) * N * h3 * w3;
+      const int row = lane >> 1, X = lane & 1;
+      const float* q = L2 + row * 8 + 2 * X;
+      const float v = (((q[0] + q[1]) + q[4]) + q[5]) * 0.25f;
+      const int i = iw + row, Y3 = (y0 >> 3), X3 = (x0 >> 3) + X;
+      if (i < N && Y3 < h3 && X3 < w3) p3[(static_cast<long long>(i) * h3 + Y3) * w3 + X3] = v;
+    }
+  }
+}
+
 template <bool ALIGNED>
 __global__ __launch_bounds__(NT) void corr_pyramid_kernel(const float* __restrict__ f1, const float* __restrict__ f2,
                                                           float* __restrict__ pyr, int B, int C, int h, int w,
@@ -178,86 +269,185 @@ __global__ __launch_bounds__(NT) void corr_pyramid_kernel(const float* __restric
   }
 
   // ---------------------------------- epilogue ----------------------------------
-  float* S = smem + wave * 2304;    // [32 i][32 j]   j = yy*16 + xx within sub-tile s (patch rows 2s, 2s+1)
-  float* L1 = S + 1024;             // [32 i][4 Y1][8 X1]
-  float* L2 = S + 2048;             // [32 i][2 Y2][4 X2]
-  const int iw = i0 + wave * 32;    // first i row of this wave
-  float* p0 = pyr + info.off[0] + static_cast<long long>(b) * N * N;
-  const int h1 = info.hl[1], w1 = info.wl[1];
-  float* p1 = info.levels > 1 ? pyr + info.off[1] + static_cast<long long>(b) * N * h1 * w1 : nullptr;
+  pyramid_epilogue<ALIGNED>(acc[0], acc[1], acc[2], acc[3], smem, pyr, info, b, N, h, w, i0, y0, x0, scale, wave, lane);
+}
 
+// ------------------------------------------------------------------------------------------------------------------
+// fp16x3 variant: the same tiling and epilogue, operands split into fp16 hi + lo halves and multiplied with three
+// v_mfma_f32_32x32x16_f16 per k-slab (a_lo*b_hi + a_hi*b_lo + a_hi*b_hi, fp32 accumulation) -- fp32-class accuracy (the
+// dropped lo*lo term is 2^-22 relative) at 3/16 of the matrix-pipe time of the fp32 MFMA, which turns the build from
+// MFMA-bound (62 % of 157 TF) into an HBM-write-bound kernel.  Operands arrive pixel-major (NHWC: (B, h*w, C)), the
+// layout the encoder engine produces, so that a lane's 8 consecutive-k fragment is one 16-byte LDS read.
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+constexpr int HBK = 32;     // channels per k-slab
+constexpr int HRS = 40;     // LDS row stride in halfs (80 bytes: conflict-free ds_read_b128 over 32 consecutive rows)
+
+__device__ __forceinline__ void split4_h3(const float4 v, float s, h4& hi, h4& lo) {
+  const float x[4] = {v.x * s, v.y * s, v.z * s, v.w * s};
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    // accumulators -> LDS (C layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
-      S[row * 32 + l31] = acc[s][r] * scale;
-    }
-    __syncthreads();
-    // level 0: 32 rows x 2 segments of 16 floats
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int f = lane + 64 * p;
-      const int row = f >> 3;
-      const int c = (f & 7) << 2;
-      const int yy = c >> 4, xx = c & 15;
-      const int i = iw + row, y = y0 + 2 * s + yy, x = x0 + xx;
-      if (i < N && y < h) {
-        const float4 v = *reinterpret_cast<const float4*>(S + row * 32 + c);
-        float* dst = p0 + static_cast<long long>(i) * N + static_cast<long long>(y) * w + x;
-        if (ALIGNED && x + 3 < w) {
-          *reinterpret_cast<float4*>(dst) = v;
-        } else {
-          if (x + 0 < w) dst[0] = v.x;
-          if (x + 1 < w) dst[1] = v.y;
-          if (x + 2 < w) dst[2] = v.z;
-          if (x + 3 < w) dst[3] = v.w;
-        }
-      }
-    }
-    // level 1: 32 rows x 8 cells (2x2 means), kept in LDS for level 2
-    if (info.levels > 1) {
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        const int f = lane + 64 * p;
-        const int row = f >> 3;
-        const int X = f & 7;
-        const float2 top = *reinterpret_cast<const float2*>(S + row * 32 + 2 * X);
-        const float2 bot = *reinterpret_cast<const float2*>(S + row * 32 + 16 + 2 * X);
-        const float v = (((top.x + top.y) + bot.x) + bot.y) * 0.25f;
-        L1[row * 32 + s * 8 + X] = v;
-        const int i = iw + row, Y1 = (y0 >> 1) + s, X1 = (x0 >> 1) + X;
-        if (i < N && Y1 < h1 && X1 < w1) p1[(static_cast<long long>(i) * h1 + Y1) * w1 + X1] = v;
-      }
-    }
-    __syncthreads();
+  for (int i = 0; i < 4; ++i) {
+    const float c = fminf(fmaxf(x[i], -65504.f), 65504.f);
+    const _Float16 hh = static_cast<_Float16>(c);
+    hi[i] = hh;
+    lo[i] = static_cast<_Float16>(c - static_cast<float>(hh));
   }
-  if (info.levels > 2) {
-    const int h2 = info.hl[2], w2 = info.wl[2];
-    float* p2 = pyr + info.off[2] + static_cast<long long>(b) * N * h2 * w2;
+}
+
+// pre-pass: fp32 features -> pixel-major fp16 hi / lo planes ((B*N, C) halfs each), scaled by a_scale, saturated.
+// layout 0: source is (B, C, N) (NCHW, transposed through a 32 x 33 LDS tile); layout 1: source is (B, N, C).
+__global__ __launch_bounds__(256) void split_features_kernel(const float* __restrict__ src, _Float16* __restrict__ hi,
+                                                             _Float16* __restrict__ lo, int C, int N, int layout,
+                                                             float a_scale) {
+  const int b = blockIdx.z;
+  if (layout == 1) {
+    const long long total4 = static_cast<long long>(N) * C / 4;
+    const long long i = (static_cast<long long>(blockIdx.y) * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+    if (i >= total4) return;
+    const float4 v = reinterpret_cast<const float4*>(src + static_cast<long long>(b) * N * C)[i];
+    h4 h, l;
+    split4_h3(v, a_scale, h, l);
+    reinterpret_cast<h4*>(hi + static_cast<long long>(b) * N * C)[i] = h;
+    reinterpret_cast<h4*>(lo + static_cast<long long>(b) * N * C)[i] = l;
+    return;
+  }
+  __shared__ float tile[32][33];
+  const int n0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int f = lane + 64 * p;
-      const int row = f >> 3;
-      const int Y = (f & 7) >> 2, X = f & 3;
-      const float* q = L1 + row * 32 + (2 * Y) * 8 + 2 * X;
-      const float v = (((q[0] + q[1]) + q[8]) + q[9]) * 0.25f;
-      L2[row * 8 + Y * 4 + X] = v;
-      const int i = iw + row, Y2 = (y0 >> 2) + Y, X2 = (x0 >> 2) + X;
-      if (i < N && Y2 < h2 && X2 < w2) p2[(static_cast<long long>(i) * h2 + Y2) * w2 + X2] = v;
-    }
-    __syncthreads();
-    if (info.levels > 3) {
-      const int h3 = info.hl[3], w3 = info.wl[3];
-      float* p3 = pyr + info.off[3] + static_cast<long long>(b) * N * h3 * w3;
-      const int row = lane >> 1, X = lane & 1;
-      const float* q = L2 + row * 8 + 2 * X;
-      const float v = (((q[0] + q[1]) + q[4]) + q[5]) * 0.25f;
-      const int i = iw + row, Y3 = (y0 >> 3), X3 = (x0 >> 3) + X;
-      if (i < N && Y3 < h3 && X3 < w3) p3[(static_cast<long long>(i) * h3 + Y3) * w3 + X3] = v;
+  for (int r = 0; r < 4; ++r) {
+    const int c = c0 + ty + 8 * r, n = n0 + tx;
+    tile[ty + 8 * r][tx] = (c < C && n < N) ? src[(static_cast<long long>(b) * C + c) * N + n] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int n = n0 + ty + 8 * r, c = c0 + tx;
+    if (n < N && c < C) {
+      const float x = fminf(fmaxf(tile[tx][ty + 8 * r] * a_scale, -65504.f), 65504.f);
+      const _Float16 h = static_cast<_Float16>(x);
+      hi[(static_cast<long long>(b) * N + n) * C + c] = h;
+      lo[(static_cast<long long>(b) * N + n) * C + c] = static_cast<_Float16>(x - static_cast<float>(h));
     }
   }
+}
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <bool ALIGNED>
+__global__ __launch_bounds__(NT, 2) void corr_pyramid_h3_kernel(const _Float16* __restrict__ f1h, const _Float16* __restrict__ f1l,
+                                                                const _Float16* __restrict__ f2h, const _Float16* __restrict__ f2l,
+                                                                float* __restrict__ pyr, int B, int C, int h, int w, int n_it,
+                                                                int n_py, int n_px, float scale, PyrInfo info) {
+  // [A | B][hi | lo][128 rows x HRS] halfs = 40 KiB (single buffer, the next slab waits in registers);
+  // the epilogue's 36 KiB of float staging aliases it
+  __shared__ __attribute__((aligned(16))) _Float16 sT[2 * 2 * 128 * HRS];
+  float* smem = reinterpret_cast<float*>(sT);
+  const int N = h * w;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  const int ntiles = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int per = ntiles >> 3, rem = ntiles & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    bid = xcd * per + (xcd < rem ? xcd : rem) + idx;
+  }
+  const int n_patch = n_py * n_px;
+  const int n_ps = (n_patch + ST - 1) / ST, n_is = (n_it + ST - 1) / ST;
+  const int per_img = n_ps * n_is * ST * ST;
+  const int b = bid / per_img;
+  const int tloc = bid - b * per_img;
+  const int sidx = tloc / (ST * ST), within = tloc - sidx * (ST * ST);
+  const int it = (sidx / n_ps) * ST + within / ST;
+  const int patch = (sidx % n_ps) * ST + within % ST;
+  if (it >= n_it || patch >= n_patch) return;
+  const int i0 = it * BM;
+  const int y0 = (patch / n_px) * PY;
+  const int x0 = (patch % n_px) * PX;
+
+  // per-thread staging: rows (tid >> 2) + 64 r (r = 0, 1), 16-byte chunk q = tid & 3 of the 64-byte k-slab of a row.
+  // Offsets in halfs (< 2^31, host check); rows outside the problem read element 0 and are masked to zero.
+  const int q = tid & 3;
+  unsigned offa0, offa1, offb0, offb1, ma0, ma1, mb0, mb1;
+  {
+    const int r0 = tid >> 2, r1 = r0 + 64;
+    const bool va0 = i0 + r0 < N, va1 = i0 + r1 < N;
+    offa0 = va0 ? (static_cast<unsigned>(b) * N + i0 + r0) * C + q * 8 : 0u;
+    offa1 = va1 ? (static_cast<unsigned>(b) * N + i0 + r1) * C + q * 8 : 0u;
+    const int ya = y0 + (r0 >> 4), xa = x0 + (r0 & 15), yb = y0 + (r1 >> 4), xb = x0 + (r1 & 15);
+    const bool vb0 = ya < h && xa < w, vb1 = yb < h && xb < w;
+    offb0 = vb0 ? (static_cast<unsigned>(b) * N + ya * w + xa) * C + q * 8 : 0u;
+    offb1 = vb1 ? (static_cast<unsigned>(b) * N + yb * w + xb) * C + q * 8 : 0u;
+    ma0 = va0 ? 0xffffffffu : 0u; ma1 = va1 ? 0xffffffffu : 0u;
+    mb0 = vb0 ? 0xffffffffu : 0u; mb1 = vb1 ? 0xffffffffu : 0u;
+  }
+
+  f32x16 acc0, acc1, acc2, acc3;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; acc2[r] = 0.f; acc3[r] = 0.f; }
+
+  u32x4 rah0, rah1, ral0, ral1, rbh0, rbh1, rbl0, rbl1;
+#define RPH_LOAD(K0_)                                                                          \
+  do {                                                                                         \
+    rah0 = *reinterpret_cast<const u32x4*>(f1h + offa0 + (K0_));                               \
+    rah1 = *reinterpret_cast<const u32x4*>(f1h + offa1 + (K0_));                               \
+    ral0 = *reinterpret_cast<const u32x4*>(f1l + offa0 + (K0_));                               \
+    ral1 = *reinterpret_cast<const u32x4*>(f1l + offa1 + (K0_));                               \
+    rbh0 = *reinterpret_cast<const u32x4*>(f2h + offb0 + (K0_));                               \
+    rbh1 = *reinterpret_cast<const u32x4*>(f2h + offb1 + (K0_));                               \
+    rbl0 = *reinterpret_cast<const u32x4*>(f2l + offb0 + (K0_));                               \
+    rbl1 = *reinterpret_cast<const u32x4*>(f2l + offb1 + (K0_));                               \
+  } while (0)
+  // plane p (0 = A hi, 1 = A lo, 2 = B hi, 3 = B lo) x 128 rows x HRS halfs
+#define RPH_ST(V_, M_, P_, R_) *reinterpret_cast<u32x4*>(sT + (P_) * (128 * HRS) + ((tid >> 2) + 64 * (R_)) * HRS + q * 8) = (V_) & (M_)
+#define RPH_STORE                                                                              \
+  do {                                                                                         \
+    RPH_ST(rah0, ma0, 0, 0); RPH_ST(rah1, ma1, 0, 1); RPH_ST(ral0, ma0, 1, 0); RPH_ST(ral1, ma1, 1, 1); \
+    RPH_ST(rbh0, mb0, 2, 0); RPH_ST(rbh1, mb1, 2, 1); RPH_ST(rbl0, mb0, 3, 0); RPH_ST(rbl1, mb1, 3, 1); \
+  } while (0)
+
+  RPH_LOAD(0);
+  RPH_STORE;
+  __syncthreads();
+  const int nk = C / HBK;
+  const _Float16* sAh = sT + (wave * 32 + l31) * HRS + lh * 8;
+  const _Float16* sBh = sT + 2 * 128 * HRS + l31 * HRS + lh * 8;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int knext = (kt + 1 < nk ? kt + 1 : kt) * HBK;          // (the last slab is re-requested: loads stay unconditional)
+    RPH_LOAD(knext);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const h8 ah = *reinterpret_cast<const h8*>(sAh + kk * 16);
+      const h8 al = *reinterpret_cast<const h8*>(sAh + 128 * HRS + kk * 16);
+      h8 bh[4], bl[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        bh[s] = *reinterpret_cast<const h8*>(sBh + s * 32 * HRS + kk * 16);
+        bl[s] = *reinterpret_cast<const h8*>(sBh + 128 * HRS + s * 32 * HRS + kk * 16);
+      }
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[0], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[1], acc1, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[2], acc2, 0, 0, 0);
+      acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[3], acc3, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[0], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[1], acc1, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[2], acc2, 0, 0, 0);
+      acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[3], acc3, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[0], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[1], acc1, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[2], acc2, 0, 0, 0);
+      acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[3], acc3, 0, 0, 0);
+    }
+    __syncthreads();
+    RPH_STORE;
+    __syncthreads();
+  }
+#undef RPH_LOAD
+#undef RPH_STORE
+#undef RPH_ST
+  pyramid_epilogue<ALIGNED>(acc0, acc1, acc2, acc3, smem, pyr, info, b, N, h, w, i0, y0, x0, scale, wave, lane);
 }
 
 }  // namespace
@@ -306,6 +496,54 @@ int rnnpose_corr_pyramid_f32(const float* fmap1, const float* fmap2, int B, int 
   } else {
     hipLaunchKernelGGL(corr_pyramid_kernel<false>, grid, block, 0, rp::as_stream(stream), fmap1, fmap2, pyramid, B, C,
                        h, w, n_it, n_py, n_px, scale, info);
+  }
+  return rp::check_launch(fn);
+}
+
+size_t rnnpose_corr_pyramid_f16x3_workspace_bytes(int B, int C, int h, int w) {
+  if (B <= 0 || C <= 0 || h <= 0 || w <= 0) return 0;
+  return static_cast<size_t>(B) * h * w * C * sizeof(_Float16) * 4;      // (hi, lo) x (fmap1, fmap2)
+}
+
+int rnnpose_corr_pyramid_f16x3(const float* fmap1, const float* fmap2, int layout, int B, int C, int h, int w, int levels,
+                               float a_scale, void* workspace, size_t workspace_bytes, float* pyramid,
+                               rnnpose_stream_t stream) {
+  const char* fn = "rnnpose_corr_pyramid_f16x3";
+  RP_REQUIRE(fmap1 && fmap2 && pyramid && workspace, fn, "null pointer");
+  RP_REQUIRE(layout == 0 || layout == 1, fn, "layout must be 0 (B,C,h,w) or 1 (B,h,w,C)");
+  RP_REQUIRE(C > 0 && C % HBK == 0, fn, "C must be a positive multiple of 32");
+  RP_REQUIRE(a_scale > 0.f, fn, "a_scale must be positive");
+  RP_REQUIRE(workspace_bytes >= rnnpose_corr_pyramid_f16x3_workspace_bytes(B, C, h, w) &&
+                 reinterpret_cast<uintptr_t>(workspace) % 16 == 0, fn, "workspace too small or not 16-byte aligned");
+  RP_REQUIRE(layout == 0 || (reinterpret_cast<uintptr_t>(fmap1) % 16 == 0 && reinterpret_cast<uintptr_t>(fmap2) % 16 == 0), fn,
+             "pixel-major feature maps must be 16-byte aligned");
+  int64_t offs[RNNPOSE_MAX_LEVELS + 1];
+  PyrInfo info{};
+  if (int e = rnnpose_corr_pyramid_layout(B, h, w, levels, offs, info.hl, info.wl)) return e;
+  for (int l = 0; l < levels; ++l) info.off[l] = offs[l];
+  info.levels = levels;
+  const int N = h * w;
+  RP_REQUIRE(B < 65536 && static_cast<long long>(B) * N * C < (1LL << 31), fn, "feature maps too large for 32-bit element offsets");
+  hipStream_t st = rp::as_stream(stream);
+  const size_t plane = static_cast<size_t>(B) * N * C;
+  _Float16* ws = static_cast<_Float16*>(workspace);
+  _Float16 *f1h = ws, *f1l = ws + plane, *f2h = ws + 2 * plane, *f2l = ws + 3 * plane;
+  dim3 sg = layout == 1 ? dim3(1024, static_cast<unsigned>(rp::cdiv(static_cast<long long>(N) * C / 4, 256 * 1024)), B)
+                        : dim3(rp::cdiv(N, 32), rp::cdiv(C, 32), B);
+  hipLaunchKernelGGL(split_features_kernel, sg, dim3(256), 0, st, fmap1, f1h, f1l, C, N, layout, a_scale);
+  hipLaunchKernelGGL(split_features_kernel, sg, dim3(256), 0, st, fmap2, f2h, f2l, C, N, layout, a_scale);
+  const int n_it = rp::cdiv(N, BM), n_py = rp::cdiv(h, PY), n_px = rp::cdiv(w, PX);
+  const long long ntiles = static_cast<long long>(B) * rp::cdiv(n_it, ST) * rp::cdiv(n_py * n_px, ST) * ST * ST;
+  RP_REQUIRE(ntiles < (1LL << 31), fn, "grid too large");
+  const float scale = 1.0f / (sqrtf(static_cast<float>(C)) * a_scale * a_scale);
+  const bool aligned = (N % 4 == 0) && (w % 4 == 0) && (reinterpret_cast<uintptr_t>(pyramid) % 16 == 0);
+  dim3 grid(static_cast<unsigned>(ntiles)), block(NT);
+  if (aligned) {
+    hipLaunchKernelGGL(corr_pyramid_h3_kernel<true>, grid, block, 0, st, f1h, f1l, f2h, f2l, pyramid, B, C, h, w, n_it, n_py,
+                       n_px, scale, info);
+  } else {
+    hipLaunchKernelGGL(corr_pyramid_h3_kernel<false>, grid, block, 0, st, f1h, f1l, f2h, f2l, pyramid, B, C, h, w, n_it, n_py,
+                       n_px, scale, info);
   }
   return rp::check_launch(fn);
 }

@@ -91,19 +91,51 @@ def pyramid_layout(B, h, w, levels=4):
     return list(offs), list(hl), list(wl)
 
 
-def corr_pyramid(fmap1, fmap2, levels: int = 4, out=None):
+def corr_pyramid(fmap1, fmap2, levels: int = 4, out=None, precision: str = "f32"):
     """fmap1,fmap2 (B,C,h,w) -> (flat buffer, [views (B*h*w,1,h_l,w_l)])   thirdparty/raft/corr.py:13-34.
-    `out`: an existing flat buffer of the right size to overwrite (keeps the address stable for captured graphs)."""
+    `out`: an existing flat buffer of the right size to overwrite (keeps the address stable for captured graphs).
+    precision "f32": fp32 MFMA kernel on the NCHW maps; "f16x3": transpose to pixel-major + fp16x3-split kernel."""
     fmap1, fmap2 = _chk(fmap1, "fmap1"), _chk(fmap2, "fmap2")
     if fmap1.shape != fmap2.shape or fmap1.dim() != 4:
         raise ValueError("fmap1/fmap2 must both be (B,C,h,w)")
     B, Cc, h, w = fmap1.shape
+    if precision == "f16x3":
+        return _corr_pyramid_f16x3(fmap1, fmap2, 0, B, Cc, h, w, levels, out, 64.0)
+    if precision != "f32":
+        raise ValueError("precision must be 'f32' or 'f16x3'")
     offs, hl, wl = pyramid_layout(B, h, w, levels)
     buf = out if (out is not None and out.numel() == offs[-1] and out.device == fmap1.device) else \
         torch.empty(offs[-1], device=fmap1.device, dtype=F32)
     _launch("rnnpose_corr_pyramid_f32", _ptr(fmap1), _ptr(fmap2), B, Cc, h, w, levels, _ptr(buf), _stream())
     views = [buf[offs[l]:offs[l + 1]].view(B * h * w, 1, hl[l], wl[l]) for l in range(levels)]
     return buf, views
+
+
+_pyr_ws = {}
+
+
+def _corr_pyramid_f16x3(f1, f2, layout, B, Cc, h, w, levels, out, a_scale):
+    n = int(_lib.load().rnnpose_corr_pyramid_f16x3_workspace_bytes(B, Cc, h, w))
+    key = (f1.device, n)
+    ws = _pyr_ws.get(key)
+    if ws is None:
+        ws = _pyr_ws[key] = torch.empty(n // 2, device=f1.device, dtype=torch.float16)
+    offs, hl, wl = pyramid_layout(B, h, w, levels)
+    buf = out if (out is not None and out.numel() == offs[-1] and out.device == f1.device) else \
+        torch.empty(offs[-1], device=f1.device, dtype=F32)
+    _launch("rnnpose_corr_pyramid_f16x3", _ptr(f1), _ptr(f2), layout, B, Cc, h, w, levels, float(a_scale), _ptr(ws), n,
+            _ptr(buf), _stream(), work=2.0 * B * (h * w) ** 2 * Cc)
+    views = [buf[offs[l]:offs[l + 1]].view(B * h * w, 1, hl[l], wl[l]) for l in range(levels)]
+    return buf, views
+
+
+def corr_pyramid_nhwc(f1, f2, levels: int = 4, out=None, a_scale: float = 64.0):
+    """f1,f2 (B,h,w,C) pixel-major -> same (buffer, views) as corr_pyramid, fp16x3-split MFMA (fp32-class accuracy)."""
+    f1, f2 = _nhwc(f1, "f1"), _nhwc(f2, "f2")
+    if f1.shape != f2.shape:
+        raise ValueError("f1/f2 must have the same (B,h,w,C) shape")
+    B, h, w, Cc = f1.shape
+    return _corr_pyramid_f16x3(f1, f2, 1, B, Cc, h, w, levels, out, a_scale)
 
 
 # ---- a3 ------------------------------------------------------------------------------------------------

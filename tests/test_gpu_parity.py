@@ -66,26 +66,43 @@ def test_corr_pyramid_vs_oracle(ops, B, C, h, w, levels):
         close(views[l][:, 0], want[l], 1e-5, what=f"level {l}")
 
 
-def test_corr_pyramid_golden(ops, golden):
+@pytest.mark.parametrize("B,C,h,w,levels", [(2, 256, 16, 24, 4), (1, 256, 30, 30, 4), (2, 64, 17, 19, 4),
+                                            (1, 256, 16, 16, 2), (1, 32, 40, 23, 3)])
+def test_corr_pyramid_f16x3_vs_oracle(ops, B, C, h, w, levels):
+    """fp16x3-split kernel (pixel-major operands): same tolerance as the fp32 MFMA kernel, ragged tiles included."""
+    f1 = syn.normal("fmap1", (B, C, h, w), 11)
+    f2 = syn.normal("fmap2", (B, C, h, w), 11)
+    want = orc.corr_pyramid(f1, f2, levels)
+    buf, views = ops.corr_pyramid(D(f1), D(f2), levels, precision="f16x3")
+    for l in range(levels):
+        close(views[l][:, 0], want[l], 1e-5, what=f"f16x3 level {l}")
+    # large-magnitude features stay finite and accurate (a_scale = 64: |x| up to ~1000)
+    buf2, v2 = ops.corr_pyramid(D(f1 * 37.0), D(f2 * 11.0), levels, precision="f16x3")
+    close(v2[0][:, 0] / (37.0 * 11.0), want[0], 1e-5, what="f16x3 scaled inputs")
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_corr_pyramid_golden(ops, golden, precision):
     g = golden("corr")
     B, C, h, w = 2, 256, 16, 24
     f1 = syn.normal("fmap1", (B, C, h, w), 11)
     f2 = syn.normal("fmap2", (B, C, h, w), 11)
-    _, views = ops.corr_pyramid(D(f1), D(f2), 4)
+    _, views = ops.corr_pyramid(D(f1), D(f2), 4, precision=precision)
     close(views[0].reshape(B * h * w, h * w)[::5], g["level0_rows"], 1e-5, what="level0 rows")
     for l in (1, 2, 3):
         close(views[l], g[f"level{l}"], 1e-5, what=f"level{l}")
     assert abs(float(views[0].double().sum()) - float(g["level0_sum"])) < 1e-2
 
 
-def test_corr_pyramid_full_size_properties(ops):
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_corr_pyramid_full_size_properties(ops, precision):
     """BASELINE config-2 size (B=8, 60x80x256): size-independent properties instead of a CPU replay.
     (1) level 0 rows == direct dot products; (2) pooled volume == volume of pooled features (avg-pool is
     linear); (3) bilinearity: corr(a*f1, f2 + f2') == a*corr(f1,f2) + a*corr(f1,f2')."""
     B, C, h, w = 8, 256, 60, 80
     f1 = D(syn.normal("fmap1", (B, C, h, w), 0))
     f2 = D(syn.normal("fmap2", (B, C, h, w), 0))
-    buf, v = ops.corr_pyramid(f1, f2, 4)
+    buf, v = ops.corr_pyramid(f1, f2, 4, precision=precision)
     Np = h * w
     rows = torch.tensor([0, 1, 79, 80, 2399, 4799], device="cuda")
     for b in (0, 3, 7):
@@ -99,8 +116,8 @@ def test_corr_pyramid_full_size_properties(ops):
             wantl = (a.t() @ pooled / 16).float()
             close(v[l].view(B, Np, hl * wl)[b, rows], wantl, 2e-5, what=f"level{l} b={b}")
     f2b = D(syn.normal("fmap2b", (B, C, h, w), 1))
-    _, v2 = ops.corr_pyramid(f1 * 0.5, f2 + f2b, 4)
-    _, v3 = ops.corr_pyramid(f1, f2b, 4)
+    _, v2 = ops.corr_pyramid(f1 * 0.5, f2 + f2b, 4, precision=precision)
+    _, v3 = ops.corr_pyramid(f1, f2b, 4, precision=precision)
     for l in range(4):
         close(v2[l], 0.5 * (v[l] + v3[l]), 5e-5, what=f"bilinearity level {l}")
 

@@ -28,6 +28,9 @@ def timeit(fn, n=50):
     return e0.elapsed_time(e1) / n
 
 
+print("pyramid f32   %.4f ms" % timeit(lambda: ops.corr_pyramid(f1, f2, 4, out=buf), n=10))
+f1n, f2n = ops.nchw_to_nhwc(f1), ops.nchw_to_nhwc(f2)
+print("pyramid f16x3 %.4f ms" % timeit(lambda: ops.corr_pyramid_nhwc(f1n, f2n, 4, out=buf), n=10))
 print("lookup nhwc  %.4f ms" % timeit(lambda: ops.corr_lookup_nhwc(buf, coords, out, 4, 4)))
 print("lookup nchw  %.4f ms" % timeit(lambda: ops.corr_lookup(buf, coords, 4, 4)))
 flow4 = torch.randn(B, h, w, 4, device=dev, generator=g)
