@@ -182,6 +182,10 @@ typedef struct {
   float* dst2;
   int dst2_c_stride, dst2_c_offset;
   int gru_c;
+  float* tile_stats;           /* optional (NULL = off), linear epilogue only: (ceil(M/128), c_out, 2) fp32 receives, per
+                                  128-row output tile, the column sums and sums of squares of the outputs (bias included)
+                                  -- the instance-norm statistics pass of the encoder without re-reading the tensor
+                                  (rnnpose_instnorm_tiles_nhwc_f32).  M = B*H_out*W_out. */
 } rnnpose_conv_desc_t;
 
 /* number of fp16 elements of EACH of the two packed arrays (hi, lo); -1 on bad arguments */
@@ -226,6 +230,11 @@ size_t rnnpose_instnorm_workspace_bytes(int B, int HW, int C);
 int rnnpose_instnorm_nhwc_f32(const float* x, int B, int HW, int C, float eps, int relu, const float* residual,
                               void* workspace, size_t workspace_bytes, float* mean_rstd, float* out,
                               rnnpose_stream_t stream);
+/* Same normalisation with the statistics taken from the producing convolution's `tile_stats` (rows_per_tile = 128;
+ * HW % rows_per_tile == 0 so that no tile straddles two images): only the finalize + apply passes run. */
+int rnnpose_instnorm_tiles_nhwc_f32(const float* x, int B, int HW, int C, float eps, int relu, const float* residual,
+                                    const float* tile_stats, int rows_per_tile, float* mean_rstd, float* out,
+                                    rnnpose_stream_t stream);
 
 /* ---- f3 ("next"): brute-force nearest neighbour for ADD-S ------ thirdparty/nn/src/nearest_neighborhood.cu:48-163
  * idxs[b,q] = argmin_r |ref[b,r,:] - que[b,q,:]|^2, first minimum wins, optional r != q; dim 2 or 3.

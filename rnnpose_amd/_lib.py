@@ -27,7 +27,8 @@ class ConvDesc(C.Structure):       # rnnpose_conv_desc_t
                 ("dst", C.c_void_p), ("dst_c_stride", C.c_int), ("dst_c_offset", C.c_int),
                 ("aux0", C.c_void_p), ("aux0_c_stride", C.c_int), ("aux0_c_offset", C.c_int),
                 ("aux1", C.c_void_p), ("aux1_c_stride", C.c_int), ("aux1_c_offset", C.c_int),
-                ("dst2", C.c_void_p), ("dst2_c_stride", C.c_int), ("dst2_c_offset", C.c_int), ("gru_c", C.c_int)]
+                ("dst2", C.c_void_p), ("dst2_c_stride", C.c_int), ("dst2_c_offset", C.c_int), ("gru_c", C.c_int),
+                ("tile_stats", C.c_void_p)]
 
 
 # name -> (restype, argtypes); mirrors include/rnnpose_hip.h one to one
@@ -66,6 +67,7 @@ PROTOTYPES = {
     "rnnpose_flow_head_out_f32": (_i, [_p, _i, _i, _i, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p]),
     "rnnpose_convex_upsample_nhwc_f32": (_i, [_p, _p, _i, _i, _i, _p, _p]),
     "rnnpose_instnorm_workspace_bytes": (_z, [_i, _i, _i]),
+    "rnnpose_instnorm_tiles_nhwc_f32": (_i, [_p, _i, _i, _i, _f, _i, _p, _p, _i, _p, _p, _p]),
     "rnnpose_instnorm_nhwc_f32": (_i, [_p, _i, _i, _i, _f, _i, _p, _p, _z, _p, _p, _p]),
     "rnnpose_nn_search_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "findNearestPointIdxLauncher": (None, [_p, _p, _p, _i, _i, _i, _i, _i]),

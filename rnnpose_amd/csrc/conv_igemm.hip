@@ -66,6 +66,7 @@ struct KParams {
   float* dst2;
   int dst2_cs, dst2_co;
   int gru_c;
+  float* tstats;   // optional per-tile column statistics (linear epilogue)
   int n_mt, n_nt;
   int dbg;   // ablation switches for tools/conv_ablate.py (RNNPOSE_CONV_DBG); 0 in production
 };
@@ -343,6 +344,7 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_f16x3_kernel(const KParams p
   __syncthreads();
   constexpr int ES = 32 * NI + 4;                       // row stride (floats) of the staging tile
   constexpr int F4 = 8 * NI;                            // float4 per tile row
+  float ts0 = 0.f, ts1 = 0.f, ts2 = 0.f, ts3 = 0.f, tq0 = 0.f, tq1 = 0.f, tq2 = 0.f, tq3 = 0.f;   // tile statistics of this lane's column quad
   float* S = reinterpret_cast<float*>(&sA[0][0][0]) + wave * (32 * ES);    // 4 x 32 x 68 floats = 34.8 KB <= 43.5 KB
   const int colw = n0 + wn * (32 * NI);
 #pragma unroll
@@ -370,6 +372,12 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_f16x3_kernel(const KParams p
 #pragma unroll
       for (int e = 0; e < 4; ++e) y[e] += (e < nv) ? p.bias[col + e] : 0.f;
       float* dptr = p.dst + pix * p.dst_cs + p.dst_co + col;
+      if (p.tstats) {              // (column quad of a lane is the same for every k and mi: 64 % F4 == 0)
+        if (nv > 0) { ts0 += y[0]; tq0 += y[0] * y[0]; }
+        if (nv > 1) { ts1 += y[1]; tq1 += y[1] * y[1]; }
+        if (nv > 2) { ts2 += y[2]; tq2 += y[2] * y[2]; }
+        if (nv > 3) { ts3 += y[3]; tq3 += y[3] * y[3]; }
+      }
       if (p.epi == 1) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) y[e] = fmaxf(y[e], 0.f);
@@ -397,6 +405,34 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_f16x3_kernel(const KParams p
         for (int e = 0; e < 3; ++e)
           if (e < nv) dptr[e] = y[e];
       }
+    }
+  }
+  if (p.tstats) {
+    // lanes sharing a column quad (same lane % F4) -> lanes 0..F4-1, fixed order; then rows 0-63 (wm = 0) + rows 64-127
+    // (wm = 1) through LDS; one (sum, sum of squares) pair per tile and column: deterministic, no atomics
+#pragma unroll
+    for (int o = F4; o < 64; o <<= 1) {
+      ts0 += __shfl_xor(ts0, o); ts1 += __shfl_xor(ts1, o); ts2 += __shfl_xor(ts2, o); ts3 += __shfl_xor(ts3, o);
+      tq0 += __shfl_xor(tq0, o); tq1 += __shfl_xor(tq1, o); tq2 += __shfl_xor(tq2, o); tq3 += __shfl_xor(tq3, o);
+    }
+    float* TS = reinterpret_cast<float*>(&sA[0][0][0]) + 4 * (32 * ES);      // behind the four staging tiles
+    __syncthreads();
+    if (lane < F4) {
+      float* t = TS + (wave * F4 + lane) * 8;
+      t[0] = ts0; t[1] = ts1; t[2] = ts2; t[3] = ts3; t[4] = tq0; t[5] = tq1; t[6] = tq2; t[7] = tq3;
+    }
+    __syncthreads();
+    if (wm == 0 && lane < F4) {
+      const float* t0 = TS + (wave * F4 + lane) * 8;
+      const float* t1 = TS + ((wave + 2) * F4 + lane) * 8;
+      const int col = colw + lane * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (col + e < p.Cout) {
+          float* o = p.tstats + (static_cast<long long>(mt_i) * p.Cout + col + e) * 2;
+          o[0] = t0[e] + t1[e];
+          o[1] = t0[4 + e] + t1[4 + e];
+        }
     }
   }
 }
@@ -569,6 +605,8 @@ int rnnpose_conv2d_nhwc_f16x3(const rnnpose_conv_desc_t* d, rnnpose_stream_t str
   p.aux1 = d->aux1; p.aux1_cs = d->aux1_c_stride; p.aux1_co = d->aux1_c_offset;
   p.dst2 = d->dst2; p.dst2_cs = d->dst2_c_stride; p.dst2_co = d->dst2_c_offset;
   p.gru_c = d->gru_c;
+  p.tstats = d->tile_stats;
+  if (d->tile_stats) RP_REQUIRE(d->epilogue == 0, fn, "tile_stats needs the linear epilogue");
   const long long Mtot = static_cast<long long>(d->B) * Ho * Wo;
   RP_REQUIRE(Mtot < (1LL << 31) - 256 && static_cast<long long>(d->B) * d->H * d->W < (1LL << 31) - 256, fn, "too many pixels");
   p.n_mt = rp::cdiv(Mtot, BM);

@@ -169,20 +169,32 @@ class EncoderEngine:
         return y.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
 
     @staticmethod
-    def _conv(pc, x, stride=1):
+    def _conv(pc, x, stride=1, stats=True):
+        """-> (out, tile_stats or None): when no 128-row tile straddles two images the convolution's epilogue also emits
+        the per-tile column statistics the following instance norm needs (saves re-reading the tensor once)."""
         B, H, W, _ = x.shape
-        out = torch.empty(B, -(-H // stride), -(-W // stride), pc.c_out, device=x.device, dtype=torch.float32)
-        ops.conv2d_nhwc(pc, [(x, 0)], (out, 0), ops.EPI_LINEAR, stride=stride)
-        return out
+        Ho, Wo = -(-H // stride), -(-W // stride)
+        out = torch.empty(B, Ho, Wo, pc.c_out, device=x.device, dtype=torch.float32)
+        ts = None
+        if stats and (Ho * Wo) % 128 == 0:
+            ts = torch.empty(B * Ho * Wo // 128, pc.c_out, 2, device=x.device, dtype=torch.float32)
+        ops.conv2d_nhwc(pc, [(x, 0)], (out, 0), ops.EPI_LINEAR, stride=stride, tile_stats=ts)
+        return out, ts
+
+    @staticmethod
+    def _norm(y_ts, relu, residual=None):
+        y, ts = y_ts
+        if ts is None:
+            return ops.instnorm_nhwc(y, relu=relu, residual=residual)
+        return ops.instnorm_tiles_nhwc(y, ts, relu=relu, residual=residual)
 
     def _block(self, W, name, blk, x):
         st = blk.conv1.stride[0]
-        y = ops.instnorm_nhwc(self._conv(W[name + ".c1"], x, st), relu=True)
+        y = self._norm(self._conv(W[name + ".c1"], x, st), relu=True)
         res = x
         if blk.downsample is not None:
-            res = ops.instnorm_nhwc(self._conv(W[name + ".down"], x, st), relu=False)         # norm3, no ReLU
-        y = self._conv(W[name + ".c2"], y)
-        return ops.instnorm_nhwc(y, relu=True, residual=res)                                  # relu(x + relu(IN(.)))
+            res = self._norm(self._conv(W[name + ".down"], x, st), relu=False)                    # norm3, no ReLU
+        return self._norm(self._conv(W[name + ".c2"], y), relu=True, residual=res)                # relu(x + relu(IN(.)))
 
     @torch.no_grad()
     def __call__(self, x_nchw):
@@ -194,5 +206,5 @@ class EncoderEngine:
         for li, layer in enumerate((f.layer1, f.layer2, f.layer3), start=1):
             for bi, blk in enumerate(layer):
                 y = self._block(W, f"l{li}.{bi}", blk, y.contiguous())
-        out = self._conv(W["out"], y)
+        out, _ = self._conv(W["out"], y, stats=False)
         return ops.nhwc_to_nchw(out)

@@ -362,7 +362,7 @@ def _nhwc(t, name):
 
 
 def conv2d_nhwc(pc: PackedConv, srcs, dst, epilogue: int = EPI_LINEAR, aux0=None, aux1=None, dst2=None, gru_c: int = 0,
-                stride: int = 1):
+                stride: int = 1, tile_stats=None):
     """srcs: list of (tensor (B,H,W,C), c_offset) matched with pc.seg_counts; dst/aux0/aux1/dst2: (tensor, c_offset).
     Writes in place into dst (and dst2); returns nothing."""
     d = _lib.ConvDesc()
@@ -393,6 +393,13 @@ def conv2d_nhwc(pc: PackedConv, srcs, dst, epilogue: int = EPI_LINEAR, aux0=None
     put("aux1", aux1)
     put("dst2", dst2)
     d.gru_c = gru_c
+    if tile_stats is not None:
+        # (ceil(M/128), c_out, 2) fp32: per-tile column sums / sums of squares for instnorm_tiles_nhwc
+        M = B * (-(-H // stride)) * (-(-W // stride))
+        if not (tile_stats.is_cuda and tile_stats.dtype == F32 and tile_stats.is_contiguous()
+                and tile_stats.numel() >= -(-M // 128) * pc.c_out * 2):
+            raise ValueError("tile_stats must be a contiguous fp32 CUDA tensor of (ceil(M/128), c_out, 2)")
+        d.tile_stats = tile_stats.data_ptr()
     _launch("rnnpose_conv2d_nhwc_f16x3", C.byref(d), _stream(),
             work=2.0 * B * (-(-H // stride)) * (-(-W // stride)) * pc.c_out * pc.c_in_real * pc.kh * pc.kw)
 
@@ -473,6 +480,18 @@ def instnorm_nhwc(x, relu=True, residual=None, out=None, eps: float = 1e-5):
         out = torch.empty_like(x)
     stats = torch.empty(B, Cc, 2, device=x.device, dtype=F32)
     _launch("rnnpose_instnorm_nhwc_f32", _ptr(x), B, H * W, Cc, eps, int(bool(relu)), _ptr(residual), _ptr(ws), n,
+            _ptr(stats), _ptr(out), _stream())
+    return out
+
+
+def instnorm_tiles_nhwc(x, tile_stats, relu=True, residual=None, out=None, eps: float = 1e-5):
+    """instnorm_nhwc with the statistics pass replaced by the producing convolution's tile_stats (H*W % 128 == 0)."""
+    _nhwc(x, "x")
+    B, H, W, Cc = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    stats = torch.empty(B, Cc, 2, device=x.device, dtype=F32)
+    _launch("rnnpose_instnorm_tiles_nhwc_f32", _ptr(x), B, H * W, Cc, eps, int(bool(relu)), _ptr(residual), _ptr(tile_stats), 128,
             _ptr(stats), _ptr(out), _stream())
     return out
 

@@ -140,3 +140,27 @@ def test_flow_conv7x7_direct(ops, B, h, w, cout):
     print(f"flow conv7x7 err {err:.3e} (max {float(ref.max()):.2f})")
     assert err <= 2e-5 * max(1.0, float(ref.abs().max()))
     assert float(out[..., :4].min()) == -7.0 and float(out[..., :4].max()) == -7.0      # channel window respected
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout,k,stride", [(2, 16, 24, 64, 64, 3, 1), (3, 32, 16, 64, 96, 3, 2), (2, 16, 16, 96, 128, 1, 1)])
+def test_conv_tile_stats_feed_instnorm(ops, B, H, W, cin, cout, k, stride):
+    """The epilogue's per-128-row-tile column statistics (sum, sum of squares) and the instance norm built on them
+    (thirdparty/raft/extractor.py:28-31,48-58) against torch in fp64."""
+    x = syn.normal("ts.x", (B, cin, H, W), 9, std=1.0)
+    w = syn.normal("ts.w", (cout, cin, k, k), 9, std=float(np.sqrt(2.0 / (cin * k * k))))
+    b = syn.uniform("ts.b", (cout,), 9, -0.5, 0.5)
+    pc = ops.PackedConv(D(w), D(b), [cin])
+    Ho, Wo = -(-H // stride), -(-W // stride)
+    assert (Ho * Wo) % 128 == 0
+    out = torch.empty(B, Ho, Wo, cout, device="cuda")
+    ts = torch.full((B * Ho * Wo // 128, cout, 2), -1.0, device="cuda")
+    ops.conv2d_nhwc(pc, [(nhwc(D(x)), 0)], (out, 0), ops.EPI_LINEAR, stride=stride, tile_stats=ts)
+    y64 = F.conv2d(D(x).double(), D(w).double(), D(b).double(), stride=stride, padding=k // 2)
+    rows = y64.permute(0, 2, 3, 1).reshape(-1, 128, cout)                       # tiles of 128 consecutive pixels
+    want = torch.stack([rows.sum(1), (rows * rows).sum(1)], -1)
+    err = float((ts.double() - want).abs().max())
+    print(f"tile stats err {err:.3e} (max {float(want.abs().max()):.1f})")
+    assert err <= 2e-5 * float(want.abs().max())
+    got = ops.instnorm_tiles_nhwc(out, ts, relu=True)
+    ref = F.relu(F.instance_norm(y64, eps=1e-5))
+    assert float((nchw(got).double() - ref).abs().max()) < 2e-5
