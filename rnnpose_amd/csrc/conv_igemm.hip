@@ -108,9 +108,15 @@ __device__ long long g_conv_ts[64 * 8];
 #define RP_TS(K_) do { } while (0)
 #endif
 
-template <int NI, bool STRIDED>
-__global__ __launch_bounds__(NT, 2) void conv_igemm_f16x3_kernel(const KParams p) {
-  constexpr int BNT = 64 * NI;
+// COLS4 = wave layout of the 128-wide tile: false = 2 (rows) x 2 (columns) waves of 64 x 32*NI; true = 4 waves side by
+// side, each ALL 128 rows x 32 columns (NI must be 1).  Same MFMA count per wave, but a wave then requests 2 weight
+// fragments per k-slab from L2/L1 instead of 4 (the fragment loads were stalling in the vector-memory queue when two
+// workgroups share a CU: r01 timestamps) and reads 8 activation fragments from LDS instead of 4.
+template <int NI, bool STRIDED, bool COLS4 = false>
+__global__ __launch_bounds__(NT, (COLS4 ? 3 : 2)) void conv_igemm_f16x3_kernel(const KParams p) {
+  static_assert(!COLS4 || NI == 1, "the 4-column layout has one 32-column MFMA tile per wave");
+  constexpr int MI = COLS4 ? 4 : 2;                     // 32-row MFMA tiles per wave
+  constexpr int BNT = COLS4 ? 128 : 64 * NI;
   // activation tile only, double-buffered: [buffer][hi, lo][row * RS + k]  (43.5 KB).  Weights never touch LDS: each
   // wave loads its own MFMA B fragments straight from the fragment-ordered packed array (two waves of a workgroup read
   // the same lines; the second hits L1).  r01 ablation: staging weights through LDS cost 16 % in ds_write alone, made
@@ -118,7 +124,7 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_f16x3_kernel(const KParams p
   __shared__ __attribute__((aligned(16))) _Float16 sA[2][2][AROWS * RS];
   _Float16* const sAf = &sA[0][0][0];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = COLS4 ? 0 : wave >> 1, wn = COLS4 ? wave : wave & 1;
   const int l31 = lane & 31, lh = lane >> 5;
 
   // ---- tile id: XCD-contiguous chunks, n fastest (the n tiles of one m tile share the activation tile) ----
@@ -153,16 +159,16 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_f16x3_kernel(const KParams p
   }
   RP_ROW_INIT(0) RP_ROW_INIT(1) RP_ROW_INIT(2) RP_ROW_INIT(3) RP_ROW_INIT(4)
   // ---- per-lane fragment rows: fast-axis coordinate for the tap masks ----
-  int fv[2];
+  int fv[MI];
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
+  for (int mi = 0; mi < MI; ++mi) {
     const int m = m0 + wm * 64 + mi * 32 + l31;
     fv[mi] = (m < Mtot) ? m % p.V : -1000;
   }
 
-  f32x16 acc[2][NI];
+  f32x16 acc[MI][NI];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < NI; ++j)
 #pragma unroll
@@ -241,14 +247,13 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_f16x3_kernel(const KParams p
 #define RP_MMA_KK(S_, KK_, AB_)                                                                             \
   {                                                                                                         \
     const int ko = KK_ * 16 + lh * 8;                                                                       \
-    h8 ah[2], al[2], bh[2], bl[2];                                                                          \
-    _Pragma("unroll") for (int mi = 0; mi < 2; ++mi) {                                                      \
+    h8 ah[MI], al[MI], bh[2], bl[2];                                                                        \
+    _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) {                                                     \
       const int row = wm * 64 + mi * 32 + l31 + HALO + dv_;                                                 \
       ah[mi] = *reinterpret_cast<const h8*>(sAf + (AB_) * (2 * AROWS * RS) + row * RS + ko);               \
       al[mi] = *reinterpret_cast<const h8*>(sAf + (AB_) * (2 * AROWS * RS) + AROWS * RS + row * RS + ko);  \
+      if (!okm_[mi]) { ah[mi] = zero_; al[mi] = zero_; }                                                    \
     }                                                                                                       \
-    if (!ok0_) { ah[0] = zero_; al[0] = zero_; }                                                            \
-    if (!ok1_) { ah[1] = zero_; al[1] = zero_; }                                                            \
     bh[0] = __builtin_bit_cast(h8, b##S_##h0##KK_);                                                         \
     bl[0] = __builtin_bit_cast(h8, b##S_##l0##KK_);                                                         \
     if (NI == 2) {                                                                                          \
@@ -256,18 +261,19 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_f16x3_kernel(const KParams p
       bl[1] = __builtin_bit_cast(h8, b##S_##l1##KK_);                                                       \
     }                                                                                                       \
     /* term-major: the accumulator tiles are independent, consecutive MFMAs never wait on each other */    \
-    _Pragma("unroll") for (int mi = 0; mi < 2; ++mi) _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)      \
+    _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)     \
         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);        \
-    _Pragma("unroll") for (int mi = 0; mi < 2; ++mi) _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)      \
+    _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)     \
         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);        \
-    _Pragma("unroll") for (int mi = 0; mi < 2; ++mi) _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)      \
+    _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)     \
         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);        \
   }
 #define RP_MMA(S_, DV_, AB_)                                                                                \
   do {                                                                                                      \
     const int dv_ = (DV_);                                                                                  \
-    const bool ok0_ = static_cast<unsigned>(fv[0] + dv_) < static_cast<unsigned>(p.V);                      \
-    const bool ok1_ = static_cast<unsigned>(fv[1] + dv_) < static_cast<unsigned>(p.V);                      \
+    bool okm_[MI];                                                                                          \
+    _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                                       \
+        okm_[mi] = static_cast<unsigned>(fv[mi] + dv_) < static_cast<unsigned>(p.V);                        \
     const h8 zero_ = {0, 0, 0, 0, 0, 0, 0, 0};                                                              \
     RP_MMA_KK(S_, 0, AB_)                                                                                   \
     RP_MMA_KK(S_, 1, AB_)                                                                                   \
@@ -348,7 +354,7 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_f16x3_kernel(const KParams p
   float* S = reinterpret_cast<float*>(&sA[0][0][0]) + wave * (32 * ES);    // 4 x 32 x 68 floats = 34.8 KB <= 43.5 KB
   const int colw = n0 + wn * (32 * NI);
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
+  for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
@@ -415,24 +421,38 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_f16x3_kernel(const KParams p
       ts0 += __shfl_xor(ts0, o); ts1 += __shfl_xor(ts1, o); ts2 += __shfl_xor(ts2, o); ts3 += __shfl_xor(ts3, o);
       tq0 += __shfl_xor(tq0, o); tq1 += __shfl_xor(tq1, o); tq2 += __shfl_xor(tq2, o); tq3 += __shfl_xor(tq3, o);
     }
-    float* TS = reinterpret_cast<float*>(&sA[0][0][0]) + 4 * (32 * ES);      // behind the four staging tiles
-    __syncthreads();
-    if (lane < F4) {
-      float* t = TS + (wave * F4 + lane) * 8;
-      t[0] = ts0; t[1] = ts1; t[2] = ts2; t[3] = ts3; t[4] = tq0; t[5] = tq1; t[6] = tq2; t[7] = tq3;
-    }
-    __syncthreads();
-    if (wm == 0 && lane < F4) {
-      const float* t0 = TS + (wave * F4 + lane) * 8;
-      const float* t1 = TS + ((wave + 2) * F4 + lane) * 8;
-      const int col = colw + lane * 4;
+    if (COLS4) {                       // a wave owns all 128 rows of its 32 columns: nothing to combine
+      if (lane < F4) {
+        const int col = colw + lane * 4;
+        const float ts[4] = {ts0, ts1, ts2, ts3}, tq[4] = {tq0, tq1, tq2, tq3};
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (col + e < p.Cout) {
-          float* o = p.tstats + (static_cast<long long>(mt_i) * p.Cout + col + e) * 2;
-          o[0] = t0[e] + t1[e];
-          o[1] = t0[4 + e] + t1[4 + e];
-        }
+        for (int e = 0; e < 4; ++e)
+          if (col + e < p.Cout) {
+            float* o = p.tstats + (static_cast<long long>(mt_i) * p.Cout + col + e) * 2;
+            o[0] = ts[e];
+            o[1] = tq[e];
+          }
+      }
+    } else {
+      float* TS = reinterpret_cast<float*>(&sA[0][0][0]) + 4 * (32 * ES);      // behind the four staging tiles
+      __syncthreads();
+      if (lane < F4) {
+        float* t = TS + (wave * F4 + lane) * 8;
+        t[0] = ts0; t[1] = ts1; t[2] = ts2; t[3] = ts3; t[4] = tq0; t[5] = tq1; t[6] = tq2; t[7] = tq3;
+      }
+      __syncthreads();
+      if (wm == 0 && lane < F4) {
+        const float* t0 = TS + (wave * F4 + lane) * 8;
+        const float* t1 = TS + ((wave + 2) * F4 + lane) * 8;
+        const int col = colw + lane * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (col + e < p.Cout) {
+            float* o = p.tstats + (static_cast<long long>(mt_i) * p.Cout + col + e) * 2;
+            o[0] = t0[e] + t1[e];
+            o[1] = t0[4 + e] + t1[4 + e];
+          }
+      }
     }
   }
 }
@@ -618,22 +638,23 @@ int rnnpose_conv2d_nhwc_f16x3(const rnnpose_conv_desc_t* d, rnnpose_stream_t str
   bool wide = (d->c_out % 128 == 0) && (static_cast<long long>(p.n_mt) * (d->c_out / 128) >= 512);
   if (p.dbg & 32) wide = false;
   if (p.dbg & 64) wide = (d->c_out % 128 == 0);
+  const dim3 block(NT);
   if (wide) {
     p.n_nt = p.Npad / 128;
-    if (p.stride == 2)
-      hipLaunchKernelGGL((conv_igemm_f16x3_kernel<2, true>), dim3(static_cast<unsigned>(p.n_mt) * p.n_nt), dim3(NT), 0,
-                         rp::as_stream(stream), p);
-    else
-      hipLaunchKernelGGL((conv_igemm_f16x3_kernel<2, false>), dim3(static_cast<unsigned>(p.n_mt) * p.n_nt), dim3(NT), 0,
-                         rp::as_stream(stream), p);
+    const dim3 grid(static_cast<unsigned>(p.n_mt) * p.n_nt);
+    const bool cols4 = !(p.dbg & 128);          // 4-column wave layout (default); dbg bit 128 = the 2x2 layout
+    if (p.stride == 2) {
+      if (cols4) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<1, true, true>), grid, block, 0, rp::as_stream(stream), p);
+      else hipLaunchKernelGGL((conv_igemm_f16x3_kernel<2, true, false>), grid, block, 0, rp::as_stream(stream), p);
+    } else {
+      if (cols4) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<1, false, true>), grid, block, 0, rp::as_stream(stream), p);
+      else hipLaunchKernelGGL((conv_igemm_f16x3_kernel<2, false, false>), grid, block, 0, rp::as_stream(stream), p);
+    }
   } else {
     p.n_nt = rp::cdiv(d->c_out, 64);
-    if (p.stride == 2)
-      hipLaunchKernelGGL((conv_igemm_f16x3_kernel<1, true>), dim3(static_cast<unsigned>(p.n_mt) * p.n_nt), dim3(NT), 0,
-                         rp::as_stream(stream), p);
-    else
-      hipLaunchKernelGGL((conv_igemm_f16x3_kernel<1, false>), dim3(static_cast<unsigned>(p.n_mt) * p.n_nt), dim3(NT), 0,
-                         rp::as_stream(stream), p);
+    const dim3 grid(static_cast<unsigned>(p.n_mt) * p.n_nt);
+    if (p.stride == 2) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<1, true, false>), grid, block, 0, rp::as_stream(stream), p);
+    else hipLaunchKernelGGL((conv_igemm_f16x3_kernel<1, false, false>), grid, block, 0, rp::as_stream(stream), p);
   }
   return rp::check_launch(fn);
 }
