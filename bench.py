@@ -39,7 +39,7 @@ PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense fp16/bf16 MFMA peak 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=8, help="images per GPU")
     ap.add_argument("--height", type=int, default=480)

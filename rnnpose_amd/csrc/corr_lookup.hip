@@ -6,13 +6,17 @@
 //
 // HBM-bound gather.  All 81 taps of a level share one fractional offset, so a pixel needs a 10x10 texel
 // footprint per level (400 B) and produces 81 outputs.
-//   phase 1: the wave walks its 64 pixels; for each one the 64 lanes fetch the 100 footprint texels
+//   phase 1: the wave walks its 16 pixels; for each one the 64 lanes fetch the 100 footprint texels
 //            (row-contiguous 40-byte runs -> ~10-14 cache lines per instruction instead of 64) into LDS;
 //   phase 2: lane = pixel; each lane slides a two-row register window over its footprint (100 LDS reads,
 //            stride 101 floats -> conflict-free) and writes 81 channels; consecutive lanes are consecutive
 //            pixels, so every channel row is one coalesced 256-byte store.
-// One wave per workgroup (one pyramid level x 64 pixels), 25.9 KB LDS -> 6 workgroups per CU.
+// One wave per workgroup (one pyramid level x 16 pixels), 6.5 KB LDS.  The gather is latency-bound: r01 ablation =
+// 0.075 of 0.11 ms in the footprint loads; 64 pixels per wave (25.9 KB LDS, 6 waves per CU) ran at 0.111 ms, 32 at
+// 0.067, 16 at 0.057 (16 waves per CU, the VGPR limit) -- phase 2 then only uses 16 lanes, but it is 5 % of the time.
 #include "common.hpp"
+
+#include <cstdlib>
 
 namespace {
 
@@ -20,7 +24,7 @@ constexpr int R = 4;
 constexpr int WIN = 2 * R + 1;      // 9
 constexpr int FP = WIN + 1;         // 10: footprint side
 constexpr int FS = FP * FP + 1;     // 101: per-pixel LDS stride (odd -> conflict-free lane-per-pixel reads)
-constexpr int PIX = 64;
+constexpr int PIX = 16;             // pixels per wave (see the occupancy note above)
 
 struct LookupInfo {
   long long off[RNNPOSE_MAX_LEVELS];
@@ -30,14 +34,14 @@ struct LookupInfo {
 
 __global__ __launch_bounds__(64) void corr_lookup_kernel(const float* __restrict__ pyr, const float* __restrict__ coords,
                                                          float* __restrict__ out, int B, int h, int w, int levels,
-                                                         LookupInfo info, int nhwc) {
+                                                         LookupInfo info, int nhwc, int dbg) {
   __shared__ float foot[PIX * FS];
   const int N = h * w;
   const long long total = static_cast<long long>(B) * N;
   const int lane = threadIdx.x;
   const int lvl = blockIdx.y;
   const long long p = static_cast<long long>(blockIdx.x) * PIX + lane;   // flat (b, Y, X)
-  const bool live = p < total;
+  const bool live = lane < PIX && p < total;
   const int hl = info.hl[lvl], wl = info.wl[lvl];
   const float inv = 1.0f / static_cast<float>(1 << lvl);
 
@@ -72,20 +76,20 @@ __global__ __launch_bounds__(64) void corr_lookup_kernel(const float* __restrict
     {
       const int x = qbx + tx0, y = qby + ty0;
       float v = 0.f;
-      if (x >= 0 && x < wl && y >= 0 && y < hl) v = src[y * wl + x];
+      if (!(dbg & 1) && x >= 0 && x < wl && y >= 0 && y < hl) v = src[y * wl + x];
       foot[q * FS + t0] = v;
     }
     if (t1 < FP * FP) {
       const int x = qbx + tx1, y = qby + ty1;
       float v = 0.f;
-      if (x >= 0 && x < wl && y >= 0 && y < hl) v = src[y * wl + x];
+      if (!(dbg & 1) && x >= 0 && x < wl && y >= 0 && y < hl) v = src[y * wl + x];
       foot[q * FS + t1] = v;
     }
   }
   __syncthreads();
   // ---- phase 2: lane = pixel ----
   const float w00 = (1.f - ax) * (1.f - ay), w10 = ax * (1.f - ay), w01 = (1.f - ax) * ay, w11 = ax * ay;
-  const float* f = foot + lane * FS;
+  const float* f = foot + (lane < PIX ? lane : 0) * FS;      // (lanes >= PIX idle through phase 2)
   float res[WIN * WIN];
   float prev[FP], cur[FP];
 #pragma unroll
@@ -100,6 +104,7 @@ __global__ __launch_bounds__(64) void corr_lookup_kernel(const float* __restrict
 #pragma unroll
     for (int x = 0; x < FP; ++x) prev[x] = cur[x];
   }
+  if (dbg & 2) return;
   if (!nhwc) {
     // (B, L*81, h, w): consecutive lanes are consecutive pixels -> one coalesced 256-byte row per channel
     if (live) {
@@ -111,8 +116,10 @@ __global__ __launch_bounds__(64) void corr_lookup_kernel(const float* __restrict
     // (B, h, w, L*81): transpose through LDS (aliasing the footprints) so that every pixel's 81 values of this
     // level leave as one contiguous 324-byte run
     __syncthreads();
+    if (lane < PIX) {
 #pragma unroll
-    for (int c = 0; c < WIN * WIN; ++c) foot[lane * (WIN * WIN) + c] = res[c];
+      for (int c = 0; c < WIN * WIN; ++c) foot[lane * (WIN * WIN) + c] = res[c];
+    }
     __syncthreads();
     const int ctot = levels * WIN * WIN;
     float* o = out + first * ctot + lvl * (WIN * WIN);
@@ -140,7 +147,7 @@ static int launch_lookup(const char* fn, const float* pyramid, const float* coor
   const long long total = static_cast<long long>(B) * h * w;
   dim3 grid(static_cast<unsigned>(rp::cdiv(total, PIX)), static_cast<unsigned>(levels)), block(64);
   hipLaunchKernelGGL(corr_lookup_kernel, grid, block, 0, rp::as_stream(stream), pyramid, coords, out, B, h, w, levels,
-                     info, nhwc);
+                     info, nhwc, getenv("RNNPOSE_LOOKUP_DBG") ? atoi(getenv("RNNPOSE_LOOKUP_DBG")) : 0);
   return rp::check_launch(fn);
 }
 

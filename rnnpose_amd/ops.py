@@ -20,13 +20,16 @@ F64 = torch.float64
 _prof = None   # None or dict name -> list[(start_evt, end_evt)]
 
 
+_event_pool = []        # timing events are reused across profile() contexts: creating ~1300 of them costs ~10 ms per step
+
+
 @contextmanager
 def profile(names=None):
     """Record HIP events around every op call (or only the ops in `names`) on the current stream.
     Yields a dict; after the context exits and the device is synchronised, call summarize()."""
     global _prof
     prev = _prof
-    rec = {"_only": set(names) if names else None}
+    rec = {"_only": set(names) if names else None, "_next": 0}
     _prof = rec
     try:
         yield rec
@@ -45,7 +48,7 @@ def summarize(rec) -> dict:
     torch.cuda.synchronize()
     out = {}
     for k, evs in rec.items():
-        if k == "_only":
+        if k.startswith("_"):
             continue
         ms = [a.elapsed_time(b) for a, b, _ in evs]
         out[k] = (len(ms), sum(ms) / max(len(ms), 1), sum(ms), sum(w for _, _, w in evs))
@@ -55,7 +58,11 @@ def summarize(rec) -> dict:
 def _launch(name, *args, work=0):
     rec = _prof
     if rec is not None and (rec["_only"] is None or name in rec["_only"]):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        i = rec["_next"]
+        rec["_next"] = i + 2
+        while len(_event_pool) < i + 2:
+            _event_pool.append(torch.cuda.Event(enable_timing=True))
+        a, b = _event_pool[i], _event_pool[i + 1]
         a.record()
         _lib.call(name, *args)
         b.record()
