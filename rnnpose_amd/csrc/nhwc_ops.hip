@@ -220,25 +220,27 @@ __global__ void instnorm_finalize_kernel(const double* __restrict__ part, float*
 __global__ __launch_bounds__(256) void instnorm_finalize_tiles_kernel(const float* __restrict__ tile_stats,
                                                                       float* __restrict__ mean_rstd, int tiles_per_image,
                                                                       int C, int HW, float eps) {
-  // grid (B, ceil(C/32)): 32 channels x 8 tile groups per workgroup; group g sums tiles g, g+8, ... (fixed order), the
-  // 8 group sums are combined in order through LDS: deterministic, and 8x shorter dependent chains than one thread/channel
-  __shared__ double s1[8][32], s2[8][32];
-  const int b = blockIdx.x, c = blockIdx.y * 32 + (threadIdx.x & 31), g = threadIdx.x >> 5;
+  // grid (B, ceil(C/8)): 8 channels x 32 tile groups per workgroup; group g sums tiles g, g+32, ... (fixed order), the
+  // 32 group sums are combined in order through LDS: deterministic, and the dependent chain is tiles/32 loads long
+  // (this kernel is pure latency: 600 tiles per image at 240x320)
+  __shared__ double s1[32][8], s2[32][8];
+  const int b = blockIdx.x, cl = threadIdx.x & 7, c = blockIdx.y * 8 + cl, g = threadIdx.x >> 3;
   double t1 = 0, t2 = 0;
   if (c < C) {
     const float* p = tile_stats + (static_cast<long long>(b) * tiles_per_image * C + c) * 2;
-    for (int k = g; k < tiles_per_image; k += 8) {
+#pragma unroll 4
+    for (int k = g; k < tiles_per_image; k += 32) {
       const float2 v = *reinterpret_cast<const float2*>(p + static_cast<long long>(k) * C * 2);
       t1 += v.x;
       t2 += v.y;
     }
   }
-  s1[g][threadIdx.x & 31] = t1;
-  s2[g][threadIdx.x & 31] = t2;
+  s1[g][cl] = t1;
+  s2[g][cl] = t2;
   __syncthreads();
   if (g == 0 && c < C) {
     double a1 = 0, a2 = 0;
-    for (int k = 0; k < 8; ++k) { a1 += s1[k][threadIdx.x]; a2 += s2[k][threadIdx.x]; }
+    for (int k = 0; k < 32; ++k) { a1 += s1[k][cl]; a2 += s2[k][cl]; }
     const double m = a1 / HW;
     double var = a2 / HW - m * m;
     if (var < 0) var = 0;
@@ -409,7 +411,7 @@ int rnnpose_instnorm_tiles_nhwc_f32(const float* x, int B, int HW, int C, float 
   RP_REQUIRE(B > 0 && B < 65536 && HW > 0 && C > 0 && C % 4 == 0, fn, "bad size (C % 4 == 0)");
   RP_REQUIRE(rows_per_tile > 0 && HW % rows_per_tile == 0, fn, "HW must be a multiple of rows_per_tile (no tile may straddle two images)");
   hipStream_t st = rp::as_stream(stream);
-  hipLaunchKernelGGL(instnorm_finalize_tiles_kernel, dim3(B, rp::cdiv(C, 32)), dim3(256), 0, st, tile_stats, mean_rstd, HW / rows_per_tile, C, HW, eps);
+  hipLaunchKernelGGL(instnorm_finalize_tiles_kernel, dim3(B, rp::cdiv(C, 8)), dim3(256), 0, st, tile_stats, mean_rstd, HW / rows_per_tile, C, HW, eps);
   const long long total4 = static_cast<long long>(B) * HW * (C >> 2);
   hipLaunchKernelGGL(instnorm_apply_kernel, dim3(rp::cdiv(total4, 256)), dim3(256), 0, st, x, mean_rstd, residual, out, HW,
                      C, relu, total4);
