@@ -31,6 +31,7 @@ namespace {
 constexpr int BM = 128, BN = 128, BK = 32, NT = 256;
 constexpr int HALO = 4;                 // rows of halo on each side (taps up to +-3 along the fast axis)
 constexpr int AROWS = BM + 2 * HALO;    // 136
+constexpr int PROWS = AROWS + 1;        // rows per LDS plane: + one all-zero row that masked-out fragment lanes read
 constexpr int RS = 40;                  // LDS row stride in halfs: 32 + 8 pad = 80 bytes
 constexpr int MAX_CB = 24;
 
@@ -77,15 +78,29 @@ struct KParams {
 // branches the compiler cannot count how many younger loads are in flight and falls back to s_waitcnt vmcnt(0) -- r01
 // in-kernel timestamps showed two full memory-latency stalls per 32-channel block (the weight prefetch drained
 // before the activation loads and again before the LDS store).
+// fp32 -> fp16 hi + lo with as few vector-ALU instructions as possible (the split runs once per activation element and
+// per 32-channel block; for 1x1 convolutions it used more VALU-port time than the MFMAs of the block):
+//   hi = x with the mantissa TRUNCATED to fp16's 11 significant bits (one v_and; exactly representable, so the packed
+//        convert is exact), lo = fp16(x - hi) (x - hi is exact in fp32; 11 more bits) -> 21-22 significant bits.
+// Packed fp32 math (v_pk_mul_f32 / v_pk_add_f32) and v_cvt_pk_f16_f32 halve the rest.  |x*s| > 65504: hi converts to
+// inf and is clamped to +-65504 (lo stays tiny): saturation, never NaN from finite inputs.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split4(const float4 v, float s, h4& hi, h4& lo) {
-  const float x[4] = {v.x * s, v.y * s, v.z * s, v.w * s};
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    float c = fminf(fmaxf(x[i], -65504.f), 65504.f);   // saturate instead of producing inf
-    const _Float16 h = static_cast<_Float16>(c);
-    hi[i] = h;
-    lo[i] = static_cast<_Float16>(c - static_cast<float>(h));
-  }
+  const f32x2 s2 = {s, s};
+  const f32x2 x01 = f32x2{v.x, v.y} * s2, x23 = f32x2{v.z, v.w} * s2;
+  const u32x2 m = {0xffffe000u, 0xffffe000u};
+  const f32x2 t01 = __builtin_bit_cast(f32x2, __builtin_bit_cast(u32x2, x01) & m);
+  const f32x2 t23 = __builtin_bit_cast(f32x2, __builtin_bit_cast(u32x2, x23) & m);
+  const f32x2 l01 = x01 - t01, l23 = x23 - t23;
+  const h2 cap = {static_cast<_Float16>(65504.f), static_cast<_Float16>(65504.f)};
+  h2 h01 = __builtin_convertvector(t01, h2), h23 = __builtin_convertvector(t23, h2);
+  h01 = __builtin_elementwise_max(__builtin_elementwise_min(h01, cap), -cap);
+  h23 = __builtin_elementwise_max(__builtin_elementwise_min(h23, cap), -cap);
+  const h2 q01 = __builtin_convertvector(l01, h2), q23 = __builtin_convertvector(l23, h2);
+  hi = h4{h01.x, h01.y, h23.x, h23.y};
+  lo = h4{q01.x, q01.y, q23.x, q23.y};
 }
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
@@ -121,7 +136,7 @@ __global__ __launch_bounds__(NT, (COLS4 ? 3 : 2)) void conv_igemm_f16x3_kernel(c
   // wave loads its own MFMA B fragments straight from the fragment-ordered packed array (two waves of a workgroup read
   // the same lines; the second hits L1).  r01 ablation: staging weights through LDS cost 16 % in ds_write alone, made
   // the LDS pipe a co-bottleneck with the matrix pipe, and needed a barrier per tap (now: one per 32-channel block).
-  __shared__ __attribute__((aligned(16))) _Float16 sA[2][2][AROWS * RS];
+  __shared__ __attribute__((aligned(16))) _Float16 sA[2][2][PROWS * RS];
   _Float16* const sAf = &sA[0][0][0];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = COLS4 ? 0 : wave >> 1, wn = COLS4 ? wave : wave & 1;
@@ -211,8 +226,8 @@ __global__ __launch_bounds__(NT, (COLS4 ? 3 : 2)) void conv_igemm_f16x3_kernel(c
       h4 hi_, lo_;                                                                                          \
       const float4 z4_ = make_float4(0.f, 0.f, 0.f, 0.f);                                                   \
       split4((amask_n >> R_) & 1u ? av##R_ : z4_, p.a_scale, hi_, lo_);   /* padding / out-of-range rows: zeros */ \
-      *reinterpret_cast<h4*>(sAf + (AB_) * (2 * AROWS * RS) + j_ * RS + c4 * 4) = hi_;                      \
-      *reinterpret_cast<h4*>(sAf + (AB_) * (2 * AROWS * RS) + AROWS * RS + j_ * RS + c4 * 4) = lo_;         \
+      *reinterpret_cast<h4*>(sAf + (AB_) * (2 * PROWS * RS) + j_ * RS + c4 * 4) = hi_;                      \
+      *reinterpret_cast<h4*>(sAf + (AB_) * (2 * PROWS * RS) + PROWS * RS + j_ * RS + c4 * 4) = lo_;         \
     }                                                                                                       \
   }
 #define RP_STORE_A(AB_) do { RP_STORE_A_ROW(0, AB_) RP_STORE_A_ROW(1, AB_) RP_STORE_A_ROW(2, AB_) RP_STORE_A_ROW(3, AB_) RP_STORE_A_ROW(4, AB_) } while (0)
@@ -249,10 +264,13 @@ __global__ __launch_bounds__(NT, (COLS4 ? 3 : 2)) void conv_igemm_f16x3_kernel(c
     const int ko = KK_ * 16 + lh * 8;                                                                       \
     h8 ah[MI], al[MI], bh[2], bl[2];                                                                        \
     _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) {                                                     \
-      const int row = wm * 64 + mi * 32 + l31 + HALO + dv_;                                                 \
-      ah[mi] = *reinterpret_cast<const h8*>(sAf + (AB_) * (2 * AROWS * RS) + row * RS + ko);               \
-      al[mi] = *reinterpret_cast<const h8*>(sAf + (AB_) * (2 * AROWS * RS) + AROWS * RS + row * RS + ko);  \
-      if (!okm_[mi]) { ah[mi] = zero_; al[mi] = zero_; }                                                    \
+      /* tap outside the image row: 2x2 layout -> the lane reads the all-zero LDS row (1 select per fragment row instead \
+         of 8 v_cndmask per fragment; -4 % on the 64-wide kernels); the 4-column layout sits at its 168-VGPR cap, where \
+         the extra address registers spilled (measured slower), so it masks the loaded fragments instead */ \
+      const int row = (COLS4 || okm_[mi]) ? wm * 64 + mi * 32 + l31 + HALO + dv_ : AROWS;                   \
+      ah[mi] = *reinterpret_cast<const h8*>(sAf + (AB_) * (2 * PROWS * RS) + row * RS + ko);               \
+      al[mi] = *reinterpret_cast<const h8*>(sAf + (AB_) * (2 * PROWS * RS) + PROWS * RS + row * RS + ko);  \
+      if (COLS4 && !okm_[mi]) { ah[mi] = zero_; al[mi] = zero_; }                                           \
     }                                                                                                       \
     bh[0] = __builtin_bit_cast(h8, b##S_##h0##KK_);                                                         \
     bl[0] = __builtin_bit_cast(h8, b##S_##l0##KK_);                                                         \
@@ -271,10 +289,10 @@ __global__ __launch_bounds__(NT, (COLS4 ? 3 : 2)) void conv_igemm_f16x3_kernel(c
 #define RP_MMA(S_, DV_, AB_)                                                                                \
   do {                                                                                                      \
     const int dv_ = (DV_);                                                                                  \
+    const h8 zero_ = {0, 0, 0, 0, 0, 0, 0, 0};                                                              \
     bool okm_[MI];                                                                                          \
     _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                                       \
         okm_[mi] = static_cast<unsigned>(fv[mi] + dv_) < static_cast<unsigned>(p.V);                        \
-    const h8 zero_ = {0, 0, 0, 0, 0, 0, 0, 0};                                                              \
     RP_MMA_KK(S_, 0, AB_)                                                                                   \
     RP_MMA_KK(S_, 1, AB_)                                                                                   \
   } while (0)
@@ -315,6 +333,10 @@ __global__ __launch_bounds__(NT, (COLS4 ? 3 : 2)) void conv_igemm_f16x3_kernel(c
 #else
 #define RP_TS_NEXT do { } while (0)
 #endif
+  if (tid < 4 * (RS / 8)) {       // the zero row of each (buffer, hi/lo) plane: 80 bytes = 5 x 16, never overwritten
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    *reinterpret_cast<uint4*>(sAf + (tid / (RS / 8)) * (PROWS * RS) + AROWS * RS + (tid % (RS / 8)) * 8) = z;
+  }
   RP_LOAD_A(0, 0);
   RP_STORE_A(0);
   int ab = 0;                      // LDS buffer holding the activation tile being consumed
