@@ -116,6 +116,110 @@ __global__ __launch_bounds__(256) void conv3x3_cout2_kernel(const float* __restr
   }
 }
 
+// Fast path of the same operation for Cin <= 256: a wave owns a run of 4 horizontally adjacent pixels; lane l carries
+// channels 4l..4l+3 with its 72 weights (2 outputs x 9 taps x 4 channels) in registers for the whole kernel, loads the
+// 3 x 6 input quads the run needs (4.5 loads per pixel instead of 9, no weight traffic at all) and the 8 partial sums
+// (4 pixels x 2 outputs) are reduced over the 64 lanes with a halving butterfly (10 shuffles instead of 48).
+__global__ __launch_bounds__(256) void conv3x3_cout2_run4_kernel(const float* __restrict__ x, int cs, int co, int Cin,
+                                                                 const float* __restrict__ wgt, const float* __restrict__ bias,
+                                                                 const float* __restrict__ coords1, float* __restrict__ delta,
+                                                                 float* __restrict__ coords1_out, float* __restrict__ flow_lr,
+                                                                 int B, int h, int w) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane * 4;
+  const bool cl = c < Cin;
+  float4 w0[9], w1[9];                       // [tap] x 4 channels, outputs 0 / 1
+  {
+    float t0[36], t1[36];                 // wgt (2, Cin, 3, 3): 36 consecutive floats per (output, 4 channels) = 9 aligned quads
+#pragma unroll
+    for (int e = 0; e < 9; ++e) {
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 q0 = cl ? *reinterpret_cast<const float4*>(wgt + (static_cast<long long>(0) * Cin + c) * 9 + e * 4) : z;
+      const float4 q1 = cl ? *reinterpret_cast<const float4*>(wgt + (static_cast<long long>(1) * Cin + c) * 9 + e * 4) : z;
+      t0[e * 4 + 0] = q0.x; t0[e * 4 + 1] = q0.y; t0[e * 4 + 2] = q0.z; t0[e * 4 + 3] = q0.w;
+      t1[e * 4 + 0] = q1.x; t1[e * 4 + 1] = q1.y; t1[e * 4 + 2] = q1.z; t1[e * 4 + 3] = q1.w;
+    }
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      w0[tap] = make_float4(t0[tap], t0[9 + tap], t0[18 + tap], t0[27 + tap]);
+      w1[tap] = make_float4(t1[tap], t1[9 + tap], t1[18 + tap], t1[27 + tap]);
+    }
+  }
+  const int n = h * w;
+  const int runs_per_row = (w + 3) >> 2;
+  const long long total_runs = static_cast<long long>(B) * h * runs_per_row;
+  for (long long r = static_cast<long long>(blockIdx.x) * 4 + wave; r < total_runs; r += static_cast<long long>(gridDim.x) * 4) {
+    const int xr = static_cast<int>(r % runs_per_row);
+    const long long by = r / runs_per_row;
+    const int Y = static_cast<int>(by % h), b = static_cast<int>(by / h);
+    const int X0 = xr * 4;
+    float4 v[3][6];
+#pragma unroll
+    for (int ry = 0; ry < 3; ++ry)
+#pragma unroll
+      for (int cx = 0; cx < 6; ++cx) {
+        const int yy = Y + ry - 1, xx = X0 + cx - 1;
+        const bool ok = cl && yy >= 0 && yy < h && xx >= 0 && xx < w;
+        v[ry][cx] = ok ? *reinterpret_cast<const float4*>(x + (static_cast<long long>(b) * n + yy * w + xx) * cs + co + c)
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    float acc[8];                            // [pixel][output]
+#pragma unroll
+    for (int px = 0; px < 4; ++px) {
+      float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+      for (int ry = 0; ry < 3; ++ry)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const float4 q = v[ry][px + k], u0 = w0[ry * 3 + k], u1 = w1[ry * 3 + k];
+          a0 += q.x * u0.x + q.y * u0.y + q.z * u0.z + q.w * u0.w;
+          a1 += q.x * u1.x + q.y * u1.y + q.z * u1.z + q.w * u1.w;
+        }
+      acc[px * 2 + 0] = a0;
+      acc[px * 2 + 1] = a1;
+    }
+    // halving butterfly: after the xor-32 / 16 / 8 steps a lane keeps ONE of the 8 sums (index = lane bits 5,4,3)
+    float s4[4], s2[2], s1;
+    {
+      const bool up = lane & 32;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float keep = up ? acc[4 + i] : acc[i], give = up ? acc[i] : acc[4 + i];
+        s4[i] = keep + __shfl_xor(give, 32);
+      }
+      const bool up2 = lane & 16;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float keep = up2 ? s4[2 + i] : s4[i], give = up2 ? s4[i] : s4[2 + i];
+        s2[i] = keep + __shfl_xor(give, 16);
+      }
+      const bool up3 = lane & 8;
+      const float keep = up3 ? s2[1] : s2[0], give = up3 ? s2[0] : s2[1];
+      s1 = keep + __shfl_xor(give, 8);
+      s1 += __shfl_xor(s1, 4);
+      s1 += __shfl_xor(s1, 2);
+      s1 += __shfl_xor(s1, 1);
+    }
+    // lane bits (5,4,3) = (i2, i1, i0): value index = 4*i2 + 2*i1 + i0 = pixel*2 + output
+    const int idx = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
+    const int px = idx >> 1, o = idx & 1;
+    const float other = __shfl_xor(s1, 8);          // the pixel's other output component lives 8 lanes away
+    if ((lane & 7) == 0 && o == 0 && X0 + px < w) {
+      const int X = X0 + px, pix = Y * w + X;
+      const long long p = static_cast<long long>(b) * n + pix;
+      const float dx = s1 + bias[0], dy = other + bias[1];
+      *reinterpret_cast<float2*>(delta + p * 2) = make_float2(dx, dy);
+      const float cxv = coords1[(static_cast<long long>(b) * 2 + 0) * n + pix] + dx;
+      const float cyv = coords1[(static_cast<long long>(b) * 2 + 1) * n + pix] + dy;
+      if (coords1_out) {
+        coords1_out[(static_cast<long long>(b) * 2 + 0) * n + pix] = cxv;
+        coords1_out[(static_cast<long long>(b) * 2 + 1) * n + pix] = cyv;
+      }
+      *reinterpret_cast<float2*>(flow_lr + p * 2) = make_float2(cxv - static_cast<float>(X), cyv - static_cast<float>(Y));
+    }
+  }
+}
+
 // ---- a6 with NHWC inputs: mask (B,h,w,576) [channel k*64 + i*8 + j], flow (B,h,w,2) -> flow_up (B,2,8h,8w) planar
 // Workgroup = 4 consecutive low-res pixels x 64 sub-pixels: every mask read is a coalesced 256-byte run, every
 // output row segment is 4 x 8 contiguous floats.
@@ -359,7 +463,15 @@ int rnnpose_flow_head_out_f32(const float* x, int x_c_stride, int x_c_offset, in
   RP_REQUIRE(x && w_oihw && bias && coords1 && delta && flow_lr, fn, "null pointer");
   RP_REQUIRE(B > 0 && h > 0 && w > 0 && c_in > 0 && c_in % 4 == 0 && c_in <= 1024, fn, "bad size");
   RP_REQUIRE(x_c_stride % 4 == 0 && x_c_offset % 4 == 0 && x_c_offset + c_in <= x_c_stride, fn, "bad channel window");
+  RP_REQUIRE(reinterpret_cast<uintptr_t>(w_oihw) % 16 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0, fn, "x and weights must be 16-byte aligned");
   const long long total = static_cast<long long>(B) * h * w;
+  if (c_in <= 256) {
+    const long long runs = static_cast<long long>(B) * h * ((w + 3) / 4);
+    const int nb = static_cast<int>(runs / 4 + 1 < 512 ? runs / 4 + 1 : 512);      // 2 workgroups per CU: a wave keeps its weights for ~5 runs
+    hipLaunchKernelGGL(conv3x3_cout2_run4_kernel, dim3(nb), dim3(256), 0, rp::as_stream(stream), x, x_c_stride, x_c_offset, c_in,
+                       w_oihw, bias, coords1, delta, coords1_out, flow_lr, B, h, w);
+    return rp::check_launch(fn);
+  }
   const int blocks = static_cast<int>(total / 4 + 1 < 4096 ? total / 4 + 1 : 4096);
   const size_t lds = static_cast<size_t>(2) * 9 * c_in * sizeof(float);
   hipLaunchKernelGGL(conv3x3_cout2_kernel, dim3(blocks), dim3(256), lds, rp::as_stream(stream), x, x_c_stride, x_c_offset,

@@ -164,3 +164,25 @@ def test_conv_tile_stats_feed_instnorm(ops, B, H, W, cin, cout, k, stride):
     got = ops.instnorm_tiles_nhwc(out, ts, relu=True)
     ref = F.relu(F.instance_norm(y64, eps=1e-5))
     assert float((nchw(got).double() - ref).abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("B,h,w,cin,coff", [(2, 9, 23, 256, 0), (1, 16, 20, 128, 256), (1, 5, 3, 64, 4), (1, 6, 9, 320, 0)])
+def test_flow_head_out_direct(ops, B, h, w, cin, coff):
+    """FlowHead.conv2 (3x3, cin -> 2, update.py:10,14) + coords1 += delta (CFNet.py:157): ragged widths, channel
+    windows, the register-resident fast path (cin <= 256) and the general path."""
+    cs = coff + cin + 4
+    x = D(syn.normal("fh.x", (B, h, w, cs), 13, std=1.0))
+    wt = D(syn.normal("fh.w", (2, cin, 3, 3), 13, std=0.05))
+    bias = D(syn.normal("fh.b", (2,), 13, std=0.1))
+    from rnnpose_amd.corr import coords_grid
+    coords1 = coords_grid(B, h, w, device="cuda") + D(syn.normal("fh.c", (B, 2, h, w), 13, std=2.0))
+    delta = torch.empty(B, h, w, 2, device="cuda")
+    c1o = torch.empty(B, 2, h, w, device="cuda")
+    flr = torch.empty(B, h, w, 2, device="cuda")
+    ops.flow_head_out(x, coff, cin, wt, bias, coords1, delta, c1o, flr)
+    xin = x[..., coff:coff + cin].permute(0, 3, 1, 2).double()
+    ref = F.conv2d(xin, wt.double(), bias.double(), padding=1)
+    assert float((delta.permute(0, 3, 1, 2).double() - ref).abs().max()) < 2e-5
+    assert float((c1o.double() - (coords1.double() + ref)).abs().max()) < 5e-5
+    grid = coords_grid(B, h, w, device="cuda").double()
+    assert float((flr.permute(0, 3, 1, 2).double() - (coords1.double() + ref - grid)).abs().max()) < 5e-5

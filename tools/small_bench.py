@@ -48,3 +48,10 @@ flow = torch.stack([3.3 + 0.01 * yy, -2.7 + 0.005 * xx], 0)[None].repeat(B, 1, 1
 depth = torch.ones(B, 1, H, W, device=dev)
 sigma = torch.ones(1, device=dev)
 print("corr_weight  %.4f ms" % timeit(lambda: ops.corr_weight(g1, g2, flow, depth, sigma)))
+
+# FlowHead.conv2 + coords update (3x3, 256 -> 2) on the heads buffer (B,h,w,512)
+heads = torch.randn(B, h, w, 512, device=dev, generator=g)
+w2 = torch.randn(2, 256, 3, 3, device=dev, generator=g) * 0.05
+b2 = torch.randn(2, device=dev, generator=g)
+delta = torch.empty(B, h, w, 2, device=dev); c1o = torch.empty(B, 2, h, w, device=dev); flr = torch.empty(B, h, w, 2, device=dev)
+print("flow_head_out %.4f ms" % timeit(lambda: ops.flow_head_out(heads, 0, 256, w2, b2, coords, delta, c1o, flr)))
