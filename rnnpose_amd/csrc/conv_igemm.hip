@@ -2,26 +2,31 @@
 // (thirdparty/raft/update.py:6-14,33-60,79-97,164-188).
 //
 // Numerics -- "fp16x3 split" fp32 emulation on the fp16 matrix cores.  gfx950 has no TF32/xf32, and its exact
-// fp32 MFMA runs at 1/16 of the fp16 rate.  Every fp32 operand x is split as x*S = hi + lo with
-// hi = fp16(x*S), lo = fp16(x*S - hi) (S a power of two keeping lo out of the subnormal range), and
+// fp32 MFMA runs at 1/16 of the fp16 rate.  Every fp32 operand x is split as x*S = hi + lo (S a power of two keeping
+// lo out of the subnormal range; weights: hi = fp16(x*S) rounded, activations: hi = x*S truncated to 11 significant
+// bits -- one v_and --, lo = fp16(x*S - hi)) and
 //     a*b  ~=  a_hi*b_hi + a_hi*b_lo + a_lo*b_hi          (3 MFMAs, fp32 accumulation)
-// The neglected terms are O(2^-22) relative per product -- fp32 round-off class (measured against an fp64
-// reference in tests/test_gpu_conv.py), at 16/3 = 5.3x the fp32-MFMA rate.  Weights are split once on the
-// host side (rnnpose_conv_pack_weights_f16x3); activations are split on the fly while staging to LDS.
+// The neglected terms are O(2^-21) relative per product -- fp32 round-off class (measured against an fp64
+// reference in tests/test_gpu_conv.py: within 3x of MIOpen's fp32 error), at 16/3 = 5.3x the fp32-MFMA rate.
+// Weights are split once (rnnpose_conv_pack_weights_f16x3); activations are split on the fly while staging to LDS.
 //
-// Structure (per 128x128 output tile, 4 waves as 2x2, each 64x64 = 2x2 MFMA tiles of 32x32x16):
+// Structure (per 128x128 or 128x64 output tile, 4 waves; see the COLS4 note at the kernel for the two wave layouts):
 //   * activations are NHWC, so the GEMM K axis (channels) is contiguous: one 128-byte row per pixel per 32-ch
 //     block.  Up to 4 source tensors are read as a VIRTUAL CONCAT (hidden state | context | motion features
 //     never get copied into one buffer).
 //   * taps that differ along the tile's fast axis share ONE staged activation tile: the tile is loaded with a
-//     halo (BM + 8 rows) and tap dv just reads LDS rows shifted by dv; rows whose neighbour falls outside the
-//     image line are masked to zero in registers.  A 1x5 conv therefore reads its input once, not 5 times.
-//     (5x1 convs tile the image column-major so the same trick applies; 3x3 = 3 groups of 3 taps.)
-//   * weights: pre-packed [group][tap][32-ch block][n][32] fp16 hi/lo -> each (tap, block) tile is one contiguous
-//     8-KB burst per half; double-buffered in LDS, prefetched into registers one tap ahead.
-//   * LDS rows are padded to 80 bytes: ds_read_b128 of 32 consecutive rows is bank-conflict free.
-//   * fused epilogues: bias + {linear, ReLU, GRU z|r gate (sigmoid, r*h), GRU state update (tanh, (1-z)h+zq)},
-//     writing straight into a channel slice of the destination NHWC tensor (no cat / clone / relu kernels).
+//     halo (BM + 8 rows) and tap dv just reads LDS rows shifted by dv; lanes whose neighbour falls outside the
+//     image line read an all-zero LDS row (2x2 layout) or are masked in registers (4-column layout).  A 1x5 conv
+//     therefore reads its input once, not 5 times.  (5x1 convs tile the image column-major so the same trick
+//     applies; 3x3 = 3 groups of 3 taps; stride 2: every tap is its own group.)
+//   * weights: pre-packed in MFMA B-fragment order [group][tap][32-ch block][32-col tile][k half][lane][8] fp16 hi/lo;
+//     every wave loads its own fragments straight into registers two taps ahead (no weight LDS, one barrier per
+//     32-channel block).  All main-loop loads are unconditional so that the waits stay counted (vmcnt(8..15)).
+//   * the activation tile is double-buffered in LDS, rows padded to 80 bytes: ds_read_b128 of 32 consecutive rows is
+//     bank-conflict free.
+//   * fused epilogues (accumulators -> wave-private LDS tile -> 16-byte row-contiguous stores): bias + {linear,
+//     ReLU, GRU z|r gate (sigmoid, r*h), GRU state update (tanh, (1-z)h+zq)}, optional per-tile column statistics
+//     for the encoder's instance norm, writing straight into a channel slice of the destination NHWC tensor.
 #include "common.hpp"
 
 #include <cstdlib>

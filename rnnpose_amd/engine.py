@@ -5,7 +5,8 @@ kernel (csrc/conv_igemm.hip) with bias / ReLU / GRU gates fused into its epilogu
 
 Per step: lookup (NHWC) -> convc1 -> convc2 | convf1 -> convf2 -> conv -> z|r (1x5) -> q (1x5) -> z|r (5x1) -> q (5x1)
 -> flow/mask heads (one 128->512 conv) -> flow_head.conv2 + coords update -> mask.2 (x0.25 folded) -> convex upsample:
-16 launches, no ATen elementwise / cat / clone kernels.  The module's parameters stay the single source of truth:
+16 launches (the flow-feature chain and the flow head on a side stream = parallel hipGraph branches), no ATen
+elementwise / cat / clone kernels.  The module's parameters stay the single source of truth:
 packed fp16 hi/lo copies are rebuilt whenever a parameter's version or storage changes.
 """
 from __future__ import annotations
