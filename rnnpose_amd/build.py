@@ -50,10 +50,25 @@ def hipcc() -> str:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile csrc/*.hip for gfx950 into lib/librnnpose_hip.so unless the stamp matches.  Safe to call from several
+    processes at once (one rank per GPU all call it): an exclusive file lock serialises them and the losers find the
+    fresh stamp."""
+    import fcntl
     os.makedirs(LIBDIR, exist_ok=True)
     dig = _digest()
     if not force and os.path.exists(LIB) and os.path.exists(STAMP) and open(STAMP).read().strip() == dig:
         return LIB
+    with open(os.path.join(LIBDIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and os.path.exists(LIB) and os.path.exists(STAMP) and open(STAMP).read().strip() == dig:
+                return LIB
+            return _build_locked(dig, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(dig: str, verbose: bool) -> str:
     objs = []
     procs = []
     for src in sources():
