@@ -74,7 +74,7 @@ struct KParams {
   int gru_c;
   float* tstats;   // optional per-tile column statistics (linear epilogue)
   int n_mt, n_nt;
-  int dbg;   // ablation switches for tools/conv_ablate.py (RNNPOSE_CONV_DBG); 0 in production
+  int dbg;   // tile-shape overrides for A/B timing (RNNPOSE_CONV_DBG: 32 = 64-wide tiles, 64 = 128-wide tiles, 128 = 2x2 wave layout); 0 in production
 };
 
 
