@@ -157,12 +157,8 @@ int rnnpose_gru_update_f32(const float* z, const float* q_pre, const float* hcat
  * All destination / aux tensors are NHWC with their own channel stride and offset (so results land directly
  * in a slice of a wider tensor).  dst must not alias a source of the same launch.                      */
 typedef struct {
-  const void* ptr;             /* fp32 NHWC tensor; or, if lo != NULL, the fp16 "hi" plane of a PRE-SPLIT tensor */
+  const float* ptr;
   int c_stride, c_offset, c_count;
-  const void* lo;              /* NULL for fp32 sources.  Pre-split tensor = two fp16 planes (hi, lo) of the same NHWC shape
-                                  holding x * a_scale = hi + lo, as written by a producer's dst_hi / dst_lo (or
-                                  rnnpose_split_nhwc_f16x2): the convolution then skips its per-tile fp32 -> fp16 split.
-                                  All sources of one call must be of the same kind; stride 1 only. */
 } rnnpose_conv_src_t;
 
 typedef struct {
@@ -186,12 +182,6 @@ typedef struct {
   float* dst2;
   int dst2_c_stride, dst2_c_offset;
   int gru_c;
-  void* dst_hi;                /* optional pre-split copy of the output (hi / lo planes, same channel window as dst, values */
-  void* dst_lo;                /*   scaled by a_scale): columns >= dst_split_c0.  dst may be NULL when only the split copy is wanted */
-  int dst_f32_cols;            /* fp32 dst receives columns [0, dst_f32_cols); 0 = all c_out */
-  int dst_split_c0;
-  void* dst2_hi;               /* same for dst2 (r*h of the GRU gate epilogue) */
-  void* dst2_lo;
   float* tile_stats;           /* optional (NULL = off), linear epilogue only: (ceil(M/128), c_out, 2) fp32 receives, per
                                   128-row output tile, the column sums and sums of squares of the outputs (bias included)
                                   -- the instance-norm statistics pass of the encoder without re-reading the tensor
@@ -203,11 +193,6 @@ long long rnnpose_conv_packed_halfs(int c_out, int kh, int kw, const int* h_seg_
 int rnnpose_conv_pack_weights_f16x3(const float* w_oihw, int c_out, int c_in, int kh, int kw, const int* h_seg_counts,
                                     int n_seg, float w_scale, void* w_hi, void* w_lo, rnnpose_stream_t stream);
 int rnnpose_conv2d_nhwc_f16x3(const rnnpose_conv_desc_t* h_desc, rnnpose_stream_t stream);
-/* fp32 tensor -> the pre-split fp16 hi / lo planes a convolution accepts as a source (same arithmetic as the
- * convolution's own split: results are bit-identical either way).  layout 0: src (B,C,HW); layout 1: the C channels at
- * src_c_offset of src (B,HW,src_c_stride).  Destination: channels [dst_c_offset, +C) of planes (B,HW,dst_c_stride). */
-int rnnpose_split_nhwc_f16x2(const float* src, int layout, int B, int C, int HW, int src_c_stride, int src_c_offset, float a_scale,
-                             void* hi, void* lo, int dst_c_stride, int dst_c_offset, rnnpose_stream_t stream);
 
 /* ---- NHWC companions of the fused update-block engine ----------------------------------------------------
  * corr_lookup_nhwc: a3 with the output laid out (B,h,w,levels*81) (thirdparty/raft/corr.py:36-57).

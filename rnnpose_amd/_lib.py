@@ -16,8 +16,8 @@ _f = C.c_float
 _d = C.c_double
 _z = C.c_size_t
 
-class ConvSrc(C.Structure):   # rnnpose_conv_src_t
-    _fields_ = [("ptr", C.c_void_p), ("c_stride", C.c_int), ("c_offset", C.c_int), ("c_count", C.c_int), ("lo", C.c_void_p)]
+class ConvSrc(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("c_stride", C.c_int), ("c_offset", C.c_int), ("c_count", C.c_int)]
 
 
 class ConvDesc(C.Structure):       # rnnpose_conv_desc_t
@@ -28,8 +28,7 @@ class ConvDesc(C.Structure):       # rnnpose_conv_desc_t
                 ("aux0", C.c_void_p), ("aux0_c_stride", C.c_int), ("aux0_c_offset", C.c_int),
                 ("aux1", C.c_void_p), ("aux1_c_stride", C.c_int), ("aux1_c_offset", C.c_int),
                 ("dst2", C.c_void_p), ("dst2_c_stride", C.c_int), ("dst2_c_offset", C.c_int), ("gru_c", C.c_int),
-                ("dst_hi", C.c_void_p), ("dst_lo", C.c_void_p), ("dst_f32_cols", C.c_int), ("dst_split_c0", C.c_int),
-                ("dst2_hi", C.c_void_p), ("dst2_lo", C.c_void_p), ("tile_stats", C.c_void_p)]
+                ("tile_stats", C.c_void_p)]
 
 
 # name -> (restype, argtypes); mirrors include/rnnpose_hip.h one to one
@@ -60,7 +59,6 @@ PROTOTYPES = {
     "rnnpose_conv_packed_halfs": (C.c_longlong, [_i, _i, _i, C.POINTER(_i), _i]),
     "rnnpose_conv_pack_weights_f16x3": (_i, [_p, _i, _i, _i, _i, C.POINTER(_i), _i, _f, _p, _p, _p]),
     "rnnpose_conv2d_nhwc_f16x3": (_i, [C.POINTER(ConvDesc), _p]),
-    "rnnpose_split_nhwc_f16x2": (_i, [_p, _i, _i, _i, _i, _i, _i, _f, _p, _p, _i, _i, _p]),
     "rnnpose_corr_lookup_nhwc_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p]),
     "rnnpose_nchw_to_nhwc_f32": (_i, [_p, _i, _i, _i, _p, _i, _i, _p]),
     "rnnpose_nhwc_to_nchw_f32": (_i, [_p, _i, _i, _i, _i, _i, _p, _p]),

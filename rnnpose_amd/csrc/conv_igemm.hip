@@ -45,8 +45,7 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct Seg {
-  const void* ptr;        // fp32 tensor, or the fp16 hi plane of a pre-split tensor
-  const void* lo;         // fp16 lo plane (pre-split sources only)
+  const float* ptr;
   int cstride, coff, ccount;
 };
 
@@ -72,8 +71,6 @@ struct KParams {
   int aux1_cs, aux1_co;
   float* dst2;
   int dst2_cs, dst2_co;
-  _Float16 *dst_hi, *dst_lo, *dst2_hi, *dst2_lo;   // optional pre-split copies of the outputs (same channel windows)
-  int dst_f32_cols, dst_split_c0;                   // fp32 dst gets columns [0, f32_cols); split dst columns >= split_c0
   int gru_c;
   float* tstats;   // optional per-tile column statistics (linear epilogue)
   int n_mt, n_nt;
@@ -135,12 +132,7 @@ __device__ long long g_conv_ts[64 * 8];
 // side, each ALL 128 rows x 32 columns (NI must be 1).  Same MFMA count per wave, but a wave then requests 2 weight
 // fragments per k-slab from L2/L1 instead of 4 (the fragment loads were stalling in the vector-memory queue when two
 // workgroups share a CU: r01 timestamps) and reads 8 activation fragments from LDS instead of 4.
-// SPLIT = the sources are PRE-SPLIT tensors (fp16 hi / lo planes scaled by a_scale, written by the producing kernel's
-// epilogue): the activation path is then two 8-byte loads and two ds_write_b64 per row quad with no conversion at all.
-// The split costs ~16 VALU instructions per quad and used to run once per consumer tile (a GRU input is consumed by
-// 4 convolutions x 2 column tiles per iteration); the VALU port -- which MFMAs also issue through -- was the limiter
-// of the 1x1 and 3x3 layers (r01 instruction counts: 182 VALU slots per 12..24 MFMAs for a 1x1 block).
-template <int NI, bool STRIDED, bool COLS4 = false, bool SPLIT = false>
+template <int NI, bool STRIDED, bool COLS4 = false>
 __global__ __launch_bounds__(NT, (COLS4 ? 3 : 2)) void conv_igemm_f16x3_kernel(const KParams p) {
   static_assert(!COLS4 || NI == 1, "the 4-column layout has one 32-column MFMA tile per wave");
   constexpr int MI = COLS4 ? 4 : 2;                     // 32-row MFMA tiles per wave
@@ -213,13 +205,7 @@ __global__ __launch_bounds__(NT, (COLS4 ? 3 : 2)) void conv_igemm_f16x3_kernel(c
     const unsigned px_ = STRIDED ? static_cast<unsigned>(a_pix##R_) + static_cast<unsigned>(uu_) * p.su + static_cast<unsigned>(vv_) * p.sv \
                                  : static_cast<unsigned>(a_pix##R_ + dpix_);   /* (unsigned: rows outside wrap harmlessly) */ \
     const unsigned off_ = in_ ? px_ * static_cast<unsigned>(sg_.cstride) + cc_ : 0u;   /* < 2^31 (host check) */ \
-    if (SPLIT) {                                                                                            \
-      const uint2 h_ = *reinterpret_cast<const uint2*>(static_cast<const _Float16*>(sg_.ptr) + off_);       \
-      const uint2 l_ = *reinterpret_cast<const uint2*>(static_cast<const _Float16*>(sg_.lo) + off_);        \
-      av##R_ = __builtin_bit_cast(float4, make_uint4(h_.x, h_.y, l_.x, l_.y));                              \
-    } else {                                                                                                \
-      av##R_ = *reinterpret_cast<const float4*>(static_cast<const float*>(sg_.ptr) + off_);                 \
-    }                                                                                                       \
+    av##R_ = *reinterpret_cast<const float4*>(sg_.ptr + off_);                                              \
     amask_n |= in_ ? (1u << R_) : 0u;                                                                       \
   }
 #define RP_LOAD_A(G_, CB_)                                                                                  \
@@ -242,18 +228,11 @@ __global__ __launch_bounds__(NT, (COLS4 ? 3 : 2)) void conv_igemm_f16x3_kernel(c
   {                                                                                                         \
     const int j_ = (tid >> 3) + 32 * R_;                                                                    \
     if (j_ < AROWS) {                                                                                       \
+      h4 hi_, lo_;                                                                                          \
       const float4 z4_ = make_float4(0.f, 0.f, 0.f, 0.f);                                                   \
-      const float4 v4_ = (amask_n >> R_) & 1u ? av##R_ : z4_;             /* padding / out-of-range rows: zeros */ \
-      if (SPLIT) {                                                                                          \
-        const uint4 u_ = __builtin_bit_cast(uint4, v4_);                                                    \
-        *reinterpret_cast<uint2*>(sAf + (AB_) * (2 * PROWS * RS) + j_ * RS + c4 * 4) = make_uint2(u_.x, u_.y);              \
-        *reinterpret_cast<uint2*>(sAf + (AB_) * (2 * PROWS * RS) + PROWS * RS + j_ * RS + c4 * 4) = make_uint2(u_.z, u_.w); \
-      } else {                                                                                              \
-        h4 hi_, lo_;                                                                                        \
-        split4(v4_, p.a_scale, hi_, lo_);                                                                   \
-        *reinterpret_cast<h4*>(sAf + (AB_) * (2 * PROWS * RS) + j_ * RS + c4 * 4) = hi_;                    \
-        *reinterpret_cast<h4*>(sAf + (AB_) * (2 * PROWS * RS) + PROWS * RS + j_ * RS + c4 * 4) = lo_;       \
-      }                                                                                                     \
+      split4((amask_n >> R_) & 1u ? av##R_ : z4_, p.a_scale, hi_, lo_);   /* padding / out-of-range rows: zeros */ \
+      *reinterpret_cast<h4*>(sAf + (AB_) * (2 * PROWS * RS) + j_ * RS + c4 * 4) = hi_;                      \
+      *reinterpret_cast<h4*>(sAf + (AB_) * (2 * PROWS * RS) + PROWS * RS + j_ * RS + c4 * 4) = lo_;         \
     }                                                                                                       \
   }
 #define RP_STORE_A(AB_) do { RP_STORE_A_ROW(0, AB_) RP_STORE_A_ROW(1, AB_) RP_STORE_A_ROW(2, AB_) RP_STORE_A_ROW(3, AB_) RP_STORE_A_ROW(4, AB_) } while (0)
@@ -425,10 +404,7 @@ __global__ __launch_bounds__(NT, (COLS4 ? 3 : 2)) void conv_igemm_f16x3_kernel(c
       const int nv = p.Cout - col < 4 ? p.Cout - col : 4;      // valid columns of this quad (Cout = 126 -> tail of 2)
 #pragma unroll
       for (int e = 0; e < 4; ++e) y[e] += (e < nv) ? p.bias[col + e] : 0.f;
-      float* dptr = p.dst ? p.dst + pix * p.dst_cs + p.dst_co + col : nullptr;
-      bool wr_f32 = p.dst && col < p.dst_f32_cols, wr_sp = p.dst_hi && col >= p.dst_split_c0;
-      _Float16* hptr = p.dst_hi + pix * p.dst_cs + p.dst_co + col;
-      _Float16* lptr = p.dst_lo + pix * p.dst_cs + p.dst_co + col;
+      float* dptr = p.dst + pix * p.dst_cs + p.dst_co + col;
       if (p.tstats) {              // (column quad of a lane is the same for every k and mi: 64 % F4 == 0)
         if (nv > 0) { ts0 += y[0]; tq0 += y[0] * y[0]; }
         if (nv > 1) { ts1 += y[1]; tq1 += y[1] * y[1]; }
@@ -447,11 +423,7 @@ __global__ __launch_bounds__(NT, (COLS4 ? 3 : 2)) void conv_igemm_f16x3_kernel(c
           const float4 hv = *reinterpret_cast<const float4*>(p.aux0 + pix * p.aux0_cs + p.aux0_co + c2);
           y[0] = sigmoidf_(y[0]) * hv.x; y[1] = sigmoidf_(y[1]) * hv.y;                   // r * h
           y[2] = sigmoidf_(y[2]) * hv.z; y[3] = sigmoidf_(y[3]) * hv.w;
-          dptr = p.dst2 ? p.dst2 + pix * p.dst2_cs + p.dst2_co + c2 : nullptr;
-          hptr = p.dst2_hi + pix * p.dst2_cs + p.dst2_co + c2;
-          lptr = p.dst2_lo + pix * p.dst2_cs + p.dst2_co + c2;
-          wr_f32 = p.dst2 != nullptr;
-          wr_sp = p.dst2_hi != nullptr;
+          dptr = p.dst2 + pix * p.dst2_cs + p.dst2_co + c2;
         }
       } else if (p.epi == 3) {
         const float4 z = *reinterpret_cast<const float4*>(p.aux1 + pix * p.aux1_cs + p.aux1_co + col);
@@ -459,26 +431,12 @@ __global__ __launch_bounds__(NT, (COLS4 ? 3 : 2)) void conv_igemm_f16x3_kernel(c
         y[0] = (1.f - z.x) * hv.x + z.x * tanhf(y[0]); y[1] = (1.f - z.y) * hv.y + z.y * tanhf(y[1]);   // h' = (1-z)h + z q
         y[2] = (1.f - z.z) * hv.z + z.z * tanhf(y[2]); y[3] = (1.f - z.w) * hv.w + z.w * tanhf(y[3]);
       }
-      if (wr_f32) {
-        if (nv == 4) {
-          *reinterpret_cast<float4*>(dptr) = make_float4(y[0], y[1], y[2], y[3]);
-        } else {
+      if (nv == 4) {
+        *reinterpret_cast<float4*>(dptr) = make_float4(y[0], y[1], y[2], y[3]);
+      } else {
 #pragma unroll
-          for (int e = 0; e < 3; ++e)
-            if (e < nv) dptr[e] = y[e];
-        }
-      }
-      if (wr_sp) {               // the consumer's fp16 hi / lo operand planes, split here once instead of in every consumer tile
-        h4 hi4, lo4;
-        split4(make_float4(y[0], y[1], y[2], y[3]), p.a_scale, hi4, lo4);
-        if (nv == 4) {
-          *reinterpret_cast<h4*>(hptr) = hi4;
-          *reinterpret_cast<h4*>(lptr) = lo4;
-        } else {
-#pragma unroll
-          for (int e = 0; e < 3; ++e)
-            if (e < nv) { hptr[e] = hi4[e]; lptr[e] = lo4[e]; }
-        }
+        for (int e = 0; e < 3; ++e)
+          if (e < nv) dptr[e] = y[e];
       }
     }
   }
@@ -627,11 +585,11 @@ int rnnpose_conv2d_nhwc_f16x3(const rnnpose_conv_desc_t* d, rnnpose_stream_t str
   RP_REQUIRE(d->n_src >= 1 && d->n_src <= 4, fn, "1..4 sources");
   RP_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->c_out > 0, fn, "bad size");
   RP_REQUIRE((d->kh & 1) && (d->kw & 1) && d->kh <= 7 && d->kw <= 7, fn, "odd kernel sizes up to 7");
-  RP_REQUIRE(d->w_hi && d->w_lo && d->bias && (d->dst || d->dst_hi), fn, "null pointer");
+  RP_REQUIRE(d->w_hi && d->w_lo && d->bias && d->dst, fn, "null pointer");
   RP_REQUIRE(d->epilogue >= 0 && d->epilogue <= 3, fn, "epilogue must be 0..3");
   RP_REQUIRE(d->stride == 1 || d->stride == 2, fn, "stride must be 1 or 2");
   RP_REQUIRE(d->a_scale > 0.f && d->w_scale > 0.f, fn, "scales must be positive");
-  if (d->epilogue == 2) RP_REQUIRE(d->aux0 && (d->dst2 || d->dst2_hi) && d->gru_c > 0 && d->c_out == 2 * d->gru_c, fn, "gru_zr needs aux0 (h), dst2 (r*h), c_out == 2*gru_c");
+  if (d->epilogue == 2) RP_REQUIRE(d->aux0 && d->dst2 && d->gru_c > 0 && d->c_out == 2 * d->gru_c, fn, "gru_zr needs aux0 (h), dst2 (r*h), c_out == 2*gru_c");
   if (d->epilogue == 3) RP_REQUIRE(d->aux0 && d->aux1, fn, "gru_q needs aux0 (h) and aux1 (z)");
   RP_REQUIRE(d->dst_c_stride % 4 == 0 && d->dst_c_offset % 4 == 0 && reinterpret_cast<uintptr_t>(d->dst) % 16 == 0, fn,
              "dst: 16-byte aligned, channel stride/offset multiples of 4");
@@ -641,8 +599,6 @@ int rnnpose_conv2d_nhwc_f16x3(const rnnpose_conv_desc_t* d, rnnpose_stream_t str
                "aux0: 16-byte aligned, channel stride/offset multiples of 4");
   }
   if (d->epilogue == 2) RP_REQUIRE(d->dst2_c_stride % 4 == 0 && d->dst2_c_offset % 4 == 0 && reinterpret_cast<uintptr_t>(d->dst2) % 16 == 0, fn, "dst2 alignment");
-  const bool split_in = d->src[0].lo != nullptr;
-  RP_REQUIRE(!split_in || d->stride == 1, fn, "pre-split sources are implemented for stride 1");
   if (d->epilogue == 3) RP_REQUIRE(d->aux1_c_stride % 4 == 0 && d->aux1_c_offset % 4 == 0 && reinterpret_cast<uintptr_t>(d->aux1) % 16 == 0, fn, "aux1 alignment");
   KParams p{};
   int counts[4];
@@ -651,11 +607,9 @@ int rnnpose_conv2d_nhwc_f16x3(const rnnpose_conv_desc_t* d, rnnpose_stream_t str
     RP_REQUIRE(sr.ptr && sr.c_count > 0 && sr.c_count % 4 == 0 && sr.c_stride % 4 == 0 && sr.c_offset % 4 == 0 &&
                    sr.c_offset + sr.c_count <= sr.c_stride && reinterpret_cast<uintptr_t>(sr.ptr) % 16 == 0,
                fn, "source: 16-byte aligned pointer, channel stride/offset/count multiples of 4");
-    RP_REQUIRE((sr.lo != nullptr) == (d->src[0].lo != nullptr), fn, "sources must be all fp32 or all pre-split");
-    RP_REQUIRE(!sr.lo || reinterpret_cast<uintptr_t>(sr.lo) % 16 == 0, fn, "lo plane must be 16-byte aligned");
     RP_REQUIRE(static_cast<long long>(d->B) * d->H * d->W * sr.c_stride < (1LL << 31), fn,
                "source tensor too large for 32-bit element offsets (B*H*W*c_stride must be < 2^31)");
-    const Seg sg{sr.ptr, sr.lo, sr.c_stride, sr.c_offset, sr.c_count};
+    const Seg sg{sr.ptr, sr.c_stride, sr.c_offset, sr.c_count};
     (s == 0 ? p.seg0 : s == 1 ? p.seg1 : s == 2 ? p.seg2 : p.seg3) = sg;
     counts[s] = sr.c_count;
   }
@@ -697,16 +651,6 @@ int rnnpose_conv2d_nhwc_f16x3(const rnnpose_conv_desc_t* d, rnnpose_stream_t str
   p.aux0 = d->aux0; p.aux0_cs = d->aux0_c_stride; p.aux0_co = d->aux0_c_offset;
   p.aux1 = d->aux1; p.aux1_cs = d->aux1_c_stride; p.aux1_co = d->aux1_c_offset;
   p.dst2 = d->dst2; p.dst2_cs = d->dst2_c_stride; p.dst2_co = d->dst2_c_offset;
-  p.dst_hi = static_cast<_Float16*>(d->dst_hi); p.dst_lo = static_cast<_Float16*>(d->dst_lo);
-  p.dst2_hi = static_cast<_Float16*>(d->dst2_hi); p.dst2_lo = static_cast<_Float16*>(d->dst2_lo);
-  p.dst_f32_cols = d->dst_f32_cols > 0 ? d->dst_f32_cols : d->c_out;
-  p.dst_split_c0 = d->dst_split_c0;
-  RP_REQUIRE((d->dst_hi != nullptr) == (d->dst_lo != nullptr) && (d->dst2_hi != nullptr) == (d->dst2_lo != nullptr), fn,
-             "split outputs need both planes");
-  RP_REQUIRE(!d->dst_hi || (reinterpret_cast<uintptr_t>(d->dst_hi) % 8 == 0 && reinterpret_cast<uintptr_t>(d->dst_lo) % 8 == 0), fn,
-             "split output planes must be 8-byte aligned");
-  RP_REQUIRE(d->dst_split_c0 >= 0 && d->dst_split_c0 % 4 == 0 && d->dst_f32_cols >= 0 && d->dst_f32_cols % 4 == 0, fn,
-             "column limits must be multiples of 4");
   p.gru_c = d->gru_c;
   p.tstats = d->tile_stats;
   if (d->tile_stats) RP_REQUIRE(d->epilogue == 0, fn, "tile_stats needs the linear epilogue");
@@ -722,22 +666,23 @@ int rnnpose_conv2d_nhwc_f16x3(const rnnpose_conv_desc_t* d, rnnpose_stream_t str
   if (p.dbg & 32) wide = false;
   if (p.dbg & 64) wide = (d->c_out % 128 == 0);
   const dim3 block(NT);
-#define RP_GO(NI_, ST_, C4_, SP_) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<NI_, ST_, C4_, SP_>), grid, block, 0, rp::as_stream(stream), p)
   if (wide) {
     p.n_nt = p.Npad / 128;
     const dim3 grid(static_cast<unsigned>(p.n_mt) * p.n_nt);
-    const bool cols4 = !(p.dbg & 128) || split_in;      // 4-column wave layout (default); dbg bit 128 = the 2x2 layout
-    if (split_in) RP_GO(1, false, true, true);
-    else if (p.stride == 2) { if (cols4) RP_GO(1, true, true, false); else RP_GO(2, true, false, false); }
-    else { if (cols4) RP_GO(1, false, true, false); else RP_GO(2, false, false, false); }
+    const bool cols4 = !(p.dbg & 128);          // 4-column wave layout (default); dbg bit 128 = the 2x2 layout
+    if (p.stride == 2) {
+      if (cols4) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<1, true, true>), grid, block, 0, rp::as_stream(stream), p);
+      else hipLaunchKernelGGL((conv_igemm_f16x3_kernel<2, true, false>), grid, block, 0, rp::as_stream(stream), p);
+    } else {
+      if (cols4) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<1, false, true>), grid, block, 0, rp::as_stream(stream), p);
+      else hipLaunchKernelGGL((conv_igemm_f16x3_kernel<2, false, false>), grid, block, 0, rp::as_stream(stream), p);
+    }
   } else {
     p.n_nt = rp::cdiv(d->c_out, 64);
     const dim3 grid(static_cast<unsigned>(p.n_mt) * p.n_nt);
-    if (split_in) RP_GO(1, false, false, true);
-    else if (p.stride == 2) RP_GO(1, true, false, false);
-    else RP_GO(1, false, false, false);
+    if (p.stride == 2) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<1, true, false>), grid, block, 0, rp::as_stream(stream), p);
+    else hipLaunchKernelGGL((conv_igemm_f16x3_kernel<1, false, false>), grid, block, 0, rp::as_stream(stream), p);
   }
-#undef RP_GO
   return rp::check_launch(fn);
 }
 

@@ -420,63 +420,6 @@ __global__ __launch_bounds__(128) void conv7x7_cin2_kernel(const float* __restri
   }
 }
 
-// ---- fp32 -> pre-split fp16 hi / lo planes (the operand format of conv_igemm's SPLIT sources) -----------------------
-// Same arithmetic as the convolution's own split (mantissa truncation, saturation at +-65504): a convolution fed the
-// planes computes bit-identical results to one fed the fp32 tensor.  layout 0: src (B,C,HW) is transposed through LDS;
-// layout 1: src is (B,HW,src_c_stride) with the C channels starting at src_c_offset.
-typedef _Float16 sp_h4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void sp_split1(float x, float s, _Float16& hi, _Float16& lo) {
-  const float v = x * s;
-  const float t = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & 0xffffe000u);
-  _Float16 h = static_cast<_Float16>(t);
-  const _Float16 cap = static_cast<_Float16>(65504.f);
-  h = h > cap ? cap : (h < -cap ? -cap : h);
-  hi = h;
-  lo = static_cast<_Float16>(v - t);
-}
-
-__global__ __launch_bounds__(256) void split_nhwc_kernel(const float* __restrict__ src, int layout, int C, int HW, int src_cs,
-                                                         int src_co, float a_scale, _Float16* __restrict__ hi,
-                                                         _Float16* __restrict__ lo, int dst_cs, int dst_co) {
-  const int b = blockIdx.z;
-  if (layout == 1) {
-    const long long q = (static_cast<long long>(blockIdx.y) * gridDim.x + blockIdx.x) * 256 + threadIdx.x;   // quad index
-    const int cq = C >> 2;
-    if (q >= static_cast<long long>(HW) * cq) return;
-    const long long row = q / cq;
-    const int c = static_cast<int>(q - row * cq) * 4;
-    const float4 v = *reinterpret_cast<const float4*>(src + (static_cast<long long>(b) * HW + row) * src_cs + src_co + c);
-    _Float16 h0, h1, h2, h3, l0, l1, l2, l3;
-    sp_split1(v.x, a_scale, h0, l0); sp_split1(v.y, a_scale, h1, l1);
-    sp_split1(v.z, a_scale, h2, l2); sp_split1(v.w, a_scale, h3, l3);
-    const sp_h4 h = {h0, h1, h2, h3}, l = {l0, l1, l2, l3};
-    const long long o = (static_cast<long long>(b) * HW + row) * dst_cs + dst_co + c;
-    *reinterpret_cast<sp_h4*>(hi + o) = h;
-    *reinterpret_cast<sp_h4*>(lo + o) = l;
-    return;
-  }
-  __shared__ float tile[32][33];
-  const int n0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int c = c0 + ty + 8 * r, n = n0 + tx;
-    tile[ty + 8 * r][tx] = (c < C && n < HW) ? src[(static_cast<long long>(b) * C + c) * HW + n] : 0.f;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int n = n0 + ty + 8 * r, c = c0 + tx;
-    if (n < HW && c < C) {
-      _Float16 h, l;
-      sp_split1(tile[tx][ty + 8 * r], a_scale, h, l);
-      const long long o = (static_cast<long long>(b) * HW + n) * dst_cs + dst_co + c;
-      hi[o] = h;
-      lo[o] = l;
-    }
-  }
-}
-
 }  // namespace
 
 extern "C" {
@@ -596,29 +539,6 @@ int rnnpose_flow_conv7x7_relu_f32(const float* flow4, const float* w_t, const fl
              "bad output window / flow4 alignment");
   hipLaunchKernelGGL(conv7x7_cin2_kernel, dim3(rp::cdiv(w, F1_TX), h, B), dim3(128), 0, rp::as_stream(stream), flow4, w_t,
                      bias, out, out_c_stride, out_c_offset, c_out, h, w);
-  return rp::check_launch(fn);
-}
-
-int rnnpose_split_nhwc_f16x2(const float* src, int layout, int B, int C, int HW, int src_c_stride, int src_c_offset, float a_scale,
-                             void* hi, void* lo, int dst_c_stride, int dst_c_offset, rnnpose_stream_t stream) {
-  const char* fn = "rnnpose_split_nhwc_f16x2";
-  RP_REQUIRE(src && hi && lo, fn, "null pointer");
-  RP_REQUIRE(layout == 0 || layout == 1, fn, "layout must be 0 (B,C,HW) or 1 (B,HW,C window)");
-  RP_REQUIRE(B > 0 && B < 65536 && C > 0 && HW > 0 && a_scale > 0.f, fn, "bad size");
-  RP_REQUIRE(dst_c_offset >= 0 && dst_c_offset + C <= dst_c_stride, fn, "bad destination channel window");
-  if (layout == 1) {
-    RP_REQUIRE(C % 4 == 0 && src_c_stride % 4 == 0 && src_c_offset % 4 == 0 && src_c_offset + C <= src_c_stride &&
-                   dst_c_stride % 4 == 0 && dst_c_offset % 4 == 0 && reinterpret_cast<uintptr_t>(src) % 16 == 0 &&
-                   reinterpret_cast<uintptr_t>(hi) % 8 == 0 && reinterpret_cast<uintptr_t>(lo) % 8 == 0,
-               fn, "NHWC source: channel counts / strides multiples of 4, aligned pointers");
-    const long long quads = static_cast<long long>(HW) * (C / 4);
-    hipLaunchKernelGGL(split_nhwc_kernel, dim3(1024, static_cast<unsigned>(rp::cdiv(quads, 256 * 1024)), B), dim3(256), 0,
-                       rp::as_stream(stream), src, 1, C, HW, src_c_stride, src_c_offset, a_scale, static_cast<_Float16*>(hi),
-                       static_cast<_Float16*>(lo), dst_c_stride, dst_c_offset);
-  } else {
-    hipLaunchKernelGGL(split_nhwc_kernel, dim3(rp::cdiv(HW, 32), rp::cdiv(C, 32), B), dim3(256), 0, rp::as_stream(stream), src, 0,
-                       C, HW, 0, 0, a_scale, static_cast<_Float16*>(hi), static_cast<_Float16*>(lo), dst_c_stride, dst_c_offset);
-  }
   return rp::check_launch(fn);
 }
 

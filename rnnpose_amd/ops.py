@@ -368,80 +368,23 @@ def _nhwc(t, name):
     return t
 
 
-class SplitTensor:
-    """A (B,H,W,C) activation tensor stored PRE-SPLIT for the convolution kernel: two fp16 planes (hi, lo) holding
-    x * 64 = hi + lo.  Written by a producer (conv2d_nhwc(..., dst_split=), split_nhwc, the NHWC lookup, ...) once and read
-    by every consuming convolution without its per-tile fp32 -> fp16 split."""
-
-    def __init__(self, B, H, W, C, device):
-        self.t = torch.zeros(2, B, H, W, C, device=device, dtype=torch.float16)
-
-    @property
-    def hi(self):
-        return self.t[0]
-
-    @property
-    def lo(self):
-        return self.t[1]
-
-    @property
-    def shape(self):
-        return self.t.shape[1:]
-
-    def float(self):
-        """(hi + lo) / 64 as fp32 (21-22 significant bits)."""
-        return (self.t[0].float() + self.t[1].float()) / 64.0
-
-
-def split_nhwc(src, dst: SplitTensor, c_offset: int = 0, nchw: bool = False, src_c_offset: int = 0, c_count=None):
-    """fp32 tensor -> channels [c_offset, ..) of a SplitTensor.  nchw=True: src is (B,C,H,W); else (B,H,W,Cs)."""
-    src = _chk(src, "src")
-    if nchw:
-        B, Cc, H, W = src.shape
-        cs, co = 0, 0
-    else:
-        B, H, W, cs = src.shape
-        Cc, co = (cs - src_c_offset if c_count is None else c_count), src_c_offset
-    _launch("rnnpose_split_nhwc_f16x2", _ptr(src), 0 if nchw else 1, B, Cc, H * W, cs, co, 64.0, _ptr(dst.hi), _ptr(dst.lo),
-            dst.shape[3], c_offset, _stream())
-    return dst
-
-
 def conv2d_nhwc(pc: PackedConv, srcs, dst, epilogue: int = EPI_LINEAR, aux0=None, aux1=None, dst2=None, gru_c: int = 0,
-                stride: int = 1, tile_stats=None, dst_split=None, dst2_split=None, dst_f32_cols: int = 0,
-                dst_split_c0: int = 0):
-    """srcs: list of (tensor (B,H,W,C) or SplitTensor, c_offset) matched with pc.seg_counts (all of one kind);
-    dst/aux0/aux1/dst2: (fp32 tensor, c_offset); dst_split/dst2_split: (SplitTensor, c_offset) pre-split copies of the
-    outputs (dst may then be None; dst_f32_cols / dst_split_c0 route column ranges, see the header).  Writes in place."""
+                stride: int = 1, tile_stats=None):
+    """srcs: list of (tensor (B,H,W,C), c_offset) matched with pc.seg_counts; dst/aux0/aux1/dst2: (tensor, c_offset).
+    Writes in place into dst (and dst2); returns nothing."""
     d = _lib.ConvDesc()
     if len(srcs) != len(pc.seg_counts):
         raise ValueError("number of sources differs from the packed segment list")
     B, H, W, _ = srcs[0][0].shape
     for i, ((t, off), cnt) in enumerate(zip(srcs, pc.seg_counts)):
-        if tuple(t.shape[:3]) != (B, H, W):
+        _nhwc(t, f"src{i}")
+        if t.shape[:3] != (B, H, W):
             raise ValueError("sources must share (B,H,W)")
-        if isinstance(t, SplitTensor):
-            d.src[i] = _lib.ConvSrc(t.hi.data_ptr(), t.shape[3], off, cnt, t.lo.data_ptr())
-        else:
-            _nhwc(t, f"src{i}")
-            d.src[i] = _lib.ConvSrc(t.data_ptr(), t.shape[3], off, cnt, None)
+        d.src[i] = _lib.ConvSrc(t.data_ptr(), t.shape[3], off, cnt)
     d.n_src = len(srcs)
     d.B, d.H, d.W, d.kh, d.kw, d.stride = B, H, W, pc.kh, pc.kw, stride
     d.w_hi, d.w_lo, d.bias = pc.w_hi.data_ptr(), pc.w_lo.data_ptr(), pc.bias.data_ptr()
     d.c_out, d.a_scale, d.w_scale, d.epilogue = pc.c_out, pc.a_scale, pc.w_scale, epilogue
-    d.dst_f32_cols, d.dst_split_c0 = dst_f32_cols, dst_split_c0
-
-    def put_split(prefix, spec):
-        if spec is None:
-            return
-        st, off = spec
-        setattr(d, prefix + "_hi", st.hi.data_ptr())
-        setattr(d, prefix + "_lo", st.lo.data_ptr())
-        fp = dst if prefix == "dst" else dst2
-        if fp is not None and (fp[0].shape[3] != st.shape[3] or fp[1] != off):
-            raise ValueError("the split copy shares the channel stride / offset of its fp32 twin")
-        setattr(d, prefix + "_c_stride", st.shape[3])
-        setattr(d, prefix + "_c_offset", off)
 
     def put(prefix, spec):
         if spec is None:
@@ -452,8 +395,6 @@ def conv2d_nhwc(pc: PackedConv, srcs, dst, epilogue: int = EPI_LINEAR, aux0=None
         setattr(d, prefix + "_c_stride", t.shape[3])
         setattr(d, prefix + "_c_offset", off)
 
-    put_split("dst", dst_split)
-    put_split("dst2", dst2_split)
     put("dst", dst)
     put("aux0", aux0)
     put("aux1", aux1)

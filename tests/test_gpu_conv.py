@@ -186,66 +186,3 @@ def test_flow_head_out_direct(ops, B, h, w, cin, coff):
     assert float((c1o.double() - (coords1.double() + ref)).abs().max()) < 5e-5
     grid = coords_grid(B, h, w, device="cuda").double()
     assert float((flr.permute(0, 3, 1, 2).double() - (coords1.double() + ref - grid)).abs().max()) < 5e-5
-
-
-@pytest.mark.parametrize("segs,cout,kh,kw,epi", [([324], 256, 1, 1, "relu"), ([192, 64], 126, 3, 3, "relu"),
-                                                  ([128, 128, 128], 256, 1, 5, "zr"), ([128, 128, 128], 128, 5, 1, "q"),
-                                                  ([128], 512, 3, 3, "heads")])
-def test_conv_presplit_io_is_bit_identical(ops, segs, cout, kh, kw, epi):
-    """Pre-split sources (fp16 hi/lo planes written by a producer) and split outputs: the same bits as the fp32 path
-    (the split arithmetic is identical, it just happens once at the producer instead of in every consumer tile)."""
-    B, H, W = 2, 12, 20
-    cin = sum(segs)
-    x = D(syn.normal("ps.x", (B, H, W, cin), 21, std=1.5))
-    w = D(syn.normal("ps.w", (cout, cin, kh, kw), 21, std=float(np.sqrt(2.0 / (cin * kh * kw)))))
-    b = D(syn.uniform("ps.b", (cout,), 21, -0.5, 0.5))
-    pc = ops.PackedConv(w, b, segs)
-    srcs32, srcsS, off = [], [], 0
-    for c in segs:
-        t = x[..., off:off + c].contiguous()
-        st = ops.SplitTensor(B, H, W, c, "cuda")
-        ops.split_nhwc(t, st)
-        np.testing.assert_array_equal(st.float().cpu().numpy() != 0, (t != 0).cpu().numpy())
-        assert float((st.float() - t).abs().max()) <= 2.0 ** -20 * float(t.abs().max())
-        srcs32.append((t, 0)); srcsS.append((st, 0)); off += c
-    hbuf = D(syn.normal("ps.h", (B, H, W, 128), 21, std=0.5))
-    zbuf = torch.sigmoid(D(syn.normal("ps.z", (B, H, W, 128), 21, std=1.0)))
-    kw32, kwS = {}, {}
-    if epi == "zr":
-        e = ops.EPI_GRU_ZR
-        o32, r32 = torch.empty(B, H, W, 128, device="cuda"), torch.empty(B, H, W, 128, device="cuda")
-        oS, rS32, rS = torch.empty_like(o32), torch.empty_like(r32), ops.SplitTensor(B, H, W, 128, "cuda")
-        kw32 = dict(aux0=(hbuf, 0), dst2=(r32, 0), gru_c=128)
-        kwS = dict(aux0=(hbuf, 0), dst2=(rS32, 0), dst2_split=(rS, 0), gru_c=128)
-    elif epi == "q":
-        e = ops.EPI_GRU_Q
-        o32, oS = torch.empty(B, H, W, 128, device="cuda"), torch.empty(B, H, W, 128, device="cuda")
-        kw32 = dict(aux0=(hbuf, 0), aux1=(zbuf, 0))
-        kwS = dict(aux0=(hbuf, 0), aux1=(zbuf, 0))
-    else:
-        e = ops.EPI_RELU
-        cs = (cout + 3) // 4 * 4
-        o32, oS = torch.zeros(B, H, W, cs, device="cuda"), torch.zeros(B, H, W, cs, device="cuda")
-    ops.conv2d_nhwc(pc, srcs32, (o32, 0), e, **kw32)
-    oSplit = ops.SplitTensor(B, H, W, o32.shape[3], "cuda")
-    f32_cols, c0 = (256, 256) if epi == "heads" else (0, 0)
-    ops.conv2d_nhwc(pc, srcsS, (oS, 0), e, dst_split=(oSplit, 0), dst_f32_cols=f32_cols, dst_split_c0=c0, **kwS)
-    ncol = f32_cols if f32_cols else (128 if epi in ("zr", "q") else cout)
-    assert torch.equal(oS[..., :ncol], o32[..., :ncol]), "fp32 output differs between fp32 and pre-split sources"
-    if epi == "heads":
-        assert float(oS[..., 256:].abs().max()) == 0.0                      # columns >= f32_cols not written as fp32
-    if epi == "zr":
-        assert torch.equal(rS32, r32)
-        want = ops.SplitTensor(B, H, W, 128, "cuda")
-        ops.split_nhwc(r32, want)
-        assert torch.equal(rS.t, want.t), "split r*h differs from splitting the fp32 r*h"
-    else:
-        want = ops.SplitTensor(B, H, W, o32.shape[3], "cuda")
-        ops.split_nhwc(o32, want)
-        lo_c, hi_c = (c0, cout) if epi != "q" else (0, 128)
-        assert torch.equal(oSplit.t[..., lo_c:hi_c], want.t[..., lo_c:hi_c]), "split output differs from splitting the fp32 output"
-    # and a convolution fed the NCHW -> split transposing path sees the same planes
-    if len(segs) == 1:
-        st2 = ops.SplitTensor(B, H, W, cin, "cuda")
-        ops.split_nhwc(x.permute(0, 3, 1, 2).contiguous(), st2, nchw=True)
-        assert torch.equal(st2.t, srcsS[0][0].t)
