@@ -35,7 +35,13 @@ def init_from_env(backend: str | None = None):
     if torch.cuda.is_available():
         torch.cuda.set_device(local % torch.cuda.device_count())
     if not dist.is_initialized():
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        kw = {}
+        if backend == "nccl" and torch.cuda.is_available():      # bind the communicator to this rank's GPU up front
+            kw["device_id"] = torch.device("cuda", local % torch.cuda.device_count())
+        try:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+        except TypeError:                                        # older torch: no device_id argument
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
 
