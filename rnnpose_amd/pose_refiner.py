@@ -77,7 +77,10 @@ class PoseRefiner(nn.Module):
         # hipGraph replay of the inner-iteration body (~25 launches): at the reference's own working size (B=1,
         # 240x240) the loop is launch-bound, not GPU-bound.  Falls back to eager launches if capture is refused.
         self.use_graph = use_graph
-        self._graph = None
+        self._graph = None                # inner-iteration graph captured on the caller's tensors (keyed by their addresses)
+        self._graph_static = None         # ... and the one over persistent input copies, once the addresses keep changing
+        self._static_buf = None
+        self._ptr_captures = 0
         self._outer_graphs = {}
         self._outer_captures = 0
         self._clear()
@@ -156,9 +159,18 @@ class PoseRefiner(nn.Module):
                tuple(depth.shape), self.cfg.OPTIM_ITER_COUNT, float(ep_l), float(lm_l), eng._key)
         gr = self._graph
         if gr is None or gr["key"] != key:
-            gr = self._capture(key, depth, K, g1, g2, G, coords0, h, w, ep_l, lm_l)
-        if gr is None:                                     # capture refused: eager launches
-            return self._body(depth, K, g1, g2, G, coords0, h, w, ep_l, lm_l)
+            if self._ptr_captures >= 2:
+                # the views keep moving (a renderer that allocates fresh tensors every outer iteration): re-capturing per
+                # pointer set would cost more than it saves.  Switch to ONE graph over persistent input buffers and pay
+                # a device copy of depth / K / descriptors (~0.65 GB at 480x640, B=8: ~0.25 ms) per outer iteration.
+                sb = self._static_inputs(depth, K, g1, g2)
+                skey = ("static",) + key[4:]
+                gr = self._graph_static
+                if gr is None or gr["key"] != skey:
+                    gr = self._capture(skey, sb["depth"], sb["K"], sb["g1"], sb["g2"], G, coords0, h, w, ep_l, lm_l, static=True)
+            else:
+                self._ptr_captures += 1
+                gr = self._capture(key, depth, K, g1, g2, G, coords0, h, w, ep_l, lm_l)
         gr["G"].copy_(G.reshape(-1, 4, 4))
         gr["graph"].replay()
         flow_up, wmap, Gn, Hm, bv, xi, info = gr["out"]
@@ -166,7 +178,21 @@ class PoseRefiner(nn.Module):
         # small ones, and of the flow only when a caller keeps it (first and last iteration)
         return flow_up, wmap, Gn.clone(), Hm, bv, xi, info
 
-    def _capture(self, key, depth, K, g1, g2, G, coords0, h, w, ep_l, lm_l):
+    def _static_inputs(self, depth, K, g1, g2):
+        """Persistent copies of the per-outer-iteration inputs of the inner graph; refreshed when the sources change."""
+        shapes = (tuple(depth.shape), tuple(K.shape), tuple(g1.shape), tuple(g2.shape))
+        sb = self._static_buf
+        if sb is None or sb["shapes"] != shapes:
+            sb = self._static_buf = dict(shapes=shapes, depth=torch.empty_like(depth), K=torch.empty_like(K),
+                                         g1=torch.empty_like(g1), g2=torch.empty_like(g2), src=None)
+            self._graph_static = None
+        src = (depth.data_ptr(), K.data_ptr(), g1.data_ptr(), g2.data_ptr(), depth._version, g1._version, g2._version)
+        if sb["src"] != src:
+            sb["depth"].copy_(depth); sb["K"].copy_(K); sb["g1"].copy_(g1); sb["g2"].copy_(g2)
+            sb["src"] = src
+        return sb
+
+    def _capture(self, key, depth, K, g1, g2, G, coords0, h, w, ep_l, lm_l, static=False):
         try:
             Gs = G.reshape(-1, 4, 4).clone()
             side = torch.cuda.Stream()
@@ -181,13 +207,18 @@ class PoseRefiner(nn.Module):
             with torch.cuda.graph(graph):
                 out = self._body(depth, K, g1, g2, Gs, coords0, h, w, ep_l, lm_l)
             self.cf_net.engine()._b["hA"].copy_(hA)        # capture does not execute, but keep the invariant explicit
-            self._graph = dict(key=key, graph=graph, G=Gs, out=out)
+            gr = dict(key=key, graph=graph, G=Gs, out=out)
+            if static:
+                self._graph_static = gr
+            else:
+                self._graph = gr
+            return gr
         except Exception as e:                             # noqa: BLE001 -- any capture failure means "run eagerly"
             import warnings
             warnings.warn(f"hipGraph capture of the refinement iteration failed ({e!r}); running eager launches")
             self.use_graph = False
-            self._graph = None
-        return self._graph
+            self._graph = self._graph_static = None
+        return None
 
     @torch.no_grad()
     def forward(self, image, Ts, intrinsics, fea_3d=None, Tj_gt=None, obj_cls=None, geofea_3d=None, geofea_2d=None):
