@@ -23,7 +23,9 @@ class UpdateEngine:
         self._w = None
         self._buf_key = None
         self._b = None
-        self._side = None         # side stream of step(): the flow-feature chain / flow head run next to the main chain
+        self._side = None         # helper streams of step() (parallel hipGraph branches)
+        import os
+        self.split_batch = os.environ.get("RNNPOSE_SPLIT_BATCH", "1") != "0"   # two concurrent half-batch chains
 
     # ---- weights ---------------------------------------------------------------------------------------------
     def _params(self):
@@ -70,10 +72,11 @@ class UpdateEngine:
             self._buf_key = key
         return self._b
 
-    def _side_stream(self, device):
-        if self._side is None or self._side.device != device:
-            self._side = torch.cuda.Stream(device=device)
-        return self._side
+    def _stream(self, device, i):
+        """Helper stream i (1: second batch half; 2, 3: the flow-feature / flow-head side chains of the two halves)."""
+        if self._side is None or self._side[0].device != device:
+            self._side = [torch.cuda.Stream(device=device) for _ in range(4)]
+        return self._side[i]
 
     def load_state(self, net, inp):
         """net, inp: (B,128,h,w) NCHW (tanh / relu of the context features, model/CFNet.py:131-133)."""
@@ -90,27 +93,62 @@ class UpdateEngine:
         W = self._weights()
         B, _, h, w = coords1.shape
         b = self._b
+        main = torch.cuda.current_stream()
+        ops.corr_lookup_nhwc(corr_fn._buf, coords1, b["corr"], corr_fn.num_levels, corr_fn.radius)
+        # Batch split: the two halves of the batch run their (otherwise strictly sequential) convolution chains on two
+        # streams = two parallel hipGraph branches.  Every convolution of this workload is a ONE-round kernel (600-1200
+        # tiles on 768 resident slots) whose ramp-up, lock-step prologue and epilogue burst cost ~30 % against the
+        # multi-round steady state (tools/conv_quant.py, tools/conv_streams.py); two out-of-phase kernels in flight
+        # fill those gaps: -6...-12 % per layer, bit-identical results (images are independent).
+        halves = [(0, B)] if (B < 2 or not self.split_batch) else [(0, B // 2), (B // 2, B)]
+        fork = torch.cuda.Event()
+        fork.record(main)
+        joins = []
+        for hi_, (b0, b1) in enumerate(halves):
+            view = {k: v[b0:b1] for k, v in b.items()}
+            st = main if hi_ == 0 else self._stream(coords1.device, 1)
+            if st is not main:
+                st.wait_event(fork)
+            with torch.cuda.stream(st):
+                # (one level of fork/join only: nested forks segfault hipStreamEndCapture on ROCm 7.2; the flow-feature /
+                #  flow-head side chain is kept for the unsplit B = 1 case, where it is the only concurrency there is)
+                self._chain(W, view, coords1[b0:b1], st, self._stream(coords1.device, 2) if len(halves) == 1 else None)
+                if st is not main:
+                    j = torch.cuda.Event()
+                    j.record(st)
+                    joins.append(j)
+        for j in joins:
+            main.wait_event(j)
+        flow_up = ops.convex_upsample_nhwc(b["flow_lr"], b["mask"])
+        return b["coords1"], flow_up
+
+    def _chain(self, W, b, coords1, main, side):
+        """The update block on the (sub-)batch views `b`, issued on stream `main` (current) with `side` as helper."""
         c = ops.conv2d_nhwc
         R = ops.EPI_RELU
         # Two independent chains feed the motion encoder's last convolution (update.py:89-92): correlation features
-        # (lookup -> convc1 -> convc2) and flow features (flow_prep -> convf1 -> convf2).  The second one runs on a side
-        # stream (a parallel branch when the step is captured into a hipGraph): its small kernels fill the CUs the
-        # first chain's ragged last wave of workgroups leaves idle.  Same for flow_head.conv2 next to mask.2.
-        main = torch.cuda.current_stream()
-        side = self._side_stream(coords1.device)
-        fork = torch.cuda.Event()
-        fork.record(main)
-        side.wait_event(fork)
-        with torch.cuda.stream(side):
+        # (convc1 -> convc2) and flow features (flow_prep -> convf1 -> convf2).  The second one runs on a side stream
+        # (a parallel branch when the step is captured into a hipGraph).  Same for flow_head.conv2 next to mask.2.
+        def flow_chain():
             ops.flow_prep(coords1, b["flow4"], b["motion"], 126)                   # flow -> convf1 input, motion[126:128]
             ops.flow_conv7x7_relu(b["flow4"], W["convf1_wt"], W["convf1_b"], b["flo1"])  # :91 (direct fp32, K = 98)
             c(W["convf2"], [(b["flo1"], 0)], (b["corflo"], 192), R)                 # :92
-            join = torch.cuda.Event()
-            join.record(side)
-        ops.corr_lookup_nhwc(corr_fn._buf, coords1, b["corr"], corr_fn.num_levels, corr_fn.radius)
+
+        join = None
+        if side is None:
+            flow_chain()
+        else:
+            fork = torch.cuda.Event()
+            fork.record(main)
+            side.wait_event(fork)
+            with torch.cuda.stream(side):
+                flow_chain()
+                join = torch.cuda.Event()
+                join.record(side)
         c(W["convc1"], [(b["corr"], 0)], (b["cor1"], 0), R)                         # update.py:89
         c(W["convc2"], [(b["cor1"], 0)], (b["corflo"], 0), R)                       # :90
-        main.wait_event(join)
+        if join is not None:
+            main.wait_event(join)
         c(W["conv"], [(b["corflo"], 0)], (b["motion"], 0), R)                       # :95-96 (126 ch; flow already at 126)
         hx = lambda hbuf: [(hbuf, 0), (b["inp"], 0), (b["motion"], 0)]              # [h | inp | motion]  (:181, :47)
         c(W["zr1"], hx(b["hA"]), (b["z"], 0), ops.EPI_GRU_ZR, aux0=(b["hA"], 0), dst2=(b["rh"], 0), gru_c=128)
@@ -118,17 +156,21 @@ class UpdateEngine:
         c(W["zr2"], hx(b["hB"]), (b["z"], 0), ops.EPI_GRU_ZR, aux0=(b["hB"], 0), dst2=(b["rh"], 0), gru_c=128)
         c(W["q2"], hx(b["rh"]), (b["hA"], 0), ops.EPI_GRU_Q, aux0=(b["hB"], 0), aux1=(b["z"], 0))
         c(W["heads"], [(b["hA"], 0)], (b["heads"], 0), R)                           # flow_head.conv1 | mask.0
+        head = lambda: ops.flow_head_out(b["heads"], 0, 256, W["flow2_w"], W["flow2_b"], coords1, b["delta"], b["coords1"],
+                                         b["flow_lr"])
+        if side is None:
+            head()
+            c(W["mask2"], [(b["heads"], 256)], (b["mask"], 0), ops.EPI_LINEAR)      # 0.25 * mask.2(relu(mask.0(h)))
+            return
         fork2 = torch.cuda.Event()
         fork2.record(main)
         side.wait_event(fork2)
         with torch.cuda.stream(side):
-            ops.flow_head_out(b["heads"], 0, 256, W["flow2_w"], W["flow2_b"], coords1, b["delta"], b["coords1"], b["flow_lr"])
+            head()
             join2 = torch.cuda.Event()
             join2.record(side)
         c(W["mask2"], [(b["heads"], 256)], (b["mask"], 0), ops.EPI_LINEAR)          # 0.25 * mask.2(relu(mask.0(h)))
         main.wait_event(join2)
-        flow_up = ops.convex_upsample_nhwc(b["flow_lr"], b["mask"])
-        return b["coords1"], flow_up
 
 
 class EncoderEngine:
