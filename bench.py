@@ -217,7 +217,10 @@ def main():
                     "bound": "mfma", "achieved": round(3 * eq, 1), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(3 * eq / PEAK_F16_MFMA_TFLOPS, 4),
                     "note": "achieved = EXECUTED fp16 MFMA flops (3 products per algorithmic multiply-add) / summed HIP-event time of "
-                            "all launches in the timed region; fp32-equivalent algorithmic rate = achieved/3",
+                            "all launches in the timed region; fp32-equivalent algorithmic rate = achieved/3.  The update step runs "
+                            "the two halves of the batch as two concurrent convolution chains (two streams): every launch is timed "
+                            "while it SHARES the chip with its twin, so the per-launch rate understates the aggregate matrix-pipe use "
+                            "(RNNPOSE_SPLIT_BATCH=0, one full-batch chain: 650 TF per launch at 5 % lower iters/s)",
                     "fp32_equivalent_TFLOPps": round(eq, 1), "launches_timed": n, "mean_ms": round(mean_ms, 4),
                     "share_of_step": round(tot_ms / prof_steps / (dt / args.steps * 1e3), 4), "algorithmic_flops_timed": work,
                     "traffic": traffic.get("conv_igemm_bytes_per_launch")}
