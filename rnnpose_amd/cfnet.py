@@ -134,19 +134,23 @@ class GRU_CFUpdator(nn.Module):
             self.engine().load_state(self._net, self.inp)
             self._net_in_engine = True
 
-    def step(self, coords0, coords1):
-        """One GRU iteration given low-res coords (CFNet.py:147-168) -> (coords1_new, flow_up)."""
+    def step(self, coords0, coords1, tail=None):
+        """One GRU iteration given low-res coords (CFNet.py:147-168) -> (coords1_new, flow_up).
+        tail(b0, b1, flow_up[b0:b1]): optional consumer of the up-sampled flow of images [b0, b1), issued on the stream
+        that produced it (the HIP engine runs the two batch halves as two staggered chains)."""
         if self.conv_backend == "hip":
             if not self._net_in_engine:                  # hidden state was assigned from outside
                 self.engine().load_state(self._net, self.inp)
                 self._net_in_engine = True
-            coords1_new, flow_up = self.engine().step(self.corr_fn, coords1)
+            coords1_new, flow_up = self.engine().step(self.corr_fn, coords1, tail=tail)
             return coords1_new.clone(), flow_up
         corr = self.corr_fn(coords1)
         flow = coords1 - coords0
         self.net, up_mask, delta_flow = self.update_block(self.net, self.inp, corr, flow)
         coords1 = coords1 + delta_flow
         flow_up = self.upsample_flow(coords1 - coords0, up_mask)
+        if tail is not None:
+            tail(0, flow_up.shape[0], flow_up)
         return coords1, flow_up
 
     @torch.no_grad()

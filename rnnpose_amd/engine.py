@@ -26,6 +26,9 @@ class UpdateEngine:
         self._side = None         # helper streams of step() (parallel hipGraph branches)
         import os
         self.split_batch = os.environ.get("RNNPOSE_SPLIT_BATCH", "1") != "0"   # two concurrent half-batch chains
+        # start the second half two GRU layers late, so that the first half's memory-bound tail runs under the second
+        # half's convolutions: measured SLOWER (462 vs 517 iters/s: the convolutions lose their twin), off by default
+        self.stagger = os.environ.get("RNNPOSE_STAGGER", "0") != "0"
 
     # ---- weights ---------------------------------------------------------------------------------------------
     def _params(self):
@@ -88,41 +91,48 @@ class UpdateEngine:
     def hidden_nchw(self):
         return ops.nhwc_to_nchw(self._b["hA"])
 
-    def step(self, corr_fn, coords1):
-        """coords1 (B,2,h,w) -> (coords1 + delta_flow (B,2,h,w), flow_up (B,2,8h,8w))."""
+    def step(self, corr_fn, coords1, tail=None):
+        """coords1 (B,2,h,w) -> (coords1 + delta_flow (B,2,h,w), flow_up (B,2,8h,8w)).
+        tail(b0, b1, flow_up[b0:b1]) is called on the stream of each batch half right after its up-sampling."""
         W = self._weights()
         B, _, h, w = coords1.shape
         b = self._b
         main = torch.cuda.current_stream()
         ops.corr_lookup_nhwc(corr_fn._buf, coords1, b["corr"], corr_fn.num_levels, corr_fn.radius)
-        # Batch split: the two halves of the batch run their (otherwise strictly sequential) convolution chains on two
-        # streams = two parallel hipGraph branches.  Every convolution of this workload is a ONE-round kernel (600-1200
-        # tiles on 768 resident slots) whose ramp-up, lock-step prologue and epilogue burst cost ~30 % against the
-        # multi-round steady state (tools/conv_quant.py, tools/conv_streams.py); two out-of-phase kernels in flight
-        # fill those gaps: -6...-12 % per layer, bit-identical results (images are independent).
+        # Batch split: the two halves of the batch run their (otherwise strictly sequential) chains on two streams = two
+        # parallel hipGraph branches.  Every convolution of this workload is a ONE-round kernel (600-1200 tiles on 768
+        # resident slots) whose ramp-up, lock-step prologue and epilogue burst cost ~30 % against the multi-round steady
+        # state (tools/conv_quant.py, tools/conv_streams.py); two kernels in flight fill those gaps.  Each half also runs
+        # its own tail (up-sampling, descriptor weight, LM) on its stream.  Results are bit-identical (images are
+        # independent).
         halves = [(0, B)] if (B < 2 or not self.split_batch) else [(0, B // 2), (B // 2, B)]
+        flow_up = torch.empty(B, 2, 8 * h, 8 * w, device=coords1.device, dtype=torch.float32)
         fork = torch.cuda.Event()
         fork.record(main)
         joins = []
+        stagger = torch.cuda.Event() if (len(halves) > 1 and self.stagger) else None
         for hi_, (b0, b1) in enumerate(halves):
             view = {k: v[b0:b1] for k, v in b.items()}
             st = main if hi_ == 0 else self._stream(coords1.device, 1)
             if st is not main:
-                st.wait_event(fork)
+                st.wait_event(stagger if stagger is not None else fork)
             with torch.cuda.stream(st):
                 # (one level of fork/join only: nested forks segfault hipStreamEndCapture on ROCm 7.2; the flow-feature /
                 #  flow-head side chain is kept for the unsplit B = 1 case, where it is the only concurrency there is)
-                self._chain(W, view, coords1[b0:b1], st, self._stream(coords1.device, 2) if len(halves) == 1 else None)
+                self._chain(W, view, coords1[b0:b1], st, self._stream(coords1.device, 2) if len(halves) == 1 else None,
+                            mark=stagger if hi_ == 0 else None)
+                ops.convex_upsample_nhwc(view["flow_lr"], view["mask"], out=flow_up[b0:b1])
+                if tail is not None:
+                    tail(b0, b1, flow_up[b0:b1])
                 if st is not main:
                     j = torch.cuda.Event()
                     j.record(st)
                     joins.append(j)
         for j in joins:
             main.wait_event(j)
-        flow_up = ops.convex_upsample_nhwc(b["flow_lr"], b["mask"])
         return b["coords1"], flow_up
 
-    def _chain(self, W, b, coords1, main, side):
+    def _chain(self, W, b, coords1, main, side, mark=None):
         """The update block on the (sub-)batch views `b`, issued on stream `main` (current) with `side` as helper."""
         c = ops.conv2d_nhwc
         R = ops.EPI_RELU
@@ -153,6 +163,8 @@ class UpdateEngine:
         hx = lambda hbuf: [(hbuf, 0), (b["inp"], 0), (b["motion"], 0)]              # [h | inp | motion]  (:181, :47)
         c(W["zr1"], hx(b["hA"]), (b["z"], 0), ops.EPI_GRU_ZR, aux0=(b["hA"], 0), dst2=(b["rh"], 0), gru_c=128)
         c(W["q1"], hx(b["rh"]), (b["hB"], 0), ops.EPI_GRU_Q, aux0=(b["hA"], 0), aux1=(b["z"], 0))
+        if mark is not None:
+            mark.record(main)                                                       # the other batch half starts here
         c(W["zr2"], hx(b["hB"]), (b["z"], 0), ops.EPI_GRU_ZR, aux0=(b["hB"], 0), dst2=(b["rh"], 0), gru_c=128)
         c(W["q2"], hx(b["rh"]), (b["hA"], 0), ops.EPI_GRU_Q, aux0=(b["hB"], 0), aux1=(b["z"], 0))
         c(W["heads"], [(b["hA"], 0)], (b["heads"], 0), R)                           # flow_head.conv1 | mask.0

@@ -220,12 +220,13 @@ def _target_mode(target, H, W):
     raise ValueError(f"target has shape {tuple(target.shape)}; expected (B,H,W,2) or (B,2,H,W)")
 
 
-def corr_weight(g1, g2, target, depth, sigma):
+def corr_weight(g1, g2, target, depth, sigma, out=None):
     g1, g2, target, depth = _chk(g1, "g1"), _chk(g2, "g2"), _chk(target, "target"), _chk(depth, "depth")
     sigma = _chk(sigma.reshape(-1)[:1], "sigma")
     B, D, H, W = g1.shape
     mode = _target_mode(target, H, W)
-    out = torch.empty(B, H, W, device=g1.device, dtype=F32)
+    if out is None:
+        out = torch.empty(B, H, W, device=g1.device, dtype=F32)
     _launch("rnnpose_corr_weight_f32", _ptr(g1), _ptr(g2), _ptr(target), mode, _ptr(depth), _ptr(sigma), B, D, H, W,
             _ptr(out), _stream())
     return out
@@ -235,9 +236,10 @@ def corr_weight(g1, g2, target, depth, sigma):
 _ws_cache = {}
 
 
-def _workspace(B, H, W, device):
+def _workspace(B, H, W, device, slot=0):
+    """slot: calls that may run concurrently on different streams (the two batch halves) need distinct workspaces."""
     n = int(_lib.load().rnnpose_lm_workspace_bytes(B, H, W))
-    key = (device, n)
+    key = (device, n, slot)
     ws = _ws_cache.get(key)
     if ws is None:
         ws = torch.empty(n // 8, device=device, dtype=F64)
@@ -271,18 +273,27 @@ def lm_solve_update(Hm, bv, G, ep_lambda=100.0, lm_lambda=1e-4, max_update=1.0):
     return G_new, xi, info
 
 
-def lm_step(target, weight, depth, K, G, num_iters=1, ep_lambda=100.0, lm_lambda=1e-4, max_update=1.0, eps=1e-5):
-    """num_iters fused GN steps; returns (G_new (B,4,4), Hm, bv, xi, info) of the last iteration."""
+def lm_step(target, weight, depth, K, G, num_iters=1, ep_lambda=100.0, lm_lambda=1e-4, max_update=1.0, eps=1e-5, out=None,
+            slot=0):
+    """num_iters fused GN steps; returns (G_new (B,4,4), Hm, bv, xi, info) of the last iteration.
+    out: optional preallocated (G_new, Hm, bv, xi, info) views to write into; slot: workspace slot (see _workspace)."""
     target, weight, depth = _chk(target, "target"), _chk(weight, "weight"), _chk(depth, "depth")
     K = _chk(K, "intrinsics")
-    G = _chk(G, "G").reshape(-1, 4, 4).clone()
     B, H, W = depth.shape[0], depth.shape[-2], depth.shape[-1]
     mode = _target_mode(target, H, W)
-    ws, n = _workspace(B, H, W, depth.device)
-    Hm = torch.empty(B, 6, 6, device=depth.device, dtype=F64)
-    bv = torch.empty(B, 6, device=depth.device, dtype=F64)
-    xi = torch.zeros(B, 6, device=depth.device, dtype=F32)
-    info = torch.zeros(B, device=depth.device, dtype=torch.int32)
+    ws, n = _workspace(B, H, W, depth.device, slot)
+    if out is not None:
+        Gd, Hm, bv, xi, info = out
+        Gd.copy_(_chk(G, "G").reshape(-1, 4, 4))
+        G = Gd
+        xi.zero_()
+        info.zero_()
+    else:
+        G = _chk(G, "G").reshape(-1, 4, 4).clone()
+        Hm = torch.empty(B, 6, 6, device=depth.device, dtype=F64)
+        bv = torch.empty(B, 6, device=depth.device, dtype=F64)
+        xi = torch.zeros(B, 6, device=depth.device, dtype=F32)
+        info = torch.zeros(B, device=depth.device, dtype=torch.int32)
     _launch("rnnpose_lm_step_f32", _ptr(target), mode, _ptr(weight), _ptr(depth), eps, _ptr(K), _ptr(G), B, H, W,
             int(num_iters), float(ep_lambda), float(lm_lambda), float(max_update), _ptr(ws), n, _ptr(Hm), _ptr(bv),
             _ptr(xi), _ptr(info), _stream())

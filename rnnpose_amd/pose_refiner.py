@@ -143,11 +143,24 @@ class PoseRefiner(nn.Module):
 
     # ---- one inner iteration of the fused schedule, eager or as a replayed hipGraph ---------------------------
     def _body(self, depth, K, g1, g2, G, coords0, h, w, ep_l, lm_l):
+        B, dev = depth.shape[0], depth.device
         coords1 = ops.induced_coords_lowres(depth, K, G, h, w, EPS)
-        _, flow_up = self.cf_net.step(coords0, coords1)
-        wmap = ops.corr_weight(g1, g2, flow_up, depth, self.sigma[0])
-        Gn, Hm, bv, xi, info = ops.lm_step(flow_up, wmap, depth, K, G, num_iters=self.cfg.OPTIM_ITER_COUNT,
-                                           ep_lambda=ep_l, lm_lambda=lm_l, max_update=1.0, eps=EPS)
+        G3 = G.reshape(-1, 4, 4)
+        wmap = torch.empty(B, depth.shape[-2], depth.shape[-1], device=dev, dtype=torch.float32)
+        Gn = torch.empty(B, 4, 4, device=dev, dtype=torch.float32)
+        Hm = torch.empty(B, 6, 6, device=dev, dtype=torch.float64)
+        bv = torch.empty(B, 6, device=dev, dtype=torch.float64)
+        xi = torch.empty(B, 6, device=dev, dtype=torch.float32)
+        info = torch.empty(B, device=dev, dtype=torch.int32)
+
+        def tail(b0, b1, flow_up):
+            """descriptor weight + LM step of images [b0, b1) on the stream that produced their flow (PoseRefiner.py:342-356)"""
+            ops.corr_weight(g1[b0:b1], g2[b0:b1], flow_up, depth[b0:b1], self.sigma[0], out=wmap[b0:b1])
+            ops.lm_step(flow_up, wmap[b0:b1], depth[b0:b1], K[b0:b1], G3[b0:b1], num_iters=self.cfg.OPTIM_ITER_COUNT,
+                        ep_lambda=ep_l, lm_lambda=lm_l, max_update=1.0, eps=EPS,
+                        out=(Gn[b0:b1], Hm[b0:b1], bv[b0:b1], xi[b0:b1], info[b0:b1]), slot=b0)
+
+        _, flow_up = self.cf_net.step(coords0, coords1, tail=tail)
         return flow_up, wmap, Gn, Hm, bv, xi, info
 
     def _iteration(self, depth, K, g1, g2, G, coords0, h, w, ep_l, lm_l):
