@@ -192,9 +192,12 @@ class EncoderEngine:
     Only the 7x7 stride-2 stem on 3 input channels (1.4 of 41 GFLOP/image) stays on MIOpen, channels_last (= NHWC)."""
 
     def __init__(self, fnet):
+        import os
         self.fnet = fnet
         self._key = None
         self._w = None
+        self._side = None
+        self.split_batch = os.environ.get("RNNPOSE_SPLIT_ENCODER", "1") != "0"
 
     def _mine(self):
         f = self.fnet
@@ -255,11 +258,41 @@ class EncoderEngine:
     def __call__(self, x_nchw):
         """x (N,3,H,W) already normalised -> (N,256,H/8,W/8) NCHW."""
         W = self._weights()
+        N, _, H, Wd = x_nchw.shape
+        out = torch.empty(N, self.fnet.conv2.out_channels, H // 8, Wd // 8, device=x_nchw.device, dtype=torch.float32)
+        # Two halves of the image batch (rendered | observed) as two independent streams = two hipGraph branches with a
+        # single join at the end: the chains drift apart, so one half's HBM-bound instance-norm passes and latency-bound
+        # finalize launches run under the other half's convolutions.  Bit-identical (instance norm is per image).
+        halves = [(0, N)] if (N < 2 or not self.split_batch) else [(0, N // 2), (N // 2, N)]
+        main = torch.cuda.current_stream()
+        fork = torch.cuda.Event()
+        fork.record(main)
+        joins = []
+        for hi_, (b0, b1) in enumerate(halves):
+            st = main if hi_ == 0 else self._second_stream(x_nchw.device)
+            if st is not main:
+                st.wait_event(fork)
+            with torch.cuda.stream(st):
+                self._forward(W, x_nchw[b0:b1], out[b0:b1])
+                if st is not main:
+                    j = torch.cuda.Event()
+                    j.record(st)
+                    joins.append(j)
+        for j in joins:
+            main.wait_event(j)
+        return out
+
+    def _second_stream(self, device):
+        if self._side is None or self._side.device != device:
+            self._side = torch.cuda.Stream(device=device)
+        return self._side
+
+    def _forward(self, W, x_nchw, out):
         f = self.fnet
         x = x_nchw.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
         y = ops.instnorm_nhwc(self._torch_conv(x, f.conv1).contiguous(), relu=True)
         for li, layer in enumerate((f.layer1, f.layer2, f.layer3), start=1):
             for bi, blk in enumerate(layer):
                 y = self._block(W, f"l{li}.{bi}", blk, y.contiguous())
-        out, _ = self._conv(W["out"], y, stats=False)
-        return ops.nhwc_to_nchw(out)
+        o, _ = self._conv(W["out"], y, stats=False)
+        ops.nhwc_to_nchw(o, out=out)

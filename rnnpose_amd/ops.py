@@ -443,11 +443,11 @@ def nchw_to_nhwc(src, dst=None, c_offset: int = 0):
     return dst
 
 
-def nhwc_to_nchw(src, c_offset: int = 0, c_count: int | None = None):
+def nhwc_to_nchw(src, c_offset: int = 0, c_count: int | None = None, out=None):
     """channels [c_offset, c_offset+c_count) of src (B,H,W,Cs) -> (B,c_count,H,W)"""
     B, H, W, Cs = src.shape
     c_count = Cs - c_offset if c_count is None else c_count
-    dst = torch.empty(B, c_count, H, W, device=src.device, dtype=F32)
+    dst = out if out is not None else torch.empty(B, c_count, H, W, device=src.device, dtype=F32)
     _launch("rnnpose_nhwc_to_nchw_f32", _ptr(src), B, c_count, H * W, Cs, c_offset, _ptr(dst), _stream())
     return dst
 
@@ -490,7 +490,7 @@ def instnorm_nhwc(x, relu=True, residual=None, out=None, eps: float = 1e-5):
     _nhwc(x, "x")
     B, H, W, Cc = x.shape
     n = int(_lib.load().rnnpose_instnorm_workspace_bytes(B, H * W, Cc))
-    key = (x.device, n)
+    key = (x.device, n, torch.cuda.current_stream().cuda_stream)     # (calls on different streams may run concurrently)
     ws = _in_ws.get(key)
     if ws is None:
         ws = _in_ws[key] = torch.empty(n // 8, device=x.device, dtype=F64)
