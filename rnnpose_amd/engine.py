@@ -198,6 +198,7 @@ class EncoderEngine:
         self._w = None
         self._side = None
         self.split_batch = os.environ.get("RNNPOSE_SPLIT_ENCODER", "1") != "0"
+        self.parts = int(os.environ.get("RNNPOSE_ENCODER_PARTS", "2"))
 
     def _mine(self):
         f = self.fnet
@@ -263,13 +264,15 @@ class EncoderEngine:
         # Two halves of the image batch (rendered | observed) as two independent streams = two hipGraph branches with a
         # single join at the end: the chains drift apart, so one half's HBM-bound instance-norm passes and latency-bound
         # finalize launches run under the other half's convolutions.  Bit-identical (instance norm is per image).
-        halves = [(0, N)] if (N < 2 or not self.split_batch) else [(0, N // 2), (N // 2, N)]
+        parts = max(1, min(self.parts if self.split_batch else 1, N))
+        cuts = [N * i // parts for i in range(parts + 1)]
+        halves = list(zip(cuts[:-1], cuts[1:]))
         main = torch.cuda.current_stream()
         fork = torch.cuda.Event()
         fork.record(main)
         joins = []
         for hi_, (b0, b1) in enumerate(halves):
-            st = main if hi_ == 0 else self._second_stream(x_nchw.device)
+            st = main if hi_ == 0 else self._second_stream(x_nchw.device, hi_)
             if st is not main:
                 st.wait_event(fork)
             with torch.cuda.stream(st):
@@ -282,10 +285,10 @@ class EncoderEngine:
             main.wait_event(j)
         return out
 
-    def _second_stream(self, device):
-        if self._side is None or self._side.device != device:
-            self._side = torch.cuda.Stream(device=device)
-        return self._side
+    def _second_stream(self, device, i):
+        if self._side is None or self._side[0].device != device or len(self._side) < i:
+            self._side = [torch.cuda.Stream(device=device) for _ in range(max(i, 3))]
+        return self._side[i - 1]
 
     def _forward(self, W, x_nchw, out):
         f = self.fnet
