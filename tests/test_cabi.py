@@ -81,3 +81,35 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         _lib.load()
+
+
+def test_header_is_plain_c99_and_links_against_the_library(tmp_path):
+    """The boundary is a C ABI: the header must compile as strict C99 (no C++-isms, no torch types), and a C program
+    must link against the shared library and resolve a symbol without any Python or torch in the process."""
+    import shutil
+    import subprocess
+    from rnnpose_amd import build
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("gcc not available")
+    lib_path = build.build()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "t.c"
+    src.write_text('#include <stdio.h>\n#include <stdint.h>\n#include "rnnpose_hip.h"\n'
+                   "int main(void) {\n"
+                   "  rnnpose_conv_desc_t d; rnnpose_conv_src_t s; (void)d; (void)s;\n"
+                   "  int64_t off[5]; int hl[4], wl[4];\n"
+                   "  if (rnnpose_corr_pyramid_layout(2, 16, 24, 4, off, hl, wl) != 0) return 2;\n"
+                   '  printf("%d %lld\\n", rnnpose_abi_version(), (long long)off[4]);\n'
+                   "  return 0;\n}\n")
+    exe = tmp_path / "t"
+    r = subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"),
+                        str(src), "-o", str(exe), lib_path, "-Wl,-rpath," + os.path.dirname(lib_path)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    out = subprocess.run([str(exe)], capture_output=True, text=True, env=env)
+    assert out.returncode == 0, out.stderr
+    ver, total = out.stdout.split()
+    n = 2 * 16 * 24
+    assert int(ver) == 1 and int(total) == n * (16 * 24 + 8 * 12 + 4 * 6 + 2 * 3)
