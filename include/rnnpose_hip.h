@@ -261,6 +261,14 @@ int rnnpose_pose_metrics_f64(const float* model, int P, const float* pose_pred, 
  *   -> theta (B,2,3) (the F.affine_grid matrices) and K_crop (B,3,3) = inverse(window transform) @ K.
  * zoom_crop: out (B,C,crop_h,crop_w) = F.grid_sample(in (B,C,H,W), F.affine_grid(theta)) (bilinear, zero padding,
  *   align_corners=False); grid_out (B,crop_h,crop_w,2) optionally receives the sampling grid; out may be NULL.  */
+/* pointcloud_depth: DiffRender.render_pointcloud (geometry/diff_render_optim.py:369-401) for a batch: image b splats
+ *   the vertices verts[vert_offsets[b] .. vert_offsets[b+1]) (device int array of B+1 entries; max_verts >= the largest
+ *   count) with pose T (B,4,4) and intrinsics K (B,3,3): out (B,1,H,W) = 0 where nothing lands, else the depth of the
+ *   HIGHEST-index vertex on that pixel (the reference leaves the winner of a collision unspecified); pixels are round-half-even and
+ *   clamped into the image like the reference's.  workspace: B*H*W ints.  This is the foreground source of the zoom crop. */
+size_t rnnpose_pointcloud_depth_workspace_bytes(int B, int H, int W);
+int rnnpose_pointcloud_depth_f32(const float* verts, const int* vert_offsets, int max_verts, const float* T, const float* K, int B,
+                                 int H, int W, void* workspace, size_t workspace_bytes, float* out, rnnpose_stream_t stream);
 int rnnpose_mask_bbox_f32(const float* depth, int B, int H, int W, int* bbox, rnnpose_stream_t stream);
 int rnnpose_zoom_crop_params_f32(const int* bbox, const float* K, const float* T, int B, int H, int W, int crop_h, int crop_w,
                                  float margin_ratio, float* theta, float* K_crop, rnnpose_stream_t stream);

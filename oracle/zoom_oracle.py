@@ -81,3 +81,24 @@ def grid_sample(x, grid):
             for b in range(B):
                 out[b] += x[b][:, yc[b], xc[b]] * (w[b] * ok[b])[None]
     return out.astype(np.float32)
+
+
+def render_pointcloud(verts, T, K, H, W):
+    """One image: geometry/diff_render_optim.py:369-401 (fp32).  verts (P,3), T (4,4), K (3,3) -> (H,W) depth splat.
+    Several vertices on one pixel: the reference's torch indexed assignment leaves the winner unspecified; numpy keeps the
+    LAST of repeated indices, and so does the HIP kernel (highest vertex index).  Only `> 0` is consumed downstream."""
+    R = T[:3, :3].T.astype(np.float32)
+    t = T[:3, 3].astype(np.float32)
+    v = verts.astype(np.float32)
+    Xc = ((v[:, 0:1] * R[0] + v[:, 1:2] * R[1]) + v[:, 2:3] * R[2] + t).astype(np.float32)
+    Kt = K.T.astype(np.float32)
+    x = ((Xc[:, 0:1] * Kt[0] + Xc[:, 1:2] * Kt[1]) + Xc[:, 2:3] * Kt[2]).astype(np.float32)
+    depth = x[:, 2].copy()
+    with np.errstate(all="ignore"):
+        u = np.rint(x[:, 0] / x[:, 2])
+        w = np.rint(x[:, 1] / x[:, 2])
+    px = np.where(np.isfinite(u) & (np.abs(u) < 1e9), np.clip(u, 0, W - 1), 0).astype(np.int64)
+    py = np.where(np.isfinite(w) & (np.abs(w) < 1e9), np.clip(w, 0, H - 1), 0).astype(np.int64)
+    out = np.zeros((H, W), np.float32)
+    out[py, px] = depth
+    return out

@@ -71,6 +71,8 @@ PROTOTYPES = {
     "rnnpose_instnorm_nhwc_f32": (_i, [_p, _i, _i, _i, _f, _i, _p, _p, _z, _p, _p, _p]),
     "rnnpose_nn_search_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "findNearestPointIdxLauncher": (None, [_p, _p, _p, _i, _i, _i, _i, _i]),
+    "rnnpose_pointcloud_depth_workspace_bytes": (_z, [_i, _i, _i]),
+    "rnnpose_pointcloud_depth_f32": (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _p, _z, _p, _p]),
     "rnnpose_mask_bbox_f32": (_i, [_p, _i, _i, _i, _p, _p]),
     "rnnpose_zoom_crop_params_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _f, _p, _p, _p]),
     "rnnpose_zoom_crop_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p]),

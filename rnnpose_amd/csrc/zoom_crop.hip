@@ -136,6 +136,56 @@ __global__ __launch_bounds__(256) void zoom_crop_kernel(const float* __restrict_
   }
 }
 
+// ---- point-cloud depth splat: DiffRender.render_pointcloud (geometry/diff_render_optim.py:369-401) ---------------------
+// Every model vertex is projected (X_cam = R v + t, x = K X_cam, fp32, no fma contraction), its pixel is
+// round-half-even(x/z, y/z) CLAMPED into the image (the reference clamps, so off-screen vertices land on the border) and
+// receives the vertex depth.  Which of several vertices on one pixel wins is unspecified in the reference (torch's indexed
+// assignment with repeated indices); here: pass 1 elects the highest vertex index per pixel (atomicMax, order
+// independent), pass 2 lets that vertex write its depth -- deterministic, = sequential last-writer-wins.  Only `depth > 0` (the foreground mask of the
+// zoom crop, PoseRefiner.py:259) is consumed downstream.
+__device__ __forceinline__ bool pc_project(const float* __restrict__ v, const float* __restrict__ T, const float* __restrict__ K,
+                                           int H, int W, int& px, int& py, float& depth) {
+  const float X = (v[0] * T[0] + v[1] * T[1]) + v[2] * T[2] + T[3];
+  const float Y = (v[0] * T[4] + v[1] * T[5]) + v[2] * T[6] + T[7];
+  const float Z = (v[0] * T[8] + v[1] * T[9]) + v[2] * T[10] + T[11];
+  const float x = (X * K[0] + Y * K[1]) + Z * K[2];
+  const float y = (X * K[3] + Y * K[4]) + Z * K[5];
+  const float z = (X * K[6] + Y * K[7]) + Z * K[8];
+  depth = z;
+  const float u = rintf(x / z), w = rintf(y / z);          // rintf = round half to even (torch.round)
+  // non-finite -> the reference's .long() yields INT64_MIN, which the clamp turns into 0
+  px = (u == u && fabsf(u) < 1.0e9f) ? min(max(static_cast<int>(u), 0), W - 1) : 0;
+  py = (w == w && fabsf(w) < 1.0e9f) ? min(max(static_cast<int>(w), 0), H - 1) : 0;
+  return true;
+}
+
+__global__ __launch_bounds__(256) void pc_owner_kernel(const float* __restrict__ verts, const int* __restrict__ offs,
+                                                       const float* __restrict__ T, const float* __restrict__ K,
+                                                       int* __restrict__ owner, int H, int W) {
+  const int b = blockIdx.y;
+  const int p0 = offs[b], n = offs[b + 1] - p0;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  int px, py;
+  float d;
+  pc_project(verts + 3LL * (p0 + i), T + b * 16, K + b * 9, H, W, px, py, d);
+  atomicMax(owner + (static_cast<long long>(b) * H + py) * W + px, i + 1);
+}
+
+__global__ __launch_bounds__(256) void pc_write_kernel(const float* __restrict__ verts, const int* __restrict__ offs,
+                                                       const float* __restrict__ T, const float* __restrict__ K,
+                                                       const int* __restrict__ owner, float* __restrict__ out, int H, int W) {
+  const int b = blockIdx.y;
+  const int p0 = offs[b], n = offs[b + 1] - p0;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  int px, py;
+  float d;
+  pc_project(verts + 3LL * (p0 + i), T + b * 16, K + b * 9, H, W, px, py, d);
+  const long long o = (static_cast<long long>(b) * H + py) * W + px;
+  if (owner[o] == i + 1) out[o] = d;
+}
+
 }  // namespace
 
 extern "C" {
@@ -167,6 +217,30 @@ int rnnpose_zoom_crop_f32(const float* in, const float* theta, int B, int C, int
   RP_REQUIRE(B > 0 && B < 65536 && C >= 0 && H > 0 && W > 0 && crop_h > 0 && crop_w > 0 && crop_h < 262144, fn, "bad size");
   hipLaunchKernelGGL(zoom_crop_kernel, dim3(rp::cdiv(crop_w, 64), rp::cdiv(crop_h, 4), B), dim3(256), 0, rp::as_stream(stream),
                      in, theta, out, grid_out, C, H, W, crop_h, crop_w);
+  return rp::check_launch(fn);
+}
+
+size_t rnnpose_pointcloud_depth_workspace_bytes(int B, int H, int W) {
+  if (B <= 0 || H <= 0 || W <= 0) return 0;
+  return static_cast<size_t>(B) * H * W * sizeof(int);
+}
+
+int rnnpose_pointcloud_depth_f32(const float* verts, const int* vert_offsets, int max_verts, const float* T, const float* K, int B,
+                                 int H, int W, void* workspace, size_t workspace_bytes, float* out, rnnpose_stream_t stream) {
+  const char* fn = "rnnpose_pointcloud_depth_f32";
+  RP_REQUIRE(verts && vert_offsets && T && K && workspace && out, fn, "null pointer");
+  RP_REQUIRE(B > 0 && B < 65536 && H > 0 && W > 0 && max_verts > 0, fn, "bad size");
+  RP_REQUIRE(workspace_bytes >= rnnpose_pointcloud_depth_workspace_bytes(B, H, W), fn, "workspace too small");
+  hipStream_t st = rp::as_stream(stream);
+  if (hipMemsetAsync(workspace, 0, rnnpose_pointcloud_depth_workspace_bytes(B, H, W), st) != hipSuccess ||
+      hipMemsetAsync(out, 0, static_cast<size_t>(B) * H * W * sizeof(float), st) != hipSuccess)
+  {
+    rp::set_error("%s: hipMemsetAsync failed", fn);
+    return 2;
+  }
+  const dim3 grid(rp::cdiv(max_verts, 256), B);
+  hipLaunchKernelGGL(pc_owner_kernel, grid, dim3(256), 0, st, verts, vert_offsets, T, K, static_cast<int*>(workspace), H, W);
+  hipLaunchKernelGGL(pc_write_kernel, grid, dim3(256), 0, st, verts, vert_offsets, T, K, static_cast<const int*>(workspace), out, H, W);
   return rp::check_launch(fn);
 }
 

@@ -539,6 +539,22 @@ def pose_metrics(model, pose_pred, pose_gt, K, symmetric: bool = False):
 
 
 # ---- f4: zoom-crop on device ---------------------------------------------------------------------------------------
+def pointcloud_depth(verts, vert_offsets, T, K, size):
+    """verts (P,3) fp32 (all models concatenated), vert_offsets (B+1,) int32 device tensor, T (B,4,4), K (B,3,3), size (H,W)
+    -> (B,1,H,W) depth splat of every image's vertices (geometry/diff_render_optim.py:369-401)."""
+    verts, T, K = _chk(verts, "verts"), _chk(T, "T"), _chk(K, "K")
+    if not (vert_offsets.is_cuda and vert_offsets.dtype == torch.int32 and vert_offsets.is_contiguous()):
+        raise RuntimeError("vert_offsets must be a contiguous int32 GPU tensor of B+1 entries")
+    B = T.shape[0]
+    H, W = int(size[0]), int(size[1])
+    n = int(_lib.load().rnnpose_pointcloud_depth_workspace_bytes(B, H, W))
+    ws = torch.empty(n // 4, device=T.device, dtype=torch.int32)
+    out = torch.empty(B, 1, H, W, device=T.device, dtype=F32)
+    _launch("rnnpose_pointcloud_depth_f32", _ptr(verts), _ptr(vert_offsets), int(verts.shape[0]), _ptr(T), _ptr(K), B, H, W, _ptr(ws), n,
+            _ptr(out), _stream())
+    return out
+
+
 def mask_bbox(depth):
     """depth (B,1,H,W) -> (B,4) int32 [xmin, ymin, xmax, ymax] of depth > 0 (model/PoseRefiner.py:154-158,259)."""
     depth = _chk(depth, "depth")

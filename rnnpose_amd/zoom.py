@@ -25,3 +25,12 @@ def gen_zoom_crop_grids(fg_depth, K, T, output_size, margin_ratio=0.4, want_grid
 def zoom_crop(x, theta, crop_size):
     """F.grid_sample(x, F.affine_grid(theta, ...)) in one kernel (PoseRefiner.py:286-291)."""
     return ops.zoom_crop(x.float().contiguous(), theta, crop_size)
+
+
+def render_pointcloud(verts_per_image, T, K, render_image_size):
+    """`DiffRendererWrapper.render_pointcloud` (geometry/diff_render_optim.py:474-480) for a batch: verts_per_image is a
+    list of (P_b,3) vertex tensors (one model per image) -> (B,1,H,W) depth splat, foreground = depth > 0."""
+    verts = torch.cat([v.float() for v in verts_per_image], 0).contiguous()
+    counts = torch.tensor([0] + [int(v.shape[0]) for v in verts_per_image], dtype=torch.int32)
+    offs = torch.cumsum(counts, 0).to(torch.int32).to(verts.device)
+    return ops.pointcloud_depth(verts, offs, T.float().contiguous(), K.float().contiguous(), render_image_size)

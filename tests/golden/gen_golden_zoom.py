@@ -35,3 +35,24 @@ np.savez_compressed(os.path.join(ROOT, "tests", "golden", "zoom_small.npz"), dep
                     theta_oracle=theta, K_crop_oracle=K_crop, grid_torch=grid.numpy(), crop_torch=crop.numpy(),
                     crop_size=np.int64([hc, wc]))
 print("wrote zoom_small.npz", os.path.getsize(os.path.join(ROOT, "tests", "golden", "zoom_small.npz")), "bytes")
+
+# ---- point-cloud depth splat: the torch statements of DiffRender.render_pointcloud (geometry/diff_render_optim.py:381-401),
+# executed on CPU on a seeded vertex cloud (the class itself imports PyTorch3D and cannot be instantiated here)
+P, Hs, Ws = 4000, 60, 80
+verts = syn.normal("pc.v", (P, 3), 11, std=0.05).astype(np.float32)
+Tp = np.eye(4, dtype=np.float32)
+Tp[:3, :3] = syn.se3_exp_np(np.float32([0, 0, 0, 0.3, -0.2, 0.1]))[0, :3, :3]
+Tp[:3, 3] = np.float32([0.02, -0.03, 0.6])
+Kp = np.float32([[70.0, 0, 40.0], [0, 70.0, 30.0], [0, 0, 1]])
+Tt, Kt, vt = torch.from_numpy(Tp)[None], torch.from_numpy(Kp)[None], torch.from_numpy(verts)
+R = Tt[..., :3, :3].transpose(-1, -2)
+t = Tt[..., :3, 3]
+X_cam = (vt @ R + t)
+xx = X_cam @ Kt.transpose(-1, -2)
+dep = xx[..., -1]
+xx = xx / xx[..., -1:]
+outp = torch.zeros([1, 1, Hs, Ws])
+outp[:, :, torch.round(xx[0, :, 1]).long().clamp(0, Hs - 1), torch.round(xx[0, :, 0]).long().clamp(0, Ws - 1)] = dep
+np.savez_compressed(os.path.join(ROOT, "tests", "golden", "pointcloud_small.npz"), verts=verts, T=Tp, K=Kp,
+                    depth_torch=outp[0, 0].numpy(), size=np.int64([Hs, Ws]))
+print("wrote pointcloud_small.npz")

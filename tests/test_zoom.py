@@ -130,3 +130,50 @@ def test_gpu_zoom_pipeline_full_size_vs_torch(ops, B, C, H, W, hc, wc):
     th_o, Kc_o = zo.zoom_params(bb, K.cpu().numpy(), T.cpu().numpy(), H, W, hc, wc)
     np.testing.assert_allclose(theta.cpu().numpy(), th_o, rtol=2e-6, atol=1e-7)
     np.testing.assert_allclose(K_crop.cpu().numpy(), Kc_o, rtol=1e-5, atol=1e-3)
+
+
+# ---------------------------------------------------------------- point-cloud depth splat (foreground source of the crop)
+PC_GOLD = os.path.join(os.path.dirname(__file__), "golden", "pointcloud_small.npz")
+
+
+def test_oracle_pointcloud_matches_torch_statements():
+    """oracle vs the reference's own torch statements (diff_render_optim.py:381-401) run on CPU: the SAME foreground mask
+    (all the zoom crop consumes).  Which of several vertices landing on one pixel leaves its depth there is unspecified in
+    the reference (torch's indexed assignment with repeated indices); the oracle and the kernel keep the highest vertex
+    index -- so every torch depth must be the depth of SOME vertex of that pixel, and ours that of the last one."""
+    g = dict(np.load(PC_GOLD))
+    H, W = [int(v) for v in g["size"]]
+    d = zo.render_pointcloud(g["verts"], g["T"], g["K"], H, W)
+    np.testing.assert_array_equal(d > 0, g["depth_torch"] > 0)
+    # per-pixel candidate depths, by brute force
+    R, t = g["T"][:3, :3].astype(np.float32), g["T"][:3, 3].astype(np.float32)
+    Xc = g["verts"] @ R.T + t
+    x = Xc @ g["K"].T
+    px = np.clip(np.rint(x[:, 0] / x[:, 2]), 0, W - 1).astype(int)
+    py = np.clip(np.rint(x[:, 1] / x[:, 2]), 0, H - 1).astype(int)
+    for yy, xx in zip(*np.nonzero(d > 0)):
+        cand = x[(px == xx) & (py == yy), 2]
+        assert np.abs(cand - g["depth_torch"][yy, xx]).min() < 1e-5
+        assert abs(cand[-1] - d[yy, xx]) < 1e-5
+
+
+@pytest.mark.gpu
+def test_gpu_pointcloud_depth_matches_oracle_and_feeds_the_crop(ops):
+    from rnnpose_amd import zoom
+    g = dict(np.load(PC_GOLD))
+    H, W = [int(v) for v in g["size"]]
+    want = zo.render_pointcloud(g["verts"], g["T"], g["K"], H, W)
+    T2 = np.stack([g["T"], g["T"]])
+    T2[1, :3, 3] += np.float32([0.05, 0.02, 0.1])
+    K2 = np.stack([g["K"], g["K"]])
+    got = zoom.render_pointcloud([D(g["verts"]), D(g["verts"][:1500])], D(T2), D(K2), (H, W)).cpu().numpy()
+    np.testing.assert_array_equal(got[0, 0], want)                                  # bit-exact incl. collisions
+    np.testing.assert_array_equal(got[1, 0], zo.render_pointcloud(g["verts"][:1500], T2[1], g["K"], H, W))
+    bb = ops.mask_bbox(D(got)).cpu().numpy()
+    assert bb.tolist() == zo.mask_bbox(got).tolist()
+    # off-screen and behind-the-camera vertices: clamped to the border / negative depth, never out of bounds
+    far = np.float32([[5.0, 0, 0], [-5.0, 0, 0], [0, 5.0, 0], [0, 0, -2.0], [0, 0, 0]])
+    Tn = np.eye(4, dtype=np.float32)
+    Tn[2, 3] = 0.5
+    g2 = zoom.render_pointcloud([D(far)], D(Tn[None]), D(g["K"][None]), (H, W)).cpu().numpy()
+    np.testing.assert_array_equal(g2[0, 0], zo.render_pointcloud(far, Tn, g["K"], H, W))
