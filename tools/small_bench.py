@@ -1,7 +1,6 @@
 """Micro-benchmarks of the small per-iteration kernels at the S2 shape (B=8, 60x80): lookup, 7x7 flow conv, flow head."""
-import sys
 import torch
-from rnnpose_amd import build, ops, synthetic as syn
+from rnnpose_amd import build, ops
 
 build.build()
 B, h, w = 8, 60, 80
