@@ -1,6 +1,7 @@
 """Host-side logic that needs no GPU: module trees / state_dict keys, synthetic generator determinism,
 sharding rule, refusal to run on CPU tensors (there is no CPU product path)."""
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -107,3 +108,20 @@ def test_metric_accumulator_single_process():
     out = acc.reduce()
     assert out["cat"]["n"] == 2 and out["cat"]["add"] == 0.5 and out["cat"]["proj2d"] == 1.0
     assert out["ape"]["n"] == 0 and np.isnan(out["ape"]["add"])
+
+
+def test_concurrent_build_calls_are_serialised(tmp_path):
+    """One process per GPU: every rank calls build.build() at start-up.  Two processes forcing a rebuild at the same time
+    must both succeed and leave a loadable library (the file lock makes the loser wait and re-check the stamp)."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); from rnnpose_amd import build; "
+            "p = build.build(force=(sys.argv[1] == 'force')); print(p)") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = [subprocess.Popen([sys.executable, "-c", code, mode], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for mode in ("force", "check")]
+    outs = [p.communicate(timeout=900) for p in procs]
+    for p, (out, err) in zip(procs, outs):
+        assert p.returncode == 0, err[-2000:]
+        assert out.strip().endswith("librnnpose_hip.so")
+    import ctypes
+    ctypes.CDLL(outs[0][0].strip())
