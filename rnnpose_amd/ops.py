@@ -37,6 +37,19 @@ def profile(names=None):
         _prof = prev
 
 
+def profile_begin(names=None):
+    """Non-context form of profile(): start recording, return the record dict; stop with profile_end()."""
+    global _prof
+    rec = {"_only": set(names) if names else None, "_next": 0, "_prev": _prof}
+    _prof = rec
+    return rec
+
+
+def profile_end(rec):
+    global _prof
+    _prof = rec.get("_prev")
+
+
 def profiling() -> bool:
     """True while a profile() context is recording (HIP events cannot be recorded into a captured graph)."""
     return _prof is not None
