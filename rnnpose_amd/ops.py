@@ -299,8 +299,9 @@ def lm_step(target, weight, depth, K, G, num_iters=1, ep_lambda=100.0, lm_lambda
         Gd, Hm, bv, xi, info = out
         Gd.copy_(_chk(G, "G").reshape(-1, 4, 4))
         G = Gd
-        xi.zero_()
-        info.zero_()
+        if int(num_iters) < 1:            # (every step writes xi and info for every image; only the no-op case needs zeros)
+            xi.zero_()
+            info.zero_()
     else:
         G = _chk(G, "G").reshape(-1, 4, 4).clone()
         Hm = torch.empty(B, 6, 6, device=depth.device, dtype=F64)
