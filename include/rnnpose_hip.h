@@ -126,6 +126,12 @@ int rnnpose_lm_step_f32(const float* target, int target_mode, const float* weigh
                         double ep_lambda, double lm_lambda, double max_update, void* workspace,
                         size_t workspace_bytes, double* Hm, double* bv, float* xi, int* info,
                         rnnpose_stream_t stream);
+/* same with separate input and output poses (num_iters >= 1; G_out may alias G_in): saves the caller a device copy */
+int rnnpose_lm_step_io_f32(const float* target, int target_mode, const float* weight, const float* depth,
+                           float depth_eps, const float* K, const float* G_in, float* G_out, int B, int H, int W,
+                           int num_iters, double ep_lambda, double lm_lambda, double max_update, void* workspace,
+                           size_t workspace_bytes, double* Hm, double* bv, float* xi, int* info,
+                           rnnpose_stream_t stream);
 
 /* ---- a11/a12 helpers: batched SE(3) ------------------------- geometry/se3.py:194-209,228-306
  * se3_exp: xi (B,6) -> (B,4,4);  se3_compose: out = A*Bm (B,4,4);  se3_inverse: out = A^-1.        */

@@ -134,7 +134,7 @@ class GRU_CFUpdator(nn.Module):
             self.engine().load_state(self._net, self.inp)
             self._net_in_engine = True
 
-    def step(self, coords0, coords1, tail=None):
+    def step(self, coords0, coords1, tail=None, need_coords=True):
         """One GRU iteration given low-res coords (CFNet.py:147-168) -> (coords1_new, flow_up).
         tail(b0, b1, flow_up[b0:b1]): optional consumer of the up-sampled flow of images [b0, b1), issued on the stream
         that produced it (the HIP engine runs the two batch halves as two staggered chains)."""
@@ -143,7 +143,7 @@ class GRU_CFUpdator(nn.Module):
                 self.engine().load_state(self._net, self.inp)
                 self._net_in_engine = True
             coords1_new, flow_up = self.engine().step(self.corr_fn, coords1, tail=tail)
-            return coords1_new.clone(), flow_up
+            return (coords1_new.clone() if need_coords else None), flow_up      # (engine buffer: overwritten by the next step)
         corr = self.corr_fn(coords1)
         flow = coords1 - coords0
         self.net, up_mask, delta_flow = self.update_block(self.net, self.inp, corr, flow)

@@ -330,23 +330,40 @@ int rnnpose_lm_solve_update_f32(const double* Hm, const double* bv, const float*
   return rp::check_launch(fn);
 }
 
-int rnnpose_lm_step_f32(const float* target, int target_mode, const float* weight, const float* depth, float depth_eps,
-                        const float* K, float* G, int B, int H, int W, int num_iters, double ep_lambda, double lm_lambda,
-                        double max_update, void* workspace, size_t workspace_bytes, double* Hm, double* bv, float* xi,
-                        int* info, rnnpose_stream_t stream) {
-  const char* fn = "rnnpose_lm_step_f32";
-  RP_REQUIRE(target && weight && depth && K && G && workspace && Hm && bv && xi, fn, "null pointer");
+static int lm_step_impl(const char* fn, const float* target, int target_mode, const float* weight, const float* depth,
+                        float depth_eps, const float* K, const float* G_in, float* G_out, int B, int H, int W, int num_iters,
+                        double ep_lambda, double lm_lambda, double max_update, void* workspace, size_t workspace_bytes,
+                        double* Hm, double* bv, float* xi, int* info, rnnpose_stream_t stream) {
+  RP_REQUIRE(target && weight && depth && K && G_in && G_out && workspace && Hm && bv && xi, fn, "null pointer");
   RP_REQUIRE(target_mode == 0 || target_mode == 1, fn, "target_mode must be 0 or 1");
   RP_REQUIRE(B > 0 && B < 65536 && H > 0 && W > 0 && num_iters >= 0, fn, "bad size");
   RP_REQUIRE(workspace_bytes >= rnnpose_lm_workspace_bytes(B, H, W), fn, "workspace too small");
   hipStream_t st = rp::as_stream(stream);
   for (int it = 0; it < num_iters; ++it) {
-    launch_normal_eq(target, target_mode, weight, depth, depth_eps, K, G, B, H, W, workspace, Hm, bv, st);
-    // in place: each thread reads its whole G before writing it
-    hipLaunchKernelGGL(lm_solve_update_kernel, dim3(rp::cdiv(B, 64)), dim3(64), 0, st, Hm, bv, G, B, ep_lambda,
-                       lm_lambda, max_update, G, xi, info);
+    const float* g = it == 0 ? G_in : G_out;            // later iterations continue in place on the output
+    launch_normal_eq(target, target_mode, weight, depth, depth_eps, K, g, B, H, W, workspace, Hm, bv, st);
+    // (g may alias G_out: each thread reads its whole pose before writing it)
+    hipLaunchKernelGGL(lm_solve_update_kernel, dim3(rp::cdiv(B, 64)), dim3(64), 0, st, Hm, bv, g, B, ep_lambda,
+                       lm_lambda, max_update, G_out, xi, info);
   }
   return rp::check_launch(fn);
+}
+
+int rnnpose_lm_step_f32(const float* target, int target_mode, const float* weight, const float* depth, float depth_eps,
+                        const float* K, float* G, int B, int H, int W, int num_iters, double ep_lambda, double lm_lambda,
+                        double max_update, void* workspace, size_t workspace_bytes, double* Hm, double* bv, float* xi,
+                        int* info, rnnpose_stream_t stream) {
+  return lm_step_impl("rnnpose_lm_step_f32", target, target_mode, weight, depth, depth_eps, K, G, G, B, H, W, num_iters,
+                      ep_lambda, lm_lambda, max_update, workspace, workspace_bytes, Hm, bv, xi, info, stream);
+}
+
+int rnnpose_lm_step_io_f32(const float* target, int target_mode, const float* weight, const float* depth, float depth_eps,
+                           const float* K, const float* G_in, float* G_out, int B, int H, int W, int num_iters,
+                           double ep_lambda, double lm_lambda, double max_update, void* workspace, size_t workspace_bytes,
+                           double* Hm, double* bv, float* xi, int* info, rnnpose_stream_t stream) {
+  RP_REQUIRE(num_iters >= 1, "rnnpose_lm_step_io_f32", "needs at least one iteration (G_out would stay unwritten)");
+  return lm_step_impl("rnnpose_lm_step_io_f32", target, target_mode, weight, depth, depth_eps, K, G_in, G_out, B, H, W,
+                      num_iters, ep_lambda, lm_lambda, max_update, workspace, workspace_bytes, Hm, bv, xi, info, stream);
 }
 
 int rnnpose_se3_exp_f32(const float* xi, int B, float* out, rnnpose_stream_t stream) {

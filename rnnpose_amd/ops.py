@@ -295,13 +295,21 @@ def lm_step(target, weight, depth, K, G, num_iters=1, ep_lambda=100.0, lm_lambda
     B, H, W = depth.shape[0], depth.shape[-2], depth.shape[-1]
     mode = _target_mode(target, H, W)
     ws, n = _workspace(B, H, W, depth.device, slot)
+    if out is not None and int(num_iters) >= 1:
+        Gd, Hm, bv, xi, info = out          # (every step writes all five outputs for every image)
+        Gin = _chk(G, "G").reshape(-1, 4, 4)
+        if not Gin.is_contiguous():
+            Gin = Gin.contiguous()
+        _launch("rnnpose_lm_step_io_f32", _ptr(target), mode, _ptr(weight), _ptr(depth), eps, _ptr(K), _ptr(Gin), _ptr(Gd), B, H, W,
+                int(num_iters), float(ep_lambda), float(lm_lambda), float(max_update), _ptr(ws), n, _ptr(Hm), _ptr(bv),
+                _ptr(xi), _ptr(info), _stream())
+        return Gd, Hm, bv, xi, info
     if out is not None:
         Gd, Hm, bv, xi, info = out
         Gd.copy_(_chk(G, "G").reshape(-1, 4, 4))
         G = Gd
-        if int(num_iters) < 1:            # (every step writes xi and info for every image; only the no-op case needs zeros)
-            xi.zero_()
-            info.zero_()
+        xi.zero_()
+        info.zero_()
     else:
         G = _chk(G, "G").reshape(-1, 4, 4).clone()
         Hm = torch.empty(B, 6, 6, device=depth.device, dtype=F64)

@@ -167,7 +167,7 @@ class PoseRefiner(nn.Module):
                         ep_lambda=ep_l, lm_lambda=lm_l, max_update=1.0, eps=EPS,
                         out=(Gn[b0:b1], Hm[b0:b1], bv[b0:b1], xi[b0:b1], info[b0:b1]), slot=b0)
 
-        _, flow_up = self.cf_net.step(coords0, coords1, tail=tail)
+        _, flow_up = self.cf_net.step(coords0, coords1, tail=tail, need_coords=False)
         return flow_up, wmap, Gn, Hm, bv, xi, info
 
     def _iteration(self, depth, K, g1, g2, G, coords0, h, w, ep_l, lm_l):
