@@ -1,8 +1,11 @@
 """CPU ORACLE (test infrastructure only) for the evaluator rows f2/f3: numpy restatement of
 utils/eval_metric.py:28-37 (project), :102-192 (projection_2d, add*_metric, cm_degree_5_metric) and of the serial
 nearest-neighbour loop of thirdparty/nn/src/nearest_neighborhood.cu:48-81.
-PARITY UNPINNED against the reference itself: utils/eval_metric.py cannot be imported here (plyfile, open3d, the
-compiled cffi extension) and the reference holds no fixture for it; the formulas below are line-by-line restatements."""
+PINNED (f2): tests/test_oracle_golden.py::test_eval_oracle_matches_reference_eval_metric checks pose_metrics against
+distances, threshold decisions and summarize() output produced by the reference's own utils/eval_metric.py
+(tests/golden/gen_golden_eval.py imports it with empty stand-in modules for plyfile/open3d/cv2/transforms3d, none of which
+the metric arithmetic touches).  The symmetric (ADD-S) vectors use the reference arithmetic around a numpy first-minimum
+search: the CUDA extension thirdparty/nn cannot run here, so nn_idx itself (f3) stays PARITY UNPINNED against the .cu."""
 import numpy as np
 
 

@@ -76,3 +76,25 @@ def test_evaluator_accumulates_like_the_reference(ops):
     s = ev.summarize()
     assert s["seq_len"] == 3 and abs(s["add"] - 2 / 3) < 1e-12 and abs(s["add2"] - 2 / 3) < 1e-12
     assert s["cmd5"] == 1.0 and abs(s["proj2d"] - 2 / 3) < 1e-12
+
+
+@pytest.mark.parametrize("pre,sym,cls", [("cat_", False, "cat"), ("driller_", False, "driller"), ("sym_eggbox_", True, "eggbox")])
+def test_pose_metrics_vs_reference_eval_metric(ops, golden, pre, sym, cls):
+    """Row f2 pinned to the reference: distances, threshold decisions and summarize() of utils/eval_metric.py:102-192,
+    261-302, run on the reference's own module (tests/golden/gen_golden_eval.py)."""
+    from test_oracle_golden import EVAL_DIAMETERS, check_eval_against_reference, eval_flags
+    from rnnpose_amd.evaluator import LineMODEvaluator
+    g = golden("eval_metric")
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    K = g["linemod_K"].astype(np.float32)
+    m = ops.pose_metrics(t(g[pre + "model"]), t(g[pre + "pred"]), t(g[pre + "gt"]), t(K), sym).cpu().numpy()
+    check_eval_against_reference(m, g, pre, sym)
+    assert np.array_equal(eval_flags(m, EVAL_DIAMETERS[pre], sym), g[pre + "flags"])
+    ev = LineMODEvaluator(cls, g[pre + "model"], diameter=EVAL_DIAMETERS[pre])
+    ev.evaluate(t(g[pre + "pred"])[:, None], t(g[pre + "gt"])[:, None])
+    s = ev.summarize()
+    want = g[pre + "flags"].mean(0)
+    assert np.allclose([s["add"], s["add2"], s["add5"], s["proj2d"], s["cmd5"]], want) and s["seq_len"] == g[pre + "flags"].shape[0]
+    if not sym:
+        r = g[pre + "summary"]
+        assert np.allclose([s["proj2d"], s["add"], s["add2"], s["add5"], s["cmd5"], s["seq_len"]], r)

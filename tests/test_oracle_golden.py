@@ -211,3 +211,42 @@ def test_loop(golden, name, shape, outer, inner, opt):
     else:
         assert maxdiff(fl[:, :, ::3, ::3], g["flow_last"]) < 1e-4
         assert maxdiff(res["weight"][:, ::3, ::3], g["w_last"]) < 1e-4
+
+
+# ---- row f2: evaluator arithmetic pinned to the reference's own utils/eval_metric.py (tests/golden/gen_golden_eval.py) ----
+EVAL_SETS = [("cat_", False), ("driller_", False), ("sym_eggbox_", True)]
+
+
+def check_eval_against_reference(m, g, pre, sym):
+    """m (n,5) [ADD, ADD-S, proj2d px, trans cm, rot deg] vs the distances the reference computed.
+    The reference does the model transform, the rotation product and np.mean in fp32 (float32 model / poses), so its own
+    values carry ~1e-6 relative noise; the angle comes from arccos((trace-1)/2) of an fp32 trace, whose resolution near
+    0 is sqrt(eps32) ~ 0.03 deg: that is the absolute floor of the rotation comparison (thresholds sit at 5 deg)."""
+    d = m[:, 1] if sym else m[:, 0]
+    assert np.allclose(d, g[pre + "add"], rtol=2e-5, atol=1e-9)
+    assert np.allclose(m[:, 2], g[pre + "proj2d"], rtol=1e-4, atol=1e-5)
+    assert np.allclose(m[:, 3], g[pre + "trans_cm"], rtol=1e-6, atol=1e-5)
+    assert np.allclose(m[:, 4], g[pre + "rot_deg"], rtol=1e-4, atol=0.05)
+
+
+def eval_flags(m, diameter, sym):
+    d = m[:, 1] if sym else m[:, 0]
+    return np.stack([d < 0.1 * diameter, d < 0.02 * diameter, d < 0.05 * diameter, m[:, 2] < 5.0,
+                     (m[:, 3] < 5.0) & (m[:, 4] < 5.0)], 1)
+
+
+EVAL_DIAMETERS = {"cat_": 15.2633 / 100, "driller_": 25.9425 / 100, "sym_eggbox_": 17.6364 / 100}   # linemod_config.py:2-19
+
+
+@pytest.mark.parametrize("pre,sym", EVAL_SETS)
+def test_eval_oracle_matches_reference_eval_metric(golden, pre, sym):
+    from oracle import eval_oracle as eo
+    g = golden("eval_metric")
+    m = eo.pose_metrics(g[pre + "model"], g[pre + "pred"], g[pre + "gt"], g["linemod_K"], sym)
+    check_eval_against_reference(m, g, pre, sym)
+    flags = eval_flags(m, EVAL_DIAMETERS[pre], sym)
+    assert np.array_equal(flags, g[pre + "flags"])               # every threshold decision of the reference reproduced
+    assert 0 < flags.sum() < flags.size                          # ... and the set crosses the thresholds
+    if not sym:
+        s = g[pre + "summary"]                                   # LineMODEvaluator.summarize(): proj2d, add, add2, add5, cmd5, n
+        assert np.allclose(flags.mean(0)[[3, 0, 1, 2, 4]], s[:5]) and s[5] == len(flags)
