@@ -120,3 +120,79 @@ def make_module_weights(shapes: dict, seed: int = 0, gain: float = 1.0) -> dict:
             fan_in = int(np.prod(shape[1:]))
             out[name] = normal("w:" + name, shape, seed, std=gain * float(np.sqrt(2.0 / fan_in)))
     return out
+
+
+# ---- the same generator on torch tensors (any device) -------------------------------------------------------------
+# Bit-identical to the numpy functions above: exact 64-bit integer arithmetic (two's-complement wrap == the uint64 wrap in
+# the low 32 bits that survive the mask) and IEEE fp64 -> fp32 conversions.  Used for config-5-sized test inputs, which the
+# single-threaded numpy path needs minutes for; tests/test_host_logic.py checks the two against each other.
+_CHUNK = 1 << 25
+
+
+def _mix32_t(x):
+    x = x & 0xFFFFFFFF
+    x = x ^ (x >> 16)
+    x = (x * 0x85EBCA6B) & 0xFFFFFFFF
+    x = x ^ (x >> 13)
+    x = (x * 0xC2B2AE35) & 0xFFFFFFFF
+    x = x ^ (x >> 16)
+    return x
+
+
+def _uniform01_t(name, n0, n1, seed, device):
+    import torch
+    idx = torch.arange(n0, n1, dtype=torch.int64, device=device)
+    h = _mix32_t(idx * 0x9E3779B1 + int(_stream_key(name, seed)))
+    h = _mix32_t(h ^ (idx >> 32) ^ 0x68E31DA4)
+    return (h >> 8).to(torch.float64) * (1.0 / 16777216.0)
+
+
+def uniform_t(name, shape, seed=0, lo=0.0, hi=1.0, device="cpu"):
+    import torch
+    n = int(np.prod(shape))
+    out = torch.empty(n, dtype=torch.float32, device=device)
+    for n0 in range(0, n, _CHUNK):
+        n1 = min(n, n0 + _CHUNK)
+        out[n0:n1] = (lo + (hi - lo) * _uniform01_t(name, n0, n1, seed, device)).to(torch.float32)
+    return out.reshape(shape)
+
+
+def normal_t(name, shape, seed=0, std=1.0, device="cpu"):
+    import torch
+    n = int(np.prod(shape))
+    out = torch.empty(n, dtype=torch.float32, device=device)
+    scale = float(np.sqrt(3.0) * std)
+    for n0 in range(0, n, _CHUNK):
+        n1 = min(n, n0 + _CHUNK)
+        acc = torch.zeros(n1 - n0, dtype=torch.float64, device=device)
+        for k in range(4):
+            # (the numpy path rounds every uniform to fp32 before summing: 0.0 + 1.0 * u in fp64, then fp32)
+            acc += (0.0 + 1.0 * _uniform01_t(f"{name}#{k}", n0, n1, seed, device)).to(torch.float32).to(torch.float64)
+        out[n0:n1] = ((acc - 2.0) * scale).to(torch.float32)
+    return out.reshape(shape)
+
+
+def make_inputs_t(B, H, W, seed=0, C=256, D=32, pose_sigma=0.02, device="cpu", with_images=False):
+    """make_inputs() as torch tensors generated on `device` (bit-identical values)."""
+    import torch
+    h, w = H // 8, W // 8
+    out = {
+        "fmap1": normal_t("fmap1", (B, C, h, w), seed, device=device),
+        "fmap2": normal_t("fmap2", (B, C, h, w), seed, device=device),
+        "ctx": normal_t("ctx", (B, 256, H, W), seed, std=0.1, device=device),
+        "K": torch.from_numpy(intrinsics(B, H, W)).to(device),
+        "sigma": torch.ones(1, dtype=torch.float32, device=device),
+    }
+    for nm in ("g1", "g2"):
+        g = normal_t(nm, (B, D, H, W), seed, device=device).to(torch.float64)
+        g /= torch.sqrt((g * g).sum(dim=1, keepdim=True)) + 1e-12
+        out[nm] = g.to(torch.float32)
+    depth = uniform_t("depth", (B, 1, H, W), seed, 0.9, 1.2, device=device)
+    depth[:, :, : H // 4] = 0.0
+    out["depth"] = depth
+    xi = normal("xi0", (B, 6), seed, std=pose_sigma)
+    out["G0"] = torch.from_numpy(se3_exp_np(xi).astype(np.float32).reshape(B, 1, 4, 4)).to(device)
+    if with_images:
+        out["img_render"] = uniform_t("img_render", (B, 3, H, W), seed, device=device)
+        out["img_target"] = uniform_t("img_target", (B, 3, H, W), seed, device=device)
+    return out

@@ -69,6 +69,16 @@ def syn_digest():
     return "0baa51015be23deba3ab0ca1b76b004dced002a7442ceb5c7affcb82cb54795b"
 
 
+def test_torch_generator_is_bit_identical_to_numpy_generator():
+    """make_inputs_t (used for config-5-sized GPU tests) == make_inputs, element for element."""
+    a = syn.make_inputs(2, 64, 96, seed=7, with_images=True)
+    b = syn.make_inputs_t(2, 64, 96, seed=7, with_images=True)
+    assert set(a) == set(b)
+    for k in a:
+        assert np.array_equal(a[k], b[k].numpy()), k
+    assert np.array_equal(syn.uniform("u", (5, 7), 3, -2.0, 3.0), syn.uniform_t("u", (5, 7), 3, -2.0, 3.0).numpy())
+
+
 def test_ops_refuse_cpu_tensors():
     from rnnpose_amd import ops
     x = torch.zeros(1, 256, 16, 16)
