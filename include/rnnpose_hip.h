@@ -200,10 +200,33 @@ int rnnpose_conv_pack_weights_f16x3(const float* w_oihw, int c_out, int c_in, in
                                     int n_seg, float w_scale, void* w_hi, void* w_lo, rnnpose_stream_t stream);
 int rnnpose_conv2d_nhwc_f16x3(const rnnpose_conv_desc_t* h_desc, rnnpose_stream_t stream);
 
+/* fp16x3 range guard.  Activations are split as x*a_scale = hi + lo in fp16: |x*a_scale| > 65504 does not fit, the hi
+ * part is clamped and the result is WRONG (the reference computes in fp32 and has no such cliff).  With the check
+ * enabled, every launch of the fp16x3 kernels (convolution, encoder stem, correlation-volume operand split) counts the
+ * input quads it had to clamp (or that were not finite) in a device counter; rnnpose_f16x3_saturation_count
+ * synchronises `stream`, returns the count since the last reset and optionally resets it.  Off by default (the test costs
+ * ~3 vector instructions per staged float4).  Process-global switch; not meant to be toggled concurrently with launches. */
+int rnnpose_f16x3_saturation_check(int enable);
+int rnnpose_f16x3_saturation_count(unsigned long long* h_count, int reset, rnnpose_stream_t stream);
+
+/* ---- f1: RAFT encoder stem -- input normalisation + 7x7 stride-2 convolution 3 -> 64 in one kernel -------------
+ *      model/CFNet.py:42-43 (image = 2*(image/255) - 1), thirdparty/raft/extractor.py:131,197 (conv1)
+ * img (N,3,H,W) fp32 NCHW -> out (N, ceil(H/2), ceil(W/2), 64) fp32 NHWC = conv7x7_s2_p3(normalize ? 2*(img/255)-1 : img) + bias.
+ * Weights (64,3,7,7) packed once by rnnpose_stem_pack_weights_f16x3 (2 arrays of rnnpose_stem_packed_halfs() fp16).
+ * tile_stats (optional): (N * tiles_per_image, 64, 2) per-tile column sums / sums of squares for
+ * rnnpose_instnorm_tiles_nhwc_f32 (rows_per_tile = 128); only when rnnpose_stem_tiles reports exact tiling. */
+long long rnnpose_stem_packed_halfs(void);
+int rnnpose_stem_pack_weights_f16x3(const float* w_oihw, float w_scale, void* w_hi, void* w_lo, rnnpose_stream_t stream);
+int rnnpose_stem_tiles(int H, int W, int* h_tiles_per_image, int* h_exact);
+int rnnpose_stem_conv7x7_s2_f16x3(const float* img_nchw, int N, int H, int W, int normalize, const void* w_hi,
+                                  const void* w_lo, const float* bias, float a_scale, float w_scale, float* out_nhwc,
+                                  float* tile_stats, rnnpose_stream_t stream);
+
 /* ---- NHWC companions of the fused update-block engine ----------------------------------------------------
  * corr_lookup_nhwc: a3 with the output laid out (B,h,w,levels*81) (thirdparty/raft/corr.py:36-57).
  * nchw_to_nhwc / nhwc_to_nchw: (B,C,HW) <-> channel window [c_offset, c_offset+C) of a (B,HW,c_stride) tensor.
- * flow_prep: flow = coords1 - grid (model/CFNet.py:150) written as (B,h,w,4) [fx,fy,0,0] (input of the 7x7 flow
+ * flow_prep: flow = coords1 - grid (model/CFNet.py:150; subtract_grid = 0: coords1 already holds the flow, the
+ *   BasicUpdateBlock.forward boundary of update.py:178) written as (B,h,w,4) [fx,fy,0,0] (input of the 7x7 flow
  *   convolution, update.py:84) and into channels [motion_c_offset, +2) of the motion-feature tensor (update.py:97).
  * flow_conv7x7_relu: BasicMotionEncoder.convf1 + ReLU (7x7, 2 -> c_out <= 128, update.py:84,91) as a direct fp32
  *   convolution (K = 98 is too thin for the matrix cores): flow4 from flow_prep, w_t = the (c_out,2,7,7) weight
@@ -218,8 +241,8 @@ int rnnpose_nchw_to_nhwc_f32(const float* src, int B, int C, int HW, float* dst,
                              rnnpose_stream_t stream);
 int rnnpose_nhwc_to_nchw_f32(const float* src, int B, int C, int HW, int src_c_stride, int src_c_offset, float* dst,
                              rnnpose_stream_t stream);
-int rnnpose_flow_prep_f32(const float* coords1, int B, int h, int w, float* flow4, float* motion, int motion_c_stride,
-                          int motion_c_offset, rnnpose_stream_t stream);
+int rnnpose_flow_prep_f32(const float* coords1, int subtract_grid, int B, int h, int w, float* flow4, float* motion,
+                          int motion_c_stride, int motion_c_offset, rnnpose_stream_t stream);
 int rnnpose_flow_conv7x7_relu_f32(const float* flow4, const float* w_t, const float* bias, int B, int h, int w, int c_out,
                                   float* out, int out_c_stride, int out_c_offset, rnnpose_stream_t stream);
 int rnnpose_flow_head_out_f32(const float* x, int x_c_stride, int x_c_offset, int c_in, const float* w_oihw,

@@ -60,10 +60,16 @@ PROTOTYPES = {
     "rnnpose_conv_packed_halfs": (C.c_longlong, [_i, _i, _i, C.POINTER(_i), _i]),
     "rnnpose_conv_pack_weights_f16x3": (_i, [_p, _i, _i, _i, _i, C.POINTER(_i), _i, _f, _p, _p, _p]),
     "rnnpose_conv2d_nhwc_f16x3": (_i, [C.POINTER(ConvDesc), _p]),
+    "rnnpose_f16x3_saturation_check": (_i, [_i]),
+    "rnnpose_f16x3_saturation_count": (_i, [C.POINTER(C.c_ulonglong), _i, _p]),
+    "rnnpose_stem_packed_halfs": (C.c_longlong, []),
+    "rnnpose_stem_pack_weights_f16x3": (_i, [_p, _f, _p, _p, _p]),
+    "rnnpose_stem_tiles": (_i, [_i, _i, C.POINTER(_i), C.POINTER(_i)]),
+    "rnnpose_stem_conv7x7_s2_f16x3": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _f, _f, _p, _p, _p]),
     "rnnpose_corr_lookup_nhwc_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p]),
     "rnnpose_nchw_to_nhwc_f32": (_i, [_p, _i, _i, _i, _p, _i, _i, _p]),
     "rnnpose_nhwc_to_nchw_f32": (_i, [_p, _i, _i, _i, _i, _i, _p, _p]),
-    "rnnpose_flow_prep_f32": (_i, [_p, _i, _i, _i, _p, _p, _i, _i, _p]),
+    "rnnpose_flow_prep_f32": (_i, [_p, _i, _i, _i, _i, _p, _p, _i, _i, _p]),
     "rnnpose_flow_conv7x7_relu_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _i, _i, _p]),
     "rnnpose_flow_head_out_f32": (_i, [_p, _i, _i, _i, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p]),
     "rnnpose_convex_upsample_nhwc_f32": (_i, [_p, _p, _i, _i, _i, _p, _p]),

@@ -37,29 +37,27 @@ def _as_args(args):
 
 class ImageFeaEncoder(nn.Module):
     """model/CFNet.py:26-49.  `pretrained` = path of img_fea_enc.pth (the reference loads
-    <repo>/weights/img_fea_enc.pth unconditionally); None keeps the random initialisation."""
+    <repo>/weights/img_fea_enc.pth unconditionally); None keeps the random initialisation.
+    forward(image1, image2) -> (fmap1, fmap2): both images go through the NHWC encoder engine as one batch on two streams;
+    the reference's input normalisation `2*(x/255)-1` (CFNet.py:42-43, applied even to inputs already in [0,1]) is fused
+    into the stem kernel's load."""
 
-    def __init__(self, input_dim=3, output_dim=256, pretrained=None, conv_backend="hip"):
+    def __init__(self, input_dim=3, output_dim=256, pretrained=None):
         super().__init__()
         self.fnet = BasicEncoder(output_dim=output_dim, norm_fn="instance", dropout=False, input_dim=input_dim)
         if pretrained is not None:
             self.load_state_dict(torch.load(pretrained, map_location="cpu"), strict=True)
-        self.conv_backend = conv_backend      # "hip": NHWC engine (rnnpose_amd/engine.py); "miopen": nn.Module forward
-        self._engine = None
 
+    def engine(self):
+        return self.fnet.engine()
+
+    @torch.no_grad()
     def forward(self, image1, image2):
-        # inputs already in [0,1] are normalised AGAIN by the reference (CFNet.py:42-43); reproduced as is
-        image1 = (2 * (image1 / 255.0) - 1.0).contiguous()
-        image2 = (2 * (image2 / 255.0) - 1.0).contiguous()
-        if self.conv_backend == "hip" and image1.is_cuda:
-            if self._engine is None:
-                from .engine import EncoderEngine
-                self._engine = EncoderEngine(self.fnet)
-            B = image1.shape[0]
-            f = self._engine(torch.cat([image1, image2], 0))
-            return f[:B], f[B:]
-        fmap1, fmap2 = self.fnet([image1, image2])
-        return fmap1, fmap2
+        if not image1.is_cuda:
+            raise RuntimeError("ImageFeaEncoder runs on the GPU only (no CPU path in rnnpose_amd)")
+        B = image1.shape[0]
+        f = self.engine()([image1, image2], normalize=True)
+        return f[:B], f[B:]
 
 
 class GRU_CFUpdator(nn.Module):
@@ -86,20 +84,16 @@ class GRU_CFUpdator(nn.Module):
         self._net = None
         self.inp = None
         self.fmap1 = self.fmap2 = None
-        # "hip": every convolution in the hand-written NHWC implicit-GEMM kernel (rnnpose_amd/engine.py);
-        # "miopen": the literal reference call sequence, convolutions through torch/MIOpen (update.py facade)
-        self.conv_backend = args.get("conv_backend", "hip")
-        # volume build: "f16x3" = fp16 hi/lo split on the fp16 matrix cores (fp32-class accuracy, default with the hip
-        # backend); "f32" = fp32 MFMA kernel
-        self.corr_precision = args.get("corr_precision", "f16x3" if self.conv_backend == "hip" else "f32")
-        self._engine = None
+        # volume build: "f16x3" = fp16 hi/lo split on the fp16 matrix cores (fp32-class accuracy, default);
+        # "f32" = exact fp32 MFMA kernel
+        self.corr_precision = args.get("corr_precision", "f16x3")
         self._net_in_engine = False
 
     @property
     def net(self):
         """Hidden state (B,128,h,w); converted from the engine's NHWC buffer on demand."""
         if self._net_in_engine:
-            return self._engine.hidden_nchw()
+            return self.engine().hidden_nchw()
         return self._net
 
     @net.setter
@@ -108,10 +102,8 @@ class GRU_CFUpdator(nn.Module):
         self._net_in_engine = False
 
     def engine(self):
-        if self._engine is None:
-            from .engine import UpdateEngine
-            self._engine = UpdateEngine(self.update_block)
-        return self._engine
+        """The fused NHWC execution engine of the update block (rnnpose_amd/engine.py)."""
+        return self.update_block.engine()
 
     def initialize_flow(self, img, downsample_rate=8):
         N, _, H, W = img.shape
@@ -130,28 +122,18 @@ class GRU_CFUpdator(nn.Module):
         assert context_fea is not None
         h, w = self.fmap1.shape[-2:]
         self.net, self.inp = ops.context_prep(context_fea, h, w, self.hidden_dim)
-        if self.conv_backend == "hip":
-            self.engine().load_state(self._net, self.inp)
-            self._net_in_engine = True
+        self.engine().load_state(self._net, self.inp)
+        self._net_in_engine = True
 
-    def step(self, coords0, coords1, tail=None, need_coords=True):
+    def step(self, coords0, coords1, tail=None, need_coords=True, flow_up_out=None):
         """One GRU iteration given low-res coords (CFNet.py:147-168) -> (coords1_new, flow_up).
         tail(b0, b1, flow_up[b0:b1]): optional consumer of the up-sampled flow of images [b0, b1), issued on the stream
         that produced it (the HIP engine runs the two batch halves as two staggered chains)."""
-        if self.conv_backend == "hip":
-            if not self._net_in_engine:                  # hidden state was assigned from outside
-                self.engine().load_state(self._net, self.inp)
-                self._net_in_engine = True
-            coords1_new, flow_up = self.engine().step(self.corr_fn, coords1, tail=tail)
-            return (coords1_new.clone() if need_coords else None), flow_up      # (engine buffer: overwritten by the next step)
-        corr = self.corr_fn(coords1)
-        flow = coords1 - coords0
-        self.net, up_mask, delta_flow = self.update_block(self.net, self.inp, corr, flow)
-        coords1 = coords1 + delta_flow
-        flow_up = self.upsample_flow(coords1 - coords0, up_mask)
-        if tail is not None:
-            tail(0, flow_up.shape[0], flow_up)
-        return coords1, flow_up
+        if not self._net_in_engine:                      # hidden state was assigned from outside
+            self.engine().load_state(self._net, self.inp)
+            self._net_in_engine = True
+        coords1_new, flow_up = self.engine().step(self.corr_fn, coords1, tail=tail, flow_up=flow_up_out)
+        return (coords1_new.clone() if need_coords else None), flow_up      # (engine buffer: overwritten by the next step)
 
     @torch.no_grad()
     def forward(self, fmap1, fmap2, iters=1, flow_init=None, upsample=True, test_mode=False, context_fea=None,

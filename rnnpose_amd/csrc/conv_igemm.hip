@@ -28,6 +28,7 @@
 //     ReLU, GRU z|r gate (sigmoid, r*h), GRU state update (tanh, (1-z)h+zq)}, optional per-tile column statistics
 //     for the encoder's instance norm, writing straight into a channel slice of the destination NHWC tensor.
 #include "common.hpp"
+#include "f16x3.cuh"
 
 #include <cstdlib>
 
@@ -40,9 +41,7 @@ constexpr int PROWS = AROWS + 1;        // rows per LDS plane: + one all-zero ro
 constexpr int RS = 40;                  // LDS row stride in halfs: 32 + 8 pad = 80 bytes
 constexpr int MAX_CB = 24;
 
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+using rp::h8; using rp::h4; using rp::h2; using rp::f32x2; using rp::f32x16; using rp::u32x2; using rp::split4;
 
 struct Seg {
   const float* ptr;
@@ -74,6 +73,7 @@ struct KParams {
   int gru_c;
   float* tstats;   // optional per-tile column statistics (linear epilogue)
   int n_mt, n_nt;
+  unsigned long long* sat;   // fp16x3 range guard: counter of clamped / non-finite activation quads (NULL = check off)
   int dbg;   // tile-shape overrides for A/B timing (RNNPOSE_CONV_DBG: 32 = 64-wide tiles, 64 = 128-wide tiles, 128 = 2x2 wave layout); 0 in production
 };
 
@@ -89,25 +89,6 @@ struct KParams {
 //        convert is exact), lo = fp16(x - hi) (x - hi is exact in fp32; 11 more bits) -> 21-22 significant bits.
 // Packed fp32 math (v_pk_mul_f32 / v_pk_add_f32) and v_cvt_pk_f16_f32 halve the rest.  |x*s| > 65504: hi converts to
 // inf and is clamped to +-65504 (lo stays tiny): saturation, never NaN from finite inputs.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void split4(const float4 v, float s, h4& hi, h4& lo) {
-  const f32x2 s2 = {s, s};
-  const f32x2 x01 = f32x2{v.x, v.y} * s2, x23 = f32x2{v.z, v.w} * s2;
-  const u32x2 m = {0xffffe000u, 0xffffe000u};
-  const f32x2 t01 = __builtin_bit_cast(f32x2, __builtin_bit_cast(u32x2, x01) & m);
-  const f32x2 t23 = __builtin_bit_cast(f32x2, __builtin_bit_cast(u32x2, x23) & m);
-  const f32x2 l01 = x01 - t01, l23 = x23 - t23;
-  const h2 cap = {static_cast<_Float16>(65504.f), static_cast<_Float16>(65504.f)};
-  h2 h01 = __builtin_convertvector(t01, h2), h23 = __builtin_convertvector(t23, h2);
-  h01 = __builtin_elementwise_max(__builtin_elementwise_min(h01, cap), -cap);
-  h23 = __builtin_elementwise_max(__builtin_elementwise_min(h23, cap), -cap);
-  const h2 q01 = __builtin_convertvector(l01, h2), q23 = __builtin_convertvector(l23, h2);
-  hi = h4{h01.x, h01.y, h23.x, h23.y};
-  lo = h4{q01.x, q01.y, q23.x, q23.y};
-}
-
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
 
 // NI = MFMA column tiles per wave: output tile = 128 x (64*NI).  NI=2 (128x128) for wide layers, NI=1 (128x64) when
@@ -195,6 +176,7 @@ __global__ __launch_bounds__(NT, (COLS4 ? 3 : 2)) void conv_igemm_f16x3_kernel(c
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   float4 av0, av1, av2, av3, av4;
+  int sat_n = 0;                    // range guard (p.sat != NULL): staged quads this thread had to clamp
   unsigned amask_n = 0u;            // bit r: staged row r of the tile in flight is inside the image (else: zeros)
 #define RP_LOAD_A_ROW(R_)                                                                                   \
   {                                                                                                         \
@@ -235,7 +217,12 @@ __global__ __launch_bounds__(NT, (COLS4 ? 3 : 2)) void conv_igemm_f16x3_kernel(c
       *reinterpret_cast<h4*>(sAf + (AB_) * (2 * PROWS * RS) + PROWS * RS + j_ * RS + c4 * 4) = lo_;         \
     }                                                                                                       \
   }
-#define RP_STORE_A(AB_) do { RP_STORE_A_ROW(0, AB_) RP_STORE_A_ROW(1, AB_) RP_STORE_A_ROW(2, AB_) RP_STORE_A_ROW(3, AB_) RP_STORE_A_ROW(4, AB_) } while (0)
+#define RP_SAT_ROW(R_) sat_n += (((amask_n >> R_) & 1u) && rp::quad_saturates(av##R_, p.a_scale)) ? 1 : 0;
+#define RP_STORE_A(AB_)                                                                                     \
+  do {                                                                                                      \
+    if (p.sat) { RP_SAT_ROW(0) RP_SAT_ROW(1) RP_SAT_ROW(2) RP_SAT_ROW(3) RP_SAT_ROW(4) }   /* uniform branch, VALU only */ \
+    RP_STORE_A_ROW(0, AB_) RP_STORE_A_ROW(1, AB_) RP_STORE_A_ROW(2, AB_) RP_STORE_A_ROW(3, AB_) RP_STORE_A_ROW(4, AB_) \
+  } while (0)
   // weight fragment registers: two stages (named locals + macros: structs/arrays handed to lambdas end up in LDS or
   // scratch with this compiler).  Stage S holds, for the tap being consumed, this wave's B fragments
   // [ni][kk] x (hi, lo): 16 bytes per lane each, already in MFMA operand order.
@@ -370,6 +357,7 @@ __global__ __launch_bounds__(NT, (COLS4 ? 3 : 2)) void conv_igemm_f16x3_kernel(c
 #ifdef RP_CONV_TS
   if (ts_on) for (int e = lane; e < 64 * 8; e += 64) g_conv_ts[e] = ts_lds[e];
 #endif
+  if (p.sat && sat_n) atomicAdd(p.sat, static_cast<unsigned long long>(sat_n));
   // ------------------------------------------- epilogue -------------------------------------------
   // accumulators -> wave-private LDS tile (aliasing the weight staging buffers) -> 16-byte row-contiguous stores:
   // 16 lanes cover 256 contiguous bytes of one output pixel (the MFMA C layout would give 4-byte stores spread
@@ -653,6 +641,7 @@ int rnnpose_conv2d_nhwc_f16x3(const rnnpose_conv_desc_t* d, rnnpose_stream_t str
   p.dst2 = d->dst2; p.dst2_cs = d->dst2_c_stride; p.dst2_co = d->dst2_c_offset;
   p.gru_c = d->gru_c;
   p.tstats = d->tile_stats;
+  p.sat = rp::sat_counter();
   if (d->tile_stats) RP_REQUIRE(d->epilogue == 0, fn, "tile_stats needs the linear epilogue");
   const long long Mtot = static_cast<long long>(d->B) * Ho * Wo;
   RP_REQUIRE(Mtot < (1LL << 31) - 256 && static_cast<long long>(d->B) * d->H * d->W < (1LL << 31) - 256, fn, "too many pixels");

@@ -21,6 +21,7 @@
 //   * Block id -> tile: consecutive ids on one XCD (id % 8) walk the j patches of one i tile, so the A
 //     tile and the B panel stay in that XCD's L2.
 #include "common.hpp"
+#include "f16x3.cuh"
 
 namespace {
 
@@ -298,7 +299,7 @@ __device__ __forceinline__ void split4_h3(const float4 v, float s, h4& hi, h4& l
 // layout 0: source is (B, C, N) (NCHW, transposed through a 32 x 33 LDS tile); layout 1: source is (B, N, C).
 __global__ __launch_bounds__(256) void split_features_kernel(const float* __restrict__ src, _Float16* __restrict__ hi,
                                                              _Float16* __restrict__ lo, int C, int N, int layout,
-                                                             float a_scale) {
+                                                             float a_scale, unsigned long long* sat) {
   const int b = blockIdx.z;
   if (layout == 1) {
     const long long total4 = static_cast<long long>(N) * C / 4;
@@ -307,6 +308,7 @@ __global__ __launch_bounds__(256) void split_features_kernel(const float* __rest
     const float4 v = reinterpret_cast<const float4*>(src + static_cast<long long>(b) * N * C)[i];
     h4 h, l;
     split4_h3(v, a_scale, h, l);
+    if (sat && rp::quad_saturates(v, a_scale)) atomicAdd(sat, 1ull);       // range guard (f16x3.cuh)
     reinterpret_cast<h4*>(hi + static_cast<long long>(b) * N * C)[i] = h;
     reinterpret_cast<h4*>(lo + static_cast<long long>(b) * N * C)[i] = l;
     return;
@@ -324,7 +326,9 @@ __global__ __launch_bounds__(256) void split_features_kernel(const float* __rest
   for (int r = 0; r < 4; ++r) {
     const int n = n0 + ty + 8 * r, c = c0 + tx;
     if (n < N && c < C) {
-      const float x = fminf(fmaxf(tile[tx][ty + 8 * r] * a_scale, -65504.f), 65504.f);
+      const float raw = tile[tx][ty + 8 * r] * a_scale;
+      if (sat && !(fabsf(raw) <= 65504.f)) atomicAdd(sat, 1ull);           // range guard (f16x3.cuh)
+      const float x = fminf(fmaxf(raw, -65504.f), 65504.f);
       const _Float16 h = static_cast<_Float16>(x);
       hi[(static_cast<long long>(b) * N + n) * C + c] = h;
       lo[(static_cast<long long>(b) * N + n) * C + c] = static_cast<_Float16>(x - static_cast<float>(h));
@@ -530,8 +534,8 @@ int rnnpose_corr_pyramid_f16x3(const float* fmap1, const float* fmap2, int layou
   _Float16 *f1h = ws, *f1l = ws + plane, *f2h = ws + 2 * plane, *f2l = ws + 3 * plane;
   dim3 sg = layout == 1 ? dim3(1024, static_cast<unsigned>(rp::cdiv(static_cast<long long>(N) * C / 4, 256 * 1024)), B)
                         : dim3(rp::cdiv(N, 32), rp::cdiv(C, 32), B);
-  hipLaunchKernelGGL(split_features_kernel, sg, dim3(256), 0, st, fmap1, f1h, f1l, C, N, layout, a_scale);
-  hipLaunchKernelGGL(split_features_kernel, sg, dim3(256), 0, st, fmap2, f2h, f2l, C, N, layout, a_scale);
+  hipLaunchKernelGGL(split_features_kernel, sg, dim3(256), 0, st, fmap1, f1h, f1l, C, N, layout, a_scale, rp::sat_counter());
+  hipLaunchKernelGGL(split_features_kernel, sg, dim3(256), 0, st, fmap2, f2h, f2l, C, N, layout, a_scale, rp::sat_counter());
   const int n_it = rp::cdiv(N, BM), n_py = rp::cdiv(h, PY), n_px = rp::cdiv(w, PX);
   const long long ntiles = static_cast<long long>(B) * rp::cdiv(n_it, ST) * rp::cdiv(n_py * n_px, ST) * ST * ST;
   RP_REQUIRE(ntiles < (1LL << 31), fn, "grid too large");

@@ -45,18 +45,19 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restri
 }
 
 // ---- flow bookkeeping of one GRU step (model/CFNet.py:147-157, update.py:97) -----------------------------
-// coords1 (B,2,h,w) planar -> flow = coords1 - grid written (a) as a 4-channel zero-padded NHWC tensor (input of the
-// 7x7 flow convolution) and (b) into channels [co, co+2) of the NHWC motion-feature tensor.
+// coords1 (B,2,h,w) planar -> flow = coords1 - grid (subtract_grid != 0; or coords1 already IS the flow: the
+// BasicUpdateBlock facade) written (a) as a 4-channel zero-padded NHWC tensor (input of the 7x7 flow convolution) and
+// (b) into channels [co, co+2) of the NHWC motion-feature tensor.
 __global__ __launch_bounds__(256) void flow_prep_kernel(const float* __restrict__ coords1, float* __restrict__ flow4,
                                                         float* __restrict__ motion, int motion_cs, int motion_co, int h,
-                                                        int w, long long total) {
+                                                        int w, long long total, int subtract_grid) {
   const long long t = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (t >= total) return;
   const int n = h * w;
   const int b = static_cast<int>(t / n), pix = static_cast<int>(t - static_cast<long long>(b) * n);
   const int X = pix % w, Y = pix / w;
-  const float fx = coords1[(static_cast<long long>(b) * 2 + 0) * n + pix] - static_cast<float>(X);
-  const float fy = coords1[(static_cast<long long>(b) * 2 + 1) * n + pix] - static_cast<float>(Y);
+  const float fx = coords1[(static_cast<long long>(b) * 2 + 0) * n + pix] - (subtract_grid ? static_cast<float>(X) : 0.f);
+  const float fy = coords1[(static_cast<long long>(b) * 2 + 1) * n + pix] - (subtract_grid ? static_cast<float>(Y) : 0.f);
   *reinterpret_cast<float4*>(flow4 + t * 4) = make_float4(fx, fy, 0.f, 0.f);
   *reinterpret_cast<float2*>(motion + t * motion_cs + motion_co) = make_float2(fx, fy);
 }
@@ -444,15 +445,15 @@ int rnnpose_nhwc_to_nchw_f32(const float* src, int B, int C, int HW, int src_c_s
   return rp::check_launch(fn);
 }
 
-int rnnpose_flow_prep_f32(const float* coords1, int B, int h, int w, float* flow4, float* motion, int motion_c_stride,
-                          int motion_c_offset, rnnpose_stream_t stream) {
+int rnnpose_flow_prep_f32(const float* coords1, int subtract_grid, int B, int h, int w, float* flow4, float* motion,
+                          int motion_c_stride, int motion_c_offset, rnnpose_stream_t stream) {
   const char* fn = "rnnpose_flow_prep_f32";
   RP_REQUIRE(coords1 && flow4 && motion, fn, "null pointer");
   RP_REQUIRE(B > 0 && h > 0 && w > 0 && motion_c_offset % 2 == 0 && motion_c_stride % 2 == 0 &&
                  motion_c_offset + 2 <= motion_c_stride, fn, "bad size");
   const long long total = static_cast<long long>(B) * h * w;
   hipLaunchKernelGGL(flow_prep_kernel, dim3(rp::cdiv(total, 256)), dim3(256), 0, rp::as_stream(stream), coords1, flow4,
-                     motion, motion_c_stride, motion_c_offset, h, w, total);
+                     motion, motion_c_stride, motion_c_offset, h, w, total, subtract_grid);
   return rp::check_launch(fn);
 }
 

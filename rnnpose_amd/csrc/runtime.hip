@@ -28,9 +28,56 @@ int check_launch(const char* fn) {
   return 0;
 }
 
+// fp16x3 range guard (rnnpose_f16x3_saturation_check): one 8-byte device counter per device, allocated when the check is
+// switched on (never inside a launch path: hipMalloc is illegal under stream capture)
+static bool g_sat_on = false;
+static unsigned long long* g_sat[64] = {};
+
+unsigned long long* sat_counter() {
+  if (!g_sat_on) return nullptr;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  return g_sat[dev];
+}
+
 }  // namespace rp
 
 extern "C" {
+
+int rnnpose_f16x3_saturation_check(int enable) {
+  if (enable) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return rp::fail_arg("rnnpose_f16x3_saturation_check", "no current device");
+    if (!rp::g_sat[dev]) {
+      if (hipMalloc(reinterpret_cast<void**>(&rp::g_sat[dev]), sizeof(unsigned long long)) != hipSuccess ||
+          hipMemset(rp::g_sat[dev], 0, sizeof(unsigned long long)) != hipSuccess) {
+        rp::g_sat[dev] = nullptr;
+        rp::set_error("rnnpose_f16x3_saturation_check: cannot allocate the device counter");
+        return 2;
+      }
+    }
+  }
+  rp::g_sat_on = enable != 0;
+  return 0;
+}
+
+int rnnpose_f16x3_saturation_count(unsigned long long* h_count, int reset, rnnpose_stream_t stream) {
+  const char* fn = "rnnpose_f16x3_saturation_count";
+  RP_REQUIRE(h_count, fn, "null pointer");
+  int dev = 0;
+  RP_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64, fn, "no current device");
+  *h_count = 0;
+  if (!rp::g_sat[dev]) return 0;
+  hipStream_t st = rp::as_stream(stream);
+  hipError_t e = hipMemcpyAsync(h_count, rp::g_sat[dev], sizeof(unsigned long long), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess && reset) e = hipMemsetAsync(rp::g_sat[dev], 0, sizeof(unsigned long long), st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) {
+    rp::set_error("%s: HIP error %d (%s)", fn, static_cast<int>(e), hipGetErrorString(e));
+    return 2;
+  }
+  return 0;
+}
 
 int rnnpose_abi_version(void) { return RNNPOSE_ABI_VERSION; }
 

@@ -1,0 +1,206 @@
+// f1: the RAFT encoder stem as ONE kernel -- input normalisation 2*(x/255)-1 (model/CFNet.py:42-43) fused into the
+// 7x7 stride-2 convolution 3 -> 64 (thirdparty/raft/extractor.py:131,197), NCHW image in, NHWC feature map out, plus the
+// per-tile column statistics the following instance norm needs (extractor.py:129,198).
+//
+// K = 3*49 = 147 is too thin for the implicit-GEMM kernel's 32-channel blocks (it would multiply 8x zeros), so this is an
+// im2col-in-LDS GEMM: one workgroup = 8 x 16 output pixels (128 GEMM rows) x 64 output channels, K padded to 160.
+//   * the 21 x 37 x 3 input patch of the tile is staged ONCE in LDS (normalised fp32; zero padding applied AFTER the
+//     normalisation, as F.conv2d pads the normalised tensor);
+//   * every lane gathers its MFMA A operand (8 consecutive k = (c, ky, kx) values of one output pixel) from the patch
+//     with compile-time tap offsets, splits it into fp16 hi/lo (f16x3.cuh) and issues 3 x 2 v_mfma_f32_32x32x16_f16;
+//   * weights are pre-packed in B-fragment order [k step][32-col tile][lane][8] fp16 hi/lo (20 KB each, L1/L2 resident);
+//   * epilogue: accumulators -> wave-private LDS tile -> 16-byte stores (256 B per pixel) + bias, tile statistics in
+//     fixed order (no atomics).
+// HBM-bound by its output (315 MB per 16 x 480 x 640 images vs 59 MB in); the MFMA work is 75 GFLOP executed.
+#include "common.hpp"
+#include "f16x3.cuh"
+
+namespace {
+
+using rp::f32x16;
+using rp::h4;
+using rp::h8;
+
+constexpr int TH = 8, TW = 16;                     // output tile
+constexpr int PH = 2 * TH + 5, PW = 2 * TW + 5;    // 21 x 37 input patch (stride 2, 7 x 7 taps)
+constexpr int PLANE = PH * PW;                     // 777
+constexpr int PATCH = 3 * PLANE;                   // 2331 floats
+constexpr int KREAL = 147, KSTEPS = 10;            // K padded to 160 = 10 MFMA k-steps of 16
+constexpr int CO = 64;
+constexpr int ES = CO + 4;                         // staging row stride (floats)
+
+__host__ __device__ constexpr int koff(int k) {    // patch offset of GEMM-k index k = c*49 + ky*7 + kx (padding: tap 0, weight 0)
+  return k < KREAL ? (k / 49) * PLANE + ((k % 49) / 7) * PW + (k % 7) : 0;
+}
+
+__global__ __launch_bounds__(256) void stem_conv7x7_s2_kernel(const float* __restrict__ img, int normalize,
+                                                              const uint4* __restrict__ whi, const uint4* __restrict__ wlo,
+                                                              const float* __restrict__ bias, float a_scale, float out_scale,
+                                                              float* __restrict__ out, float* __restrict__ tstats, int H,
+                                                              int W, int Ho, int Wo, int tiles_x, int tiles_y,
+                                                              unsigned long long* sat) {
+#pragma clang fp contract(off)
+  __shared__ float patch[PATCH + 5];
+  __shared__ __attribute__((aligned(16))) float stage[4 * 32 * ES];      // 34.8 KB
+  __shared__ float tsum[4][16][8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  int t = blockIdx.x;
+  const int tx = t % tiles_x;
+  t /= tiles_x;
+  const int ty = t % tiles_y, n = t / tiles_y;
+  const int oy0 = ty * TH, ox0 = tx * TW;
+  const int iy0 = 2 * oy0 - 3, ix0 = 2 * ox0 - 3;
+
+  // ---- patch: global (NCHW) -> LDS, normalised ----
+  const float* src = img + static_cast<long long>(n) * 3 * H * W;
+  for (int i = tid; i < PATCH; i += 256) {
+    const int c = i / PLANE, r = i - c * PLANE;
+    const int py = r / PW, px = r - py * PW;
+    const int iy = iy0 + py, ix = ix0 + px;
+    float v = 0.f;
+    if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+      v = src[(static_cast<long long>(c) * H + iy) * W + ix];
+      if (normalize) v = 2.f * (v / 255.f) - 1.f;          // literal operation order of model/CFNet.py:42
+    }
+    if (sat && !(fabsf(v) * a_scale <= 65504.f)) atomicAdd(sat, 1ull);     // range guard (f16x3.cuh)
+    patch[i] = v;
+  }
+  __syncthreads();
+
+  // ---- main loop: 10 k-steps; this wave = 32 output pixels (2 tile rows) x 64 channels ----
+  const int oyl = 2 * wave + (l31 >> 4), oxl = l31 & 15;
+  const float* pl = patch + (2 * oyl) * PW + 2 * oxl;
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+  uint4 bh0 = whi[lane], bh1 = whi[64 + lane], bl0 = wlo[lane], bl1 = wlo[64 + lane];
+#pragma unroll
+  for (int kk = 0; kk < KSTEPS; ++kk) {
+    uint4 nh0 = bh0, nh1 = bh1, nl0 = bl0, nl1 = bl1;
+    if (kk + 1 < KSTEPS) {
+      nh0 = whi[(kk + 1) * 128 + lane]; nh1 = whi[(kk + 1) * 128 + 64 + lane];
+      nl0 = wlo[(kk + 1) * 128 + lane]; nl1 = wlo[(kk + 1) * 128 + 64 + lane];
+    }
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = pl[lh ? koff(kk * 16 + 8 + j) : koff(kk * 16 + j)];
+    h4 h0, l0, h1, l1;
+    rp::split4(make_float4(x[0], x[1], x[2], x[3]), a_scale, h0, l0);
+    rp::split4(make_float4(x[4], x[5], x[6], x[7]), a_scale, h1, l1);
+    const h8 ah = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+    const h8 al = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+    const h8 B0h = __builtin_bit_cast(h8, bh0), B1h = __builtin_bit_cast(h8, bh1);
+    const h8 B0l = __builtin_bit_cast(h8, bl0), B1l = __builtin_bit_cast(h8, bl1);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, B0h, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, B1h, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, B0l, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, B1l, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, B0h, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, B1h, acc1, 0, 0, 0);
+    bh0 = nh0; bh1 = nh1; bl0 = nl0; bl1 = nl1;
+  }
+
+  // ---- epilogue ----
+  float* S = stage + wave * (32 * ES);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+    S[row * ES + l31] = acc0[r] * out_scale;
+    S[row * ES + 32 + l31] = acc1[r] * out_scale;
+  }
+  // (wave-private tile: no barrier needed between a wave's own LDS writes and reads)
+  const int cq = (lane & 15) * 4;                          // this lane's column quad, the same for every k below
+  const float4 b4 = *reinterpret_cast<const float4*>(bias + cq);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int rl = (lane >> 4) + 4 * k;                    // tile row of this wave (0..31)
+    const int oy = oy0 + 2 * wave + (rl >> 4), ox = ox0 + (rl & 15);
+    if (oy >= Ho || ox >= Wo) continue;
+    float4 y = *reinterpret_cast<const float4*>(S + rl * ES + cq);
+    y.x += b4.x; y.y += b4.y; y.z += b4.z; y.w += b4.w;
+    s0 += y.x; s1 += y.y; s2 += y.z; s3 += y.w;
+    q0 += y.x * y.x; q1 += y.y * y.y; q2 += y.z * y.z; q3 += y.w * y.w;
+    *reinterpret_cast<float4*>(out + ((static_cast<long long>(n) * Ho + oy) * Wo + ox) * CO + cq) = y;
+  }
+  if (tstats) {
+    // lanes sharing a column quad (same lane & 15): fixed-order butterfly, then the 4 waves through LDS in order
+#pragma unroll
+    for (int o = 16; o < 64; o <<= 1) {
+      s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); s3 += __shfl_xor(s3, o);
+      q0 += __shfl_xor(q0, o); q1 += __shfl_xor(q1, o); q2 += __shfl_xor(q2, o); q3 += __shfl_xor(q3, o);
+    }
+    if (lane < 16) {
+      float* p = tsum[wave][lane];
+      p[0] = s0; p[1] = s1; p[2] = s2; p[3] = s3; p[4] = q0; p[5] = q1; p[6] = q2; p[7] = q3;
+    }
+    __syncthreads();
+    if (tid < 16) {
+      float* o = tstats + (static_cast<long long>(blockIdx.x) * CO + tid * 4) * 2;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[2 * e + 0] = ((tsum[0][tid][e] + tsum[1][tid][e]) + tsum[2][tid][e]) + tsum[3][tid][e];
+        o[2 * e + 1] = ((tsum[0][tid][4 + e] + tsum[1][tid][4 + e]) + tsum[2][tid][4 + e]) + tsum[3][tid][4 + e];
+      }
+    }
+  }
+}
+
+// (64,3,7,7) fp32 -> B fragments [k step][32-col tile][lane][8] fp16 hi / lo: lane l carries column 32*tile + (l & 31)
+// and k = 16*kstep + 8*(l >> 5) + j
+__global__ void stem_pack_kernel(const float* __restrict__ w, float w_scale, _Float16* __restrict__ hi, _Float16* __restrict__ lo) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= KSTEPS * 2 * 64 * 8) return;
+  const int j = i & 7, ln = (i >> 3) & 63, ni = (i >> 9) & 1, kk = i >> 10;
+  const int k = kk * 16 + (ln >> 5) * 8 + j, nn = ni * 32 + (ln & 31);
+  const float v = k < KREAL ? w[nn * KREAL + k] * w_scale : 0.f;
+  const _Float16 h = static_cast<_Float16>(v);
+  hi[i] = h;
+  lo[i] = static_cast<_Float16>(v - static_cast<float>(h));
+}
+
+}  // namespace
+
+extern "C" {
+
+long long rnnpose_stem_packed_halfs(void) { return KSTEPS * 2 * 64 * 8; }
+
+int rnnpose_stem_pack_weights_f16x3(const float* w_oihw, float w_scale, void* w_hi, void* w_lo, rnnpose_stream_t stream) {
+  const char* fn = "rnnpose_stem_pack_weights_f16x3";
+  RP_REQUIRE(w_oihw && w_hi && w_lo && w_scale > 0.f, fn, "null pointer / non-positive scale");
+  const int total = KSTEPS * 2 * 64 * 8;
+  hipLaunchKernelGGL(stem_pack_kernel, dim3(rp::cdiv(total, 256)), dim3(256), 0, rp::as_stream(stream), w_oihw, w_scale,
+                     static_cast<_Float16*>(w_hi), static_cast<_Float16*>(w_lo));
+  return rp::check_launch(fn);
+}
+
+int rnnpose_stem_tiles(int H, int W, int* tiles_per_image, int* exact) {
+  if (H <= 0 || W <= 0 || !tiles_per_image || !exact) return rp::fail_arg("rnnpose_stem_tiles", "bad argument");
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  *tiles_per_image = rp::cdiv(Ho, TH) * rp::cdiv(Wo, TW);
+  *exact = (Ho % TH == 0 && Wo % TW == 0) ? 1 : 0;
+  return 0;
+}
+
+int rnnpose_stem_conv7x7_s2_f16x3(const float* img_nchw, int N, int H, int W, int normalize, const void* w_hi,
+                                  const void* w_lo, const float* bias, float a_scale, float w_scale, float* out_nhwc,
+                                  float* tile_stats, rnnpose_stream_t stream) {
+  const char* fn = "rnnpose_stem_conv7x7_s2_f16x3";
+  RP_REQUIRE(img_nchw && w_hi && w_lo && bias && out_nhwc, fn, "null pointer");
+  RP_REQUIRE(N > 0 && H > 0 && W > 0 && a_scale > 0.f && w_scale > 0.f, fn, "bad size / scale");
+  RP_REQUIRE(reinterpret_cast<uintptr_t>(out_nhwc) % 16 == 0 && reinterpret_cast<uintptr_t>(bias) % 16 == 0 &&
+                 reinterpret_cast<uintptr_t>(w_hi) % 16 == 0 && reinterpret_cast<uintptr_t>(w_lo) % 16 == 0,
+             fn, "out / bias / packed weights must be 16-byte aligned");
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const int tiles_x = rp::cdiv(Wo, TW), tiles_y = rp::cdiv(Ho, TH);
+  if (tile_stats) RP_REQUIRE(Ho % TH == 0 && Wo % TW == 0, fn, "tile_stats needs ceil(H/2) % 8 == 0 and ceil(W/2) % 16 == 0");
+  const long long blocks = static_cast<long long>(N) * tiles_x * tiles_y;
+  RP_REQUIRE(blocks < (1LL << 31), fn, "too many tiles");
+  hipLaunchKernelGGL(stem_conv7x7_s2_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, rp::as_stream(stream), img_nchw,
+                     normalize, static_cast<const uint4*>(w_hi), static_cast<const uint4*>(w_lo), bias, a_scale,
+                     1.0f / (a_scale * w_scale), out_nhwc, tile_stats, H, W, Ho, Wo, tiles_x, tiles_y, rp::sat_counter());
+  return rp::check_launch(fn);
+}
+
+}  // extern "C"

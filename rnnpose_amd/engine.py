@@ -23,6 +23,8 @@ class UpdateEngine:
         self._w = None
         self._buf_key = None
         self._b = None
+        self._sets = {}           # (B,h,w,device) -> activation buffer set; kept alive because captured hipGraphs hold raw
+        self.epoch = 0            # pointers into them.  Bumped whenever a set is freed: graph caches keyed on it are dropped
         self._side = None         # helper streams of step() (parallel hipGraph branches)
         import os
         self.split_batch = os.environ.get("RNNPOSE_SPLIT_BATCH", "1") != "0"   # two concurrent half-batch chains
@@ -37,8 +39,17 @@ class UpdateEngine:
         return [e.convc1, e.convc2, e.convf1, e.convf2, e.conv, g.convz1, g.convr1, g.convq1, g.convz2, g.convr2,
                 g.convq2, b.flow_head.conv1, b.flow_head.conv2, b.mask[0], b.mask[2]]
 
+    def param_key(self):
+        """Identity of the live parameters: changes on load_state_dict / in-place updates / .to()."""
+        return tuple((m.weight._version, m.weight.data_ptr(), m.bias._version, m.bias.data_ptr()) for m in self._params())
+
+    def refresh(self):
+        """Re-pack the fp16 hi/lo weights if the module's parameters changed; -> the key captured graphs depend on."""
+        self._weights()
+        return self._key
+
     def _weights(self):
-        key = tuple((m.weight._version, m.weight.data_ptr(), m.bias._version, m.bias.data_ptr()) for m in self._params())
+        key = self.param_key()
         if key == self._key:
             return self._w
         b = self.blk
@@ -65,15 +76,34 @@ class UpdateEngine:
         return w
 
     # ---- activations -----------------------------------------------------------------------------------------
+    MAX_SETS = 4
+
     def _buffers(self, B, h, w, device):
+        """Select (allocating on first use) the activation buffers of shape (B,h,w).  One set per shape stays alive --
+        a partial last eval batch followed by a full one must find the full batch's buffers (and the graphs captured
+        over them) intact; beyond MAX_SETS shapes the oldest set is dropped and `epoch` invalidates every graph."""
         key = (B, h, w, str(device))
         if key != self._buf_key:
-            z = lambda c: torch.zeros(B, h, w, c, device=device, dtype=torch.float32)
-            self._b = dict(corr=z(324), cor1=z(256), corflo=z(256), flow4=z(4), flo1=z(128), motion=z(128), hA=z(128),
-                           hB=z(128), inp=z(128), z=z(128), rh=z(128), heads=z(512), delta=z(2), flow_lr=z(2),
-                           mask=z(576), coords1=torch.zeros(B, 2, h, w, device=device))
-            self._buf_key = key
+            st = self._sets.pop(key, None)
+            if st is None:
+                z = lambda c: torch.zeros(B, h, w, c, device=device, dtype=torch.float32)
+                st = dict(corr=z(324), cor1=z(256), corflo=z(256), flow4=z(4), flo1=z(128), motion=z(128), hA=z(128),
+                          hB=z(128), inp=z(128), z=z(128), rh=z(128), heads=z(512), delta=z(2), flow_lr=z(2),
+                          mask=z(576), coords1=torch.zeros(B, 2, h, w, device=device))
+                if len(self._sets) >= self.MAX_SETS:
+                    self._sets.pop(next(iter(self._sets)))
+                    self.epoch += 1
+            self._sets[key] = st          # (re-)insert as most recent
+            self._b, self._buf_key = st, key
         return self._b
+
+    def buffer_key(self):
+        return (self._buf_key, self.epoch)
+
+    def select(self, buf_key):
+        """Make the buffer set a captured graph was recorded on the current one (graph replay path)."""
+        (B, h, w, dev), _ = buf_key
+        return self._buffers(B, h, w, dev)
 
     def _stream(self, device, i):
         """Helper stream i (1: second batch half; 2, 3: the flow-feature / flow-head side chains of the two halves)."""
@@ -91,7 +121,20 @@ class UpdateEngine:
     def hidden_nchw(self):
         return ops.nhwc_to_nchw(self._b["hA"])
 
-    def step(self, corr_fn, coords1, tail=None):
+    def forward_nchw(self, net, inp, corr, flow):
+        """The reference boundary `BasicUpdateBlock.forward(net, inp, corr, flow) -> (net, mask, delta_flow)`
+        (thirdparty/raft/update.py:178-188), all NCHW: layout transposes around the fused NHWC chain."""
+        B, _, h, w = net.shape
+        b = self._buffers(B, h, w, net.device)
+        W = self._weights()
+        ops.nchw_to_nhwc(net, b["hA"])
+        ops.nchw_to_nhwc(inp, b["inp"])
+        ops.nchw_to_nhwc(corr, b["corr"])
+        flow = flow.float().contiguous()
+        self._chain(W, b, flow, torch.cuda.current_stream(), None, flow_is_delta=True)
+        return (ops.nhwc_to_nchw(b["hA"]), ops.nhwc_to_nchw(b["mask"]), ops.nhwc_to_nchw(b["delta"]))
+
+    def step(self, corr_fn, coords1, tail=None, flow_up=None):
         """coords1 (B,2,h,w) -> (coords1 + delta_flow (B,2,h,w), flow_up (B,2,8h,8w)).
         tail(b0, b1, flow_up[b0:b1]) is called on the stream of each batch half right after its up-sampling."""
         W = self._weights()
@@ -106,7 +149,8 @@ class UpdateEngine:
         # its own tail (up-sampling, descriptor weight, LM) on its stream.  Results are bit-identical (images are
         # independent).
         halves = [(0, B)] if (B < 2 or not self.split_batch) else [(0, B // 2), (B // 2, B)]
-        flow_up = torch.empty(B, 2, 8 * h, 8 * w, device=coords1.device, dtype=torch.float32)
+        if flow_up is None:
+            flow_up = torch.empty(B, 2, 8 * h, 8 * w, device=coords1.device, dtype=torch.float32)
         fork = torch.cuda.Event()
         fork.record(main)
         joins = []
@@ -132,15 +176,16 @@ class UpdateEngine:
             main.wait_event(j)
         return b["coords1"], flow_up
 
-    def _chain(self, W, b, coords1, main, side, mark=None):
-        """The update block on the (sub-)batch views `b`, issued on stream `main` (current) with `side` as helper."""
+    def _chain(self, W, b, coords1, main, side, mark=None, flow_is_delta=False):
+        """The update block on the (sub-)batch views `b`, issued on stream `main` (current) with `side` as helper.
+        flow_is_delta: `coords1` holds the flow itself (facade call) instead of absolute coordinates."""
         c = ops.conv2d_nhwc
         R = ops.EPI_RELU
         # Two independent chains feed the motion encoder's last convolution (update.py:89-92): correlation features
         # (convc1 -> convc2) and flow features (flow_prep -> convf1 -> convf2).  The second one runs on a side stream
         # (a parallel branch when the step is captured into a hipGraph).  Same for flow_head.conv2 next to mask.2.
         def flow_chain():
-            ops.flow_prep(coords1, b["flow4"], b["motion"], 126)                   # flow -> convf1 input, motion[126:128]
+            ops.flow_prep(coords1, b["flow4"], b["motion"], 126, subtract_grid=not flow_is_delta)   # flow -> convf1 input, motion[126:128]
             ops.flow_conv7x7_relu(b["flow4"], W["convf1_wt"], W["convf1_b"], b["flo1"])  # :91 (direct fp32, K = 98)
             c(W["convf2"], [(b["flo1"], 0)], (b["corflo"], 192), R)                 # :92
 
@@ -186,10 +231,10 @@ class UpdateEngine:
 
 
 class EncoderEngine:
-    """RAFT BasicEncoder (instance-norm variant, thirdparty/raft/extractor.py:118-232) executed NHWC: all 3x3
-    convolutions and the 1x1 output convolution run in the hand-written implicit-GEMM kernel, instance norm /
-    ReLU / residual adds in one fused HIP pass each; the stride-2 3x3 / 1x1 convolutions use the kernel's strided mode.
-    Only the 7x7 stride-2 stem on 3 input channels (1.4 of 41 GFLOP/image) stays on MIOpen, channels_last (= NHWC)."""
+    """RAFT BasicEncoder (instance-norm variant, thirdparty/raft/extractor.py:118-232) executed NHWC: the stem (input
+    normalisation + 7x7 stride-2 convolution on 3 channels) is one im2col-in-LDS MFMA kernel (csrc/stem.hip), all 3x3
+    convolutions and the 1x1 output convolution run in the implicit-GEMM kernel, instance norm / ReLU / residual adds in
+    one fused HIP pass each; the stride-2 3x3 / 1x1 convolutions use the kernel's strided mode.  No MIOpen, no ATen math."""
 
     def __init__(self, fnet):
         import os
@@ -212,20 +257,20 @@ class EncoderEngine:
         convs["out"] = f.conv2
         return convs
 
+    def refresh(self):
+        self._weights()
+        return self._key
+
     def _weights(self):
         convs = self._mine()
+        convs["stem"] = self.fnet.conv1
         key = tuple((m.weight._version, m.weight.data_ptr(), m.bias._version, m.bias.data_ptr()) for m in convs.values())
         if key != self._key:
+            stem = convs.pop("stem")
             self._w = {k: ops.PackedConv(m.weight, m.bias, [m.weight.shape[1]]) for k, m in convs.items()}
+            self._w["stem"] = ops.PackedStem(stem.weight, stem.bias)
             self._key = key
         return self._w
-
-    @staticmethod
-    def _torch_conv(x_nhwc, conv):
-        import torch.nn.functional as F
-        x = x_nhwc.permute(0, 3, 1, 2)                       # NCHW view of NHWC memory == channels_last
-        y = F.conv2d(x, conv.weight, conv.bias, stride=conv.stride, padding=conv.padding)
-        return y.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
 
     @staticmethod
     def _conv(pc, x, stride=1, stats=True):
@@ -247,36 +292,52 @@ class EncoderEngine:
             return ops.instnorm_nhwc(y, relu=relu, residual=residual)
         return ops.instnorm_tiles_nhwc(y, ts, relu=relu, residual=residual)
 
-    def _block(self, W, name, blk, x):
+    @staticmethod
+    def _block(W, name, blk, x):
+        """ResidualBlock (extractor.py:48-58) on an NHWC tensor; W[name + ".c1" / ".c2" / ".down"] = packed convolutions."""
+        E = EncoderEngine
         st = blk.conv1.stride[0]
-        y = self._norm(self._conv(W[name + ".c1"], x, st), relu=True)
+        y = E._norm(E._conv(W[name + ".c1"], x, st), relu=True)
         res = x
         if blk.downsample is not None:
-            res = self._norm(self._conv(W[name + ".down"], x, st), relu=False)                    # norm3, no ReLU
-        return self._norm(self._conv(W[name + ".c2"], y), relu=True, residual=res)                # relu(x + relu(IN(.)))
+            res = E._norm(E._conv(W[name + ".down"], x, st), relu=False)                          # norm3, no ReLU
+        return E._norm(E._conv(W[name + ".c2"], y), relu=True, residual=res)                      # relu(x + relu(IN(.)))
 
     @torch.no_grad()
-    def __call__(self, x_nchw):
-        """x (N,3,H,W) already normalised -> (N,256,H/8,W/8) NCHW."""
+    def __call__(self, images, normalize=True):
+        """images: one (N,3,H,W) tensor or a list of them (rendered, observed: processed as one batch, no concatenation)
+        -> (sum N, 256, H/8, W/8) NCHW.  normalize: apply 2*(x/255)-1 in the stem's load (model/CFNet.py:42-43)."""
         W = self._weights()
-        N, _, H, Wd = x_nchw.shape
-        out = torch.empty(N, self.fnet.conv2.out_channels, H // 8, Wd // 8, device=x_nchw.device, dtype=torch.float32)
+        imgs = [images] if torch.is_tensor(images) else list(images)
+        imgs = [ops._chk(t, "image") for t in imgs]
+        _, _, H, Wd = imgs[0].shape
+        N = sum(t.shape[0] for t in imgs)
+        dev = imgs[0].device
+        H8, W8 = ((H + 1) // 2 + 1) // 2, ((Wd + 1) // 2 + 1) // 2
+        H8, W8 = (H8 + 1) // 2, (W8 + 1) // 2
+        out = torch.empty(N, self.fnet.conv2.out_channels, H8, W8, device=dev, dtype=torch.float32)
         # Two halves of the image batch (rendered | observed) as two independent streams = two hipGraph branches with a
         # single join at the end: the chains drift apart, so one half's HBM-bound instance-norm passes and latency-bound
         # finalize launches run under the other half's convolutions.  Bit-identical (instance norm is per image).
-        parts = max(1, min(self.parts if self.split_batch else 1, N))
-        cuts = [N * i // parts for i in range(parts + 1)]
-        halves = list(zip(cuts[:-1], cuts[1:]))
+        if len(imgs) > 1:                      # one stream per input tensor (rendered | observed)
+            jobs, o = [], 0
+            for t in imgs:
+                jobs.append((t, o, o + t.shape[0]))
+                o += t.shape[0]
+        else:
+            parts = max(1, min(self.parts if self.split_batch else 1, N))
+            cuts = [N * i // parts for i in range(parts + 1)]
+            jobs = [(imgs[0][a:b], a, b) for a, b in zip(cuts[:-1], cuts[1:])]
         main = torch.cuda.current_stream()
         fork = torch.cuda.Event()
         fork.record(main)
         joins = []
-        for hi_, (b0, b1) in enumerate(halves):
-            st = main if hi_ == 0 else self._second_stream(x_nchw.device, hi_)
+        for hi_, (x_part, b0, b1) in enumerate(jobs):
+            st = main if hi_ == 0 else self._second_stream(dev, hi_)
             if st is not main:
                 st.wait_event(fork)
             with torch.cuda.stream(st):
-                self._forward(W, x_nchw[b0:b1], out[b0:b1])
+                self._forward(W, x_part, out[b0:b1], normalize)
                 if st is not main:
                     j = torch.cuda.Event()
                     j.record(st)
@@ -290,10 +351,9 @@ class EncoderEngine:
             self._side = [torch.cuda.Stream(device=device) for _ in range(max(i, 3))]
         return self._side[i - 1]
 
-    def _forward(self, W, x_nchw, out):
+    def _forward(self, W, x_nchw, out, normalize):
         f = self.fnet
-        x = x_nchw.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
-        y = ops.instnorm_nhwc(self._torch_conv(x, f.conv1).contiguous(), relu=True)
+        y = self._norm(ops.stem_conv(W["stem"], x_nchw, normalize), relu=True)       # extractor.py:197-199
         for li, layer in enumerate((f.layer1, f.layer2, f.layer3), start=1):
             for bi, blk in enumerate(layer):
                 y = self._block(W, f"l{li}.{bi}", blk, y.contiguous())

@@ -1,7 +1,7 @@
 """RAFT BasicEncoder (instance-norm variant) with the reference's module tree / state_dict keys
-(thirdparty/raft/extractor.py:6-58,118-232).  SURVEY.md section 8(f1): adjacent to the hot path -- it runs
-once per outer iteration -- and stays on MIOpen; kept here so `img_fea_enc.pth` loads unchanged and the
-benchmark's timed region matches SURVEY.md section 8(d)."""
+(thirdparty/raft/extractor.py:6-58,118-232), so `img_fea_enc.pth` loads unchanged.  The modules only hold the
+parameters: `BasicEncoder.forward` runs the NHWC encoder engine (rnnpose_amd/engine.py: stem kernel, implicit-GEMM
+convolutions, fused instance-norm passes -- all hand-written HIP), SURVEY.md section 8(f1)."""
 from __future__ import annotations
 
 import torch
@@ -25,11 +25,17 @@ class ResidualBlock(nn.Module):
             self.downsample = nn.Sequential(nn.Conv2d(in_planes, planes, kernel_size=1, stride=stride), self.norm3)
 
     def forward(self, x):
-        y = self.relu(self.norm1(self.conv1(x)))
-        y = self.relu(self.norm2(self.conv2(y)))
+        """(B,C,H,W) NCHW -> NCHW (extractor.py:48-58) through the NHWC kernels of the encoder engine."""
+        from . import ops
+        from .engine import EncoderEngine
+        if not x.is_cuda:
+            raise RuntimeError("ResidualBlock runs on the GPU only (no CPU path in rnnpose_amd)")
+        pc = lambda m: ops.PackedConv(m.weight, m.bias, [m.weight.shape[1]])
+        W = {"b.c1": pc(self.conv1), "b.c2": pc(self.conv2)}
         if self.downsample is not None:
-            x = self.downsample(x)
-        return self.relu(x + y)
+            W["b.down"] = pc(self.downsample[0])
+        y = EncoderEngine._block(W, "b", self, ops.nchw_to_nhwc(x))
+        return ops.nhwc_to_nchw(y)
 
 
 class BasicEncoder(nn.Module):
@@ -46,6 +52,7 @@ class BasicEncoder(nn.Module):
         self.layer2 = self._make_layer(96, stride=2)
         self.layer3 = self._make_layer(128, stride=2)
         self.conv2 = nn.Conv2d(128, output_dim, kernel_size=1)
+        self._engine = None
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
@@ -56,14 +63,20 @@ class BasicEncoder(nn.Module):
         self.in_planes = dim
         return nn.Sequential(*layers)
 
+    def engine(self):
+        if self._engine is None:
+            from .engine import EncoderEngine
+            self._engine = EncoderEngine(self)
+        return self._engine
+
+    @torch.no_grad()
     def forward(self, x):
+        """x: (N,3,H,W) or a list/tuple of two such tensors (already normalised, extractor.py:187-232)."""
         is_list = isinstance(x, (tuple, list))
+        xs = list(x) if is_list else x
+        if not (xs[0] if is_list else xs).is_cuda:
+            raise RuntimeError("BasicEncoder runs on the GPU only (no CPU path in rnnpose_amd)")
+        out = self.engine()(xs, normalize=False)
         if is_list:
-            batch_dim = x[0].shape[0]
-            x = torch.cat(x, dim=0)
-        x = self.relu1(self.norm1(self.conv1(x)))
-        x = self.layer3(self.layer2(self.layer1(x)))
-        x = self.conv2(x)
-        if is_list:
-            x = torch.split(x, [batch_dim, batch_dim], dim=0)
-        return x
+            out = torch.split(out, [t.shape[0] for t in xs], dim=0)
+        return out

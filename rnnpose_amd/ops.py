@@ -120,7 +120,7 @@ def corr_pyramid(fmap1, fmap2, levels: int = 4, out=None, precision: str = "f32"
         raise ValueError("fmap1/fmap2 must both be (B,C,h,w)")
     B, Cc, h, w = fmap1.shape
     if precision == "f16x3":
-        return _corr_pyramid_f16x3(fmap1, fmap2, 0, B, Cc, h, w, levels, out, 64.0)
+        return _corr_pyramid_f16x3(fmap1, fmap2, 0, B, Cc, h, w, levels, out, A_SCALE)
     if precision != "f32":
         raise ValueError("precision must be 'f32' or 'f16x3'")
     offs, hl, wl = pyramid_layout(B, h, w, levels)
@@ -149,7 +149,7 @@ def _corr_pyramid_f16x3(f1, f2, layout, B, Cc, h, w, levels, out, a_scale):
     return buf, views
 
 
-def corr_pyramid_nhwc(f1, f2, levels: int = 4, out=None, a_scale: float = 64.0):
+def corr_pyramid_nhwc(f1, f2, levels: int = 4, out=None, a_scale: float = 8.0):
     """f1,f2 (B,h,w,C) pixel-major -> same (buffer, views) as corr_pyramid, fp16x3-split MFMA (fp32-class accuracy)."""
     f1, f2 = _nhwc(f1, "f1"), _nhwc(f2, "f2")
     if f1.shape != f2.shape:
@@ -365,6 +365,11 @@ def gru_update(z, q_pre, hcat, hout, C: int = 128):
 
 # ---- a4 dense convolutions: NHWC implicit GEMM on the fp16 matrix cores with fp16x3 split (fp32-class accuracy) ----
 EPI_LINEAR, EPI_RELU, EPI_GRU_ZR, EPI_GRU_Q = 0, 1, 2, 3
+# Activation scale of the fp16x3 split (x * A_SCALE = hi + lo in fp16).  Range: |x| <= 65504 / A_SCALE = 8188; full 21-22
+# bit precision while lo stays a normal fp16 (|x| >= 2^-3 / A_SCALE = 0.016), below that the ABSOLUTE error stays under
+# 2^-25 / A_SCALE = 4e-9 -- fp32-class for O(1) activations either way.  (r01 used 64: range 1023, too tight for
+# real correlation magnitudes; saturation is counted by the range guard, ops.saturation_check.)
+A_SCALE = 8.0
 
 
 class PackedConv:
@@ -372,7 +377,7 @@ class PackedConv:
     weight (Cout,Cin,kh,kw), bias (Cout,), seg_counts = channel counts of the virtual-concat sources (sum = Cin).
     post_scale is folded into weight and bias (the 0.25 of the mask head, update.py:187)."""
 
-    def __init__(self, weight, bias, seg_counts=None, post_scale: float = 1.0, a_scale: float = 64.0):
+    def __init__(self, weight, bias, seg_counts=None, post_scale: float = 1.0, a_scale: float = A_SCALE):
         import math
         w = _chk(weight.detach(), "weight") * post_scale
         b = _chk(bias.detach(), "bias") * post_scale
@@ -444,6 +449,37 @@ def conv2d_nhwc(pc: PackedConv, srcs, dst, epilogue: int = EPI_LINEAR, aux0=None
             work=2.0 * B * (-(-H // stride)) * (-(-W // stride)) * pc.c_out * pc.c_in_real * pc.kh * pc.kw)
 
 
+_nchw_pc = {}
+
+
+def conv2d_nchw(weight, bias, x, relu: bool = False):
+    """NCHW facade of the implicit-GEMM kernel: F.conv2d(x, weight, bias, stride=1, padding=k//2) [+ ReLU] for the odd
+    "same" convolutions of the update block (thirdparty/raft/update.py).  Layout transposes on both sides, channel counts
+    padded to multiples of 4; packed weights are cached per parameter identity.  The fused NHWC engine does not use this."""
+    x = _chk(x, "x")
+    B, Cin, H, W = x.shape
+    Cout, Cin_w, kh, kw = weight.shape
+    if Cin_w != Cin:
+        raise ValueError(f"weight expects {Cin_w} input channels, got {Cin}")
+    cin_p, cout_p = -(-Cin // 4) * 4, -(-Cout // 4) * 4
+    key = (weight.data_ptr(), weight._version, bias.data_ptr(), bias._version, tuple(weight.shape))
+    pc = _nchw_pc.get(key)
+    if pc is None:
+        w = _chk(weight.detach(), "weight")
+        if cin_p != Cin:
+            w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, cin_p - Cin))
+        pc = PackedConv(w, bias, [cin_p])
+        pc.c_in_real = Cin
+        if len(_nchw_pc) >= 64:
+            _nchw_pc.pop(next(iter(_nchw_pc)))
+        _nchw_pc[key] = pc
+    xn = (torch.zeros if cin_p != Cin else torch.empty)(B, H, W, cin_p, device=x.device, dtype=F32)
+    nchw_to_nhwc(x, xn)
+    out = torch.empty(B, H, W, cout_p, device=x.device, dtype=F32)
+    conv2d_nhwc(pc, [(xn, 0)], (out, 0), EPI_RELU if relu else EPI_LINEAR)
+    return nhwc_to_nchw(out, 0, Cout)
+
+
 # ---- NHWC companions ------------------------------------------------------------------------------------------
 def corr_lookup_nhwc(pyramid_buf, coords, out=None, levels: int = 4, radius: int = 4):
     """coords (B,2,h,w) -> (B,h,w,levels*81)"""
@@ -474,10 +510,11 @@ def nhwc_to_nchw(src, c_offset: int = 0, c_count: int | None = None, out=None):
     return dst
 
 
-def flow_prep(coords1, flow4, motion, motion_c_offset):
+def flow_prep(coords1, flow4, motion, motion_c_offset, subtract_grid: bool = True):
+    """coords1 (B,2,h,w): absolute coordinates (subtract_grid) or the flow itself -> flow4 (B,h,w,4), motion[..., co:co+2]."""
     B, _, h, w = coords1.shape
-    _launch("rnnpose_flow_prep_f32", _ptr(coords1), B, h, w, _ptr(flow4), _ptr(motion), motion.shape[3], motion_c_offset,
-            _stream())
+    _launch("rnnpose_flow_prep_f32", _ptr(coords1), int(subtract_grid), B, h, w, _ptr(flow4), _ptr(motion), motion.shape[3],
+            motion_c_offset, _stream())
 
 
 def flow_conv7x7_relu(flow4, w_t, bias, out, out_c_offset=0):
@@ -501,6 +538,56 @@ def convex_upsample_nhwc(flow_lr, mask, out=None):
         out = torch.empty(B, 2, 8 * h, 8 * w, device=mask.device, dtype=F32)
     _launch("rnnpose_convex_upsample_nhwc_f32", _ptr(flow_lr), _ptr(mask), B, h, w, _ptr(out), _stream())
     return out
+
+
+# ---- fp16x3 range guard ------------------------------------------------------------------------------------------------
+def saturation_check(enable: bool = True):
+    """Switch the fp16x3 range guard on/off (process-global): with it on, every fp16x3 kernel counts the activation quads
+    whose scaled magnitude left the fp16 range (|x * a_scale| > 65504) -- values the fp32 reference would handle."""
+    _lib.call("rnnpose_f16x3_saturation_check", int(bool(enable)))
+
+
+def saturation_count(reset: bool = True) -> int:
+    """Clamped / non-finite quads seen since the last reset (synchronises the current stream)."""
+    n = C.c_ulonglong(0)
+    _lib.call("rnnpose_f16x3_saturation_count", C.byref(n), int(bool(reset)), _stream())
+    return int(n.value)
+
+
+# ---- f1: encoder stem ---------------------------------------------------------------------------------------------------
+class PackedStem:
+    """conv1 of the RAFT encoder (64,3,7,7) split into fp16 hi/lo MFMA fragments for csrc/stem.hip."""
+
+    def __init__(self, weight, bias, a_scale: float = 8.0):
+        import math
+        w = _chk(weight.detach(), "weight")
+        if tuple(w.shape) != (64, 3, 7, 7):
+            raise ValueError("the stem kernel is the RAFT encoder's conv1: weight must be (64,3,7,7)")
+        wmax = float(w.abs().max())
+        self.w_scale = float(2.0 ** math.floor(math.log2(1024.0 / wmax))) if wmax > 0 else 1.0
+        self.a_scale = float(a_scale)
+        n = int(_lib.load().rnnpose_stem_packed_halfs())
+        self.w_hi = torch.empty(n, device=w.device, dtype=torch.float16)
+        self.w_lo = torch.empty(n, device=w.device, dtype=torch.float16)
+        self.bias = _chk(bias.detach(), "bias")
+        _lib.call("rnnpose_stem_pack_weights_f16x3", _ptr(w), self.w_scale, _ptr(self.w_hi), _ptr(self.w_lo), _stream())
+
+
+def stem_conv(ps: PackedStem, img, normalize: bool = True):
+    """img (N,3,H,W) NCHW -> (out (N,ceil(H/2),ceil(W/2),64) NHWC, tile_stats or None)
+    = conv7x7 stride 2 pad 3 of (2*(img/255)-1 if normalize else img) + bias   (model/CFNet.py:42-43, extractor.py:131,197)."""
+    img = _chk(img, "image")
+    N, Cc, H, W = img.shape
+    if Cc != 3:
+        raise ValueError("image must have 3 channels")
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    tiles, exact = C.c_int(0), C.c_int(0)
+    _lib.call("rnnpose_stem_tiles", H, W, C.byref(tiles), C.byref(exact))
+    out = torch.empty(N, Ho, Wo, 64, device=img.device, dtype=F32)
+    ts = torch.empty(N * tiles.value, 64, 2, device=img.device, dtype=F32) if exact.value else None
+    _launch("rnnpose_stem_conv7x7_s2_f16x3", _ptr(img), N, H, W, int(bool(normalize)), _ptr(ps.w_hi), _ptr(ps.w_lo),
+            _ptr(ps.bias), ps.a_scale, ps.w_scale, _ptr(out), _ptr(ts), _stream(), work=2.0 * N * Ho * Wo * 64 * 147)
+    return out, ts
 
 
 # ---- f1: instance norm on NHWC --------------------------------------------------------------------------------

@@ -34,7 +34,8 @@ def default_config(**over):
     """Iteration counts of config/linemod/template_fw0.5.yml:76-81,92 unless overridden."""
     cfg = AttrDict(RENDER_ITER_COUNT=3, ITER_COUNT=4, OPTIM_ITER_COUNT=1, FLOW_NET="raft", ONLINE_CROP=True,
                    IS_CALIBRATED=True, RESCALE_IMAGES=False, with_corr_weight=True,
-                   raft=AttrDict(pretrained_model=None, mixed_precision=False, fea_net="default", conv_backend="hip"),
+                   raft=AttrDict(pretrained_model=None, mixed_precision=False, fea_net="default"),
+                   render_image_size=(480, 640), zoom_crop_size=(240, 240),       # BASIC.* of the reference config
                    LM_LMBDA=LM_LMBDA, EP_LMBDA=EP_LMBDA)
     cfg.update(over)
     return cfg
@@ -69,9 +70,14 @@ class PoseRefiner(nn.Module):
         self.use_regressor = use_regressor
         if cfg.get("FLOW_NET", "raft") != "raft":
             raise NotImplementedError
-        self.image_fea_enc = ImageFeaEncoder(pretrained=img_fea_enc_weights,
-                                             conv_backend=cfg.get("raft", {}).get("conv_backend", "hip"))
+        self.image_fea_enc = ImageFeaEncoder(pretrained=img_fea_enc_weights)
         self.cf_net = GRU_CFUpdator(cfg.get("raft", None))
+        if renderer is not None and not hasattr(renderer, "render_views"):
+            # an object with the reference renderer's call shape (DiffRendererWrapper, geometry/diff_render_optim.py:404-494;
+            # constructed as PoseRefiner(opt.motion_net, ..., renderer=diff_renderer) at model/RNNPose.py:76-79)
+            from .render_adapter import RendererAdapter
+            renderer = RendererAdapter(renderer, render_image_size=cfg.get("render_image_size", (480, 640)),
+                                       zoom_crop_size=cfg.get("zoom_crop_size", (240, 240)), legacy=True)
         self.renderer = renderer
         self.fused = fused
         # hipGraph replay of the inner-iteration body (~25 launches): at the reference's own working size (B=1,
@@ -84,6 +90,7 @@ class PoseRefiner(nn.Module):
         self._ptr_captures = 0
         self._outer_graphs = {}
         self._outer_captures = 0
+        self._wkey = None                 # identity of the live parameters + engine buffers every captured graph depends on
         self._clear()
 
     def _clear(self):
@@ -110,12 +117,29 @@ class PoseRefiner(nn.Module):
         self.cf_net.prepare(feats1, feats2, views["cfea"])
         return feats1, feats2
 
+    def _drop_graphs(self):
+        self._graph = self._graph_static = None
+        self._outer_graphs = {}
+        self._ptr_captures = 0
+        self._outer_captures = 0
+
+    def _refresh(self):
+        """Once per forward(): re-pack weights whose parameters changed (load_state_dict, in-place updates, .to()) and
+        return the identity every captured graph depends on -- replay never runs the packing code itself."""
+        eng = self.cf_net.engine()
+        key = (eng.refresh(), self.image_fea_enc.engine().refresh(), self.sigma[0].data_ptr(), eng.epoch)
+        if key != self._wkey:
+            if self._wkey is not None:
+                self._drop_graphs()          # graphs hold pointers to the old packed weights / freed activation buffers
+            self._wkey = key
+        return key
+
     def _outer(self, views):
-        if not (self.use_graph and self.cf_net.conv_backend == "hip") or ops.profiling():
+        if not self.use_graph or ops.profiling():
             return self._outer_body(views)
+        eng = self.cf_net.engine()
         ins = [views[k] for k in ("syn_img", "image_crop", "cfea", "fmap1", "fmap2") if views.get(k) is not None]
-        key = tuple((t.data_ptr(), tuple(t.shape)) for t in ins) + (self.cf_net.engine()._key,
-                                                                    getattr(self.image_fea_enc._engine, "_key", None))
+        key = tuple((t.data_ptr(), tuple(t.shape)) for t in ins) + (self._wkey,)
         gr = self._outer_graphs.get(key)
         if gr is None:
             if self._outer_captures >= 8:      # views keep moving (a renderer allocating fresh tensors): stay eager
@@ -131,7 +155,8 @@ class PoseRefiner(nn.Module):
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
                     out = self._outer_body(views)
-                gr = dict(graph=graph, out=out, corr_fn=self.cf_net.corr_fn, net=self.cf_net._net, inp=self.cf_net.inp)
+                gr = dict(graph=graph, out=out, corr_fn=self.cf_net.corr_fn, net=self.cf_net._net, inp=self.cf_net.inp,
+                          buf_key=eng.buffer_key())
                 if len(self._outer_graphs) >= 4:
                     self._outer_graphs.pop(next(iter(self._outer_graphs)))
                 self._outer_graphs[key] = gr
@@ -142,6 +167,7 @@ class PoseRefiner(nn.Module):
                 return self._outer_body(views)
         gr["graph"].replay()
         # the Python-side state prepare() sets is the one recorded at capture time (same device buffers)
+        eng.select(gr["buf_key"])
         self.cf_net.corr_fn = gr["corr_fn"]
         self.cf_net._net, self.cf_net.inp = gr["net"], gr["inp"]
         self.cf_net._net_in_engine = True
@@ -149,16 +175,30 @@ class PoseRefiner(nn.Module):
         return gr["out"]
 
     # ---- one inner iteration of the fused schedule, eager or as a replayed hipGraph ---------------------------
+    @staticmethod
+    def _out_views(big, small, B, H, W):
+        """Typed views of the two per-iteration output buffers (one clone each hands a replayed graph's outputs over):
+        big = [flow_up (B,2,H,W) | weight (B,H,W)] fp32; small = [Hm (B,6,6) f64 | bv (B,6) f64 | G (B,4,4) | xi (B,6) | info (B,) i32]."""
+        P = H * W
+        flow_up = big[:B * 2 * P].view(B, 2, H, W)
+        wmap = big[B * 2 * P:].view(B, H, W)
+        o = [0, B * 288, B * 336, B * 400, B * 424, B * 428]
+        Hm = small[o[0]:o[1]].view(torch.float64).view(B, 6, 6)
+        bv = small[o[1]:o[2]].view(torch.float64).view(B, 6)
+        Gn = small[o[2]:o[3]].view(torch.float32).view(B, 4, 4)
+        xi = small[o[3]:o[4]].view(torch.float32).view(B, 6)
+        info = small[o[4]:o[5]].view(torch.int32).view(B)
+        return flow_up, wmap, Gn, Hm, bv, xi, info
+
     def _body(self, depth, K, g1, g2, G, coords0, h, w, ep_l, lm_l):
+        """-> (big, small) output buffers of one inner iteration (see _out_views)."""
         B, dev = depth.shape[0], depth.device
+        H, W = depth.shape[-2], depth.shape[-1]
         coords1 = ops.induced_coords_lowres(depth, K, G, h, w, EPS)
         G3 = G.reshape(-1, 4, 4)
-        wmap = torch.empty(B, depth.shape[-2], depth.shape[-1], device=dev, dtype=torch.float32)
-        Gn = torch.empty(B, 4, 4, device=dev, dtype=torch.float32)
-        Hm = torch.empty(B, 6, 6, device=dev, dtype=torch.float64)
-        bv = torch.empty(B, 6, device=dev, dtype=torch.float64)
-        xi = torch.empty(B, 6, device=dev, dtype=torch.float32)
-        info = torch.empty(B, device=dev, dtype=torch.int32)
+        big = torch.empty(B * 3 * H * W, device=dev, dtype=torch.float32)
+        small = torch.empty(B * 428, device=dev, dtype=torch.uint8)
+        flow_all, wmap, Gn, Hm, bv, xi, info = self._out_views(big, small, B, H, W)
 
         def tail(b0, b1, flow_up):
             """descriptor weight + LM step of images [b0, b1) on the stream that produced their flow (PoseRefiner.py:342-356)"""
@@ -167,16 +207,17 @@ class PoseRefiner(nn.Module):
                         ep_lambda=ep_l, lm_lambda=lm_l, max_update=1.0, eps=EPS,
                         out=(Gn[b0:b1], Hm[b0:b1], bv[b0:b1], xi[b0:b1], info[b0:b1]), slot=b0)
 
-        _, flow_up = self.cf_net.step(coords0, coords1, tail=tail, need_coords=False)
-        return flow_up, wmap, Gn, Hm, bv, xi, info
+        self.cf_net.step(coords0, coords1, tail=tail, need_coords=False, flow_up_out=flow_all)
+        return big, small
 
     def _iteration(self, depth, K, g1, g2, G, coords0, h, w, ep_l, lm_l):
-        if not (self.use_graph and self.cf_net.conv_backend == "hip") or ops.profiling():
-            return self._body(depth, K, g1, g2, G, coords0, h, w, ep_l, lm_l)
+        B, H, W = depth.shape[0], depth.shape[-2], depth.shape[-1]
+        if not self.use_graph or ops.profiling():
+            return self._out_views(*self._body(depth, K, g1, g2, G, coords0, h, w, ep_l, lm_l), B, H, W)
         eng = self.cf_net.engine()
         # (coords0 is not part of the key: the HIP engine derives the grid in-kernel and never reads it)
         key = (depth.data_ptr(), K.data_ptr(), g1.data_ptr(), g2.data_ptr(), self.cf_net.corr_fn._buf.data_ptr(),
-               tuple(depth.shape), self.cfg.OPTIM_ITER_COUNT, float(ep_l), float(lm_l), eng._key)
+               tuple(depth.shape), self.cfg.OPTIM_ITER_COUNT, float(ep_l), float(lm_l), eng.buffer_key(), self._wkey)
         gr = self._graph
         if gr is None or gr["key"] != key:
             if self._ptr_captures >= 2:
@@ -191,12 +232,14 @@ class PoseRefiner(nn.Module):
             else:
                 self._ptr_captures += 1
                 gr = self._capture(key, depth, K, g1, g2, G, coords0, h, w, ep_l, lm_l)
+        if gr is None:                         # capture refused: eager launches from now on (use_graph is off)
+            return self._out_views(*self._body(depth, K, g1, g2, G, coords0, h, w, ep_l, lm_l), B, H, W)
         gr["G"].copy_(G.reshape(-1, 4, 4))
         gr["graph"].replay()
-        flow_up, wmap, Gn, Hm, bv, xi, info = gr["out"]
-        # outputs live in the graph's private pool and are overwritten by the next replay: hand out copies of the
-        # small ones, and of the flow only when a caller keeps it (first and last iteration)
-        return flow_up, wmap, Gn.clone(), Hm, bv, xi, info
+        # outputs live in the graph's private pool and are overwritten by the next replay: the caller gets its own copies
+        # (the reference returns distinct tensors per iteration): two device copies, ~30 MB at 480x640, B=8
+        big, small = gr["out"]
+        return self._out_views(big.clone(), small.clone(), B, H, W)
 
     def _static_inputs(self, depth, K, g1, g2):
         """Persistent copies of the per-outer-iteration inputs of the inner graph; refreshed when the sources change."""
@@ -206,27 +249,28 @@ class PoseRefiner(nn.Module):
             sb = self._static_buf = dict(shapes=shapes, depth=torch.empty_like(depth), K=torch.empty_like(K),
                                          g1=torch.empty_like(g1), g2=torch.empty_like(g2), src=None)
             self._graph_static = None
-        src = (depth.data_ptr(), K.data_ptr(), g1.data_ptr(), g2.data_ptr(), depth._version, g1._version, g2._version)
+        src = (depth.data_ptr(), K.data_ptr(), g1.data_ptr(), g2.data_ptr(), depth._version, K._version, g1._version, g2._version)
         if sb["src"] != src:
             sb["depth"].copy_(depth); sb["K"].copy_(K); sb["g1"].copy_(g1); sb["g2"].copy_(g2)
             sb["src"] = src
         return sb
 
     def _capture(self, key, depth, K, g1, g2, G, coords0, h, w, ep_l, lm_l, static=False):
+        """-> graph record, or None when capture is refused (the caller then runs eager launches).  The warm-up launches
+        advance the GRU hidden state; it is restored whatever happens, so an eager retry starts from the right state."""
+        hbuf = self.cf_net.engine()._b["hA"]
+        hA = hbuf.clone()
         try:
             Gs = G.reshape(-1, 4, 4).clone()
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):                  # warm-up on a side stream: weight packing, allocator, caches
-                hA = self.cf_net.engine()._b["hA"].clone()
                 for _ in range(2):
                     self._body(depth, K, g1, g2, Gs, coords0, h, w, ep_l, lm_l)
-                self.cf_net.engine()._b["hA"].copy_(hA)    # warm-up advanced the hidden state: restore it
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 out = self._body(depth, K, g1, g2, Gs, coords0, h, w, ep_l, lm_l)
-            self.cf_net.engine()._b["hA"].copy_(hA)        # capture does not execute, but keep the invariant explicit
             gr = dict(key=key, graph=graph, G=Gs, out=out)
             if static:
                 self._graph_static = gr
@@ -238,12 +282,15 @@ class PoseRefiner(nn.Module):
             warnings.warn(f"hipGraph capture of the refinement iteration failed ({e!r}); running eager launches")
             self.use_graph = False
             self._graph = self._graph_static = None
-        return None
+            return None
+        finally:
+            hbuf.copy_(hA)
 
     @torch.no_grad()
     def forward(self, image, Ts, intrinsics, fea_3d=None, Tj_gt=None, obj_cls=None, geofea_3d=None, geofea_2d=None):
         """image (B,3,H0,W0); Ts SE3Sequence (B,1,4,4); intrinsics (B,3,3) -> dict (PoseRefiner.py:366-376)."""
         self._clear()
+        self._refresh()
         cfg = self.cfg
         lm_l, ep_l = cfg.get("LM_LMBDA", LM_LMBDA), cfg.get("EP_LMBDA", EP_LMBDA)
         Tij_gt, syn_imgs, syn_depths = [], [], []
@@ -277,6 +324,8 @@ class PoseRefiner(nn.Module):
                 feats1, feats2 = self.image_fea_enc(views["syn_img"], views["image_crop"])   # (:311)
             B, _, H, W = syn_depth.shape
             h, w = feats1.shape[-2:]
+            if (H, W) != (8 * h, 8 * w):
+                raise ValueError(f"view size {H}x{W} must be 8x the feature-map size {h}x{w} (multiples of 8, CFNet.py:86-93)")
             use_w = self.with_corr_weight and geofea1_crop is not None and geofea2_crop is not None
             if not use_w:
                 raise NotImplementedError("with_corr_weight=False has no defined weight in the reference (:347)")
@@ -306,8 +355,6 @@ class PoseRefiner(nn.Module):
                     corr_weight = wmap[:, None, :, :, None]
                     Tij = Tij.reprojction_optim(target, corr_weight, depths, intrinsics_crop,
                                                 num_iters=cfg.OPTIM_ITER_COUNT, lm_lmbda=lm_l, ep_lmbda=ep_l)
-                if self.fused and self.use_graph and self._graph is not None and not self.flow_history:
-                    flow = [flow[0].clone()]               # "flow" of the returned dict = first iteration's flow
                 self.flow_history.append(flow)
                 self.residual_pose_history.append(Tij)
                 self.Ti_history.append(Ti.copy(stop_gradients=True))

@@ -1,19 +1,24 @@
 """BasicUpdateBlock with the reference's module tree and state_dict keys
 (thirdparty/raft/update.py:6-14,33-60,79-97,164-188), so `gru_update.pth` / `.tckpt` files load unchanged.
 
-Dense convolutions go to MIOpen through torch (north_star: "MFMA only if the feature-extraction convs
-prove the bottleneck"); what is hand-written here is everything around them: the z|r convolutions of each
-GRU half are issued as ONE conv over concatenated weights, the hidden/input concat lives in a persistent
-(B,384,h,w) buffer that the gate kernels read and update in place, and sigmoid / r*h / tanh /
-(1-z)h+zq are two fused HIP kernels per half instead of ~8 ATen launches.
+The modules only HOLD the parameters; every forward runs on the hand-written HIP kernels:
+  * `BasicUpdateBlock.forward(net, inp, corr, flow)` (the reference's boundary, NCHW in / NCHW out) executes the fused
+    NHWC schedule of rnnpose_amd/engine.py (one implicit-GEMM launch per convolution, GRU gates / ReLU / bias in the
+    epilogues, virtual concats) between layout transposes;
+  * the sub-module forwards (`FlowHead`, `SepConvGRU`, `BasicMotionEncoder`) replay the reference's literal call
+    sequence with `ops.conv2d_nchw` (the same implicit-GEMM kernel behind an NCHW facade) and the two GRU gate kernels.
+There is no torch/MIOpen convolution in this package (the A/B comparison against MIOpen lives in tools/conv_bench.py).
 """
 from __future__ import annotations
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import ops
+
+
+def _conv(m: nn.Conv2d, x, relu=False):
+    return ops.conv2d_nchw(m.weight, m.bias, x, relu=relu)
 
 
 class FlowHead(nn.Module):
@@ -23,7 +28,7 @@ class FlowHead(nn.Module):
         self.conv2 = nn.Conv2d(hidden_dim, 2, 3, padding=1)
 
     def forward(self, x):
-        return self.conv2(F.relu_(self.conv1(x)))
+        return _conv(self.conv2, _conv(self.conv1, x, relu=True))                     # update.py:13-14
 
 
 class SepConvGRU(nn.Module):
@@ -37,36 +42,19 @@ class SepConvGRU(nn.Module):
         self.convz2 = nn.Conv2d(c, hidden_dim, (5, 1), padding=(2, 0))
         self.convr2 = nn.Conv2d(c, hidden_dim, (5, 1), padding=(2, 0))
         self.convq2 = nn.Conv2d(c, hidden_dim, (5, 1), padding=(2, 0))
-        self._zr_cache = {}
-
-    def _zr(self, sfx):
-        """Concatenated z|r weights/bias of one half, rebuilt only when the parameters change."""
-        cz, cr = getattr(self, "convz" + sfx), getattr(self, "convr" + sfx)
-        key = (cz.weight._version, cr.weight._version, cz.bias._version, cr.bias._version,
-               cz.weight.data_ptr(), cr.weight.data_ptr())
-        hit = self._zr_cache.get(sfx)
-        if hit is None or hit[0] != key:
-            hit = (key, torch.cat([cz.weight, cr.weight], 0).detach(), torch.cat([cz.bias, cr.bias], 0).detach())
-            self._zr_cache[sfx] = hit
-        return hit[1], hit[2]
-
-    def step_inplace(self, hx, rhx, z):
-        """hx (B,384,h,w) = [h | x]; updates hx[:, :128] in place.  rhx: same shape with rhx[:,128:] == x."""
-        C = self.hidden_dim
-        for sfx, pad in (("1", (0, 2)), ("2", (2, 0))):
-            wzr, bzr = self._zr(sfx)
-            zr = F.conv2d(hx, wzr, bzr, padding=pad)                      # update.py:48-49 / :55-56
-            ops.gru_gate(zr, hx, z, rhx, C)                               # z = sig(.), rhx[:, :C] = sig(r)*h
-            cq = getattr(self, "convq" + sfx)
-            q = F.conv2d(rhx, cq.weight, cq.bias, padding=pad)            # :50 / :57
-            ops.gru_update(z, q, hx, hx, C)                               # h = (1-z)h + z tanh(q)   :51 / :58
 
     def forward(self, h, x):
+        """update.py:46-60, literal order: z, r from [h|x]; q from [r*h|x]; h = (1-z)h + zq; horizontal then vertical."""
+        C = self.hidden_dim
         hx = torch.cat([h, x], dim=1).contiguous()
         rhx = hx.clone()
-        z = torch.empty_like(h)
-        self.step_inplace(hx, rhx, z)
-        return hx[:, :self.hidden_dim].contiguous()
+        z = torch.empty_like(hx[:, :C]).contiguous()
+        for sfx in ("1", "2"):
+            cz, cr, cq = (getattr(self, n + sfx) for n in ("convz", "convr", "convq"))
+            zr = torch.cat([_conv(cz, hx), _conv(cr, hx)], dim=1)                     # pre-activations of z | r
+            ops.gru_gate(zr, hx, z, rhx, C)                                           # z = sig(.), rhx[:, :C] = sig(r) * h
+            ops.gru_update(z, _conv(cq, rhx), hx, hx, C)                              # h = (1-z) h + z tanh(q)
+        return hx[:, :C].contiguous()
 
 
 class BasicMotionEncoder(nn.Module):
@@ -80,12 +68,10 @@ class BasicMotionEncoder(nn.Module):
         self.conv = nn.Conv2d(64 + 192, 128 - 2, 3, padding=1)
 
     def forward(self, flow, corr):
-        cor = F.relu_(self.convc1(corr))
-        cor = F.relu_(self.convc2(cor))
-        flo = F.relu_(self.convf1(flow))
-        flo = F.relu_(self.convf2(flo))
-        out = F.relu_(self.conv(torch.cat([cor, flo], dim=1)))
-        return torch.cat([out, flow], dim=1)
+        cor = _conv(self.convc2, _conv(self.convc1, corr, relu=True), relu=True)      # update.py:89-90
+        flo = _conv(self.convf2, _conv(self.convf1, flow, relu=True), relu=True)      # :91-92
+        out = _conv(self.conv, torch.cat([cor, flo], dim=1), relu=True)               # :94-96
+        return torch.cat([out, flow], dim=1)                                          # :97
 
 
 class BasicUpdateBlock(nn.Module):
@@ -99,18 +85,17 @@ class BasicUpdateBlock(nn.Module):
             nn.Conv2d(128, 256, 3, padding=1),
             nn.ReLU(inplace=True),
             nn.Conv2d(256, downsample_scale * downsample_scale * 9, 1, padding=0))
+        self._engine = None
 
+    def engine(self):
+        if self._engine is None:
+            from .engine import UpdateEngine
+            self._engine = UpdateEngine(self)
+        return self._engine
+
+    @torch.no_grad()
     def forward(self, net, inp, corr, flow, upsample=True):
         """-> (net, mask, delta_flow)   (update.py:178-188).  GPU tensors only."""
         if not net.is_cuda:
             raise RuntimeError("BasicUpdateBlock runs on the GPU only (no CPU path in rnnpose_amd)")
-        motion = self.encoder(flow, corr)                               # (B,128,h,w)
-        hx = torch.cat([net, inp, motion], dim=1)                       # [h | x], x = inp | motion  (:181)
-        rhx = hx.clone()
-        z = torch.empty_like(net)
-        self.gru.step_inplace(hx, rhx, z)
-        net = hx[:, :net.shape[1]].contiguous()
-        delta_flow = self.flow_head(net)
-        mask = self.mask(net)
-        mask.mul_(0.25)                                                 # scale mask to balance gradients (:187)
-        return net, mask, delta_flow
+        return self.engine().forward_nchw(net, inp, corr, flow)

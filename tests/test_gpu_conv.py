@@ -113,15 +113,67 @@ def test_conv_gru_epilogues(ops, kh, kw):
     assert float((nchw(hnew).double() - h64).abs().max()) < 3e-6
 
 
-def test_conv_large_activations_saturate_not_nan(ops):
-    """|x|*a_scale beyond the fp16 range saturates (finite output), it does not poison the tile with inf/NaN."""
+@pytest.mark.parametrize("mag", [2.0e3, 7.9e3, 3.0e-3])
+def test_conv_range_accuracy(ops, mag):
+    """fp16x3 range: activations of magnitude 2e3 and 7.9e3 (r01's a_scale = 64 clipped everything above 1023)
+    and of magnitude 3e-3 (the lo part becomes an fp16 subnormal) must be ACCURATE -- relative error vs fp64 within 3x of a
+    plain fp32 convolution's -- and the range guard must stay silent."""
+    B, H, W, cin, cout = 2, 12, 20, 96, 128
+    x = syn.normal("x", (B, cin, H, W), 7, std=0.4) * mag
+    x[0, 3, 2, 5] = mag * 1.03                                   # the largest element, near the top of the range for 7.9e3
+    w = syn.normal("w", (cout, cin, 3, 3), 7, std=float(np.sqrt(2.0 / (cin * 9))))
+    b = syn.uniform("b", (cout,), 7, -0.5, 0.5) * mag
+    xd, wd, bd = D(x), D(w), D(b)
+    y64 = F.conv2d(xd.double(), wd.double(), bd.double(), padding=1)
+    y32 = F.conv2d(xd, wd, bd, padding=1)
+    ops.saturation_check(True)
+    ops.saturation_count(reset=True)
+    try:
+        pc = ops.PackedConv(wd, bd, [cin])
+        out = torch.empty(B, H, W, cout, device="cuda")
+        ops.conv2d_nhwc(pc, [(nhwc(xd), 0)], (out, 0), ops.EPI_LINEAR)
+        assert ops.saturation_count() == 0
+    finally:
+        ops.saturation_check(False)
+    check(nchw(out), y64, y32, f"|x| ~ {mag:g}")
+
+
+def test_conv_range_guard_counts_saturation(ops):
+    """Beyond 65504 / a_scale = 8188 the split clamps: the output stays finite (never inf/NaN from finite inputs) and the
+    range guard REPORTS it; with the guard off nothing is counted.  Same guard on the volume build's operand split."""
     B, H, W = 1, 8, 8
-    x = torch.full((B, H, W, 32), 2000.0, device="cuda")
+    x = torch.full((B, H, W, 32), 100.0, device="cuda")
+    x[0, 3, 4, 7] = 9000.0
+    x[0, 5, 1, 30] = -2.0e4
     w = torch.full((128, 32, 1, 1), 0.01, device="cuda")
     pc = ops.PackedConv(w, torch.zeros(128, device="cuda"), [32])
     out = torch.empty(B, H, W, 128, device="cuda")
+    ops.saturation_check(True)
+    try:
+        ops.saturation_count(reset=True)
+        ops.conv2d_nhwc(pc, [(x, 0)], (out, 0))
+        assert torch.isfinite(out).all()
+        c1 = ops.saturation_count()
+        assert c1 >= 2                                          # two staged quads (per column tile) held an out-of-range element
+        assert ops.saturation_count() == 0                      # reading resets
+        x[0, 0, 0, 0] = float("nan")
+        ops.conv2d_nhwc(pc, [(x, 0)], (out, 0))
+        assert ops.saturation_count() == c1 * 3 // 2            # non-finite inputs are reported too
+        f = torch.randn(1, 64, 8, 8, device="cuda")
+        f2 = f.clone()
+        f2[0, 5, 3, 3] = 3.0e4
+        ops.corr_pyramid(f, f2, 2, precision="f16x3")
+        assert ops.saturation_count() == 1
+        ops.corr_pyramid(f, f, 2, precision="f16x3")
+        assert ops.saturation_count() == 0
+    finally:
+        ops.saturation_check(False)
     ops.conv2d_nhwc(pc, [(x, 0)], (out, 0))
-    assert torch.isfinite(out).all()
+    ops.saturation_check(True)
+    try:
+        assert ops.saturation_count() == 0                      # launches made while the guard was off count nothing
+    finally:
+        ops.saturation_check(False)
 
 
 @pytest.mark.parametrize("B,h,w,cout", [(2, 9, 23, 128), (1, 30, 40, 128), (1, 5, 3, 96)])

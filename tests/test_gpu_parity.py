@@ -368,10 +368,9 @@ def test_solve_exp_compose_inverse(ops, golden):
 
 
 # ------------------------------------------------------------------------------------------------ a4
-def _load_update_block(seed=0, backend="hip"):
+def _load_update_block(seed=0):
     from rnnpose_amd.cfnet import GRU_CFUpdator
-    net = GRU_CFUpdator(dict(pretrained_model=None, mixed_precision=False, fea_net="default",
-                             conv_backend=backend)).cuda().eval()
+    net = GRU_CFUpdator(dict(pretrained_model=None, mixed_precision=False, fea_net="default")).cuda().eval()
     net.update_block.load_state_dict({k: T(v) for k, v in upd_weights(seed).items()}, strict=True)
     return net
 
@@ -407,6 +406,15 @@ def test_update_block(ops, golden):
     close(n2, g["net"], 1e-5, what="net golden")
     close(mask, g["mask"], 1e-4, what="mask golden")
     close(df, g["dflow"], 1e-4, what="dflow golden")
+    # the sub-module facades replay the reference's literal call sequence (update.py:13-14,46-60,89-97) on the same kernels
+    ub = net.update_block
+    with torch.no_grad():
+        motion = ub.encoder(D(flow), D(corr))
+        n3 = ub.gru(D(hid), torch.cat([D(inp), motion], dim=1))
+        df3 = ub.flow_head(n3)
+    close(n3, g["net"], 1e-5, what="SepConvGRU facade")
+    close(df3, g["dflow"], 1e-4, what="FlowHead facade")
+    close(motion[:, 126:], flow, 0.0, what="motion features carry the flow (update.py:97)")
 
 
 def test_update_engine_one_step(ops, golden):
@@ -470,17 +478,45 @@ def test_instnorm_nhwc(ops):
               what="IN + residual")
 
 
-@pytest.mark.parametrize("backend", ["hip", "miopen"])
-def test_encoder(ops, golden, backend):
+def test_encoder(ops, golden):
     from rnnpose_amd.cfnet import ImageFeaEncoder
     g = golden("encoder")
-    enc = ImageFeaEncoder(conv_backend=backend).cuda().eval()
+    enc = ImageFeaEncoder().cuda().eval()
     W = syn.make_module_weights(orc.encoder_shapes(), seed=2)
     enc.fnet.load_state_dict({k: T(v) for k, v in W.items()}, strict=True)
     with torch.no_grad():
         f1, f2 = enc(D(syn.uniform("img_render", (2, 3, 64, 96), 2)), D(syn.uniform("img_target", (2, 3, 64, 96), 2)))
     close(f1, g["fmap1"], 1e-4, what="fmap1 golden")
     close(f2, g["fmap2"], 1e-4, what="fmap2 golden")
+    # BasicEncoder.forward (no input normalisation, list input: extractor.py:187-232) == the same engine fed normalised images
+    x1 = 2 * (D(syn.uniform("img_render", (2, 3, 64, 96), 2)) / 255.0) - 1.0
+    with torch.no_grad():
+        g1 = enc.fnet(x1)
+    close(g1, g["fmap1"], 1e-4, what="BasicEncoder.forward")
+
+
+@pytest.mark.parametrize("N,H,W", [(2, 64, 96), (1, 50, 70), (3, 37, 41)])
+def test_encoder_stem_kernel(ops, N, H, W):
+    """csrc/stem.hip: normalisation + 7x7 stride-2 convolution + tile statistics against torch fp64 (ragged sizes included)."""
+    import torch.nn.functional as F
+    img = D(syn.uniform("img", (N, 3, H, W), 9, 0.0, 255.0))
+    wt = D(syn.normal("w", (64, 3, 7, 7), 9, std=0.1))
+    bias = D(syn.uniform("b", (64,), 9, -0.5, 0.5))
+    ps = ops.PackedStem(wt, bias)
+    for normalize in (True, False):
+        x = img if normalize else img / 255.0
+        out, ts = ops.stem_conv(ps, x, normalize=normalize)
+        xin = (2 * (x.double() / 255.0) - 1.0) if normalize else x.double()
+        want = F.conv2d(xin, wt.double(), bias.double(), stride=2, padding=3).permute(0, 2, 3, 1)
+        ref32 = F.conv2d(xin.float(), wt, bias, stride=2, padding=3).permute(0, 2, 3, 1)
+        err, err32 = float((out.double() - want).abs().max()), float((ref32.double() - want).abs().max())
+        assert err <= max(3 * err32, 2e-6), (err, err32)
+        if ts is not None:
+            t = ts.view(N, -1, 64, 2).double().sum(1)
+            close(t[..., 0], want.sum((1, 2)), 1e-3, 1e-5, what="tile sums")
+            close(t[..., 1], (want * want).sum((1, 2)), 1e-3, 1e-5, what="tile sums of squares")
+        else:
+            assert ((H + 1) // 2) % 8 or ((W + 1) // 2) % 16
 
 
 # ------------------------------------------------------------------------------------------------ a5/a12
@@ -491,25 +527,24 @@ def _renderer(d):
                              syn_depth=D(d["depth"]), intrinsics_crop=D(d["K"]), fmap1=D(d["fmap1"]), fmap2=D(d["fmap2"]))
 
 
-def _refiner(d, outer, inner, opt, fused, backend="hip"):
+def _refiner(d, outer, inner, opt, fused):
     from rnnpose_amd.pose_refiner import PoseRefiner, default_config
     cfg = default_config(RENDER_ITER_COUNT=outer, ITER_COUNT=inner, OPTIM_ITER_COUNT=opt)
-    cfg.raft.conv_backend = backend
     ref = PoseRefiner(cfg, renderer=_renderer(d), fused=fused).cuda().eval()
     ref.cf_net.update_block.load_state_dict({k: T(v) for k, v in upd_weights().items()}, strict=True)
     return ref
 
 
-@pytest.mark.parametrize("fused,backend", [(True, "hip"), (False, "hip"), (True, "miopen")])
+@pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("name,shape,outer,inner,opt", [("loop_128", (2, 128, 128, 21), 1, 3, 1),
                                                          ("loop_2x2", (2, 128, 160, 22), 2, 2, 2),
                                                          ("loop_S1", (1, 240, 240, 23), 1, 3, 1)])
-def test_refinement_loop_golden(ops, golden, name, shape, outer, inner, opt, fused, backend):
+def test_refinement_loop_golden(ops, golden, name, shape, outer, inner, opt, fused):
     from rnnpose_amd.transformation import SE3Sequence
     g = golden(name)
     B, H, W, seed = shape
     d = syn.make_inputs(B, H, W, seed=seed)
-    ref = _refiner(d, outer, inner, opt, fused, backend)
+    ref = _refiner(d, outer, inner, opt, fused)
     out = ref(None, SE3Sequence(matrix=D(d["G0"])), D(d["K"]))
     Gi = torch.stack([t.G for t in ref.residual_pose_history])
     close(Gi, g["G_iters"], 1e-5, what="per-iteration relative poses")
@@ -531,9 +566,8 @@ def test_refinement_loop_golden(ops, golden, name, shape, outer, inner, opt, fus
     assert set(out) >= {"Tij", "Ti_pred", "intrinsics", "flow", "vmask", "weight", "syn_depth", "syn_img", "Tij_gt"}
 
 
-@pytest.mark.parametrize("backend", ["hip", "miopen"])
 @pytest.mark.parametrize("shape,inner,opt", [((2, 128, 128, 21), 3, 1), ((2, 128, 160, 22), 3, 2), ((1, 240, 240, 23), 4, 1)])
-def test_refinement_teacher_forced(ops, shape, inner, opt, backend):
+def test_refinement_teacher_forced(ops, shape, inner, opt):
     """Per-iteration parity on IDENTICAL inputs (north_star: 1e-4 on the correspondence field, 1e-5 on the pose):
     every inner iteration starts from the oracle's pose of the previous iteration (the oracle itself is pinned to
     the reference's poses in tests/test_oracle_golden.py); the GPU hidden state and correlation volume run free."""
@@ -542,7 +576,7 @@ def test_refinement_teacher_forced(ops, shape, inner, opt, backend):
     d = syn.make_inputs(B, H, W, seed=seed)
     Wt = upd_weights()
     trace = orc.refine(d, {"upd": Wt}, outer=1, inner=inner, optim_iters=opt, capture=True)["trace"]
-    net = _load_update_block(backend=backend)
+    net = _load_update_block()
     h, w = H // 8, W // 8
     depth, K, g1, g2, sig = D(d["depth"]), D(d["K"]), D(d["g1"]), D(d["g2"]), D(d["sigma"])
     c0 = coords_grid(B, h, w, device="cuda")
@@ -562,11 +596,10 @@ def test_refinement_teacher_forced(ops, shape, inner, opt, backend):
             G_prev = tr["Tij"]
 
 
-@pytest.mark.parametrize("backend", ["hip", "miopen"])
-def test_cfupdator_facade_stateful(ops, backend):
+def test_cfupdator_facade_stateful(ops):
     """GRU_CFUpdator keeps volume + hidden state between calls (update_corr_fn=False) like the reference."""
     d = syn.make_inputs(2, 128, 160, seed=31)
-    net = _load_update_block(backend=backend)
+    net = _load_update_block()
     W = {"upd": upd_weights()}
     fi = syn.normal("fi", (2, 2, 128, 160), 31, std=2.0)
     with torch.no_grad():

@@ -36,17 +36,52 @@ def test_encoder_and_refiner_state_dict_keys():
     ref.cf_net.update_block.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}, strict=True)
 
 
-def test_zr_weight_fusion_cache_tracks_updates():
-    from rnnpose_amd.update import SepConvGRU
-    g = SepConvGRU(hidden_dim=128, input_dim=128 + 128)          # as built by BasicUpdateBlock (update.py:169)
-    w1, b1 = g._zr("1")
-    assert w1.shape == (256, 384, 1, 5) and b1.shape == (256,)
-    assert torch.equal(w1[:128], g.convz1.weight) and torch.equal(w1[128:], g.convr1.weight)
-    assert g._zr("1")[0] is w1                                    # cached
+def test_engine_param_key_tracks_updates():
+    """The identity captured hipGraphs depend on changes on load_state_dict and on in-place parameter updates."""
+    from rnnpose_amd.cfnet import GRU_CFUpdator
+    net = GRU_CFUpdator(dict(pretrained_model=None))
+    eng = net.engine()
+    k0 = eng.param_key()
+    assert eng.param_key() == k0
+    net.update_block.load_state_dict({k: v.clone() for k, v in net.update_block.state_dict().items()})
+    k1 = eng.param_key()
+    assert k1 != k0
     with torch.no_grad():
-        g.convr1.weight.add_(1.0)
-    w2, _ = g._zr("1")
-    assert w2 is not w1 and torch.equal(w2[128:], g.convr1.weight)
+        net.update_block.gru.convz1.bias.add_(1.0)
+    assert eng.param_key() != k1
+
+
+def test_motion_net_checkpoint_loader(tmp_path):
+    """A reference checkpoint is torch.save(RNNPose.state_dict()) (torchplus/train/checkpoint.py:92): the `motion_net.*`
+    sub-tree must load into PoseRefiner with the include / exclude / same-shape rule of tools/eval.py:386-413."""
+    from rnnpose_amd.pose_refiner import PoseRefiner
+    from rnnpose_amd.render_adapter import filter_param_dict, load_motion_net_checkpoint
+    src = PoseRefiner()
+    g = torch.Generator().manual_seed(3)
+    ckpt = {"motion_net." + k: torch.randn(v.shape, generator=g) for k, v in src.state_dict().items()}
+    ckpt["descriptor_net.encoder.weight"] = torch.randn(4, 4)                 # other sub-trees of RNNPose: ignored
+    ckpt["global_step"] = torch.zeros(1)
+    bad = "motion_net.cf_net.update_block.encoder.convc1.weight"
+    good_shape = ckpt[bad].shape
+    ckpt[bad] = torch.randn(7, 7)                                             # wrong shape: "Fail to load", kept at init
+    path = tmp_path / "voxelnet-1000.tckpt"
+    torch.save(ckpt, path)
+    dst = PoseRefiner()
+    before = dst.state_dict()[bad[len("motion_net."):]].clone()
+    loaded, skipped = load_motion_net_checkpoint(dst, str(path))
+    assert skipped == [bad] and len(loaded) == len(src.state_dict()) - 1
+    sd = dst.state_dict()
+    for k in loaded:
+        assert torch.equal(sd[k], ckpt["motion_net." + k]), k
+    assert torch.equal(sd[bad[len("motion_net."):]], before) and before.shape == good_shape
+    # include / exclude are regular expressions matched at the start of the FULL key (re.match, eval.py:110-127)
+    only = filter_param_dict(ckpt, include="motion_net\\.cf_net", exclude=".*bias")
+    assert only and all(k.startswith("motion_net.cf_net") and not k.endswith("bias") for k in only)
+    dst2 = PoseRefiner()
+    l2, _ = load_motion_net_checkpoint(dst2, ckpt, include="motion_net\\.image_fea_enc")
+    assert l2 and all(k.startswith("image_fea_enc.") for k in l2)
+    with pytest.raises(RuntimeError):
+        load_motion_net_checkpoint(PoseRefiner(), ckpt, strict=True)
 
 
 def test_synthetic_inputs_are_bit_reproducible():
