@@ -2,6 +2,7 @@
 """bench.py -- RNNPose recurrent pose-refinement throughput on MI355X (BASELINE.json metric).
 
     python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus 8                       # no WORLD_SIZE in the environment: spawns the 8 ranks itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -13,24 +14,30 @@ weight -> LM step.  The renderer is outside the path: vie
 Inputs are resident in HBM before the timed region.  value = refinement iterations/s (one iteration = the
 loop body for one rank's batch of 8), summed over ranks (weak scaling: every rank refines its own batch).
 
-Rank 0 prints ONE JSON line (see the task contract) carrying `roofline` for the correlation-volume kernel
-(measured live with HIP events on the launch stream) and `cpu_baseline` (the CPU oracle, timed on this
-box's host cores on a bounded sample, N=1 only).
+Rank 0 prints ONE JSON line (see the task contract) carrying
+  roofline                   the dominant kernel (the implicit-GEMM convolution) against the fp16 MFMA peak, per launch,
+                             measured live with HIP events on the launch stream;
+  chip_level                 executed matrix-core flops of the WHOLE step / wall time of the step;
+  correlation_volume_kernel  north_star's named kernel against the HBM roofline;
+  kernels                    every C-ABI launch type: mean duration, share of the step, achieved GB/s from the bytes each
+                             launch declared for its own arguments (a half-batch launch declares half the batch);
+  cpu_baseline               the CPU oracle on this box's host cores: the full batch, 1 outer x `inner` iterations (the 3x8
+                             schedule repeats that unit, so iterations/s are directly comparable), N=1 only.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-
-PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured achievable)
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
 PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense fp16/bf16 MFMA peak (no sparsity)
 
@@ -50,13 +57,28 @@ def parse():
     ap.add_argument("--no-encoder", action="store_true", help="feed synthetic feature maps (kernel-only runs)")
     ap.add_argument("--unfused", action="store_true", help="literal reference call sequence through the facade")
     ap.add_argument("--no-graph", action="store_true", help="eager launches only (no hipGraph replay; for counter passes)")
-    ap.add_argument("--conv-backend", choices=["hip", "miopen"], default="hip",
-                    help="update-block convolutions: hand-written fp16x3 implicit GEMM (default) or torch/MIOpen fp32")
     return ap.parse_args()
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` outside torchrun: launch the N ranks of one node ourselves (reference:
+    tools/eval.py:224-225 spawns one process per GPU) and relay rank 0's JSON line."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < n:
+        raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible on this node")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def synth_views(B, H, W, device, seed, with_encoder):
     """Synthetic, fixed, already-cropped views in HBM (shapes/ranges of SURVEY.md section 8d)."""
+    import torch
     from rnnpose_amd import ops
     from rnnpose_amd.pose_refiner import SyntheticRenderer
     from rnnpose_amd.synthetic import intrinsics
@@ -81,51 +103,51 @@ def synth_views(B, H, W, device, seed, with_encoder):
 
 
 def cpu_baseline(refiner, rend, K, G0, args):
-    """CPU oracle (oracle/rnnpose_oracle.py, kind 'port') on a bounded sample of the same workload:
-    the full batch, 1 outer x 2 inner iterations; per-stage timers extrapolate to the 3x8 schedule."""
+    """CPU oracle (oracle/rnnpose_oracle.py, kind 'port') on the SAME workload: the full batch, one outer iteration
+    (encoder + volume build + context prep) followed by `inner` inner iterations -- the unit the 3x8 schedule repeats
+    three times, so its iterations/s are the schedule's.  One run after a one-image warm-up (thread pools, oneDNN)."""
+    import torch
     from oracle import rnnpose_oracle as orc
     v = rend.views
     ncpu = os.cpu_count() or 1
     cores = int(os.environ.get("RNNPOSE_CPU_THREADS", min(ncpu, 64)))   # torch-CPU stops scaling well before 256 SMT threads
     torch.set_num_threads(cores)
-    nb = min(args.batch, 4)                                             # bounded sample: 4 images of the batch
-    sl = lambda t: t[:nb]
-    inp = {"ctx": sl(v["cfea"]), "g1": sl(v["geofea1"]), "g2": sl(v["geofea2_crop"]), "depth": sl(v["syn_depth"]),
-           "K": sl(K), "G0": sl(G0), "sigma": refiner.sigma[0].detach()}
+    inp = {"ctx": v["cfea"], "g1": v["geofea1"], "g2": v["geofea2_crop"], "depth": v["syn_depth"], "K": K, "G0": G0,
+           "sigma": refiner.sigma[0].detach()}
     W = {"upd": {k: p.detach().cpu().numpy() for k, p in refiner.cf_net.update_block.state_dict().items()}}
     if v["fmap1"] is None:
-        inp["img_render"], inp["img_target"] = sl(v["syn_img"]), sl(v["image_crop"])
+        inp["img_render"], inp["img_target"] = v["syn_img"], v["image_crop"]
         W["enc"] = {k: p.detach().cpu().numpy() for k, p in refiner.image_fea_enc.fnet.state_dict().items()}
     else:
-        inp["fmap1"], inp["fmap2"] = sl(v["fmap1"]), sl(v["fmap2"])
+        inp["fmap1"], inp["fmap2"] = v["fmap1"], v["fmap2"]
     inp = {k: t.detach().cpu().numpy() for k, t in inp.items()}
-    orc.refine(inp, W, outer=1, inner=1, optim_iters=args.optim_iters, fast=True)          # warm-up (thread pools, oneDNN)
+    one = {k: (a[:1] if (a.ndim and a.shape[0] == args.batch and k != "sigma") else a) for k, a in inp.items()}
+    orc.refine(one, W, outer=1, inner=1, optim_iters=args.optim_iters, fast=True)          # warm-up, one image
     tm = {}
     t0 = time.perf_counter()
-    orc.refine(inp, W, outer=1, inner=3, optim_iters=args.optim_iters, stage_timer=tm, fast=True)
+    orc.refine(inp, W, outer=1, inner=args.inner, optim_iters=args.optim_iters, stage_timer=tm, fast=True)
     wall = time.perf_counter() - t0
-    scale = args.batch / nb                                             # per-image cost is batch-independent
-    t_outer = (tm.get("encoder", 0.0) + tm.get("corr_build_ctx", 0.0)) * scale
-    t_inner = (wall * scale - t_outer) / 3.0
-    sched = args.outer * t_outer + args.outer * args.inner * t_inner
     return {
-        "value": args.outer * args.inner / sched, "unit": "iters/s", "cores": cores, "kind": "port",
-        "sample": (f"{nb} of the {args.batch} images ({args.height}x{args.width}), 1 outer x 3 inner iterations of the CPU "
-                   f"oracle in its library-call form (grid_sample/unfold as the reference uses on CPU), {wall:.1f} s wall, "
-                   f"torch {torch.__version__} CPU with {cores} threads on {ncpu} logical CPUs; scaled x{scale:g} to the "
-                   f"batch: per-outer {t_outer:.2f} s, per-inner {t_inner:.2f} s, extrapolated to {args.outer}x{args.inner}"),
+        "value": round(args.inner / wall, 4), "unit": "iters/s", "cores": cores, "kind": "port",
+        "sample": (f"full batch ({args.batch} x {args.height}x{args.width}), 1 outer x {args.inner} inner iterations of the CPU "
+                   f"oracle in its library-call form (grid_sample/unfold as the reference uses on CPU), encoder + volume build "
+                   f"included, {wall:.1f} s wall, single run after a one-image warm-up; torch {torch.__version__} CPU with "
+                   f"{cores} threads on {ncpu} logical CPUs.  The 3x8 schedule repeats this unit 3 times: same iterations/s"),
         "stages_s": {k: round(x, 3) for k, x in tm.items()},
     }
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus)
+    import torch
     from rnnpose_amd import distributed as D
     rank, world, local = D.init_from_env()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: rnnpose_amd has no CPU product path")
-    if world != args.gpus and rank == 0:
-        print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     device = torch.device("cuda", local % torch.cuda.device_count())
     torch.cuda.set_device(device)
     from rnnpose_amd import build, ops
@@ -137,7 +159,6 @@ def main():
     torch.manual_seed(0)
     rend, K, G0 = synth_views(B, H, W, device, seed=rank, with_encoder=not args.no_encoder)
     cfg = default_config(RENDER_ITER_COUNT=args.outer, ITER_COUNT=args.inner, OPTIM_ITER_COUNT=args.optim_iters)
-    cfg.raft.conv_backend = args.conv_backend
     refiner = PoseRefiner(cfg, renderer=rend, fused=not args.unfused, use_graph=not args.no_graph).to(device).eval()
 
     def step():
@@ -151,19 +172,18 @@ def main():
     step()
     for _ in range(args.warmup):
         step()
-    hip_ops = None          # HIP events around EVERY C-ABI launch (~25 per iteration; <1 % of the step)
     D.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     # HIP events bracket every C-ABI launch of the FIRST OUTER ITERATION of the first timed step only (~450 launches,
     # eager): the rest of that step and the other K-1 steps replay hipGraphs, so that a small K does not dilute `value`.
     rec = refiner.profile_first_outer() if (args.outer > 1 and not args.unfused) else ops.profile_begin(None)
-    out = step()
+    step()
     if refiner.profile_rec is not None or ops.profiling():      # single outer iteration / unfused: the whole step was recorded
         ops.profile_end(rec)
         refiner.profile_rec = None
     for _ in range(args.steps - 1):
-        out = step()
+        step()
     torch.cuda.synchronize()
     D.barrier()
     dt = D.max_over_ranks(time.perf_counter() - t0)
@@ -174,33 +194,7 @@ def main():
         return
     iters = args.outer * args.inner
     value = world * args.steps * iters / dt
-    h, w = H // 8, W // 8
-    N = h * w
-    C = 256
-    # algorithmic work per launch (SURVEY.md section 8d formulas x batch)
-    lvl = sum((h >> l) * (w >> l) for l in range(4))
-    alg = {
-        "rnnpose_corr_pyramid_f32": dict(bytes=4 * (2 * N * C + N * lvl) * B, flops=2 * N * N * C * B),
-        "rnnpose_corr_lookup_f32": dict(bytes=4 * N * (4 * 100 + 4 * 81 + 2) * B),
-        "rnnpose_convex_upsample_f32": dict(bytes=(4 * N * (576 + 2) + 8 * H * W) * B),
-        "rnnpose_corr_weight_f32": dict(bytes=(4 * 32 * 2 + 8 + 4 + 4) * H * W * B),
-        "rnnpose_lm_step_f32": dict(bytes=16 * H * W * B * args.optim_iters),
-    }
-    alg["rnnpose_corr_pyramid_f16x3"] = alg["rnnpose_corr_pyramid_f32"]
-    alg["rnnpose_corr_lookup_nhwc_f32"] = alg["rnnpose_corr_lookup_f32"]
-    alg["rnnpose_convex_upsample_nhwc_f32"] = alg["rnnpose_convex_upsample_f32"]
-    kernels = {}
-    for name, (n, mean_ms, tot_ms, work) in prof.items():
-        e = {"launches": n, "mean_ms": round(mean_ms, 4), "share_of_step": round(tot_ms / prof_steps / (dt / args.steps * 1e3), 4)}
-        if name in alg:
-            e["GBps"] = round(alg[name]["bytes"] / (mean_ms * 1e-3) / 1e9, 1)
-            e["hbm_frac"] = round(e["GBps"] / PEAK_HBM_GBS, 4)
-            if "flops" in alg[name]:
-                e["TFLOPps"] = round(alg[name]["flops"] / (mean_ms * 1e-3) / 1e12, 2)
-                e["mfma_frac"] = round(e["TFLOPps"] / PEAK_F32_MFMA_TFLOPS, 4)
-        if work:
-            e["TFLOPps_fp32_equivalent"] = round(work / (tot_ms * 1e-3) / 1e12, 2)
-        kernels[name.replace("rnnpose_", "")] = e
+    ms_step = dt / args.steps * 1e3
     traffic = {}
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
@@ -208,71 +202,90 @@ def main():
             traffic = json.load(open(tpath))
         except Exception:
             traffic = {}
-    # roofline object = the DOMINANT hand-written kernel of the timed region
+    tr = lambda k: (traffic.get(k) or {}).get("bytes_per_launch") if isinstance(traffic.get(k), dict) else traffic.get(k)
+
+    MFMA3 = ("rnnpose_conv2d_nhwc_f16x3", "rnnpose_stem_conv7x7_s2_f16x3", "rnnpose_corr_pyramid_f16x3")   # 3 fp16 products per multiply-add
+    kernels = {}
+    exec_flops_step = 0.0
+    for name, (n, mean_ms, tot_ms, work, nbytes) in prof.items():
+        e = {"launches": n, "mean_ms": round(mean_ms, 4), "share_of_step": round(tot_ms / prof_steps / ms_step, 4)}
+        if nbytes:
+            e["algorithmic_MB_per_launch"] = round(nbytes / n / 1e6, 2)
+            e["GBps"] = round(nbytes / (tot_ms * 1e-3) / 1e9, 1)
+            e["hbm_frac"] = round(e["GBps"] / PEAK_HBM_GBS, 4)
+        if work and name in MFMA3:
+            e["fp32_equivalent_TFLOPps"] = round(work / (tot_ms * 1e-3) / 1e12, 2)
+            e["executed_fp16_TFLOPps"] = round(3 * work / (tot_ms * 1e-3) / 1e12, 1)
+            e["fp16_mfma_frac"] = round(3 * work / (tot_ms * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4)
+            exec_flops_step += 3 * work / prof_steps
+        elif work and name == "rnnpose_corr_pyramid_f32":
+            e["TFLOPps"] = round(work / (tot_ms * 1e-3) / 1e12, 2)
+            e["f32_mfma_frac"] = round(e["TFLOPps"] / PEAK_F32_MFMA_TFLOPS, 4)
+        kernels[name.replace("rnnpose_", "")] = e
+
+    # roofline object = the DOMINANT hand-written kernel of the timed region (largest summed duration)
     dom = max(prof.items(), key=lambda kv: kv[1][2])[0] if prof else None
     roofline = None
     if dom == "rnnpose_conv2d_nhwc_f16x3":
-        n, mean_ms, tot_ms, work = prof[dom]
-        eq = work / (tot_ms * 1e-3) / 1e12
+        n, mean_ms, tot_ms, work, _ = prof[dom]
+        ach = 3 * work / (tot_ms * 1e-3) / 1e12
         roofline = {"kernel": "conv_igemm_f16x3_kernel (NHWC implicit-GEMM convolution, fp16x3-split MFMA = fp32-class accuracy; "
-                              "all update-block and stride-1 encoder convolutions)",
-                    "bound": "mfma", "achieved": round(3 * eq, 1), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(3 * eq / PEAK_F16_MFMA_TFLOPS, 4),
-                    "note": "achieved = EXECUTED fp16 MFMA flops (3 products per algorithmic multiply-add) / summed HIP-event time of "
-                            "all launches in the timed region; fp32-equivalent algorithmic rate = achieved/3.  The update step runs "
-                            "the two halves of the batch as two concurrent convolution chains (two streams): every launch is timed "
-                            "while it SHARES the chip with its twin, so the per-launch rate understates the aggregate matrix-pipe use "
-                            "(RNNPOSE_SPLIT_BATCH=0, one full-batch chain: 650 TF per launch at 5 % lower iters/s)",
-                    "fp32_equivalent_TFLOPps": round(eq, 1), "launches_timed": n, "mean_ms": round(mean_ms, 4),
-                    "share_of_step": round(tot_ms / prof_steps / (dt / args.steps * 1e3), 4), "algorithmic_flops_timed": work,
-                    "traffic": traffic.get("conv_igemm_bytes_per_launch")}
-    elif dom == "rnnpose_corr_pyramid_f32" or (dom and "rnnpose_corr_pyramid_f32" in prof):
-        cp = prof["rnnpose_corr_pyramid_f32"]
-        ach = alg["rnnpose_corr_pyramid_f32"]["flops"] / (cp[1] * 1e-3) / 1e12
-        roofline = {"kernel": "corr_pyramid_kernel (fp32 MFMA all-pairs correlation + fused 4-level pyramid)",
-                    "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic.get("corr_pyramid_bytes_per_launch"),
-                    "launches_timed": cp[0], "mean_ms": round(cp[1], 4)}
-    # north_star's named kernel is always reported beside it
+                              "all update-block and encoder convolutions but the stem)",
+                    "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_F16_MFMA_TFLOPS, 4), "traffic": tr("conv_igemm"),
+                    "note": "achieved = EXECUTED fp16 MFMA flops (3 products per algorithmic multiply-add: SURVEY 8d's 2*MAC count "
+                            "of every launch x 3) / summed HIP-event duration of those launches.  The update step and the encoder "
+                            "run two half-batch chains on two streams, so every launch is timed while it SHARES the chip with its "
+                            "twin: see chip_level for the aggregate",
+                    "fp32_equivalent_TFLOPps": round(work / (tot_ms * 1e-3) / 1e12, 1), "launches_timed": n,
+                    "mean_ms": round(mean_ms, 4), "share_of_step": round(tot_ms / prof_steps / ms_step, 4),
+                    "algorithmic_flops_timed": work}
+    elif dom is not None:
+        n, mean_ms, tot_ms, work, nbytes = prof[dom]
+        gbs = nbytes / (tot_ms * 1e-3) / 1e9 if nbytes else 0.0
+        roofline = {"kernel": dom, "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None, "launches_timed": n, "mean_ms": round(mean_ms, 4)}
+    chip = {"executed_fp16_TFLOP_per_step": round(exec_flops_step / 1e12, 3), "ms_per_step": round(ms_step, 3),
+            "TFLOPps": round(exec_flops_step / (ms_step * 1e-3) / 1e12, 1),
+            "frac_of_fp16_mfma_peak": round(exec_flops_step / (ms_step * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4),
+            "note": "matrix-core flops executed by the fp16x3 kernels (convolutions, stem, volume build) in one step / wall time "
+                    "of the step -- includes every memory-bound kernel and launch gap of the step"}
+    # north_star's named kernel
     corr_vol = None
-    if "rnnpose_corr_pyramid_f16x3" in prof:
-        cp = prof["rnnpose_corr_pyramid_f16x3"]
-        a = alg["rnnpose_corr_pyramid_f16x3"]
-        gbs = a["bytes"] / (cp[1] * 1e-3) / 1e9
-        corr_vol = {"kernel": "corr_pyramid_h3_kernel (+ 2 split_features_kernel pre-passes inside the same C-ABI call)",
-                    "bound": "hbm (volume + pooled levels written once; fp16x3-split MFMA: 3 fp16 products per multiply-add)",
-                    "achieved_GBps": round(gbs, 1), "peak_GBps": PEAK_HBM_GBS, "frac": round(gbs / PEAK_HBM_GBS, 4),
-                    "executed_fp16_TFLOPps": round(3 * a["flops"] / (cp[1] * 1e-3) / 1e12, 1),
-                    "fp32_equivalent_TFLOPps": round(a["flops"] / (cp[1] * 1e-3) / 1e12, 1),
-                    "algorithmic_bytes_per_launch": a["bytes"], "traffic": traffic.get("corr_pyramid_h3_bytes_per_launch"),
-                    "mean_ms": round(cp[1], 4)}
-    elif "rnnpose_corr_pyramid_f32" in prof:
-        cp = prof["rnnpose_corr_pyramid_f32"]
-        ach = alg["rnnpose_corr_pyramid_f32"]["flops"] / (cp[1] * 1e-3) / 1e12
-        corr_vol = {"kernel": "corr_pyramid_kernel", "bound": "mfma (fp32, 96 flop/B)", "achieved_TFLOPps": round(ach, 2),
-                    "peak_TFLOPps": PEAK_F32_MFMA_TFLOPS, "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-                    "hbm_GBps": kernels["corr_pyramid_f32"]["GBps"], "hbm_frac": kernels["corr_pyramid_f32"]["hbm_frac"],
-                    "algorithmic_bytes_per_launch": alg["rnnpose_corr_pyramid_f32"]["bytes"],
-                    "traffic": traffic.get("corr_pyramid_bytes_per_launch"), "mean_ms": round(cp[1], 4)}
+    for nm, label in (("rnnpose_corr_pyramid_f16x3", "corr_pyramid_h3_kernel (+ the two split_features_kernel pre-passes of the same C-ABI call)"),
+                      ("rnnpose_corr_pyramid_f32", "corr_pyramid_kernel (exact fp32 MFMA)")):
+        if nm in prof:
+            n, mean_ms, tot_ms, work, nbytes = prof[nm]
+            gbs = nbytes / (tot_ms * 1e-3) / 1e9
+            corr_vol = {"kernel": label, "bound": "hbm" if nm.endswith("f16x3") else "mfma (fp32, 96 flop/B)",
+                        "achieved_GBps": round(gbs, 1), "peak_GBps": PEAK_HBM_GBS, "frac": round(gbs / PEAK_HBM_GBS, 4),
+                        "algorithmic_bytes_per_launch": nbytes / n, "traffic": tr("corr_pyramid_h3" if nm.endswith("f16x3") else "corr_pyramid"),
+                        "mean_ms": round(mean_ms, 4), "launches_timed": n}
+            if nm.endswith("f32"):
+                corr_vol["TFLOPps"] = round(work / (tot_ms * 1e-3) / 1e12, 2)
+                corr_vol["f32_mfma_frac"] = round(corr_vol["TFLOPps"] / PEAK_F32_MFMA_TFLOPS, 4)
+            else:
+                corr_vol["executed_fp16_TFLOPps"] = round(3 * work / (tot_ms * 1e-3) / 1e12, 1)
+            break
     res = {
         "metric": "pose-refine iters/sec (640x480, B=8, 3x8 recurrent)", "value": round(value, 3), "unit": "iters/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.conv_backend == "miopen" else "f32 (convolutions: fp16x3-split MFMA, fp32-class accuracy; LM: f64)",
+        "dtype": "f32 (convolutions and volume build: fp16x3-split MFMA, fp32-class accuracy; LM: f64)",
         "data": "synthetic", "image_iters_per_sec": round(value * B, 2),
         "config": {"workload": f"synthetic {W}x{H} render+target pairs, batch {B}/GPU, {args.outer} outer x "
                                f"{args.inner} inner refinement (BASELINE.json configs[1]); 1 step = 1 refinement = "
                                f"{iters} iterations", "batch_per_gpu": B, "height": H, "width": W,
                    "outer": args.outer, "inner": args.inner, "optim_iters": args.optim_iters,
                    "encoder_in_timed_region": not args.no_encoder, "fused_schedule": not args.unfused,
-                   "conv_backend": args.conv_backend,
                    "hip_graphs": "encoder+volume build and the inner-iteration body replay as hipGraphs (except in the "
-                                 "event-instrumented first timed step)" if refiner.use_graph and not args.unfused else "off",
+                                 "event-instrumented first outer iteration of the first timed step)" if refiner.use_graph and not args.unfused else "off",
                    "weights": "random init", "lm_accumulation": "f64", "sharding": f"dp{world} (independent images, no collective in the path)"},
-        "roofline": roofline, "correlation_volume_kernel": corr_vol, "kernels": kernels,
-        "kernels_note": "HIP events around every C-ABI launch of the first outer iteration of the first timed step (eager); "
-                        "share_of_step = summed launch durations x outer iterations / step time -- launches of the two batch "
-                        "halves overlap on two streams, so the shares add up to more than 1",
+        "roofline": roofline, "chip_level": chip, "correlation_volume_kernel": corr_vol, "kernels": kernels,
+        "kernels_note": "HIP events around every C-ABI launch of the first outer iteration of the first timed step (eager); GB/s from "
+                        "the ALGORITHMIC bytes each launch declares for its own arguments (SURVEY 8d formulas; half-batch launches "
+                        "declare half the batch); share_of_step = summed launch durations x outer iterations / step time -- launches "
+                        "of the two batch halves overlap on two streams, so the shares add up to more than 1",
     }
     if world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(refiner, rend, K, G0, args)

@@ -56,19 +56,19 @@ def profiling() -> bool:
 
 
 def summarize(rec) -> dict:
-    """-> {name: (n_calls, mean_ms, total_ms, total_work)} (synchronises).  total_work = sum of the `work` each
-    launch declared (algorithmic flops for the convolution kernel), 0 if none."""
+    """-> {name: (n_calls, mean_ms, total_ms, total_work, total_bytes)} (synchronises).  total_work / total_bytes = sums of
+    the ALGORITHMIC flops / HBM bytes each launch declared for ITS OWN arguments (a half-batch launch declares half)."""
     torch.cuda.synchronize()
     out = {}
     for k, evs in rec.items():
         if k.startswith("_"):
             continue
-        ms = [a.elapsed_time(b) for a, b, _ in evs]
-        out[k] = (len(ms), sum(ms) / max(len(ms), 1), sum(ms), sum(w for _, _, w in evs))
+        ms = [a.elapsed_time(b) for a, b, _, _ in evs]
+        out[k] = (len(ms), sum(ms) / max(len(ms), 1), sum(ms), sum(w for _, _, w, _ in evs), sum(n for _, _, _, n in evs))
     return out
 
 
-def _launch(name, *args, work=0):
+def _launch(name, *args, work=0, nbytes=0):
     rec = _prof
     if rec is not None and (rec["_only"] is None or name in rec["_only"]):
         i = rec["_next"]
@@ -79,7 +79,7 @@ def _launch(name, *args, work=0):
         a.record()
         _lib.call(name, *args)
         b.record()
-        rec.setdefault(name, []).append((a, b, work))
+        rec.setdefault(name, []).append((a, b, work, nbytes))
     else:
         _lib.call(name, *args)
 
@@ -126,7 +126,8 @@ def corr_pyramid(fmap1, fmap2, levels: int = 4, out=None, precision: str = "f32"
     offs, hl, wl = pyramid_layout(B, h, w, levels)
     buf = out if (out is not None and out.numel() == offs[-1] and out.device == fmap1.device) else \
         torch.empty(offs[-1], device=fmap1.device, dtype=F32)
-    _launch("rnnpose_corr_pyramid_f32", _ptr(fmap1), _ptr(fmap2), B, Cc, h, w, levels, _ptr(buf), _stream())
+    _launch("rnnpose_corr_pyramid_f32", _ptr(fmap1), _ptr(fmap2), B, Cc, h, w, levels, _ptr(buf), _stream(),
+            work=2.0 * B * (h * w) ** 2 * Cc, nbytes=4.0 * (2 * B * h * w * Cc + offs[-1]))
     views = [buf[offs[l]:offs[l + 1]].view(B * h * w, 1, hl[l], wl[l]) for l in range(levels)]
     return buf, views
 
@@ -144,7 +145,7 @@ def _corr_pyramid_f16x3(f1, f2, layout, B, Cc, h, w, levels, out, a_scale):
     buf = out if (out is not None and out.numel() == offs[-1] and out.device == f1.device) else \
         torch.empty(offs[-1], device=f1.device, dtype=F32)
     _launch("rnnpose_corr_pyramid_f16x3", _ptr(f1), _ptr(f2), layout, B, Cc, h, w, levels, float(a_scale), _ptr(ws), n,
-            _ptr(buf), _stream(), work=2.0 * B * (h * w) ** 2 * Cc)
+            _ptr(buf), _stream(), work=2.0 * B * (h * w) ** 2 * Cc, nbytes=4.0 * (2 * B * h * w * Cc + offs[-1]))
     views = [buf[offs[l]:offs[l + 1]].view(B * h * w, 1, hl[l], wl[l]) for l in range(levels)]
     return buf, views
 
@@ -159,6 +160,11 @@ def corr_pyramid_nhwc(f1, f2, levels: int = 4, out=None, a_scale: float = 8.0):
 
 
 # ---- a3 ------------------------------------------------------------------------------------------------
+def _lookup_bytes(B, h, w, levels, radius):
+    """per pixel and level a (2r+2)^2 texel footprint read + (2r+1)^2 outputs written, + 2 coords."""
+    return 4.0 * B * h * w * (levels * (2 * radius + 2) ** 2 + levels * (2 * radius + 1) ** 2 + 2)
+
+
 def corr_lookup(pyramid_buf, coords, levels: int = 4, radius: int = 4):
     """coords (B,2,h,w) -> (B, levels*81, h, w)                       thirdparty/raft/corr.py:36-57"""
     coords = _chk(coords, "coords")
@@ -170,7 +176,8 @@ def corr_lookup(pyramid_buf, coords, levels: int = 4, radius: int = 4):
     if pyramid_buf.numel() != offs[-1]:
         raise ValueError("pyramid buffer does not match coords shape")
     out = torch.empty(B, levels * (2 * radius + 1) ** 2, h, w, device=coords.device, dtype=F32)
-    _launch("rnnpose_corr_lookup_f32", _ptr(pyramid_buf), _ptr(coords), B, h, w, levels, radius, _ptr(out), _stream())
+    _launch("rnnpose_corr_lookup_f32", _ptr(pyramid_buf), _ptr(coords), B, h, w, levels, radius, _ptr(out), _stream(),
+            nbytes=_lookup_bytes(B, h, w, levels, radius))
     return out
 
 
@@ -180,7 +187,8 @@ def context_prep(ctx, h, w, hdim: int = 128):
     B, Cc, H, W = ctx.shape
     net = torch.empty(B, hdim, h, w, device=ctx.device, dtype=F32)
     inp = torch.empty(B, Cc - hdim, h, w, device=ctx.device, dtype=F32)
-    _launch("rnnpose_context_prep_f32", _ptr(ctx), B, Cc, H, W, h, w, hdim, _ptr(net), _ptr(inp), _stream())
+    _launch("rnnpose_context_prep_f32", _ptr(ctx), B, Cc, H, W, h, w, hdim, _ptr(net), _ptr(inp), _stream(),
+            nbytes=4.0 * B * Cc * h * w * 5)        # 4 taps read + 1 value written per low-res element
     return net, inp
 
 
@@ -199,7 +207,8 @@ def convex_upsample(flow, mask, scale: int = 8):
     if mask.shape != (B, 9 * scale * scale, h, w):
         raise ValueError(f"mask must be (B,{9*scale*scale},h,w)")
     out = torch.empty(B, 2, scale * h, scale * w, device=flow.device, dtype=F32)
-    _launch("rnnpose_convex_upsample_f32", _ptr(flow), _ptr(mask), B, h, w, scale, _ptr(out), _stream())
+    _launch("rnnpose_convex_upsample_f32", _ptr(flow), _ptr(mask), B, h, w, scale, _ptr(out), _stream(),
+            nbytes=4.0 * B * h * w * (9 * scale * scale + 2 + 2 * scale * scale))
     return out
 
 
@@ -241,7 +250,7 @@ def corr_weight(g1, g2, target, depth, sigma, out=None):
     if out is None:
         out = torch.empty(B, H, W, device=g1.device, dtype=F32)
     _launch("rnnpose_corr_weight_f32", _ptr(g1), _ptr(g2), _ptr(target), mode, _ptr(depth), _ptr(sigma), B, D, H, W,
-            _ptr(out), _stream())
+            _ptr(out), _stream(), nbytes=4.0 * B * H * W * (2 * D + 2 + 1 + 1))   # g1, g2 (unique texels), target, depth, w
     return out
 
 
@@ -270,7 +279,7 @@ def lm_normal_eq(target, weight, depth, K, G, eps: float = 1e-5):
     Hm = torch.empty(B, 6, 6, device=depth.device, dtype=F64)
     bv = torch.empty(B, 6, device=depth.device, dtype=F64)
     _launch("rnnpose_lm_normal_eq_f64", _ptr(target), mode, _ptr(weight), _ptr(depth), eps, _ptr(K), _ptr(G), B, H, W,
-            _ptr(ws), n, _ptr(Hm), _ptr(bv), _stream())
+            _ptr(ws), n, _ptr(Hm), _ptr(bv), _stream(), nbytes=16.0 * B * H * W, work=200.0 * B * H * W)
     return Hm, bv
 
 
@@ -302,7 +311,7 @@ def lm_step(target, weight, depth, K, G, num_iters=1, ep_lambda=100.0, lm_lambda
             Gin = Gin.contiguous()
         _launch("rnnpose_lm_step_io_f32", _ptr(target), mode, _ptr(weight), _ptr(depth), eps, _ptr(K), _ptr(Gin), _ptr(Gd), B, H, W,
                 int(num_iters), float(ep_lambda), float(lm_lambda), float(max_update), _ptr(ws), n, _ptr(Hm), _ptr(bv),
-                _ptr(xi), _ptr(info), _stream())
+                _ptr(xi), _ptr(info), _stream(), nbytes=16.0 * B * H * W * int(num_iters), work=200.0 * B * H * W * int(num_iters))
         return Gd, Hm, bv, xi, info
     if out is not None:
         Gd, Hm, bv, xi, info = out
@@ -318,7 +327,7 @@ def lm_step(target, weight, depth, K, G, num_iters=1, ep_lambda=100.0, lm_lambda
         info = torch.zeros(B, device=depth.device, dtype=torch.int32)
     _launch("rnnpose_lm_step_f32", _ptr(target), mode, _ptr(weight), _ptr(depth), eps, _ptr(K), _ptr(G), B, H, W,
             int(num_iters), float(ep_lambda), float(lm_lambda), float(max_update), _ptr(ws), n, _ptr(Hm), _ptr(bv),
-            _ptr(xi), _ptr(info), _stream())
+            _ptr(xi), _ptr(info), _stream(), nbytes=16.0 * B * H * W * int(num_iters), work=200.0 * B * H * W * int(num_iters))
     return G, Hm, bv, xi, info
 
 
@@ -487,7 +496,8 @@ def corr_lookup_nhwc(pyramid_buf, coords, out=None, levels: int = 4, radius: int
     B, _, h, w = coords.shape
     if out is None:
         out = torch.empty(B, h, w, levels * (2 * radius + 1) ** 2, device=coords.device, dtype=F32)
-    _launch("rnnpose_corr_lookup_nhwc_f32", _ptr(pyramid_buf), _ptr(coords), B, h, w, levels, radius, _ptr(out), _stream())
+    _launch("rnnpose_corr_lookup_nhwc_f32", _ptr(pyramid_buf), _ptr(coords), B, h, w, levels, radius, _ptr(out), _stream(),
+            nbytes=_lookup_bytes(B, h, w, levels, radius))
     return out
 
 
@@ -536,7 +546,8 @@ def convex_upsample_nhwc(flow_lr, mask, out=None):
     B, h, w, _ = mask.shape
     if out is None:
         out = torch.empty(B, 2, 8 * h, 8 * w, device=mask.device, dtype=F32)
-    _launch("rnnpose_convex_upsample_nhwc_f32", _ptr(flow_lr), _ptr(mask), B, h, w, _ptr(out), _stream())
+    _launch("rnnpose_convex_upsample_nhwc_f32", _ptr(flow_lr), _ptr(mask), B, h, w, _ptr(out), _stream(),
+            nbytes=4.0 * B * h * w * (576 + 2 + 128))
     return out
 
 
@@ -607,7 +618,7 @@ def instnorm_nhwc(x, relu=True, residual=None, out=None, eps: float = 1e-5):
         out = torch.empty_like(x)
     stats = torch.empty(B, Cc, 2, device=x.device, dtype=F32)
     _launch("rnnpose_instnorm_nhwc_f32", _ptr(x), B, H * W, Cc, eps, int(bool(relu)), _ptr(residual), _ptr(ws), n,
-            _ptr(stats), _ptr(out), _stream())
+            _ptr(stats), _ptr(out), _stream(), nbytes=4.0 * x.numel() * (3 + (residual is not None)))
     return out
 
 
@@ -619,7 +630,7 @@ def instnorm_tiles_nhwc(x, tile_stats, relu=True, residual=None, out=None, eps: 
         out = torch.empty_like(x)
     stats = torch.empty(B, Cc, 2, device=x.device, dtype=F32)
     _launch("rnnpose_instnorm_tiles_nhwc_f32", _ptr(x), B, H * W, Cc, eps, int(bool(relu)), _ptr(residual), _ptr(tile_stats), 128,
-            _ptr(stats), _ptr(out), _stream())
+            _ptr(stats), _ptr(out), _stream(), nbytes=4.0 * x.numel() * (2 + (residual is not None)))
     return out
 
 
