@@ -173,3 +173,37 @@ def test_graph_replay_with_alternating_batch_shapes(ops):
         assert torch.equal(Gg, Ge) and torch.equal(fg, fe)
     # the single-image result equals image 0 of the batch (images are independent)
     assert float((res[True][1][0] - res[True][0][0][:1]).abs().max()) < 1e-6
+
+
+def test_torch_ops_namespace_runs_the_hip_kernels(ops):
+    """torch.ops.rnnpose.*  == the ops front end, bit for bit; the pyramid levels returned by corr_pyramid are
+    views of one buffer and are consumed without a copy; a re-packed list of levels gives the same lookup."""
+    import rnnpose_amd.torch_ops  # noqa: F401
+    R = torch.ops.rnnpose
+    d = syn.make_inputs(2, 128, 160, seed=13)
+    t = lambda k: T(d[k]).cuda()
+    f1, f2 = t("fmap1"), t("fmap2")
+    pyr = R.corr_pyramid(f1, f2, 4)
+    buf, views = ops.corr_pyramid(f1, f2, 4)
+    assert all(torch.equal(a, b) for a, b in zip(pyr, views))
+    from rnnpose_amd.corr import coords_grid
+    c = coords_grid(2, 16, 20, device="cuda") + T(syn.uniform("c", (2, 2, 16, 20), 1, -4.0, 4.0)).cuda()
+    want = ops.corr_lookup(buf, c)
+    assert torch.equal(R.corr_lookup(pyr, c, 4), want)
+    assert torch.equal(R.corr_lookup([p.clone() for p in pyr], c, 4), want)
+    mask = T(syn.normal("m", (2, 576, 16, 20), 1)).cuda()
+    assert torch.equal(R.convex_upsample(c, mask, 8), ops.convex_upsample(c, mask))
+    depth, K, G = t("depth"), t("K"), t("G0")
+    flow, vm = R.induced_flow(depth, K, G, 1e-5)
+    f0, v0 = ops.induced_flow(depth, K, G)
+    assert torch.equal(flow, f0) and torch.equal(vm, v0)
+    w = R.corr_weight(t("g1"), t("g2"), flow, depth, t("sigma"))
+    assert torch.equal(w, ops.corr_weight(t("g1"), t("g2"), flow, depth, t("sigma")))
+    H, b = R.lm_normal_eq(flow, w, depth, K, G)
+    H0, b0 = ops.lm_normal_eq(flow, w, depth, K, G)
+    assert torch.equal(H, H0) and torch.equal(b, b0)
+    Gn, xi = R.lm_solve_update(H, b, G, 100.0, 1e-4, 1.0)
+    G1, x1, _ = ops.lm_solve_update(H, b, G.reshape(-1, 4, 4))
+    assert torch.equal(Gn.reshape(-1, 4, 4), G1) and torch.equal(xi, x1)
+    Gs, xs = R.lm_step(flow, w, depth, K, G, 1, 100.0, 1e-4, 1.0)
+    assert torch.equal(Gs.reshape(-1, 4, 4), G1) and torch.equal(xs, x1)

@@ -170,3 +170,33 @@ def test_concurrent_build_calls_are_serialised(tmp_path):
         assert out.strip().endswith("librnnpose_hip.so")
     import ctypes
     ctypes.CDLL(outs[0][0].strip())
+
+
+def test_torch_library_ops_registered_with_fake_kernels():
+    """the operator set is visible as torch.ops.rnnpose.* with the listed schemas; fake kernels give shapes
+    and dtypes under FakeTensorMode (no GPU touched); a CPU tensor fails loudly in the dispatcher (no CPU path)."""
+    import rnnpose_amd.torch_ops as to
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    for name, schema in to._SCHEMAS.items():
+        op = getattr(torch.ops.rnnpose, name).default
+        assert str(op._schema).startswith("rnnpose::" + name + "(Tensor") and len(op._schema.arguments) == schema.split(" -> ")[0].count(",") + 1
+    with FakeTensorMode():
+        dev = "cuda"
+        f = torch.empty(2, 256, 60, 80, device=dev)
+        pyr = torch.ops.rnnpose.corr_pyramid(f, f, 4)
+        assert [tuple(p.shape) for p in pyr] == [(9600, 1, 60, 80), (9600, 1, 30, 40), (9600, 1, 15, 20), (9600, 1, 7, 10)]
+        c = torch.empty(2, 2, 60, 80, device=dev)
+        assert torch.ops.rnnpose.corr_lookup(pyr, c, 4).shape == (2, 324, 60, 80)
+        assert torch.ops.rnnpose.convex_upsample(c, torch.empty(2, 576, 60, 80, device=dev), 8).shape == (2, 2, 480, 640)
+        d = torch.empty(2, 1, 480, 640, device=dev)
+        K, G = torch.empty(2, 3, 3, device=dev), torch.empty(2, 1, 4, 4, device=dev)
+        fl, vm = torch.ops.rnnpose.induced_flow(d, K, G, 1e-5)
+        assert fl.shape == (2, 2, 480, 640) and vm.shape == (2, 480, 640)
+        g = torch.empty(2, 32, 480, 640, device=dev)
+        w = torch.ops.rnnpose.corr_weight(g, g, fl, d, torch.empty(1, device=dev))
+        H, b = torch.ops.rnnpose.lm_normal_eq(fl, w, d, K, G)
+        assert w.shape == (2, 480, 640) and H.shape == (2, 6, 6) and H.dtype == torch.float64 and b.shape == (2, 6)
+        Gn, xi = torch.ops.rnnpose.lm_solve_update(H, b, G)
+        assert Gn.shape == G.shape and xi.shape == (2, 6) and xi.dtype == torch.float32
+    with pytest.raises(NotImplementedError):
+        torch.ops.rnnpose.convex_upsample(torch.zeros(1, 2, 4, 4), torch.zeros(1, 576, 4, 4))
