@@ -36,9 +36,8 @@ __device__ __forceinline__ void split4(const float4 v, float s, h4& hi, h4& lo) 
 
 // true if any element of the quad leaves the fp16 range once scaled (|x*s| > 65504) or is not finite
 __device__ __forceinline__ bool quad_saturates(const float4 v, float s) {
-  const float lim = 65504.f / s;
-  const float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
-  return !(m <= lim);      // (NaN compares false -> counted)
+  const float lim = 65504.f / s;      // (fmaxf would drop a NaN operand: four ordered compares, NaN fails each)
+  return !(fabsf(v.x) <= lim && fabsf(v.y) <= lim && fabsf(v.z) <= lim && fabsf(v.w) <= lim);
 }
 
 }  // namespace rp

