@@ -192,6 +192,12 @@ typedef struct {
                                   128-row output tile, the column sums and sums of squares of the outputs (bias included)
                                   -- the instance-norm statistics pass of the encoder without re-reading the tensor
                                   (rnnpose_instnorm_tiles_nhwc_f32).  M = B*H_out*W_out. */
+  const float* add_map;        /* optional (NULL = off): NHWC tensor added to y before the epilogue, y += add_map[pixel,
+                                  add_c_offset + n] -- a per-pixel bias.  Used to hoist the part of a convolution whose input
+                                  does not change between calls (the context half `inp` of the GRU input, constant over the
+                                  inner iterations: update.py:181 concatenates it anew every step) out of the loop: conv is
+                                  linear, conv([h|inp|m]) = conv([h|m]) + conv(inp).  Needs c_out % 4 == 0, 16-byte alignment. */
+  int add_c_stride, add_c_offset;
 } rnnpose_conv_desc_t;
 
 /* number of fp16 elements of EACH of the two packed arrays (hi, lo); -1 on bad arguments */
@@ -237,6 +243,10 @@ int rnnpose_stem_conv7x7_s2_f16x3(const float* img_nchw, int N, int H, int W, in
  * convex_upsample_nhwc: a6 (model/CFNet.py:95-106) with mask (B,h,w,576) and flow_lr (B,h,w,2) -> (B,2,8h,8w). */
 int rnnpose_corr_lookup_nhwc_f32(const float* pyramid, const float* coords, int B, int h, int w, int levels, int radius,
                                  float* out, rnnpose_stream_t stream);
+/* NHWC lookup of the images [b0, b1) of a pyramid built for batch B: coords (b1-b0,2,h,w) and out (b1-b0,h,w,levels*81)
+ * are the sub-batch tensors, `pyramid` the whole buffer (thirdparty/raft/corr.py:36-57 per image). */
+int rnnpose_corr_lookup_nhwc_part_f32(const float* pyramid, const float* coords, int B, int b0, int b1, int h, int w,
+                                      int levels, int radius, float* out, rnnpose_stream_t stream);
 int rnnpose_nchw_to_nhwc_f32(const float* src, int B, int C, int HW, float* dst, int dst_c_stride, int dst_c_offset,
                              rnnpose_stream_t stream);
 int rnnpose_nhwc_to_nchw_f32(const float* src, int B, int C, int HW, int src_c_stride, int src_c_offset, float* dst,

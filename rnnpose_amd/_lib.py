@@ -28,7 +28,7 @@ class ConvDesc(C.Structure):       # rnnpose_conv_desc_t
                 ("aux0", C.c_void_p), ("aux0_c_stride", C.c_int), ("aux0_c_offset", C.c_int),
                 ("aux1", C.c_void_p), ("aux1_c_stride", C.c_int), ("aux1_c_offset", C.c_int),
                 ("dst2", C.c_void_p), ("dst2_c_stride", C.c_int), ("dst2_c_offset", C.c_int), ("gru_c", C.c_int),
-                ("tile_stats", C.c_void_p)]
+                ("tile_stats", C.c_void_p), ("add_map", C.c_void_p), ("add_c_stride", C.c_int), ("add_c_offset", C.c_int)]
 
 
 # name -> (restype, argtypes); mirrors include/rnnpose_hip.h one to one
@@ -67,6 +67,7 @@ PROTOTYPES = {
     "rnnpose_stem_tiles": (_i, [_i, _i, C.POINTER(_i), C.POINTER(_i)]),
     "rnnpose_stem_conv7x7_s2_f16x3": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _f, _f, _p, _p, _p]),
     "rnnpose_corr_lookup_nhwc_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p]),
+    "rnnpose_corr_lookup_nhwc_part_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
     "rnnpose_nchw_to_nhwc_f32": (_i, [_p, _i, _i, _i, _p, _i, _i, _p]),
     "rnnpose_nhwc_to_nchw_f32": (_i, [_p, _i, _i, _i, _i, _i, _p, _p]),
     "rnnpose_flow_prep_f32": (_i, [_p, _i, _i, _i, _i, _p, _p, _i, _i, _p]),

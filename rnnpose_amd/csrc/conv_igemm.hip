@@ -72,6 +72,8 @@ struct KParams {
   int dst2_cs, dst2_co;
   int gru_c;
   float* tstats;   // optional per-tile column statistics (linear epilogue)
+  const float* addm;   // optional per-pixel bias map (NHWC), added before the epilogue
+  int addm_cs, addm_co;
   int n_mt, n_nt;
   unsigned long long* sat;   // fp16x3 range guard: counter of clamped / non-finite activation quads (NULL = check off)
   int dbg;   // tile-shape overrides for A/B timing (RNNPOSE_CONV_DBG: 32 = 64-wide tiles, 64 = 128-wide tiles, 128 = 2x2 wave layout); 0 in production
@@ -392,6 +394,10 @@ __global__ __launch_bounds__(NT, (COLS4 ? 3 : 2)) void conv_igemm_f16x3_kernel(c
       const int nv = p.Cout - col < 4 ? p.Cout - col : 4;      // valid columns of this quad (Cout = 126 -> tail of 2)
 #pragma unroll
       for (int e = 0; e < 4; ++e) y[e] += (e < nv) ? p.bias[col + e] : 0.f;
+      if (p.addm) {                 // (c_out % 4 == 0 checked on the host: nv == 4 here)
+        const float4 a = *reinterpret_cast<const float4*>(p.addm + pix * p.addm_cs + p.addm_co + col);
+        y[0] += a.x; y[1] += a.y; y[2] += a.z; y[3] += a.w;
+      }
       float* dptr = p.dst + pix * p.dst_cs + p.dst_co + col;
       if (p.tstats) {              // (column quad of a lane is the same for every k and mi: 64 % F4 == 0)
         if (nv > 0) { ts0 += y[0]; tq0 += y[0] * y[0]; }
@@ -641,6 +647,9 @@ int rnnpose_conv2d_nhwc_f16x3(const rnnpose_conv_desc_t* d, rnnpose_stream_t str
   p.dst2 = d->dst2; p.dst2_cs = d->dst2_c_stride; p.dst2_co = d->dst2_c_offset;
   p.gru_c = d->gru_c;
   p.tstats = d->tile_stats;
+  p.addm = d->add_map; p.addm_cs = d->add_c_stride; p.addm_co = d->add_c_offset;
+  if (d->add_map) RP_REQUIRE(d->c_out % 4 == 0 && d->add_c_stride % 4 == 0 && d->add_c_offset % 4 == 0 &&
+                                 reinterpret_cast<uintptr_t>(d->add_map) % 16 == 0, fn, "add_map: c_out % 4 == 0, 16-byte aligned, stride/offset multiples of 4");
   p.sat = rp::sat_counter();
   if (d->tile_stats) RP_REQUIRE(d->epilogue == 0, fn, "tile_stats needs the linear epilogue");
   const long long Mtot = static_cast<long long>(d->B) * Ho * Wo;

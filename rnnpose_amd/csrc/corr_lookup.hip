@@ -16,7 +16,6 @@
 // 0.067, 16 at 0.057 (16 waves per CU, the VGPR limit) -- phase 2 then only uses 16 lanes, but it is 5 % of the time.
 #include "common.hpp"
 
-#include <cstdlib>
 
 namespace {
 
@@ -34,7 +33,7 @@ struct LookupInfo {
 
 __global__ __launch_bounds__(64) void corr_lookup_kernel(const float* __restrict__ pyr, const float* __restrict__ coords,
                                                          float* __restrict__ out, int B, int h, int w, int levels,
-                                                         LookupInfo info, int nhwc, int dbg) {
+                                                         LookupInfo info, int nhwc, long long p_off) {
   __shared__ float foot[PIX * FS];
   const int N = h * w;
   const long long total = static_cast<long long>(B) * N;
@@ -72,17 +71,17 @@ __global__ __launch_bounds__(64) void corr_lookup_kernel(const float* __restrict
 #pragma unroll 4
   for (int q = 0; q < npix; ++q) {
     const int qbx = __shfl(bx, q), qby = __shfl(by, q);
-    const float* src = lvl_base + (first + q) * img;
+    const float* src = lvl_base + (p_off + first + q) * img;       // p_off: first pyramid row of this launch's images
     {
       const int x = qbx + tx0, y = qby + ty0;
       float v = 0.f;
-      if (!(dbg & 1) && x >= 0 && x < wl && y >= 0 && y < hl) v = src[y * wl + x];
+      if (x >= 0 && x < wl && y >= 0 && y < hl) v = src[y * wl + x];
       foot[q * FS + t0] = v;
     }
     if (t1 < FP * FP) {
       const int x = qbx + tx1, y = qby + ty1;
       float v = 0.f;
-      if (!(dbg & 1) && x >= 0 && x < wl && y >= 0 && y < hl) v = src[y * wl + x];
+      if (x >= 0 && x < wl && y >= 0 && y < hl) v = src[y * wl + x];
       foot[q * FS + t1] = v;
     }
   }
@@ -104,7 +103,6 @@ __global__ __launch_bounds__(64) void corr_lookup_kernel(const float* __restrict
 #pragma unroll
     for (int x = 0; x < FP; ++x) prev[x] = cur[x];
   }
-  if (dbg & 2) return;
   if (!nhwc) {
     // (B, L*81, h, w): consecutive lanes are consecutive pixels -> one coalesced 256-byte row per channel
     if (live) {
@@ -132,32 +130,43 @@ __global__ __launch_bounds__(64) void corr_lookup_kernel(const float* __restrict
 
 }  // namespace
 
-static int launch_lookup(const char* fn, const float* pyramid, const float* coords, int B, int h, int w, int levels,
-                         int radius, float* out, int nhwc, rnnpose_stream_t stream) {
+// B_total: batch the pyramid was built for (its layout); [b0, b1): the images this launch looks up.  coords / out point at
+// image b0 (sub-batch tensors); the pyramid pointer is the whole buffer.
+static int launch_lookup(const char* fn, const float* pyramid, const float* coords, int B_total, int b0, int b1, int h, int w,
+                         int levels, int radius, float* out, int nhwc, rnnpose_stream_t stream) {
   RP_REQUIRE(pyramid && coords && out, fn, "null pointer");
   RP_REQUIRE(radius == R, fn, "radius must be 4");
+  RP_REQUIRE(b0 >= 0 && b0 < b1 && b1 <= B_total, fn, "image range must satisfy 0 <= b0 < b1 <= B");
   int64_t offs[RNNPOSE_MAX_LEVELS + 1];
   LookupInfo info{};
-  if (int e = rnnpose_corr_pyramid_layout(B, h, w, levels, offs, info.hl, info.wl)) return e;
+  if (int e = rnnpose_corr_pyramid_layout(B_total, h, w, levels, offs, info.hl, info.wl)) return e;
   for (int l = 0; l < levels; ++l) {
     info.off[l] = offs[l];
     // the reference divides by (W_l - 1): a 1-wide level yields inf/NaN there
     RP_REQUIRE(info.hl[l] >= 2 && info.wl[l] >= 2, fn, "every pyramid level must be at least 2x2");
   }
+  const int B = b1 - b0;
   const long long total = static_cast<long long>(B) * h * w;
   dim3 grid(static_cast<unsigned>(rp::cdiv(total, PIX)), static_cast<unsigned>(levels)), block(64);
-  hipLaunchKernelGGL(corr_lookup_kernel, grid, block, 0, rp::as_stream(stream), pyramid, coords, out, B, h, w, levels,
-                     info, nhwc, getenv("RNNPOSE_LOOKUP_DBG") ? atoi(getenv("RNNPOSE_LOOKUP_DBG")) : 0);
+  hipLaunchKernelGGL(corr_lookup_kernel, grid, block, 0, rp::as_stream(stream), pyramid, coords, out, B, h, w, levels, info,
+                     nhwc, static_cast<long long>(b0) * h * w);
   return rp::check_launch(fn);
 }
 
 extern "C" int rnnpose_corr_lookup_f32(const float* pyramid, const float* coords, int B, int h, int w, int levels,
                                        int radius, float* out, rnnpose_stream_t stream) {
-  return launch_lookup("rnnpose_corr_lookup_f32", pyramid, coords, B, h, w, levels, radius, out, 0, stream);
+  return launch_lookup("rnnpose_corr_lookup_f32", pyramid, coords, B, 0, B, h, w, levels, radius, out, 0, stream);
 }
 
 // same lookup, output laid out (B, h, w, levels*81) for the NHWC update-block engine
 extern "C" int rnnpose_corr_lookup_nhwc_f32(const float* pyramid, const float* coords, int B, int h, int w, int levels,
                                             int radius, float* out, rnnpose_stream_t stream) {
-  return launch_lookup("rnnpose_corr_lookup_nhwc_f32", pyramid, coords, B, h, w, levels, radius, out, 1, stream);
+  return launch_lookup("rnnpose_corr_lookup_nhwc_f32", pyramid, coords, B, 0, B, h, w, levels, radius, out, 1, stream);
+}
+
+// NHWC lookup of the images [b0, b1) of a batch-B pyramid: coords (b1-b0, 2, h, w) and out (b1-b0, h, w, levels*81) are the
+// sub-batch tensors.  Lets the two half-batch chains of the update engine each start with their own lookup.
+extern "C" int rnnpose_corr_lookup_nhwc_part_f32(const float* pyramid, const float* coords, int B, int b0, int b1, int h, int w,
+                                                 int levels, int radius, float* out, rnnpose_stream_t stream) {
+  return launch_lookup("rnnpose_corr_lookup_nhwc_part_f32", pyramid, coords, B, b0, b1, h, w, levels, radius, out, 1, stream);
 }

@@ -25,12 +25,8 @@ class UpdateEngine:
         self._b = None
         self._sets = {}           # (B,h,w,device) -> activation buffer set; kept alive because captured hipGraphs hold raw
         self.epoch = 0            # pointers into them.  Bumped whenever a set is freed: graph caches keyed on it are dropped
-        self._side = None         # helper streams of step() (parallel hipGraph branches)
         import os
         self.split_batch = os.environ.get("RNNPOSE_SPLIT_BATCH", "1") != "0"   # two concurrent half-batch chains
-        # start the second half two GRU layers late, so that the first half's memory-bound tail runs under the second
-        # half's convolutions: measured SLOWER (462 vs 517 iters/s: the convolutions lose their twin), off by default
-        self.stagger = os.environ.get("RNNPOSE_STAGGER", "0") != "0"
 
     # ---- weights ---------------------------------------------------------------------------------------------
     def _params(self):
@@ -55,6 +51,8 @@ class UpdateEngine:
         b = self.blk
         e, g = b.encoder, b.gru
         cat = lambda *t: torch.cat([x.detach() for x in t], 0)
+        hm = lambda wt: torch.cat([wt[:, :128], wt[:, 256:]], 1).contiguous()
+        zero = lambda n: torch.zeros(n, device=g.convz1.weight.device, dtype=torch.float32)
         P = ops.PackedConv
         w = dict(
             convc1=P(e.convc1.weight, e.convc1.bias, [e.convc1.weight.shape[1]]),
@@ -63,10 +61,16 @@ class UpdateEngine:
             convf1_b=e.convf1.bias.detach().float().contiguous(),
             convf2=P(e.convf2.weight, e.convf2.bias, [128]),
             conv=P(e.conv.weight, e.conv.bias, [256]),
-            zr1=P(cat(g.convz1.weight, g.convr1.weight), cat(g.convz1.bias, g.convr1.bias), [128, 128, 128]),
-            q1=P(g.convq1.weight, g.convq1.bias, [128, 128, 128]),
-            zr2=P(cat(g.convz2.weight, g.convr2.weight), cat(g.convz2.bias, g.convr2.bias), [128, 128, 128]),
-            q2=P(g.convq2.weight, g.convq2.bias, [128, 128, 128]),
+            # GRU input = [h | inp | motion] (update.py:181, :47-58).  `inp` (the context half) is constant over the inner
+            # iterations, so its share of every GRU convolution is computed ONCE per outer iteration (load_state) into
+            # per-pixel bias maps: conv([h|inp|m]) = conv([h|m]) + conv(inp) -- one third of the GRU's multiply-adds leave
+            # the loop.  hm(): the weights on [h | motion]; inp1 / inp2: z|r|q weights on `inp` for the 1x5 / 5x1 halves.
+            zr1=P(hm(cat(g.convz1.weight, g.convr1.weight)), cat(g.convz1.bias, g.convr1.bias), [128, 128]),
+            q1=P(hm(g.convq1.weight), g.convq1.bias, [128, 128]),
+            zr2=P(hm(cat(g.convz2.weight, g.convr2.weight)), cat(g.convz2.bias, g.convr2.bias), [128, 128]),
+            q2=P(hm(g.convq2.weight), g.convq2.bias, [128, 128]),
+            inp1=P(cat(g.convz1.weight, g.convr1.weight, g.convq1.weight)[:, 128:256].contiguous(), zero(384), [128]),
+            inp2=P(cat(g.convz2.weight, g.convr2.weight, g.convq2.weight)[:, 128:256].contiguous(), zero(384), [128]),
             heads=P(cat(b.flow_head.conv1.weight, b.mask[0].weight), cat(b.flow_head.conv1.bias, b.mask[0].bias), [128]),
             mask2=P(b.mask[2].weight, b.mask[2].bias, [256], post_scale=0.25),            # update.py:187
             flow2_w=b.flow_head.conv2.weight.detach().float().contiguous(),
@@ -88,7 +92,7 @@ class UpdateEngine:
             if st is None:
                 z = lambda c: torch.zeros(B, h, w, c, device=device, dtype=torch.float32)
                 st = dict(corr=z(324), cor1=z(256), corflo=z(256), flow4=z(4), flo1=z(128), motion=z(128), hA=z(128),
-                          hB=z(128), inp=z(128), z=z(128), rh=z(128), heads=z(512), delta=z(2), flow_lr=z(2),
+                          hB=z(128), inp=z(128), inp1=z(384), inp2=z(384), z=z(128), rh=z(128), heads=z(512), delta=z(2), flow_lr=z(2),
                           mask=z(576), coords1=torch.zeros(B, 2, h, w, device=device))
                 if len(self._sets) >= self.MAX_SETS:
                     self._sets.pop(next(iter(self._sets)))
@@ -106,10 +110,11 @@ class UpdateEngine:
         return self._buffers(B, h, w, dev)
 
     def _stream(self, device, i):
-        """Helper stream i (1: second batch half; 2, 3: the flow-feature / flow-head side chains of the two halves)."""
-        if self._side is None or self._side[0].device != device:
-            self._side = [torch.cuda.Stream(device=device) for _ in range(4)]
-        return self._side[i]
+        """Helper stream i (0, 1: the two batch halves; 2: the flow-feature / flow-head side chain of an unsplit step) --
+        from the per-device set that is bound to distinct hardware queues (rnnpose_amd/streams.py)."""
+        from .streams import reserve
+        ss = reserve(device)
+        return ss.chain[i] if i < 2 else ss.aux
 
     def load_state(self, net, inp):
         """net, inp: (B,128,h,w) NCHW (tanh / relu of the context features, model/CFNet.py:131-133)."""
@@ -117,6 +122,13 @@ class UpdateEngine:
         b = self._buffers(B, h, w, net.device)
         ops.nchw_to_nhwc(net, b["hA"])
         ops.nchw_to_nhwc(inp, b["inp"])
+        self._hoist_inp(self._weights(), b)
+
+    @staticmethod
+    def _hoist_inp(W, b):
+        """The `inp` share of the six GRU convolutions (z|r|q x two halves), once per hidden-state load."""
+        ops.conv2d_nhwc(W["inp1"], [(b["inp"], 0)], (b["inp1"], 0), ops.EPI_LINEAR)
+        ops.conv2d_nhwc(W["inp2"], [(b["inp"], 0)], (b["inp2"], 0), ops.EPI_LINEAR)
 
     def hidden_nchw(self):
         return ops.nhwc_to_nchw(self._b["hA"])
@@ -130,94 +142,138 @@ class UpdateEngine:
         ops.nchw_to_nhwc(net, b["hA"])
         ops.nchw_to_nhwc(inp, b["inp"])
         ops.nchw_to_nhwc(corr, b["corr"])
+        self._hoist_inp(W, b)
         flow = flow.float().contiguous()
         self._chain(W, b, flow, torch.cuda.current_stream(), None, flow_is_delta=True)
         return (ops.nhwc_to_nchw(b["hA"]), ops.nhwc_to_nchw(b["mask"]), ops.nhwc_to_nchw(b["delta"]))
 
-    def step(self, corr_fn, coords1, tail=None, flow_up=None):
-        """coords1 (B,2,h,w) -> (coords1 + delta_flow (B,2,h,w), flow_up (B,2,8h,8w)).
-        tail(b0, b1, flow_up[b0:b1]) is called on the stream of each batch half right after its up-sampling."""
+    def halves(self, B):
+        """Image ranges of the concurrent chains: two halves of the batch (one stream each), or the whole batch."""
+        return [(0, B)] if (B < 2 or not self.split_batch) else [(0, B // 2), (B // 2, B)]
+
+    def half_gen(self, corr_fn, coords1_part, B, b0, b1, st, flow_up_part, single=False):
+        """One GRU step of images [b0, b1) on stream `st` (current): window lookup -> update block -> convex up-sampling.
+        coords1_part (b1-b0,2,h,w); flow_up_part (b1-b0,2,8h,8w) is written.  Generator: yields after every launch so
+        that a caller can issue several chains alternately.  single: this is the only chain (B = 1): the flow-feature /
+        flow-head side chain then runs on a helper stream (the only concurrency there is; nested forks inside two
+        concurrent chains segfault hipStreamEndCapture on ROCm 7.2)."""
         W = self._weights()
-        B, _, h, w = coords1.shape
-        b = self._b
-        main = torch.cuda.current_stream()
-        ops.corr_lookup_nhwc(corr_fn._buf, coords1, b["corr"], corr_fn.num_levels, corr_fn.radius)
-        # Batch split: the two halves of the batch run their (otherwise strictly sequential) chains on two streams = two
-        # parallel hipGraph branches.  Every convolution of this workload is a ONE-round kernel (600-1200 tiles on 768
-        # resident slots) whose ramp-up, lock-step prologue and epilogue burst cost ~30 % against the multi-round steady
-        # state (tools/conv_quant.py, tools/conv_streams.py); two kernels in flight fill those gaps.  Each half also runs
-        # its own tail (up-sampling, descriptor weight, LM) on its stream.  Results are bit-identical (images are
-        # independent).
-        halves = [(0, B)] if (B < 2 or not self.split_batch) else [(0, B // 2), (B // 2, B)]
-        if flow_up is None:
-            flow_up = torch.empty(B, 2, 8 * h, 8 * w, device=coords1.device, dtype=torch.float32)
+        view = {k: v[b0:b1] for k, v in self._b.items()}
+        ops.corr_lookup_nhwc_part(corr_fn._buf, coords1_part, view["corr"], B, b0, b1, corr_fn.num_levels, corr_fn.radius)
+        yield
+        yield from self._chain_gen(W, view, coords1_part, st, self._stream(coords1_part.device, 2) if single else None)
+        ops.convex_upsample_nhwc(view["flow_lr"], view["mask"], out=flow_up_part)
+        yield
+
+    @staticmethod
+    def run_interleaved(jobs, main):
+        """jobs: [(generator, stream)].  Every generator's launches go to its stream; the generators are advanced in turn.
+        Streams other than `main` start after everything already on `main` and `main` waits for them at the end: ONE fork
+        and ONE join, however long the generators are -- a cross-queue dependency costs ~100 us on this GPU (r02 timeline:
+        the second chain of every inner iteration started 115 us after the event it waited for), an in-queue one ~1 us."""
         fork = torch.cuda.Event()
         fork.record(main)
-        joins = []
-        stagger = torch.cuda.Event() if (len(halves) > 1 and self.stagger) else None
-        for hi_, (b0, b1) in enumerate(halves):
-            view = {k: v[b0:b1] for k, v in b.items()}
-            st = main if hi_ == 0 else self._stream(coords1.device, 1)
+        for _, st in jobs:
             if st is not main:
-                st.wait_event(stagger if stagger is not None else fork)
-            with torch.cuda.stream(st):
-                # (one level of fork/join only: nested forks segfault hipStreamEndCapture on ROCm 7.2; the flow-feature /
-                #  flow-head side chain is kept for the unsplit B = 1 case, where it is the only concurrency there is)
-                self._chain(W, view, coords1[b0:b1], st, self._stream(coords1.device, 2) if len(halves) == 1 else None,
-                            mark=stagger if hi_ == 0 else None)
-                ops.convex_upsample_nhwc(view["flow_lr"], view["mask"], out=flow_up[b0:b1])
-                if tail is not None:
-                    tail(b0, b1, flow_up[b0:b1])
-                if st is not main:
-                    j = torch.cuda.Event()
-                    j.record(st)
-                    joins.append(j)
-        for j in joins:
-            main.wait_event(j)
-        return b["coords1"], flow_up
+                st.wait_event(fork)
+        active = list(jobs)
+        while active:
+            for item in list(active):
+                g, st = item
+                with torch.cuda.stream(st):
+                    try:
+                        next(g)
+                    except StopIteration:
+                        active.remove(item)
+        for _, st in jobs:
+            if st is not main:
+                j = torch.cuda.Event()
+                j.record(st)
+                main.wait_event(j)
 
-    def _chain(self, W, b, coords1, main, side, mark=None, flow_is_delta=False):
-        """The update block on the (sub-)batch views `b`, issued on stream `main` (current) with `side` as helper.
+    def step(self, corr_fn, coords1, tail=None, flow_up=None):
+        """coords1 (B,2,h,w) -> (coords1 + delta_flow (B,2,h,w), flow_up (B,2,8h,8w)).
+        tail(b0, b1, flow_up[b0:b1]) is called on the stream of each batch half right after its up-sampling.
+        The two halves of the batch run as two concurrent chains: every convolution of this workload is a ONE-round kernel
+        (300-1200 tiles on 768 resident slots) whose ramp-up, lock-step prologue and epilogue burst cost ~30 % against the
+        multi-round steady state; two kernels in flight fill those gaps.  Bit-identical (images are independent)."""
+        B, _, h, w = coords1.shape
+        main = torch.cuda.current_stream()
+        if flow_up is None:
+            flow_up = torch.empty(B, 2, 8 * h, 8 * w, device=coords1.device, dtype=torch.float32)
+        hv = self.halves(B)
+
+        def half(b0, b1, st):
+            yield from self.half_gen(corr_fn, coords1[b0:b1], B, b0, b1, st, flow_up[b0:b1], single=len(hv) == 1)
+            if tail is not None:
+                tail(b0, b1, flow_up[b0:b1])
+
+        jobs = []
+        for i, (b0, b1) in enumerate(hv):
+            st = main if i == 0 else self._stream(coords1.device, 1)
+            jobs.append((half(b0, b1, st), st))
+        self.run_interleaved(jobs, main)
+        return self._b["coords1"], flow_up
+
+    def _chain(self, W, b, coords1, main, side, flow_is_delta=False):
+        for _ in self._chain_gen(W, b, coords1, main, side, flow_is_delta):
+            pass
+
+    def _chain_gen(self, W, b, coords1, main, side, flow_is_delta=False):
+        """The update block on the (sub-)batch views `b`, issued on stream `main` (current) with `side` as helper; yields
+        after every launch so that the caller can interleave two chains.
         flow_is_delta: `coords1` holds the flow itself (facade call) instead of absolute coordinates."""
         c = ops.conv2d_nhwc
         R = ops.EPI_RELU
         # Two independent chains feed the motion encoder's last convolution (update.py:89-92): correlation features
-        # (convc1 -> convc2) and flow features (flow_prep -> convf1 -> convf2).  The second one runs on a side stream
-        # (a parallel branch when the step is captured into a hipGraph).  Same for flow_head.conv2 next to mask.2.
+        # (convc1 -> convc2) and flow features (flow_prep -> convf1 -> convf2).  With a helper stream the second one runs
+        # there (a parallel branch when the step is captured into a hipGraph).  Same for flow_head.conv2 next to mask.2.
         def flow_chain():
             ops.flow_prep(coords1, b["flow4"], b["motion"], 126, subtract_grid=not flow_is_delta)   # flow -> convf1 input, motion[126:128]
+            yield
             ops.flow_conv7x7_relu(b["flow4"], W["convf1_wt"], W["convf1_b"], b["flo1"])  # :91 (direct fp32, K = 98)
+            yield
             c(W["convf2"], [(b["flo1"], 0)], (b["corflo"], 192), R)                 # :92
+            yield
 
         join = None
         if side is None:
-            flow_chain()
+            yield from flow_chain()
         else:
             fork = torch.cuda.Event()
             fork.record(main)
             side.wait_event(fork)
             with torch.cuda.stream(side):
-                flow_chain()
+                for _ in flow_chain():
+                    pass
                 join = torch.cuda.Event()
                 join.record(side)
         c(W["convc1"], [(b["corr"], 0)], (b["cor1"], 0), R)                         # update.py:89
+        yield
         c(W["convc2"], [(b["cor1"], 0)], (b["corflo"], 0), R)                       # :90
+        yield
         if join is not None:
             main.wait_event(join)
         c(W["conv"], [(b["corflo"], 0)], (b["motion"], 0), R)                       # :95-96 (126 ch; flow already at 126)
-        hx = lambda hbuf: [(hbuf, 0), (b["inp"], 0), (b["motion"], 0)]              # [h | inp | motion]  (:181, :47)
-        c(W["zr1"], hx(b["hA"]), (b["z"], 0), ops.EPI_GRU_ZR, aux0=(b["hA"], 0), dst2=(b["rh"], 0), gru_c=128)
-        c(W["q1"], hx(b["rh"]), (b["hB"], 0), ops.EPI_GRU_Q, aux0=(b["hA"], 0), aux1=(b["z"], 0))
-        if mark is not None:
-            mark.record(main)                                                       # the other batch half starts here
-        c(W["zr2"], hx(b["hB"]), (b["z"], 0), ops.EPI_GRU_ZR, aux0=(b["hB"], 0), dst2=(b["rh"], 0), gru_c=128)
-        c(W["q2"], hx(b["rh"]), (b["hA"], 0), ops.EPI_GRU_Q, aux0=(b["hB"], 0), aux1=(b["z"], 0))
+        yield
+        hx = lambda hbuf: [(hbuf, 0), (b["motion"], 0)]          # [h | motion]; the `inp` share comes from the hoisted maps
+        c(W["zr1"], hx(b["hA"]), (b["z"], 0), ops.EPI_GRU_ZR, aux0=(b["hA"], 0), dst2=(b["rh"], 0), gru_c=128, add_map=(b["inp1"], 0))
+        yield
+        c(W["q1"], hx(b["rh"]), (b["hB"], 0), ops.EPI_GRU_Q, aux0=(b["hA"], 0), aux1=(b["z"], 0), add_map=(b["inp1"], 256))
+        yield
+        c(W["zr2"], hx(b["hB"]), (b["z"], 0), ops.EPI_GRU_ZR, aux0=(b["hB"], 0), dst2=(b["rh"], 0), gru_c=128, add_map=(b["inp2"], 0))
+        yield
+        c(W["q2"], hx(b["rh"]), (b["hA"], 0), ops.EPI_GRU_Q, aux0=(b["hB"], 0), aux1=(b["z"], 0), add_map=(b["inp2"], 256))
+        yield
         c(W["heads"], [(b["hA"], 0)], (b["heads"], 0), R)                           # flow_head.conv1 | mask.0
+        yield
         head = lambda: ops.flow_head_out(b["heads"], 0, 256, W["flow2_w"], W["flow2_b"], coords1, b["delta"], b["coords1"],
                                          b["flow_lr"])
         if side is None:
             head()
+            yield
             c(W["mask2"], [(b["heads"], 256)], (b["mask"], 0), ops.EPI_LINEAR)      # 0.25 * mask.2(relu(mask.0(h)))
+            yield
             return
         fork2 = torch.cuda.Event()
         fork2.record(main)
@@ -228,6 +284,7 @@ class UpdateEngine:
             join2.record(side)
         c(W["mask2"], [(b["heads"], 256)], (b["mask"], 0), ops.EPI_LINEAR)          # 0.25 * mask.2(relu(mask.0(h)))
         main.wait_event(join2)
+        yield
 
 
 class EncoderEngine:
@@ -332,30 +389,66 @@ class EncoderEngine:
         fork = torch.cuda.Event()
         fork.record(main)
         joins = []
-        for hi_, (x_part, b0, b1) in enumerate(jobs):
-            st = main if hi_ == 0 else self._second_stream(dev, hi_)
+
+        def job(x_part, b0, b1, st):
             if st is not main:
                 st.wait_event(fork)
-            with torch.cuda.stream(st):
-                self._forward(W, x_part, out[b0:b1], normalize)
-                if st is not main:
-                    j = torch.cuda.Event()
-                    j.record(st)
-                    joins.append(j)
+            yield from self._forward_gen(W, x_part, out[b0:b1], normalize)
+            if st is not main:
+                j = torch.cuda.Event()
+                j.record(st)
+                joins.append(j)
+
+        # launches of the jobs are issued alternately (see UpdateEngine.step: hipGraphLaunch submits in capture order)
+        active = []
+        for hi_, (x_part, b0, b1) in enumerate(jobs):
+            st = main if hi_ == 0 else self._second_stream(dev, hi_)
+            active.append((job(x_part, b0, b1, st), st))
+        while active:
+            for item in list(active):
+                g, st = item
+                with torch.cuda.stream(st):
+                    try:
+                        next(g)
+                    except StopIteration:
+                        active.remove(item)
         for j in joins:
             main.wait_event(j)
         return out
 
     def _second_stream(self, device, i):
-        if self._side is None or self._side[0].device != device or len(self._side) < i:
-            self._side = [torch.cuda.Stream(device=device) for _ in range(max(i, 3))]
-        return self._side[i - 1]
+        """Stream of image set / batch part i >= 1 (rnnpose_amd/streams.py: distinct hardware queues)."""
+        from .streams import reserve
+        ss = reserve(device)
+        return (ss.chain + [ss.aux])[(i - 1) % 3]
 
-    def _forward(self, W, x_nchw, out, normalize):
+    def _forward_gen(self, W, x_nchw, out, normalize):
+        """One image set through the encoder (extractor.py:187-232); yields after every launch group."""
+        E = EncoderEngine
         f = self.fnet
-        y = self._norm(ops.stem_conv(W["stem"], x_nchw, normalize), relu=True)       # extractor.py:197-199
+        t = ops.stem_conv(W["stem"], x_nchw, normalize)                              # extractor.py:197 (+ CFNet.py:42-43)
+        yield
+        x = E._norm(t, relu=True)                                                    # :198-199
+        yield
         for li, layer in enumerate((f.layer1, f.layer2, f.layer3), start=1):
             for bi, blk in enumerate(layer):
-                y = self._block(W, f"l{li}.{bi}", blk, y.contiguous())
-        o, _ = self._conv(W["out"], y, stats=False)
+                name = f"l{li}.{bi}"
+                st = blk.conv1.stride[0]
+                t = E._conv(W[name + ".c1"], x, st)
+                yield
+                y = E._norm(t, relu=True)
+                yield
+                res = x
+                if blk.downsample is not None:
+                    t = E._conv(W[name + ".down"], x, st)
+                    yield
+                    res = E._norm(t, relu=False)                                     # norm3, no ReLU
+                    yield
+                t = E._conv(W[name + ".c2"], y)
+                yield
+                x = E._norm(t, relu=True, residual=res)                              # relu(x + relu(IN(.)))
+                yield
+        o, _ = E._conv(W["out"], x, stats=False)
+        yield
         ops.nhwc_to_nchw(o, out=out)
+        yield

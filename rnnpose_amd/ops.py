@@ -225,10 +225,11 @@ def induced_flow(depth, K, G, eps: float = 1e-5, want_vmask: bool = True, absolu
     return flow, vmask
 
 
-def induced_coords_lowres(depth, K, G, h, w, eps: float = 1e-5):
+def induced_coords_lowres(depth, K, G, h, w, eps: float = 1e-5, out=None):
     depth, K, G = _chk(depth, "depth"), _chk(K, "intrinsics"), _chk(G, "G")
     B, H, W = depth.shape[0], depth.shape[-2], depth.shape[-1]
-    out = torch.empty(B, 2, h, w, device=depth.device, dtype=F32)
+    if out is None:
+        out = torch.empty(B, 2, h, w, device=depth.device, dtype=F32)
     _launch("rnnpose_induced_coords_lowres_f32", _ptr(depth), _ptr(K), _ptr(G), B, H, W, h, w, eps, _ptr(out), _stream())
     return out
 
@@ -416,7 +417,7 @@ def _nhwc(t, name):
 
 
 def conv2d_nhwc(pc: PackedConv, srcs, dst, epilogue: int = EPI_LINEAR, aux0=None, aux1=None, dst2=None, gru_c: int = 0,
-                stride: int = 1, tile_stats=None):
+                stride: int = 1, tile_stats=None, add_map=None):
     """srcs: list of (tensor (B,H,W,C), c_offset) matched with pc.seg_counts; dst/aux0/aux1/dst2: (tensor, c_offset).
     Writes in place into dst (and dst2); returns nothing."""
     d = _lib.ConvDesc()
@@ -446,6 +447,10 @@ def conv2d_nhwc(pc: PackedConv, srcs, dst, epilogue: int = EPI_LINEAR, aux0=None
     put("aux0", aux0)
     put("aux1", aux1)
     put("dst2", dst2)
+    if add_map is not None:          # (tensor (B,H,W,Cs), c_offset): per-pixel bias added before the epilogue
+        t, off = add_map
+        _nhwc(t, "add_map")
+        d.add_map, d.add_c_stride, d.add_c_offset = t.data_ptr(), t.shape[3], off
     d.gru_c = gru_c
     if tile_stats is not None:
         # (ceil(M/128), c_out, 2) fp32: per-tile column sums / sums of squares for instnorm_tiles_nhwc
@@ -498,6 +503,18 @@ def corr_lookup_nhwc(pyramid_buf, coords, out=None, levels: int = 4, radius: int
         out = torch.empty(B, h, w, levels * (2 * radius + 1) ** 2, device=coords.device, dtype=F32)
     _launch("rnnpose_corr_lookup_nhwc_f32", _ptr(pyramid_buf), _ptr(coords), B, h, w, levels, radius, _ptr(out), _stream(),
             nbytes=_lookup_bytes(B, h, w, levels, radius))
+    return out
+
+
+def corr_lookup_nhwc_part(pyramid_buf, coords, out, B, b0, b1, levels: int = 4, radius: int = 4):
+    """NHWC lookup of images [b0, b1) of a batch-B pyramid: coords (b1-b0,2,h,w) and out (b1-b0,h,w,levels*81) are the
+    SUB-BATCH tensors."""
+    coords = _chk(coords, "coords")
+    n, _, h, w = coords.shape
+    if n != b1 - b0:
+        raise ValueError("coords must hold the b1 - b0 images of the part")
+    _launch("rnnpose_corr_lookup_nhwc_part_f32", _ptr(pyramid_buf), _ptr(coords), B, b0, b1, h, w, levels, radius, _ptr(out),
+            _stream(), nbytes=_lookup_bytes(b1 - b0, h, w, levels, radius))
     return out
 
 

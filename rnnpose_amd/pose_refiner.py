@@ -90,6 +90,7 @@ class PoseRefiner(nn.Module):
         self._ptr_captures = 0
         self._outer_graphs = {}
         self._outer_captures = 0
+        self.loop_timing = None           # set to [] to collect HIP events around the per-half graph replays
         self._wkey = None                 # identity of the live parameters + engine buffers every captured graph depends on
         self._clear()
 
@@ -190,56 +191,103 @@ class PoseRefiner(nn.Module):
         info = small[o[4]:o[5]].view(torch.int32).view(B)
         return flow_up, wmap, Gn, Hm, bv, xi, info
 
-    def _body(self, depth, K, g1, g2, G, coords0, h, w, ep_l, lm_l):
-        """-> (big, small) output buffers of one inner iteration (see _out_views)."""
-        B, dev = depth.shape[0], depth.device
-        H, W = depth.shape[-2], depth.shape[-1]
-        coords1 = ops.induced_coords_lowres(depth, K, G, h, w, EPS)
-        G3 = G.reshape(-1, 4, 4)
-        big = torch.empty(B * 3 * H * W, device=dev, dtype=torch.float32)
-        small = torch.empty(B * 428, device=dev, dtype=torch.uint8)
-        flow_all, wmap, Gn, Hm, bv, xi, info = self._out_views(big, small, B, H, W)
+    def _loop_buffers(self, B, H, W, h, w, n, dev):
+        """Output / scratch buffers of the n inner iterations of one outer iteration: big (n, B*3*H*W) and small (n, .)
+        rows = iteration i (see _out_views); coords (n,B,2,h,w) the re-projected low-res coordinates."""
+        big = torch.empty(n, B * 3 * H * W, device=dev, dtype=torch.float32)
+        small = torch.empty(n, -(-B * 428 // 16) * 16, device=dev, dtype=torch.uint8)     # rows 16-byte aligned (fp64 views)
+        return dict(big=big, small=small, coords=torch.empty(n, B, 2, h, w, device=dev, dtype=torch.float32),
+                    views=[self._out_views(big[i], small[i], B, H, W) for i in range(n)])
 
-        def tail(b0, b1, flow_up):
-            """descriptor weight + LM step of images [b0, b1) on the stream that produced their flow (PoseRefiner.py:342-356)"""
-            ops.corr_weight(g1[b0:b1], g2[b0:b1], flow_up, depth[b0:b1], self.sigma[0], out=wmap[b0:b1])
-            ops.lm_step(flow_up, wmap[b0:b1], depth[b0:b1], K[b0:b1], G3[b0:b1], num_iters=self.cfg.OPTIM_ITER_COUNT,
-                        ep_lambda=ep_l, lm_lambda=lm_l, max_update=1.0, eps=EPS,
-                        out=(Gn[b0:b1], Hm[b0:b1], bv[b0:b1], xi[b0:b1], info[b0:b1]), slot=b0)
-
-        self.cf_net.step(coords0, coords1, tail=tail, need_coords=False, flow_up_out=flow_all)
-        return big, small
-
-    def _iteration(self, depth, K, g1, g2, G, coords0, h, w, ep_l, lm_l):
-        B, H, W = depth.shape[0], depth.shape[-2], depth.shape[-1]
-        if not self.use_graph or ops.profiling():
-            return self._out_views(*self._body(depth, K, g1, g2, G, coords0, h, w, ep_l, lm_l), B, H, W)
+    def _half_loop(self, bufs, b0, b1, st, depth, K, g1, g2, G3, h, w, ep_l, lm_l, n, single):
+        """Generator: the COMPLETE inner loop of images [b0, b1) on stream `st` -- re-projection of their poses -> window
+        lookup -> update block -> up-sampling -> descriptor weight -> LM step, n times (PoseRefiner.py:315-362).  Images are
+        independent, so nothing synchronises the batch halves per iteration: each half runs its own loop on its own stream
+        (r02 timeline: a per-iteration fork cost ~115 us of every 1.3-ms iteration -- cross-queue dependencies are that
+        slow on this GPU), and the halves drift out of phase, so one half's memory-bound tail runs under the other half's
+        convolutions."""
         eng = self.cf_net.engine()
-        # (coords0 is not part of the key: the HIP engine derives the grid in-kernel and never reads it)
+        B = depth.shape[0]
+        opt = self.cfg.OPTIM_ITER_COUNT
+        Gc = G3[b0:b1]
+        for i in range(n):
+            flow_up, wmap, Gn, Hm, bv, xi, info = (t[b0:b1] for t in bufs["views"][i])
+            coords1 = ops.induced_coords_lowres(depth[b0:b1], K[b0:b1], Gc, h, w, EPS, out=bufs["coords"][i, b0:b1])   # :324-328, CFNet.py:136-144
+            yield
+            yield from eng.half_gen(self.cf_net.corr_fn, coords1, B, b0, b1, st, flow_up, single=single)
+            ops.corr_weight(g1[b0:b1], g2[b0:b1], flow_up, depth[b0:b1], self.sigma[0], out=wmap)                      # :342-345
+            yield
+            ops.lm_step(flow_up, wmap, depth[b0:b1], K[b0:b1], Gc, num_iters=opt, ep_lambda=ep_l, lm_lambda=lm_l,
+                        max_update=1.0, eps=EPS, out=(Gn, Hm, bv, xi, info), slot=b0)                                   # :349-356
+            yield
+            Gc = Gn
+
+    def _loop(self, depth, K, g1, g2, G, h, w, ep_l, lm_l, n):
+        """Eager launches of the n inner iterations -> (big, small); the batch halves' launches are issued alternately."""
+        B, dev = depth.shape[0], depth.device
+        eng = self.cf_net.engine()
+        bufs = self._loop_buffers(B, depth.shape[-2], depth.shape[-1], h, w, n, dev)
+        G3 = G.reshape(-1, 4, 4)
+        hv = eng.halves(B)
+        main = torch.cuda.current_stream()
+        jobs = []
+        for k, (b0, b1) in enumerate(hv):
+            st = main if k == 0 else eng._stream(dev, 1)
+            jobs.append((self._half_loop(bufs, b0, b1, st, depth, K, g1, g2, G3, h, w, ep_l, lm_l, n, len(hv) == 1), st))
+        eng.run_interleaved(jobs, main)
+        return bufs["big"], bufs["small"]
+
+    def _inner_loop(self, depth, K, g1, g2, G, h, w, ep_l, lm_l, n):
+        """-> list of n tuples (flow_up, wmap, G, Hm, bv, xi, info): eager launches, or one replayed hipGraph PER BATCH HALF
+        (each a linear chain on its own stream) per outer iteration."""
+        B, H, W = depth.shape[0], depth.shape[-2], depth.shape[-1]
+        unpack = lambda big, small: [self._out_views(big[i], small[i], B, H, W) for i in range(n)]
+        if not self.use_graph or ops.profiling():
+            return unpack(*self._loop(depth, K, g1, g2, G, h, w, ep_l, lm_l, n))
+        eng = self.cf_net.engine()
         key = (depth.data_ptr(), K.data_ptr(), g1.data_ptr(), g2.data_ptr(), self.cf_net.corr_fn._buf.data_ptr(),
-               tuple(depth.shape), self.cfg.OPTIM_ITER_COUNT, float(ep_l), float(lm_l), eng.buffer_key(), self._wkey)
+               tuple(depth.shape), n, self.cfg.OPTIM_ITER_COUNT, float(ep_l), float(lm_l), eng.buffer_key(), self._wkey)
         gr = self._graph
         if gr is None or gr["key"] != key:
             if self._ptr_captures >= 2:
                 # the views keep moving (a renderer that allocates fresh tensors every outer iteration): re-capturing per
-                # pointer set would cost more than it saves.  Switch to ONE graph over persistent input buffers and pay
+                # pointer set would cost more than it saves.  Switch to ONE graph set over persistent input buffers and pay
                 # a device copy of depth / K / descriptors (~0.65 GB at 480x640, B=8: ~0.25 ms) per outer iteration.
                 sb = self._static_inputs(depth, K, g1, g2)
                 skey = ("static",) + key[4:]
                 gr = self._graph_static
                 if gr is None or gr["key"] != skey:
-                    gr = self._capture(skey, sb["depth"], sb["K"], sb["g1"], sb["g2"], G, coords0, h, w, ep_l, lm_l, static=True)
+                    gr = self._capture(skey, sb["depth"], sb["K"], sb["g1"], sb["g2"], G, h, w, ep_l, lm_l, n, static=True)
             else:
                 self._ptr_captures += 1
-                gr = self._capture(key, depth, K, g1, g2, G, coords0, h, w, ep_l, lm_l)
+                gr = self._capture(key, depth, K, g1, g2, G, h, w, ep_l, lm_l, n)
         if gr is None:                         # capture refused: eager launches from now on (use_graph is off)
-            return self._out_views(*self._body(depth, K, g1, g2, G, coords0, h, w, ep_l, lm_l), B, H, W)
+            return unpack(*self._loop(depth, K, g1, g2, G, h, w, ep_l, lm_l, n))
         gr["G"].copy_(G.reshape(-1, 4, 4))
-        gr["graph"].replay()
-        # outputs live in the graph's private pool and are overwritten by the next replay: the caller gets its own copies
-        # (the reference returns distinct tensors per iteration): two device copies, ~30 MB at 480x640, B=8
-        big, small = gr["out"]
-        return self._out_views(big.clone(), small.clone(), B, H, W)
+        main = torch.cuda.current_stream()
+        timing = self.loop_timing is not None          # measurement hook (tools/loop_overlap.py): when does each half run?
+        fork = torch.cuda.Event(enable_timing=timing)
+        fork.record(main)
+        marks = [fork]
+        for graph, st in gr["graphs"]:          # one linear graph per batch half, replayed on its own stream
+            if st is not main:
+                st.wait_event(fork)
+            with torch.cuda.stream(st):
+                if timing:
+                    e0 = torch.cuda.Event(enable_timing=True)
+                    e0.record(st)
+                    marks.append(e0)
+                graph.replay()
+                j = torch.cuda.Event(enable_timing=timing)
+                j.record(st)
+                marks.append(j)
+            if st is not main:
+                main.wait_event(j)
+        if timing:
+            self.loop_timing.append(marks)
+        # the output buffers belong to the graph record and are overwritten by the next replay: the caller gets its own
+        # copies (the reference returns distinct tensors per iteration): two device copies per OUTER iteration
+        return unpack(gr["bufs"]["big"].clone(), gr["bufs"]["small"].clone())
 
     def _static_inputs(self, depth, K, g1, g2):
         """Persistent copies of the per-outer-iteration inputs of the inner graph; refreshed when the sources change."""
@@ -255,23 +303,40 @@ class PoseRefiner(nn.Module):
             sb["src"] = src
         return sb
 
-    def _capture(self, key, depth, K, g1, g2, G, coords0, h, w, ep_l, lm_l, static=False):
-        """-> graph record, or None when capture is refused (the caller then runs eager launches).  The warm-up launches
-        advance the GRU hidden state; it is restored whatever happens, so an eager retry starts from the right state."""
-        hbuf = self.cf_net.engine()._b["hA"]
+    def _capture(self, key, depth, K, g1, g2, G, h, w, ep_l, lm_l, n, static=False):
+        """-> graph record, or None when capture is refused (the caller then runs eager launches).  One hipGraph per batch
+        half, each a LINEAR chain captured on the stream it will be replayed on: concurrency between the halves comes from
+        the two streams, not from branches inside a graph (a two-branch graph of this length replayed almost serially on
+        ROCm 7.2: r02 timeline, 92 % of the time one kernel in flight).  The warm-up launches advance the GRU hidden
+        state; it is restored whatever happens, so an eager retry starts from the right state."""
+        eng = self.cf_net.engine()
+        hbuf = eng._b["hA"]
         hA = hbuf.clone()
+        B, dev = depth.shape[0], depth.device
         try:
             Gs = G.reshape(-1, 4, 4).clone()
+            main = torch.cuda.current_stream()
             side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
+            side.wait_stream(main)
             with torch.cuda.stream(side):                  # warm-up on a side stream: weight packing, allocator, caches
-                for _ in range(2):
-                    self._body(depth, K, g1, g2, Gs, coords0, h, w, ep_l, lm_l)
-            torch.cuda.current_stream().wait_stream(side)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                out = self._body(depth, K, g1, g2, Gs, coords0, h, w, ep_l, lm_l)
-            gr = dict(key=key, graph=graph, G=Gs, out=out)
+                self._loop(depth, K, g1, g2, Gs, h, w, ep_l, lm_l, n)
+            main.wait_stream(side)
+            hbuf.copy_(hA)
+            bufs = self._loop_buffers(B, depth.shape[-2], depth.shape[-1], h, w, n, dev)
+            hv = eng.halves(B)
+            graphs = []
+            torch.cuda.synchronize()
+            for k, (b0, b1) in enumerate(hv):
+                # both halves replay on pool streams, never on the caller's (default) stream: a graph launched into the
+                # default stream did not overlap with the other half's graph at all (r02: HIP-event timing of the replays)
+                st = eng._stream(dev, k) if len(hv) > 1 else main
+                graph = torch.cuda.CUDAGraph()
+                cap = torch.cuda.Stream()                  # (torch captures on a side stream of its own and replays on the current one)
+                with torch.cuda.graph(graph, stream=cap):
+                    for _ in self._half_loop(bufs, b0, b1, cap, depth, K, g1, g2, Gs, h, w, ep_l, lm_l, n, len(hv) == 1):
+                        pass
+                graphs.append((graph, st))
+            gr = dict(key=key, graphs=graphs, G=Gs, bufs=bufs)
             if static:
                 self._graph_static = gr
             else:
@@ -279,7 +344,7 @@ class PoseRefiner(nn.Module):
             return gr
         except Exception as e:                             # noqa: BLE001 -- any capture failure means "run eagerly"
             import warnings
-            warnings.warn(f"hipGraph capture of the refinement iteration failed ({e!r}); running eager launches")
+            warnings.warn(f"hipGraph capture of the refinement iterations failed ({e!r}); running eager launches")
             self.use_graph = False
             self._graph = self._graph_static = None
             return None
@@ -290,6 +355,9 @@ class PoseRefiner(nn.Module):
     def forward(self, image, Ts, intrinsics, fea_3d=None, Tj_gt=None, obj_cls=None, geofea_3d=None, geofea_2d=None):
         """image (B,3,H0,W0); Ts SE3Sequence (B,1,4,4); intrinsics (B,3,3) -> dict (PoseRefiner.py:366-376)."""
         self._clear()
+        if image is not None and image.is_cuda or intrinsics.is_cuda:
+            from .streams import reserve
+            reserve(intrinsics.device)        # bind the concurrent streams to distinct hardware queues before anything else
         self._refresh()
         cfg = self.cfg
         lm_l, ep_l = cfg.get("LM_LMBDA", LM_LMBDA), cfg.get("EP_LMBDA", EP_LMBDA)
@@ -331,13 +399,16 @@ class PoseRefiner(nn.Module):
                 raise NotImplementedError("with_corr_weight=False has no defined weight in the reference (:347)")
             coords0 = coords_grid_lowres(B, h, w, device=syn_depth.device)
 
+            loop = None
+            if self.fused:      # all ITER_COUNT inner iterations of this outer iteration: one (replayable) unit
+                loop = self._inner_loop(syn_depth, intrinsics_crop, geofea1_crop, geofea2_crop, Tij.G, h, w, ep_l, lm_l,
+                                        cfg.ITER_COUNT)
             for i in range(cfg.ITER_COUNT):
                 self.intrinsics_history.append(intrinsics_crop)
                 syn_depths.append(syn_depth)
                 Tij = Tij.copy(stop_gradients=True)
                 if self.fused:
-                    flow_up, wmap, G, Hm, bv, xi, info = self._iteration(
-                        syn_depth, intrinsics_crop, geofea1_crop, geofea2_crop, Tij.G, coords0, h, w, ep_l, lm_l)
+                    flow_up, wmap, G, Hm, bv, xi, info = loop[i]
                     flow = [flow_up]
                     Tij = SE3Sequence(matrix=G.reshape(B, 1, 4, 4))
                     Tij.last_info, Tij.last_system = info, (Hm, bv, xi)

@@ -23,21 +23,16 @@ def main():
     db = sqlite3.connect(sys.argv[1])
     rows = db.execute("select name, start, end, queue_id, stream_id from kernels order by start").fetchall()
     rows = [(short(n), s, e, q, st) for n, s, e, q, st in rows]
-    # steps are delimited by corr_pyramid launches: 3 per step.  Take the span of the last complete step.
-    pyr = [i for i, r in enumerate(rows) if "corr_pyramid_h3" in r[0]]
-    if len(pyr) < 7:
+    # a step = one refinement = 3 outer iterations = 6 stem launches (2 image sets each).  Take the last step that is
+    # followed by another one: [first stem of the step, first stem of the next step)
+    stems = [i for i, r in enumerate(rows) if "stem_conv" in r[0]]
+    nst = int(sys.argv[sys.argv.index("--stems") + 1]) if "--stems" in sys.argv else 6
+    if len(stems) < 3 * nst:
         print("not enough steps in the trace")
         return
-    # a step starts at the first encoder kernel (stem) before its first volume build
-    stems = [i for i, r in enumerate(rows) if "stem_conv" in r[0]]
-    # last step = last 3 volume builds
-    first_pyr = pyr[-3]
-    i0 = max(i for i in stems if i < first_pyr and rows[i][1] < rows[first_pyr][1] and (first_pyr - i) < 400)
-    # walk back to the first stem of that encoder pass
-    while i0 > 0 and rows[i0][1] - rows[i0 - 1][2] < 20000 and (first_pyr - i0) < 400:
-        i0 -= 1
-    step = rows[i0:]
-    t0, t1 = step[0][1], max(r[2] for r in step)
+    i0, i1 = stems[-2 * nst], stems[-nst]
+    step = rows[i0:i1]
+    t0, t1 = step[0][1], rows[i1][1]
     print(f"step span {(t1 - t0) / 1e6:.3f} ms, {len(step)} dispatches")
     # busy union / concurrency histogram
     ev = []
@@ -63,11 +58,11 @@ def main():
     if "--dump" in sys.argv:
         N = int(sys.argv[sys.argv.index("--dump") + 1])
         # dump one inner iteration in the middle: from a corr_lookup to the next
-        lk = [i for i, r in enumerate(step) if "corr_lookup" in r[0]]
+        lk = [i for i, r in enumerate(step) if "induced_coords" in r[0]]      # one per inner iteration
         a = lk[len(lk) // 2]
         b = lk[len(lk) // 2 + 1]
         base = step[a][1]
-        print(f"--- inner iteration: {(step[b][1] - base) / 1e3:.1f} us between lookups")
+        print(f"--- inner iteration: {(step[b][1] - base) / 1e3:.1f} us per inner iteration")
         for n, s, e, q, st in step[a:b][:N]:
             print(f"  +{(s - base) / 1e3:8.1f} us  dur {(e - s) / 1e3:7.1f} us  q{q} s{st}  {n}")
         # and the encoder/outer part
