@@ -173,8 +173,7 @@ typedef struct {
   int B, H, W;                 /* INPUT spatial size */
   int kh, kw;
   int stride;                  /* 1, or 2 (output = ceil(H/2) x ceil(W/2), padding kh/2, kw/2: the encoder's strided convs) */
-  const void* w_hi;
-  const void* w_lo;
+  const void* w_packed;        /* from rnnpose_conv_pack_weights_f16x3 (fp16 hi and lo parts, MFMA-fragment order) */
   const float* bias;
   int c_out;
   float a_scale, w_scale;
@@ -200,10 +199,10 @@ typedef struct {
   int add_c_stride, add_c_offset;
 } rnnpose_conv_desc_t;
 
-/* number of fp16 elements of EACH of the two packed arrays (hi, lo); -1 on bad arguments */
+/* number of fp16 elements of the packed weight array (hi and lo parts interleaved); -1 on bad arguments */
 long long rnnpose_conv_packed_halfs(int c_out, int kh, int kw, const int* h_seg_counts, int n_seg);
 int rnnpose_conv_pack_weights_f16x3(const float* w_oihw, int c_out, int c_in, int kh, int kw, const int* h_seg_counts,
-                                    int n_seg, float w_scale, void* w_hi, void* w_lo, rnnpose_stream_t stream);
+                                    int n_seg, float w_scale, void* w_packed, rnnpose_stream_t stream);
 int rnnpose_conv2d_nhwc_f16x3(const rnnpose_conv_desc_t* h_desc, rnnpose_stream_t stream);
 
 /* fp16x3 range guard.  Activations are split as x*a_scale = hi + lo in fp16: |x*a_scale| > 65504 does not fit, the hi

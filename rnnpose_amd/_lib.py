@@ -22,7 +22,7 @@ class ConvSrc(C.Structure):
 
 class ConvDesc(C.Structure):       # rnnpose_conv_desc_t
     _fields_ = [("src", ConvSrc * 4), ("n_src", C.c_int), ("B", C.c_int), ("H", C.c_int), ("W", C.c_int),
-                ("kh", C.c_int), ("kw", C.c_int), ("stride", C.c_int), ("w_hi", C.c_void_p), ("w_lo", C.c_void_p), ("bias", C.c_void_p),
+                ("kh", C.c_int), ("kw", C.c_int), ("stride", C.c_int), ("w_packed", C.c_void_p), ("bias", C.c_void_p),
                 ("c_out", C.c_int), ("a_scale", C.c_float), ("w_scale", C.c_float), ("epilogue", C.c_int),
                 ("dst", C.c_void_p), ("dst_c_stride", C.c_int), ("dst_c_offset", C.c_int),
                 ("aux0", C.c_void_p), ("aux0_c_stride", C.c_int), ("aux0_c_offset", C.c_int),
@@ -58,7 +58,7 @@ PROTOTYPES = {
     "rnnpose_gru_gate_f32": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p]),
     "rnnpose_gru_update_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _i, _p]),
     "rnnpose_conv_packed_halfs": (C.c_longlong, [_i, _i, _i, C.POINTER(_i), _i]),
-    "rnnpose_conv_pack_weights_f16x3": (_i, [_p, _i, _i, _i, _i, C.POINTER(_i), _i, _f, _p, _p, _p]),
+    "rnnpose_conv_pack_weights_f16x3": (_i, [_p, _i, _i, _i, _i, C.POINTER(_i), _i, _f, _p, _p]),
     "rnnpose_conv2d_nhwc_f16x3": (_i, [C.POINTER(ConvDesc), _p]),
     "rnnpose_f16x3_saturation_check": (_i, [_i]),
     "rnnpose_f16x3_saturation_count": (_i, [C.POINTER(C.c_ulonglong), _i, _p]),

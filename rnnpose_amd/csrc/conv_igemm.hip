@@ -55,8 +55,7 @@ struct KParams {
   int B, U, V, su, sv;              // slow / fast axis extents and pixel strides
   int G, T, du0, dv0;               // groups (slow-axis taps) x taps per group (fast axis)
   int stride, Uin, Vin, gkw, dvg0;  // strided mode (stride 2): no tap sharing, G = kh*kw groups decoded as (g / gkw, g % gkw)
-  const _Float16* whi;
-  const _Float16* wlo;
+  const uint4* wpk;                 // packed weights: [g][cb][t][32-col tile][hi kk0, hi kk1, lo kk0, lo kk1][lane] x 16 bytes
   int Npad;
   const float* bias;
   int Cout;
@@ -115,8 +114,15 @@ __device__ long long g_conv_ts[64 * 8];
 // side, each ALL 128 rows x 32 columns (NI must be 1).  Same MFMA count per wave, but a wave then requests 2 weight
 // fragments per k-slab from L2/L1 instead of 4 (the fragment loads were stalling in the vector-memory queue when two
 // workgroups share a CU: r01 timestamps) and reads 8 activation fragments from LDS instead of 4.
-template <int NI, bool STRIDED, bool COLS4 = false>
+// TT = taps per group as a compile-time constant (1, 3, 5, 7: the stride-1 convolutions) or 0 (generic stage machine: the
+// stride-2 convolutions, where every tap is its own group).  With TT > 0 the main loop is a plain nest
+//     for (group, 32-channel block): [request next activation tile] ; T taps unrolled ; [split + store, barrier]
+// whose LDS buffer index, weight-register stage and tap shift are compile-time constants, and the weight fragments of
+// consecutive stages are consecutive 4-KB records: r02 counters showed ~40 vector + ~50 scalar bookkeeping instructions
+// per 12 MFMAs in the generic loop, on a SIMD that can issue ~8 instructions per MFMA slot for all its waves together.
+template <int NI, bool STRIDED, bool COLS4 = false, int TT = 0>
 __global__ __launch_bounds__(NT, (COLS4 ? 3 : 2)) void conv_igemm_f16x3_kernel(const KParams p) {
+  static_assert(TT == 0 || (!STRIDED && (TT & 1)), "the unrolled loop is for stride 1 and odd tap counts");
   static_assert(!COLS4 || NI == 1, "the 4-column layout has one 32-column MFMA tile per wave");
   constexpr int MI = COLS4 ? 4 : 2;                     // 32-row MFMA tiles per wave
   constexpr int BNT = COLS4 ? 128 : 64 * NI;
@@ -234,18 +240,20 @@ __global__ __launch_bounds__(NT, (COLS4 ? 3 : 2)) void conv_igemm_f16x3_kernel(c
   const int ntiles32 = p.Npad >> 5;
 #define RP_LOAD_B(S_, G_, T_, CB_)                                                                          \
   do {                                                                                                      \
-    const long long f_ = (((static_cast<long long>(G_) * p.T + (T_)) * p.ncb + (CB_)) * ntiles32 + ntile0) * 128 + lane; \
-    const uint4* hs_ = reinterpret_cast<const uint4*>(p.whi) + f_;                                          \
-    const uint4* ls_ = reinterpret_cast<const uint4*>(p.wlo) + f_;                                          \
-    b##S_##h00 = hs_[0];                                                                                    \
-    b##S_##h01 = hs_[64];                                                                                   \
-    b##S_##l00 = ls_[0];                                                                                    \
-    b##S_##l01 = ls_[64];                                                                                   \
+    /* record index in the packed order [ky][cb][kx]; strided mode: group G_ = ky * kw + kx, one tap each */ \
+    const long long st_ = STRIDED ? (static_cast<long long>((G_) / p.gkw) * p.ncb + (CB_)) * p.gkw + (G_) % p.gkw \
+                                  : (static_cast<long long>(G_) * p.ncb + (CB_)) * p.T + (T_);             \
+    const long long f_ = (st_ * ntiles32 + ntile0) * 256 + lane;                                            \
+    const uint4* ws_ = p.wpk + f_;                                                                          \
+    b##S_##h00 = ws_[0];                                                                                    \
+    b##S_##h01 = ws_[64];                                                                                   \
+    b##S_##l00 = ws_[128];                                                                                  \
+    b##S_##l01 = ws_[192];                                                                                  \
     if (NI == 2) {                                                                                          \
-      b##S_##h10 = hs_[128];                                                                                \
-      b##S_##h11 = hs_[192];                                                                                \
-      b##S_##l10 = ls_[128];                                                                                \
-      b##S_##l11 = ls_[192];                                                                                \
+      b##S_##h10 = ws_[256];                                                                                \
+      b##S_##h11 = ws_[320];                                                                                \
+      b##S_##l10 = ws_[384];                                                                                \
+      b##S_##l11 = ws_[448];                                                                                \
     }                                                                                                       \
   } while (0)
 #define RP_LOAD_B_CLAMPED(S_)                                                                               \
@@ -331,6 +339,76 @@ __global__ __launch_bounds__(NT, (COLS4 ? 3 : 2)) void conv_igemm_f16x3_kernel(c
     const uint4 z = make_uint4(0u, 0u, 0u, 0u);
     *reinterpret_cast<uint4*>(sAf + (tid / (RS / 8)) * (PROWS * RS) + AROWS * RS + (tid % (RS / 8)) * 8) = z;
   }
+  if constexpr (TT > 0) {
+    // ---------------- unrolled main loop (stride 1) ----------------
+    // weight fragments: two stages of [ni][hi kk0, hi kk1, lo kk0, lo kk1]; stage s of this wave = 4 (8 for NI = 2) wave
+    // loads at fixed offsets from  wp + s * sstride  (packed in consumption order)
+    uint4 bf[2][NI][4];
+    const uint4* wp = p.wpk + static_cast<long long>(ntile0) * 256 + lane;
+    const int sstride = ntiles32 * 256;
+    const int nit = p.G * p.ncb, nst = nit * TT;
+#define RP_LOADB2(S_, ST_)                                                                                  \
+    {                                                                                                       \
+      const int st_ = (ST_) < nst ? (ST_) : nst - 1;          /* unconditional: past the end re-reads the last record */ \
+      const uint4* q_ = wp + static_cast<long long>(st_) * sstride;                                         \
+      _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                                     \
+          _Pragma("unroll") for (int qq = 0; qq < 4; ++qq) bf[S_][ni][qq] = q_[ni * 256 + qq * 64];         \
+    }
+#define RP_MMA_KK2(S_, KK_, AB_)                                                                            \
+    {                                                                                                       \
+      const int ko = KK_ * 16 + lh * 8;                                                                     \
+      h8 ah[MI], al[MI], bh[NI], bl[NI];                                                                    \
+      _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) {                                                   \
+        const int row = (COLS4 || okm_[mi]) ? wm * 64 + mi * 32 + l31 + HALO + dv_ : AROWS;                 \
+        ah[mi] = *reinterpret_cast<const h8*>(sAf + (AB_) * (2 * PROWS * RS) + row * RS + ko);             \
+        al[mi] = *reinterpret_cast<const h8*>(sAf + (AB_) * (2 * PROWS * RS) + PROWS * RS + row * RS + ko); \
+        if (COLS4 && !okm_[mi]) { ah[mi] = zero_; al[mi] = zero_; }                                         \
+      }                                                                                                     \
+      _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) {                                                   \
+        bh[ni] = __builtin_bit_cast(h8, bf[S_][ni][KK_]);                                                   \
+        bl[ni] = __builtin_bit_cast(h8, bf[S_][ni][2 + KK_]);                                               \
+      }                                                                                                     \
+      _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)   \
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);      \
+      _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)   \
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);      \
+      _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)   \
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);      \
+    }
+    // one (group, channel block): PAR_ = parity of its index = LDS buffer it reads = weight stage of its first tap
+#define RP_BODY(PAR_)                                                                                       \
+    {                                                                                                       \
+      int ncb_ = ccb + 1, ng_ = cg;                                                                         \
+      if (ncb_ == p.ncb) { ncb_ = 0; ++ng_; }                                                               \
+      RP_LOAD_A(ng_ < p.G ? ng_ : cg, ng_ < p.G ? ncb_ : ccb);       /* next tile (the last one re-requests itself) */ \
+      _Pragma("unroll") for (int t = 0; t < TT; ++t) {                                                      \
+        const int dv_ = p.dv0 + t;                                                                          \
+        const h8 zero_ = {0, 0, 0, 0, 0, 0, 0, 0};                                                          \
+        bool okm_[MI];                                                                                      \
+        _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                                   \
+            okm_[mi] = static_cast<unsigned>(fv[mi] + dv_) < static_cast<unsigned>(p.V);                    \
+        RP_MMA_KK2(((PAR_) + t) & 1, 0, PAR_)                                                               \
+        RP_MMA_KK2(((PAR_) + t) & 1, 1, PAR_)                                                               \
+        RP_LOADB2(((PAR_) + t) & 1, s0 + t + 2)                                                             \
+      }                                                                                                     \
+      s0 += TT;                                                                                             \
+      ccb = ncb_; cg = ng_;                                                                                 \
+      RP_STORE_A((PAR_) ^ 1);                                                                               \
+      __syncthreads();                                                                                      \
+    }
+    RP_LOAD_A(0, 0);
+    RP_STORE_A(0);
+    RP_LOADB2(0, 0)
+    RP_LOADB2(1, 1)
+    __syncthreads();
+    int cg = 0, ccb = 0, s0 = 0, it = 0;
+    for (; it + 1 < nit; it += 2) {
+      RP_BODY(0)
+      RP_BODY(1)
+    }
+    if (it < nit) RP_BODY(0)
+  } else {
+    // ---------------- generic stage machine (stride 2) ----------------
   RP_LOAD_A(0, 0);
   RP_STORE_A(0);
   int ab = 0;                      // LDS buffer holding the activation tile being consumed
@@ -356,6 +434,7 @@ __global__ __launch_bounds__(NT, (COLS4 ? 3 : 2)) void conv_igemm_f16x3_kernel(c
   }
   if (total & 1) RP_STAGE(0);
 
+  }
 #ifdef RP_CONV_TS
   if (ts_on) for (int e = lane; e < 64 * 8; e += 64) g_conv_ts[e] = ts_lds[e];
 #endif
@@ -488,22 +567,26 @@ struct PackParams {
   float w_scale;
 };
 
-__global__ void pack_weights_kernel(const float* __restrict__ w, _Float16* __restrict__ hi, _Float16* __restrict__ lo,
-                                    const PackParams q) {
-  const long long total = static_cast<long long>(q.G) * q.T * q.ncb * q.Npad * BK;
+__global__ void pack_weights_kernel(const float* __restrict__ w, _Float16* __restrict__ pk, const PackParams q) {
+  const long long total = static_cast<long long>(q.G) * q.T * q.ncb * q.Npad * BK * 2;
   const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= total) return;
-  // fragment order: [g][t][cb][n tile of 32][kk][lane][8]: lane l carries column n = 32*tile + (l & 31) and the 8
-  // channels k = 16*kk + 8*(l >> 5) + j  -- exactly one MFMA B operand (16 bytes per lane, 1 KB per wave load)
+  // consumption order of the kernels: [g][cb][t][32-col tile][part: hi kk0, hi kk1, lo kk0, lo kk1][lane][8] -- one stage
+  // (group, channel block, tap) of one 32-column tile is 4 KB contiguous = the four 1-KB wave loads of that stage at fixed
+  // offsets from ONE address; lane l carries column n = 32*tile + (l & 31) and the 8 channels k = 16*kk + 8*(l >> 5) + j
+  // -- exactly one MFMA B operand (16 bytes per lane)
   const int j8 = static_cast<int>(i % 8);
   const int ln = static_cast<int>((i / 8) % 64);
-  const int kk = static_cast<int>((i / 512) % 2);
-  const int ntl = static_cast<int>((i / 1024) % (q.Npad / 32));
+  const int part = static_cast<int>((i / 512) % 4);
+  const int kk = part & 1;
+  const int nt32 = q.Npad / 32;
+  const int ntl = static_cast<int>((i / 2048) % nt32);
+  const long long st = i / (2048LL * nt32);                 // stage index (g * ncb + cb) * T + t
+  const int t = static_cast<int>(st % q.T);
+  const int cb = static_cast<int>((st / q.T) % q.ncb);
+  const int g = static_cast<int>(st / (static_cast<long long>(q.T) * q.ncb));
   const int k = kk * 16 + (ln >> 5) * 8 + j8;
   const int n = ntl * 32 + (ln & 31);
-  const int cb = static_cast<int>((i / (static_cast<long long>(BK) * q.Npad)) % q.ncb);
-  const int t = static_cast<int>((i / (static_cast<long long>(BK) * q.Npad * q.ncb)) % q.T);
-  const int g = static_cast<int>(i / (static_cast<long long>(BK) * q.Npad * q.ncb * q.T));
   const int s = q.cb_seg[cb];
   const int cl = q.cb_c0[cb] + k;
   float v = 0.f;
@@ -514,8 +597,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, _Float16* __res
     v = w[((static_cast<long long>(n) * q.Cin + ci) * q.kh + ky) * q.kw + kx] * q.w_scale;
   }
   const _Float16 h = static_cast<_Float16>(v);
-  hi[i] = h;
-  lo[i] = static_cast<_Float16>(v - static_cast<float>(h));
+  pk[i] = part < 2 ? h : static_cast<_Float16>(v - static_cast<float>(h));
 }
 
 int fill_cb_tables(const int* counts, int n, unsigned char* cb_seg, short* cb_c0) {
@@ -541,13 +623,13 @@ long long rnnpose_conv_packed_halfs(int c_out, int kh, int kw, const int* h_seg_
   const int ncb = fill_cb_tables(h_seg_counts, n_seg, cs, c0);
   if (ncb < 0) return -1;
   const long long Npad = static_cast<long long>(rp::cdiv(c_out, BN)) * BN;
-  return static_cast<long long>(kh) * kw * ncb * Npad * BK;
+  return static_cast<long long>(kh) * kw * ncb * Npad * BK * 2;       // hi and lo parts interleaved in one array
 }
 
 int rnnpose_conv_pack_weights_f16x3(const float* w_oihw, int c_out, int c_in, int kh, int kw, const int* h_seg_counts,
-                                    int n_seg, float w_scale, void* w_hi, void* w_lo, rnnpose_stream_t stream) {
+                                    int n_seg, float w_scale, void* w_packed, rnnpose_stream_t stream) {
   const char* fn = "rnnpose_conv_pack_weights_f16x3";
-  RP_REQUIRE(w_oihw && w_hi && w_lo && h_seg_counts, fn, "null pointer");
+  RP_REQUIRE(w_oihw && w_packed && h_seg_counts, fn, "null pointer");
   RP_REQUIRE(n_seg >= 1 && n_seg <= 4, fn, "1..4 source segments");
   RP_REQUIRE((kh & 1) && (kw & 1) && kh <= 7 && kw <= 7, fn, "odd kernel sizes up to 7");
   PackParams q{};
@@ -567,9 +649,9 @@ int rnnpose_conv_pack_weights_f16x3(const float* w_oihw, int c_out, int c_in, in
   q.T = q.vertical ? kh : kw;
   q.Npad = rp::cdiv(c_out, BN) * BN;
   q.w_scale = w_scale;
-  const long long total = static_cast<long long>(q.G) * q.T * q.ncb * q.Npad * BK;
+  const long long total = static_cast<long long>(q.G) * q.T * q.ncb * q.Npad * BK * 2;
   hipLaunchKernelGGL(pack_weights_kernel, dim3(rp::cdiv(total, 256)), dim3(256), 0, rp::as_stream(stream), w_oihw,
-                     static_cast<_Float16*>(w_hi), static_cast<_Float16*>(w_lo), q);
+                     static_cast<_Float16*>(w_packed), q);
   return rp::check_launch(fn);
 }
 
@@ -579,7 +661,8 @@ int rnnpose_conv2d_nhwc_f16x3(const rnnpose_conv_desc_t* d, rnnpose_stream_t str
   RP_REQUIRE(d->n_src >= 1 && d->n_src <= 4, fn, "1..4 sources");
   RP_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->c_out > 0, fn, "bad size");
   RP_REQUIRE((d->kh & 1) && (d->kw & 1) && d->kh <= 7 && d->kw <= 7, fn, "odd kernel sizes up to 7");
-  RP_REQUIRE(d->w_hi && d->w_lo && d->bias && d->dst, fn, "null pointer");
+  RP_REQUIRE(d->w_packed && d->bias && d->dst, fn, "null pointer");
+  RP_REQUIRE(reinterpret_cast<uintptr_t>(d->w_packed) % 16 == 0, fn, "packed weights must be 16-byte aligned");
   RP_REQUIRE(d->epilogue >= 0 && d->epilogue <= 3, fn, "epilogue must be 0..3");
   RP_REQUIRE(d->stride == 1 || d->stride == 2, fn, "stride must be 1 or 2");
   RP_REQUIRE(d->a_scale > 0.f && d->w_scale > 0.f, fn, "scales must be positive");
@@ -633,9 +716,8 @@ int rnnpose_conv2d_nhwc_f16x3(const rnnpose_conv_desc_t* d, rnnpose_stream_t str
     p.U = Ho; p.V = Wo;
     p.G = d->kh * d->kw; p.T = 1; p.gkw = d->kw; p.du0 = -(d->kh / 2); p.dvg0 = -(d->kw / 2); p.dv0 = 0;
   }
-  RP_REQUIRE(p.T / 2 <= HALO, fn, "kernel too wide for the staged halo");
-  p.whi = static_cast<const _Float16*>(d->w_hi);
-  p.wlo = static_cast<const _Float16*>(d->w_lo);
+  RP_REQUIRE(p.T / 2 <= HALO && (p.stride == 2 || p.T == 1 || p.T == 3 || p.T == 5 || p.T == 7), fn, "kernel too wide for the staged halo");
+  p.wpk = static_cast<const uint4*>(d->w_packed);
   p.Npad = rp::cdiv(d->c_out, BN) * BN;
   p.bias = d->bias; p.Cout = d->c_out;
   p.a_scale = d->a_scale;
@@ -655,32 +737,37 @@ int rnnpose_conv2d_nhwc_f16x3(const rnnpose_conv_desc_t* d, rnnpose_stream_t str
   const long long Mtot = static_cast<long long>(d->B) * Ho * Wo;
   RP_REQUIRE(Mtot < (1LL << 31) - 256 && static_cast<long long>(d->B) * d->H * d->W < (1LL << 31) - 256, fn, "too many pixels");
   p.n_mt = rp::cdiv(Mtot, BM);
-  {
-    const char* e = getenv("RNNPOSE_CONV_DBG");
-    p.dbg = e ? atoi(e) : 0;
-  }
+  p.dbg = 0;
   // tile width: 128 when Cout fills it and there are enough workgroups for 2 per CU, else 64
-  bool wide = (d->c_out % 128 == 0) && (static_cast<long long>(p.n_mt) * (d->c_out / 128) >= 512);
-  if (p.dbg & 32) wide = false;
-  if (p.dbg & 64) wide = (d->c_out % 128 == 0);
+  const bool wide = (d->c_out % 128 == 0) && (static_cast<long long>(p.n_mt) * (d->c_out / 128) >= 512);
   const dim3 block(NT);
+  hipStream_t st = rp::as_stream(stream);
+  // stride 1: the main loop unrolled over the taps of a group (T = kw, or kh for vertical kernels); stride 2: generic loop
+#define RP_LAUNCH_T(NI_, COLS4_)                                                                                   \
+  switch (p.T) {                                                                                                    \
+    case 1: hipLaunchKernelGGL((conv_igemm_f16x3_kernel<NI_, false, COLS4_, 1>), grid, block, 0, st, p); break;    \
+    case 3: hipLaunchKernelGGL((conv_igemm_f16x3_kernel<NI_, false, COLS4_, 3>), grid, block, 0, st, p); break;    \
+    case 5: hipLaunchKernelGGL((conv_igemm_f16x3_kernel<NI_, false, COLS4_, 5>), grid, block, 0, st, p); break;    \
+    default: hipLaunchKernelGGL((conv_igemm_f16x3_kernel<NI_, false, COLS4_, 7>), grid, block, 0, st, p); break;   \
+  }
   if (wide) {
     p.n_nt = p.Npad / 128;
     const dim3 grid(static_cast<unsigned>(p.n_mt) * p.n_nt);
-    const bool cols4 = !(p.dbg & 128);          // 4-column wave layout (default); dbg bit 128 = the 2x2 layout
     if (p.stride == 2) {
-      if (cols4) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<1, true, true>), grid, block, 0, rp::as_stream(stream), p);
-      else hipLaunchKernelGGL((conv_igemm_f16x3_kernel<2, true, false>), grid, block, 0, rp::as_stream(stream), p);
+      hipLaunchKernelGGL((conv_igemm_f16x3_kernel<1, true, true>), grid, block, 0, st, p);
     } else {
-      if (cols4) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<1, false, true>), grid, block, 0, rp::as_stream(stream), p);
-      else hipLaunchKernelGGL((conv_igemm_f16x3_kernel<2, false, false>), grid, block, 0, rp::as_stream(stream), p);
+      RP_LAUNCH_T(1, true)
     }
   } else {
     p.n_nt = rp::cdiv(d->c_out, 64);
     const dim3 grid(static_cast<unsigned>(p.n_mt) * p.n_nt);
-    if (p.stride == 2) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<1, true, false>), grid, block, 0, rp::as_stream(stream), p);
-    else hipLaunchKernelGGL((conv_igemm_f16x3_kernel<1, false, false>), grid, block, 0, rp::as_stream(stream), p);
+    if (p.stride == 2) {
+      hipLaunchKernelGGL((conv_igemm_f16x3_kernel<1, true, false>), grid, block, 0, st, p);
+    } else {
+      RP_LAUNCH_T(1, false)
+    }
   }
+#undef RP_LAUNCH_T
   return rp::check_launch(fn);
 }
 

@@ -403,11 +403,10 @@ class PackedConv:
         n = int(_lib.load().rnnpose_conv_packed_halfs(self.c_out, self.kh, self.kw, segs, len(self.seg_counts)))
         if n <= 0:
             raise ValueError("unsupported convolution shape")
-        self.w_hi = torch.empty(n, device=w.device, dtype=torch.float16)
-        self.w_lo = torch.empty(n, device=w.device, dtype=torch.float16)
+        self.w_packed = torch.empty(n, device=w.device, dtype=torch.float16)
         self.bias = b.contiguous()
         _lib.call("rnnpose_conv_pack_weights_f16x3", _ptr(w), self.c_out, self.c_in, self.kh, self.kw, segs,
-                  len(self.seg_counts), self.w_scale, _ptr(self.w_hi), _ptr(self.w_lo), _stream())
+                  len(self.seg_counts), self.w_scale, _ptr(self.w_packed), _stream())
 
 
 def _nhwc(t, name):
@@ -431,7 +430,7 @@ def conv2d_nhwc(pc: PackedConv, srcs, dst, epilogue: int = EPI_LINEAR, aux0=None
         d.src[i] = _lib.ConvSrc(t.data_ptr(), t.shape[3], off, cnt)
     d.n_src = len(srcs)
     d.B, d.H, d.W, d.kh, d.kw, d.stride = B, H, W, pc.kh, pc.kw, stride
-    d.w_hi, d.w_lo, d.bias = pc.w_hi.data_ptr(), pc.w_lo.data_ptr(), pc.bias.data_ptr()
+    d.w_packed, d.bias = pc.w_packed.data_ptr(), pc.bias.data_ptr()
     d.c_out, d.a_scale, d.w_scale, d.epilogue = pc.c_out, pc.a_scale, pc.w_scale, epilogue
 
     def put(prefix, spec):
