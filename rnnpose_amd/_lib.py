@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "librnnpose_hip.so")
+LIB_PATH = os.environ.get("RNNPOSE_LIB") or os.path.join(_PKG, "lib", "librnnpose_hip.so")
 
 _p = C.c_void_p
 _i = C.c_int

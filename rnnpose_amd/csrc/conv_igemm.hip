@@ -121,7 +121,7 @@ __device__ long long g_conv_ts[64 * 8];
 // consecutive stages are consecutive 4-KB records: r02 counters showed ~40 vector + ~50 scalar bookkeeping instructions
 // per 12 MFMAs in the generic loop, on a SIMD that can issue ~8 instructions per MFMA slot for all its waves together.
 template <int NI, bool STRIDED, bool COLS4 = false, int TT = 0>
-__global__ __launch_bounds__(NT, (COLS4 ? 3 : 2)) void conv_igemm_f16x3_kernel(const KParams p) {
+__global__ __launch_bounds__(NT, ((COLS4 || TT > 0) ? 3 : 2)) void conv_igemm_f16x3_kernel(const KParams p) {
   static_assert(TT == 0 || (!STRIDED && (TT & 1)), "the unrolled loop is for stride 1 and odd tap counts");
   static_assert(!COLS4 || NI == 1, "the 4-column layout has one 32-column MFMA tile per wave");
   constexpr int MI = COLS4 ? 4 : 2;                     // 32-row MFMA tiles per wave
@@ -375,32 +375,86 @@ __global__ __launch_bounds__(NT, (COLS4 ? 3 : 2)) void conv_igemm_f16x3_kernel(c
       _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)   \
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);      \
     }
+    // Software pipeline of one tap (2x2 wave layout; the compiler left alone sinks every LDS read and weight load to just
+    // before the MFMA that needs it -- r02 ISA: ds_read_b128 / s_waitcnt lgkmcnt(0) / v_mfma, over and over):
+    //     read A fragments of k-half 1 | 6 MFMAs of k-half 0 | read A fragments of the NEXT tap's k-half 0 | 6 MFMAs of k-half 1
+    //     | request the weight record two stages ahead
+    // with full scheduling fences between the groups, so every LDS read has six MFMAs (>= 192 cycles) and every weight load
+    // a whole tap to land.  Fragment registers are double-buffered (fa_[set]).  Across the barrier at the end of a
+    // (group, channel block) nothing can be prefetched (the other LDS buffer is still being written): one exposed LDS
+    // latency per T taps.  The 4-column layout (MI = 4) has no registers left for this and keeps the simple form.
+    h8 fa_h[2][MI], fa_l[2][MI];
+#ifndef RP_ABL
+#define RP_ABL 0          // ablation build (tools/conv_ablate.sh): bit 0 no weight loads, 1 no LDS fragment reads, 2 no
+#endif                    // activation staging, 3 no barrier, 4 no epilogue stores -- in the main loop of the 2x2 layout
+#define RP_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define RP_READ_A(SET_, T_, KK_, AB_)                                                                       \
+    {                                                                                                       \
+      const int dvr_ = p.dv0 + (T_);                                                                        \
+      const int ko = (KK_) * 16 + lh * 8;                                                                   \
+      _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) {                                                   \
+        const bool ok_ = static_cast<unsigned>(fv[mi] + dvr_) < static_cast<unsigned>(p.V);                \
+        const int row = ok_ ? wm * 64 + mi * 32 + l31 + HALO + dvr_ : AROWS;      /* masked tap: the all-zero row */ \
+        fa_h[SET_][mi] = *reinterpret_cast<const h8*>(sAf + (AB_) * (2 * PROWS * RS) + row * RS + ko);     \
+        fa_l[SET_][mi] = *reinterpret_cast<const h8*>(sAf + (AB_) * (2 * PROWS * RS) + PROWS * RS + row * RS + ko); \
+      }                                                                                                     \
+    }
+#define RP_MFMA6(SET_, S_, KK_)                                                                             \
+    {                                                                                                       \
+      h8 bh[NI], bl[NI];                                                                                    \
+      _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) {                                                   \
+        bh[ni] = __builtin_bit_cast(h8, bf[S_][ni][KK_]);                                                   \
+        bl[ni] = __builtin_bit_cast(h8, bf[S_][ni][2 + KK_]);                                               \
+      }                                                                                                     \
+      _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)   \
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_l[SET_][mi], bh[ni], acc[mi][ni], 0, 0, 0); \
+      _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)   \
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_h[SET_][mi], bl[ni], acc[mi][ni], 0, 0, 0); \
+      _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)   \
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_h[SET_][mi], bh[ni], acc[mi][ni], 0, 0, 0); \
+    }
     // one (group, channel block): PAR_ = parity of its index = LDS buffer it reads = weight stage of its first tap
 #define RP_BODY(PAR_)                                                                                       \
     {                                                                                                       \
       int ncb_ = ccb + 1, ng_ = cg;                                                                         \
       if (ncb_ == p.ncb) { ncb_ = 0; ++ng_; }                                                               \
-      RP_LOAD_A(ng_ < p.G ? ng_ : cg, ng_ < p.G ? ncb_ : ccb);       /* next tile (the last one re-requests itself) */ \
+      if (!COLS4 && !(RP_ABL & 2)) { RP_READ_A(0, 0, 0, PAR_) }                                             \
+      if (!(RP_ABL & 4)) RP_LOAD_A(ng_ < p.G ? ng_ : cg, ng_ < p.G ? ncb_ : ccb);   /* next tile (the last one re-requests itself) */ \
+      if (!COLS4) RP_SCHED_FENCE();                                                                         \
       _Pragma("unroll") for (int t = 0; t < TT; ++t) {                                                      \
-        const int dv_ = p.dv0 + t;                                                                          \
-        const h8 zero_ = {0, 0, 0, 0, 0, 0, 0, 0};                                                          \
-        bool okm_[MI];                                                                                      \
-        _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                                   \
-            okm_[mi] = static_cast<unsigned>(fv[mi] + dv_) < static_cast<unsigned>(p.V);                    \
-        RP_MMA_KK2(((PAR_) + t) & 1, 0, PAR_)                                                               \
-        RP_MMA_KK2(((PAR_) + t) & 1, 1, PAR_)                                                               \
-        RP_LOADB2(((PAR_) + t) & 1, s0 + t + 2)                                                             \
+        if (COLS4) {                                                                                        \
+          const int dv_ = p.dv0 + t;                                                                        \
+          const h8 zero_ = {0, 0, 0, 0, 0, 0, 0, 0};                                                        \
+          bool okm_[MI];                                                                                    \
+          _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                                 \
+              okm_[mi] = static_cast<unsigned>(fv[mi] + dv_) < static_cast<unsigned>(p.V);                  \
+          RP_MMA_KK2(((PAR_) + t) & 1, 0, PAR_)                                                             \
+          RP_MMA_KK2(((PAR_) + t) & 1, 1, PAR_)                                                             \
+          RP_LOADB2(((PAR_) + t) & 1, s0 + t + 2)                                                           \
+        } else {                                                                                            \
+          if (!(RP_ABL & 2)) { RP_READ_A(1, t, 1, PAR_) }                                                   \
+          RP_SCHED_FENCE();                                                                                 \
+          RP_MFMA6(0, ((PAR_) + t) & 1, 0)                                                                  \
+          RP_SCHED_FENCE();                                                                                 \
+          if (t + 1 < TT && !(RP_ABL & 2)) { RP_READ_A(0, t + 1, 0, PAR_) }                                 \
+          RP_SCHED_FENCE();                                                                                 \
+          RP_MFMA6(1, ((PAR_) + t) & 1, 1)                                                                  \
+          RP_SCHED_FENCE();                                                                                 \
+          if (!(RP_ABL & 1)) { RP_LOADB2(((PAR_) + t) & 1, s0 + t + 2) }                                    \
+          RP_SCHED_FENCE();                                                                                 \
+        }                                                                                                   \
       }                                                                                                     \
       s0 += TT;                                                                                             \
       ccb = ncb_; cg = ng_;                                                                                 \
-      RP_STORE_A((PAR_) ^ 1);                                                                               \
-      __syncthreads();                                                                                      \
+      if (!(RP_ABL & 4)) RP_STORE_A((PAR_) ^ 1);                                                            \
+      if (!(RP_ABL & 8)) __syncthreads();                                                                   \
     }
     RP_LOAD_A(0, 0);
     RP_STORE_A(0);
     RP_LOADB2(0, 0)
     RP_LOADB2(1, 1)
     __syncthreads();
+    if (RP_ABL & 2) { RP_READ_A(0, 0, 0, 0) RP_READ_A(1, 0, 1, 0) }
     int cg = 0, ccb = 0, s0 = 0, it = 0;
     for (; it + 1 < nit; it += 2) {
       RP_BODY(0)
@@ -462,6 +516,7 @@ __global__ __launch_bounds__(NT, (COLS4 ? 3 : 2)) void conv_igemm_f16x3_kernel(c
       const int m = m0 + wm * 64 + mi * 32 + rl;
       const int col = colw + c;
       if (m >= Mtot || col >= p.Cout) continue;
+      if ((RP_ABL & 16) && acc[0][0][0] != 12345.678f) continue;
       long long pix = m;
       if (p.sv != 1) {
         const int q = m / p.V, v = m - q * p.V;
