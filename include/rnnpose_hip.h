@@ -313,6 +313,34 @@ int rnnpose_zoom_crop_params_f32(const int* bbox, const float* K, const float* T
 int rnnpose_zoom_crop_f32(const float* in, const float* theta, int B, int C, int H, int W, int crop_h, int crop_w, float* out,
                           float* grid_out, rnnpose_stream_t stream);
 
+/* ---- f4 (second half): triangle-mesh rasteriser of the render hand-off ------------------------------------------------
+ *      geometry/diff_render_optim.py:283-367 (DiffRender.forward / render_depth on PyTorch3D's MeshRasterizer,
+ *      faces_per_pixel = 1, blur 0) and model/PoseRefiner.py:118-143 (render).  PARITY UNPINNED (PyTorch3D absent).
+ * Geometry of a batch: verts (V,3) = the vertices of all loaded models back to back; faces (F,3) int32 = LOCAL vertex
+ * indices, models back to back; image b uses vertices from vert_off[b], faces [face_off[b], face_off[b] + face_cnt[b])
+ * (device int32 arrays of B entries); T (B,4,4) object->camera, K (B,3,3).  A pixel (x, y) samples the ray through
+ * (x + pixel_center, y + pixel_center) (PyTorch3D: 0.5); the nearest face by interpolated camera z wins, equal depths go
+ * to the lower face index; faces with a vertex at z <= near are dropped.
+ * rnnpose_raster_mesh_f32: pass 1, fills the z-buffer `workspace` (rnnpose_raster_workspace_bytes).
+ * rnnpose_raster_resolve_f32: pass 2 from the same workspace and geometry arguments:
+ *   out_zbuf   (B,1,H,W)  interpolated depth, `empty_depth` where no face covers the pixel (the reference uses -1);
+ *   out_vdepth (B,1,H,W)  camera z of the vertex with the largest barycentric weight, 0 where empty (`render_depth`);
+ *   out_attr   (B, 3*with_color + C, H, W): [shaded vertex colour |] attr interpolated with the (perspective-correct if
+ *              requested) barycentrics, 0 where empty.  attr = per-vertex rows of C floats, image b's rows start at element
+ *              attr_off[b] (device int64 array); colors (V,3) per-vertex albedo aligned with verts (NULL = white);
+ *              shade != 0: (0.5 + 0.3 |n.l|) * albedo + 0.2 with the flat face normal and a point light at (1,1,-1) in
+ *              object space (PyTorch3D's default Phong terms at shininess 0).  Any output pointer may be NULL. */
+size_t rnnpose_raster_workspace_bytes(int B, int H, int W);
+int rnnpose_raster_mesh_f32(const float* verts, const int* faces, const int* vert_off, const int* face_off,
+                            const int* face_cnt, int max_faces, const float* T, const float* K, int B, int H, int W,
+                            float near, float pixel_center, int perspective_correct, void* workspace,
+                            size_t workspace_bytes, rnnpose_stream_t stream);
+int rnnpose_raster_resolve_f32(const float* verts, const int* faces, const int* vert_off, const int* face_off, const float* T,
+                               const float* K, int B, int H, int W, float near, float pixel_center, int perspective_correct,
+                               const void* workspace, const float* attr, const long long* attr_off, int C,
+                               const float* colors, int with_color, int shade, float empty_depth, float* out_attr,
+                               float* out_zbuf, float* out_vdepth, rnnpose_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

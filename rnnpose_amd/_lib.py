@@ -84,6 +84,9 @@ PROTOTYPES = {
     "rnnpose_mask_bbox_f32": (_i, [_p, _i, _i, _i, _p, _p]),
     "rnnpose_zoom_crop_params_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _f, _p, _p, _p]),
     "rnnpose_zoom_crop_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
+    "rnnpose_raster_workspace_bytes": (_z, [_i, _i, _i]),
+    "rnnpose_raster_mesh_f32": (_i, [_p, _p, _p, _p, _p, _i, _p, _p, _i, _i, _i, _f, _f, _i, _p, _z, _p]),
+    "rnnpose_raster_resolve_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _i, _p, _p, _p, _i, _p, _i, _i, _f, _p, _p, _p, _p]),
     "rnnpose_pose_metrics_workspace_bytes": (_z, [_i, _i]),
     "rnnpose_pose_metrics_f64": (_i, [_p, _i, _p, _p, _p, _i, _i, _p, _z, _p, _p]),
 }

@@ -26,7 +26,8 @@ class UpdateEngine:
         self._sets = {}           # (B,h,w,device) -> activation buffer set; kept alive because captured hipGraphs hold raw
         self.epoch = 0            # pointers into them.  Bumped whenever a set is freed: graph caches keyed on it are dropped
         import os
-        self.split_batch = os.environ.get("RNNPOSE_SPLIT_BATCH", "1") != "0"   # two concurrent half-batch chains
+        self.split_batch = os.environ.get("RNNPOSE_SPLIT_BATCH", "1") != "0"   # concurrent part-batch chains
+        self.parts = int(os.environ.get("RNNPOSE_PARTS", "2"))
 
     # ---- weights ---------------------------------------------------------------------------------------------
     def _params(self):
@@ -114,7 +115,7 @@ class UpdateEngine:
         from the per-device set that is bound to distinct hardware queues (rnnpose_amd/streams.py)."""
         from .streams import reserve
         ss = reserve(device)
-        return ss.chain[i] if i < 2 else ss.aux
+        return (ss.chain + [ss.aux] + ss.extra)[i]
 
     def load_state(self, net, inp):
         """net, inp: (B,128,h,w) NCHW (tanh / relu of the context features, model/CFNet.py:131-133)."""
@@ -148,8 +149,10 @@ class UpdateEngine:
         return (ops.nhwc_to_nchw(b["hA"]), ops.nhwc_to_nchw(b["mask"]), ops.nhwc_to_nchw(b["delta"]))
 
     def halves(self, B):
-        """Image ranges of the concurrent chains: two halves of the batch (one stream each), or the whole batch."""
-        return [(0, B)] if (B < 2 or not self.split_batch) else [(0, B // 2), (B // 2, B)]
+        """Image ranges of the concurrent chains: `parts` parts of the batch (one stream each), or the whole batch."""
+        n = 1 if (B < 2 or not self.split_batch) else min(self.parts, B)
+        cuts = [B * i // n for i in range(n + 1)]
+        return list(zip(cuts[:-1], cuts[1:]))
 
     def half_gen(self, corr_fn, coords1_part, B, b0, b1, st, flow_up_part, single=False):
         """One GRU step of images [b0, b1) on stream `st` (current): window lookup -> update block -> convex up-sampling.
@@ -210,7 +213,7 @@ class UpdateEngine:
 
         jobs = []
         for i, (b0, b1) in enumerate(hv):
-            st = main if i == 0 else self._stream(coords1.device, 1)
+            st = main if i == 0 else self._stream(coords1.device, i)
             jobs.append((half(b0, b1, st), st))
         self.run_interleaved(jobs, main)
         return self._b["coords1"], flow_up

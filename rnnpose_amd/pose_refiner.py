@@ -232,7 +232,7 @@ class PoseRefiner(nn.Module):
         main = torch.cuda.current_stream()
         jobs = []
         for k, (b0, b1) in enumerate(hv):
-            st = main if k == 0 else eng._stream(dev, 1)
+            st = main if k == 0 else eng._stream(dev, k)
             jobs.append((self._half_loop(bufs, b0, b1, st, depth, K, g1, g2, G3, h, w, ep_l, lm_l, n, len(hv) == 1), st))
         eng.run_interleaved(jobs, main)
         return bufs["big"], bufs["small"]

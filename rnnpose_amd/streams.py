@@ -23,7 +23,8 @@ class StreamSet:
     def __init__(self, device):
         self.chain = [torch.cuda.Stream(device=device) for _ in range(2)]   # the two batch halves / image sets
         self.aux = torch.cuda.Stream(device=device)                          # side chain of an unsplit (B = 1) step
-        for s in self.chain + [self.aux]:
+        self.extra = [torch.cuda.Stream(device=device) for _ in range(2)]    # (experiments with more than two parts)
+        for s in self.chain + [self.aux] + self.extra:
             with torch.cuda.stream(s):
                 torch.zeros(1, device=device)        # first use: binds the stream to its hardware queue now
             s.synchronize()
