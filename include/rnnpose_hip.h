@@ -187,16 +187,22 @@ typedef struct {
   float* dst2;
   int dst2_c_stride, dst2_c_offset;
   int gru_c;
-  float* tile_stats;           /* optional (NULL = off), linear epilogue only: (ceil(M/128), c_out, 2) fp32 receives, per
+  float* tile_stats;           /* optional (NULL = off), linear epilogue only: (B * tiles_per_image, c_out, 2) fp32 receives, per
                                   128-row output tile, the column sums and sums of squares of the outputs (bias included)
                                   -- the instance-norm statistics pass of the encoder without re-reading the tensor
-                                  (rnnpose_instnorm_tiles_nhwc_f32).  M = B*H_out*W_out. */
+                                  (rnnpose_instnorm_tiles_nhwc_f32).  With tile_stats (or src0_mean_rstd) the output rows
+                                  are tiled PER IMAGE: tiles_per_image = ceil(H_out*W_out / 128), the last tile of an
+                                  image ragged, so no tile straddles two images. */
   const float* add_map;        /* optional (NULL = off): NHWC tensor added to y before the epilogue, y += add_map[pixel,
                                   add_c_offset + n] -- a per-pixel bias.  Used to hoist the part of a convolution whose input
                                   does not change between calls (the context half `inp` of the GRU input, constant over the
                                   inner iterations: update.py:181 concatenates it anew every step) out of the loop: conv is
                                   linear, conv([h|inp|m]) = conv([h|m]) + conv(inp).  Needs c_out % 4 == 0, 16-byte alignment. */
   int add_c_stride, add_c_offset;
+  const float* src0_mean_rstd; /* optional (NULL = off): (B, src[0].c_stride, 2) mean / rstd per image and channel of source 0:
+                                  the convolution reads relu((x - mean) * rstd) instead of x -- the instance norm + ReLU
+                                  between conv1 and conv2 of a ResidualBlock (extractor.py:48-52) applied in the load, so
+                                  the normalised tensor is never written.  One source, 3x3, stride 1 only. */
 } rnnpose_conv_desc_t;
 
 /* number of fp16 elements of the packed weight array (hi and lo parts interleaved); -1 on bad arguments */
@@ -268,10 +274,11 @@ size_t rnnpose_instnorm_workspace_bytes(int B, int HW, int C);
 int rnnpose_instnorm_nhwc_f32(const float* x, int B, int HW, int C, float eps, int relu, const float* residual,
                               void* workspace, size_t workspace_bytes, float* mean_rstd, float* out,
                               rnnpose_stream_t stream);
-/* Same normalisation with the statistics taken from the producing convolution's `tile_stats` (rows_per_tile = 128;
- * HW % rows_per_tile == 0 so that no tile straddles two images): only the finalize + apply passes run. */
+/* Same normalisation with the statistics taken from the producing convolution's `tile_stats` (tiles_per_image records per
+ * image, as the producer laid them out): only the finalize + apply passes run.  out == NULL: statistics only (mean_rstd
+ * for a consumer that normalises in its load, rnnpose_conv_desc_t.src0_mean_rstd). */
 int rnnpose_instnorm_tiles_nhwc_f32(const float* x, int B, int HW, int C, float eps, int relu, const float* residual,
-                                    const float* tile_stats, int rows_per_tile, float* mean_rstd, float* out,
+                                    const float* tile_stats, int tiles_per_image, float* mean_rstd, float* out,
                                     rnnpose_stream_t stream);
 
 /* ---- f3 ("next"): brute-force nearest neighbour for ADD-S ------ thirdparty/nn/src/nearest_neighborhood.cu:48-163

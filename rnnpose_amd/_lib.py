@@ -28,7 +28,8 @@ class ConvDesc(C.Structure):       # rnnpose_conv_desc_t
                 ("aux0", C.c_void_p), ("aux0_c_stride", C.c_int), ("aux0_c_offset", C.c_int),
                 ("aux1", C.c_void_p), ("aux1_c_stride", C.c_int), ("aux1_c_offset", C.c_int),
                 ("dst2", C.c_void_p), ("dst2_c_stride", C.c_int), ("dst2_c_offset", C.c_int), ("gru_c", C.c_int),
-                ("tile_stats", C.c_void_p), ("add_map", C.c_void_p), ("add_c_stride", C.c_int), ("add_c_offset", C.c_int)]
+                ("tile_stats", C.c_void_p), ("add_map", C.c_void_p), ("add_c_stride", C.c_int), ("add_c_offset", C.c_int),
+                ("src0_mean_rstd", C.c_void_p)]
 
 
 # name -> (restype, argtypes); mirrors include/rnnpose_hip.h one to one

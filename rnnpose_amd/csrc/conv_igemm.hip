@@ -73,6 +73,8 @@ struct KParams {
   float* tstats;   // optional per-tile column statistics (linear epilogue)
   const float* addm;   // optional per-pixel bias map (NHWC), added before the epilogue
   int addm_cs, addm_co;
+  int tpi;             // > 0: M is tiled PER IMAGE (tpi tiles of 128 rows each, the last one ragged): no tile straddles two images
+  const float* in_mr;  // NORM variant: (B, seg0.cstride, 2) mean / rstd of source 0, applied with ReLU while staging
   int n_mt, n_nt;
   unsigned long long* sat;   // fp16x3 range guard: counter of clamped / non-finite activation quads (NULL = check off)
   int dbg;   // tile-shape overrides for A/B timing (RNNPOSE_CONV_DBG: 32 = 64-wide tiles, 64 = 128-wide tiles, 128 = 2x2 wave layout); 0 in production
@@ -120,7 +122,10 @@ __device__ long long g_conv_ts[64 * 8];
 // whose LDS buffer index, weight-register stage and tap shift are compile-time constants, and the weight fragments of
 // consecutive stages are consecutive 4-KB records: r02 counters showed ~40 vector + ~50 scalar bookkeeping instructions
 // per 12 MFMAs in the generic loop, on a SIMD that can issue ~8 instructions per MFMA slot for all its waves together.
-template <int NI, bool STRIDED, bool COLS4 = false, int TT = 0>
+// NORM: the (single) source is the RAW output of a convolution whose instance norm + ReLU (extractor.py:48-58: relu(norm1(conv1 x)))
+// is applied here, while the tile is split into LDS -- the normalised tensor never exists in HBM.  Needs per-image tiling
+// (one image per workgroup: the statistics of the staged channel quad are two 16-byte loads per 32-channel block).
+template <int NI, bool STRIDED, bool COLS4 = false, int TT = 0, bool NORM = false>
 __global__ __launch_bounds__(NT, ((COLS4 || TT > 0) ? 3 : 2)) void conv_igemm_f16x3_kernel(const KParams p) {
   static_assert(TT == 0 || (!STRIDED && (TT & 1)), "the unrolled loop is for stride 1 and odd tap counts");
   static_assert(!COLS4 || NI == 1, "the 4-column layout has one 32-column MFMA tile per wave");
@@ -146,7 +151,12 @@ __global__ __launch_bounds__(NT, ((COLS4 || TT > 0) ? 3 : 2)) void conv_igemm_f1
   }
   const int nt_i = bid % p.n_nt, mt_i = bid / p.n_nt;
   const int Mtot = p.B * p.U * p.V;          // < 2^31 - 256 (checked on the host): 32-bit index math throughout
-  const int m0 = mt_i * BM;
+  // global tiling: tile t = rows [128 t, 128 t + 128) of the B*U*V pixel rows; per-image tiling (tpi > 0): image t / tpi,
+  // rows [128 (t % tpi), ...) of that image, output rows end with the image (halo rows of a neighbour image are never used:
+  // they could only serve taps across an image line boundary, which the fast-axis masks already zero)
+  const int img_ = p.tpi > 0 ? mt_i / p.tpi : 0;
+  const int m0 = p.tpi > 0 ? img_ * (p.U * p.V) + (mt_i - img_ * p.tpi) * BM : mt_i * BM;
+  const int mend = p.tpi > 0 ? (img_ + 1) * (p.U * p.V) : Mtot;
   const int n0 = nt_i * BNT;
   const int UV = p.U * p.V;
 
@@ -172,7 +182,7 @@ __global__ __launch_bounds__(NT, ((COLS4 || TT > 0) ? 3 : 2)) void conv_igemm_f1
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     const int m = m0 + wm * 64 + mi * 32 + l31;
-    fv[mi] = (m < Mtot) ? m % p.V : -1000;
+    fv[mi] = (m < mend) ? m % p.V : -1000;
   }
 
   f32x16 acc[MI][NI];
@@ -184,6 +194,7 @@ __global__ __launch_bounds__(NT, ((COLS4 || TT > 0) ? 3 : 2)) void conv_igemm_f1
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   float4 av0, av1, av2, av3, av4;
+  float4 nrm01 = make_float4(0.f, 1.f, 0.f, 1.f), nrm23 = nrm01;       // NORM: (mean, rstd) x 4 channels of the tile in flight
   int sat_n = 0;                    // range guard (p.sat != NULL): staged quads this thread had to clamp
   unsigned amask_n = 0u;            // bit r: staged row r of the tile in flight is inside the image (else: zeros)
 #define RP_LOAD_A_ROW(R_)                                                                                   \
@@ -211,6 +222,11 @@ __global__ __launch_bounds__(NT, ((COLS4 || TT > 0) ? 3 : 2)) void conv_igemm_f1
     const int du_ = p.du0 + (STRIDED ? (G_) / p.gkw : (G_));                                                \
     const int dvg_ = STRIDED ? p.dvg0 + (G_) % p.gkw : 0;                                                   \
     const int dpix_ = du_ * p.su;                                                                           \
+    if (NORM) {                      /* mean, rstd of the 4 channels this thread stages (image img_, source 0) */ \
+      const float* mr_ = p.in_mr + (static_cast<long long>(img_) * sg_.cstride + cc_) * 2;                  \
+      nrm01 = *reinterpret_cast<const float4*>(mr_);                                                        \
+      nrm23 = *reinterpret_cast<const float4*>(mr_ + 4);                                                    \
+    }                                                                                                       \
     amask_n = 0u;                                                                                           \
     RP_LOAD_A_ROW(0) RP_LOAD_A_ROW(1) RP_LOAD_A_ROW(2) RP_LOAD_A_ROW(3) RP_LOAD_A_ROW(4)                    \
   } while (0)
@@ -220,7 +236,10 @@ __global__ __launch_bounds__(NT, ((COLS4 || TT > 0) ? 3 : 2)) void conv_igemm_f1
     if (j_ < AROWS) {                                                                                       \
       h4 hi_, lo_;                                                                                          \
       const float4 z4_ = make_float4(0.f, 0.f, 0.f, 0.f);                                                   \
-      split4((amask_n >> R_) & 1u ? av##R_ : z4_, p.a_scale, hi_, lo_);   /* padding / out-of-range rows: zeros */ \
+      float4 xv_ = av##R_;                                                                                  \
+      if (NORM) xv_ = make_float4(fmaxf((xv_.x - nrm01.x) * nrm01.y, 0.f), fmaxf((xv_.y - nrm01.z) * nrm01.w, 0.f), \
+                                  fmaxf((xv_.z - nrm23.x) * nrm23.y, 0.f), fmaxf((xv_.w - nrm23.z) * nrm23.w, 0.f)); \
+      split4((amask_n >> R_) & 1u ? xv_ : z4_, p.a_scale, hi_, lo_);   /* padding / out-of-range rows: zeros (AFTER the norm) */ \
       *reinterpret_cast<h4*>(sAf + (AB_) * (2 * PROWS * RS) + j_ * RS + c4 * 4) = hi_;                      \
       *reinterpret_cast<h4*>(sAf + (AB_) * (2 * PROWS * RS) + PROWS * RS + j_ * RS + c4 * 4) = lo_;         \
     }                                                                                                       \
@@ -515,7 +534,7 @@ __global__ __launch_bounds__(NT, ((COLS4 || TT > 0) ? 3 : 2)) void conv_igemm_f1
       const int rl = idx / F4, c = (idx % F4) * 4;
       const int m = m0 + wm * 64 + mi * 32 + rl;
       const int col = colw + c;
-      if (m >= Mtot || col >= p.Cout) continue;
+      if (m >= mend || col >= p.Cout) continue;
       if ((RP_ABL & 16) && acc[0][0][0] != 12345.678f) continue;
       long long pix = m;
       if (p.sv != 1) {
@@ -784,6 +803,7 @@ int rnnpose_conv2d_nhwc_f16x3(const rnnpose_conv_desc_t* d, rnnpose_stream_t str
   p.dst2 = d->dst2; p.dst2_cs = d->dst2_c_stride; p.dst2_co = d->dst2_c_offset;
   p.gru_c = d->gru_c;
   p.tstats = d->tile_stats;
+  p.in_mr = d->src0_mean_rstd;
   p.addm = d->add_map; p.addm_cs = d->add_c_stride; p.addm_co = d->add_c_offset;
   if (d->add_map) RP_REQUIRE(d->c_out % 4 == 0 && d->add_c_stride % 4 == 0 && d->add_c_offset % 4 == 0 &&
                                  reinterpret_cast<uintptr_t>(d->add_map) % 16 == 0, fn, "add_map: c_out % 4 == 0, 16-byte aligned, stride/offset multiples of 4");
@@ -792,9 +812,17 @@ int rnnpose_conv2d_nhwc_f16x3(const rnnpose_conv_desc_t* d, rnnpose_stream_t str
   const long long Mtot = static_cast<long long>(d->B) * Ho * Wo;
   RP_REQUIRE(Mtot < (1LL << 31) - 256 && static_cast<long long>(d->B) * d->H * d->W < (1LL << 31) - 256, fn, "too many pixels");
   p.n_mt = rp::cdiv(Mtot, BM);
+  p.tpi = 0;
+  if (d->tile_stats || d->src0_mean_rstd) {      // statistics / fused normalisation are per image: tile M per image
+    p.tpi = rp::cdiv(static_cast<long long>(Ho) * Wo, BM);
+    p.n_mt = d->B * p.tpi;
+  }
+  if (d->src0_mean_rstd)
+    RP_REQUIRE(d->n_src == 1 && d->stride == 1 && d->kh == 3 && d->kw == 3 && reinterpret_cast<uintptr_t>(d->src0_mean_rstd) % 16 == 0,
+               fn, "src0_mean_rstd (fused instance norm + ReLU of the input) needs one source, a 3x3 stride-1 kernel, 16-byte alignment");
   p.dbg = 0;
   // tile width: 128 when Cout fills it and there are enough workgroups for 2 per CU, else 64
-  const bool wide = (d->c_out % 128 == 0) && (static_cast<long long>(p.n_mt) * (d->c_out / 128) >= 512);
+  const bool wide = !d->src0_mean_rstd && (d->c_out % 128 == 0) && (static_cast<long long>(p.n_mt) * (d->c_out / 128) >= 512);
   const dim3 block(NT);
   hipStream_t st = rp::as_stream(stream);
   // stride 1: the main loop unrolled over the taps of a group (T = kw, or kh for vertical kernels); stride 2: generic loop
@@ -818,6 +846,8 @@ int rnnpose_conv2d_nhwc_f16x3(const rnnpose_conv_desc_t* d, rnnpose_stream_t str
     const dim3 grid(static_cast<unsigned>(p.n_mt) * p.n_nt);
     if (p.stride == 2) {
       hipLaunchKernelGGL((conv_igemm_f16x3_kernel<1, true, false>), grid, block, 0, st, p);
+    } else if (d->src0_mean_rstd) {
+      hipLaunchKernelGGL((conv_igemm_f16x3_kernel<1, false, false, 3, true>), grid, block, 0, st, p);
     } else {
       RP_LAUNCH_T(1, false)
     }

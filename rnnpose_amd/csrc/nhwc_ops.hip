@@ -517,17 +517,19 @@ int rnnpose_instnorm_nhwc_f32(const float* x, int B, int HW, int C, float eps, i
 
 
 int rnnpose_instnorm_tiles_nhwc_f32(const float* x, int B, int HW, int C, float eps, int relu, const float* residual,
-                                    const float* tile_stats, int rows_per_tile, float* mean_rstd, float* out,
+                                    const float* tile_stats, int tiles_per_image, float* mean_rstd, float* out,
                                     rnnpose_stream_t stream) {
   const char* fn = "rnnpose_instnorm_tiles_nhwc_f32";
-  RP_REQUIRE(x && tile_stats && mean_rstd && out, fn, "null pointer");
+  RP_REQUIRE(tile_stats && mean_rstd && (x || !out), fn, "null pointer");
   RP_REQUIRE(B > 0 && B < 65536 && HW > 0 && C > 0 && C % 4 == 0, fn, "bad size (C % 4 == 0)");
-  RP_REQUIRE(rows_per_tile > 0 && HW % rows_per_tile == 0, fn, "HW must be a multiple of rows_per_tile (no tile may straddle two images)");
+  RP_REQUIRE(tiles_per_image > 0, fn, "tiles_per_image must be positive");
   hipStream_t st = rp::as_stream(stream);
-  hipLaunchKernelGGL(instnorm_finalize_tiles_kernel, dim3(B, rp::cdiv(C, 8)), dim3(256), 0, st, tile_stats, mean_rstd, HW / rows_per_tile, C, HW, eps);
-  const long long total4 = static_cast<long long>(B) * HW * (C >> 2);
-  hipLaunchKernelGGL(instnorm_apply_kernel, dim3(rp::cdiv(total4, 256)), dim3(256), 0, st, x, mean_rstd, residual, out, HW,
-                     C, relu, total4);
+  hipLaunchKernelGGL(instnorm_finalize_tiles_kernel, dim3(B, rp::cdiv(C, 8)), dim3(256), 0, st, tile_stats, mean_rstd, tiles_per_image, C, HW, eps);
+  if (out) {
+    const long long total4 = static_cast<long long>(B) * HW * (C >> 2);
+    hipLaunchKernelGGL(instnorm_apply_kernel, dim3(rp::cdiv(total4, 256)), dim3(256), 0, st, x, mean_rstd, residual, out, HW,
+                       C, relu, total4);
+  }
   return rp::check_launch(fn);
 }
 

@@ -333,16 +333,15 @@ class EncoderEngine:
         return self._w
 
     @staticmethod
-    def _conv(pc, x, stride=1, stats=True):
-        """-> (out, tile_stats or None): when no 128-row tile straddles two images the convolution's epilogue also emits
-        the per-tile column statistics the following instance norm needs (saves re-reading the tensor once)."""
+    def _conv(pc, x, stride=1, stats=True, in_norm=None):
+        """-> (out, tile_stats or None): the convolution's epilogue also emits the per-tile column statistics the following
+        instance norm needs (saves re-reading the tensor once; output rows are tiled per image for that).
+        in_norm: mean / rstd of `x`, which is then a RAW convolution output normalised (+ ReLU) in this convolution's load."""
         B, H, W, _ = x.shape
         Ho, Wo = -(-H // stride), -(-W // stride)
         out = torch.empty(B, Ho, Wo, pc.c_out, device=x.device, dtype=torch.float32)
-        ts = None
-        if stats and (Ho * Wo) % 128 == 0:
-            ts = torch.empty(B * Ho * Wo // 128, pc.c_out, 2, device=x.device, dtype=torch.float32)
-        ops.conv2d_nhwc(pc, [(x, 0)], (out, 0), ops.EPI_LINEAR, stride=stride, tile_stats=ts)
+        ts = torch.empty(B * (-(-(Ho * Wo) // 128)), pc.c_out, 2, device=x.device, dtype=torch.float32) if stats else None
+        ops.conv2d_nhwc(pc, [(x, 0)], (out, 0), ops.EPI_LINEAR, stride=stride, tile_stats=ts, in_norm=in_norm)
         return out, ts
 
     @staticmethod
@@ -357,11 +356,12 @@ class EncoderEngine:
         """ResidualBlock (extractor.py:48-58) on an NHWC tensor; W[name + ".c1" / ".c2" / ".down"] = packed convolutions."""
         E = EncoderEngine
         st = blk.conv1.stride[0]
-        y = E._norm(E._conv(W[name + ".c1"], x, st), relu=True)
+        c1, ts1 = E._conv(W[name + ".c1"], x, st)
+        mr1 = ops.instnorm_tiles_nhwc(c1, ts1, stats_only=True)          # relu(norm1(conv1 x)) is applied in conv2's load
         res = x
         if blk.downsample is not None:
             res = E._norm(E._conv(W[name + ".down"], x, st), relu=False)                          # norm3, no ReLU
-        return E._norm(E._conv(W[name + ".c2"], y), relu=True, residual=res)                      # relu(x + relu(IN(.)))
+        return E._norm(E._conv(W[name + ".c2"], c1, in_norm=mr1), relu=True, residual=res)        # relu(x + relu(IN(.)))
 
     @torch.no_grad()
     def __call__(self, images, normalize=True):
@@ -437,9 +437,9 @@ class EncoderEngine:
             for bi, blk in enumerate(layer):
                 name = f"l{li}.{bi}"
                 st = blk.conv1.stride[0]
-                t = E._conv(W[name + ".c1"], x, st)
+                c1, ts1 = E._conv(W[name + ".c1"], x, st)
                 yield
-                y = E._norm(t, relu=True)
+                mr1 = ops.instnorm_tiles_nhwc(c1, ts1, stats_only=True)  # relu(norm1(.)) happens in conv2's load (extractor.py:48-52)
                 yield
                 res = x
                 if blk.downsample is not None:
@@ -447,7 +447,7 @@ class EncoderEngine:
                     yield
                     res = E._norm(t, relu=False)                                     # norm3, no ReLU
                     yield
-                t = E._conv(W[name + ".c2"], y)
+                t = E._conv(W[name + ".c2"], c1, in_norm=mr1)
                 yield
                 x = E._norm(t, relu=True, residual=res)                              # relu(x + relu(IN(.)))
                 yield

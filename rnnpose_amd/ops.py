@@ -416,7 +416,7 @@ def _nhwc(t, name):
 
 
 def conv2d_nhwc(pc: PackedConv, srcs, dst, epilogue: int = EPI_LINEAR, aux0=None, aux1=None, dst2=None, gru_c: int = 0,
-                stride: int = 1, tile_stats=None, add_map=None):
+                stride: int = 1, tile_stats=None, add_map=None, in_norm=None):
     """srcs: list of (tensor (B,H,W,C), c_offset) matched with pc.seg_counts; dst/aux0/aux1/dst2: (tensor, c_offset).
     Writes in place into dst (and dst2); returns nothing."""
     d = _lib.ConvDesc()
@@ -452,12 +452,16 @@ def conv2d_nhwc(pc: PackedConv, srcs, dst, epilogue: int = EPI_LINEAR, aux0=None
         d.add_map, d.add_c_stride, d.add_c_offset = t.data_ptr(), t.shape[3], off
     d.gru_c = gru_c
     if tile_stats is not None:
-        # (ceil(M/128), c_out, 2) fp32: per-tile column sums / sums of squares for instnorm_tiles_nhwc
-        M = B * (-(-H // stride)) * (-(-W // stride))
+        # (B * ceil(HWout/128), c_out, 2) fp32: per-tile column sums / sums of squares for instnorm_tiles_nhwc
+        tpi = -(-((-(-H // stride)) * (-(-W // stride))) // 128)
         if not (tile_stats.is_cuda and tile_stats.dtype == F32 and tile_stats.is_contiguous()
-                and tile_stats.numel() >= -(-M // 128) * pc.c_out * 2):
-            raise ValueError("tile_stats must be a contiguous fp32 CUDA tensor of (ceil(M/128), c_out, 2)")
+                and tile_stats.numel() >= B * tpi * pc.c_out * 2):
+            raise ValueError("tile_stats must be a contiguous fp32 CUDA tensor of (B * ceil(H_out*W_out/128), c_out, 2)")
         d.tile_stats = tile_stats.data_ptr()
+    if in_norm is not None:          # (B, C_src, 2) mean / rstd of source 0: read relu((x - mean) * rstd) instead of x
+        if not (in_norm.is_cuda and in_norm.dtype == F32 and in_norm.is_contiguous() and tuple(in_norm.shape) == (B, srcs[0][0].shape[3], 2)):
+            raise ValueError("in_norm must be a contiguous fp32 CUDA tensor of (B, C_source, 2)")
+        d.src0_mean_rstd = in_norm.data_ptr()
     _launch("rnnpose_conv2d_nhwc_f16x3", C.byref(d), _stream(),
             work=2.0 * B * (-(-H // stride)) * (-(-W // stride)) * pc.c_out * pc.c_in_real * pc.kh * pc.kw)
 
@@ -638,14 +642,20 @@ def instnorm_nhwc(x, relu=True, residual=None, out=None, eps: float = 1e-5):
     return out
 
 
-def instnorm_tiles_nhwc(x, tile_stats, relu=True, residual=None, out=None, eps: float = 1e-5):
-    """instnorm_nhwc with the statistics pass replaced by the producing convolution's tile_stats (H*W % 128 == 0)."""
+def instnorm_tiles_nhwc(x, tile_stats, relu=True, residual=None, out=None, eps: float = 1e-5, stats_only: bool = False):
+    """instnorm_nhwc with the statistics pass replaced by the producing convolution's tile_stats (B * ceil(HW/128) records).
+    stats_only: -> mean_rstd (B,C,2) only (for a consumer that normalises in its load: conv2d_nhwc(in_norm=...))."""
     _nhwc(x, "x")
     B, H, W, Cc = x.shape
+    tpi = -(-(H * W) // 128)
+    stats = torch.empty(B, Cc, 2, device=x.device, dtype=F32)
+    if stats_only:
+        _launch("rnnpose_instnorm_tiles_nhwc_f32", _ptr(None), B, H * W, Cc, eps, int(bool(relu)), _ptr(None), _ptr(tile_stats), tpi,
+                _ptr(stats), _ptr(None), _stream())
+        return stats
     if out is None:
         out = torch.empty_like(x)
-    stats = torch.empty(B, Cc, 2, device=x.device, dtype=F32)
-    _launch("rnnpose_instnorm_tiles_nhwc_f32", _ptr(x), B, H * W, Cc, eps, int(bool(relu)), _ptr(residual), _ptr(tile_stats), 128,
+    _launch("rnnpose_instnorm_tiles_nhwc_f32", _ptr(x), B, H * W, Cc, eps, int(bool(relu)), _ptr(residual), _ptr(tile_stats), tpi,
             _ptr(stats), _ptr(out), _stream(), nbytes=4.0 * x.numel() * (2 + (residual is not None)))
     return out
 

@@ -218,6 +218,38 @@ def test_conv_tile_stats_feed_instnorm(ops, B, H, W, cin, cout, k, stride):
     assert float((nchw(got).double() - ref).abs().max()) < 2e-5
 
 
+@pytest.mark.parametrize("B,H,W,cin,cout", [(3, 15, 20, 64, 64), (2, 60, 80, 96, 128), (2, 9, 7, 64, 96)])
+def test_conv_per_image_tiles_and_fused_input_norm(ops, B, H, W, cin, cout):
+    """(1) tile_stats with H*W not a multiple of 128: rows are tiled PER IMAGE (ragged last tile), the instance norm built on
+    them is exact.  (2) conv2d_nhwc(in_norm=...): relu(instance_norm(x)) applied in the load == the materialised sequence
+    norm -> ReLU -> convolution (thirdparty/raft/extractor.py:48-52), bit for bit, and within fp32-class error of fp64."""
+    x = syn.normal("pn.x", (B, cin, H, W), 4, std=2.0) + 0.7
+    w1 = syn.normal("pn.w1", (cin, cin, 3, 3), 4, std=float(np.sqrt(2.0 / (cin * 9))))
+    w2 = syn.normal("pn.w2", (cout, cin, 3, 3), 5, std=float(np.sqrt(2.0 / (cin * 9))))
+    b1, b2 = syn.uniform("pn.b1", (cin,), 4, -0.5, 0.5), syn.uniform("pn.b2", (cout,), 5, -0.5, 0.5)
+    p1, p2 = ops.PackedConv(D(w1), D(b1), [cin]), ops.PackedConv(D(w2), D(b2), [cout if False else cin])
+    tpi = -(-(H * W) // 128)
+    c1 = torch.empty(B, H, W, cin, device="cuda")
+    ts = torch.full((B * tpi, cin, 2), -1.0, device="cuda")
+    ops.conv2d_nhwc(p1, [(nhwc(D(x)), 0)], (c1, 0), ops.EPI_LINEAR, tile_stats=ts)
+    y64 = F.conv2d(D(x).double(), D(w1).double(), D(b1).double(), padding=1)
+    n64 = F.relu(F.instance_norm(y64, eps=1e-5))
+    t = ts.view(B, tpi, cin, 2).double().sum(1)
+    assert float((t[..., 0] - y64.sum((2, 3))).abs().max()) <= 2e-5 * float(y64.abs().sum((2, 3)).max())
+    got = ops.instnorm_tiles_nhwc(c1, ts, relu=True)
+    assert float((nchw(got).double() - n64).abs().max()) < 2e-5
+    mr = ops.instnorm_tiles_nhwc(c1, ts, stats_only=True)
+    assert mr.shape == (B, cin, 2)
+    fused = torch.empty(B, H, W, cout, device="cuda")
+    ops.conv2d_nhwc(p2, [(c1, 0)], (fused, 0), ops.EPI_LINEAR, in_norm=mr)
+    plain = torch.empty(B, H, W, cout, device="cuda")
+    ops.conv2d_nhwc(p2, [(got, 0)], (plain, 0), ops.EPI_LINEAR)
+    assert torch.equal(fused, plain)
+    z64 = F.conv2d(n64, D(w2).double(), D(b2).double(), padding=1)
+    z32 = F.conv2d(n64.float(), D(w2), D(b2), padding=1)
+    check(nchw(fused), z64, z32, "fused norm + conv")
+
+
 @pytest.mark.parametrize("B,h,w,cin,coff", [(2, 9, 23, 256, 0), (1, 16, 20, 128, 256), (1, 5, 3, 64, 4), (1, 6, 9, 320, 0)])
 def test_flow_head_out_direct(ops, B, h, w, cin, coff):
     """FlowHead.conv2 (3x3, cin -> 2, update.py:10,14) + coords1 += delta (CFNet.py:157): ragged widths, channel
