@@ -378,10 +378,12 @@ __global__ __launch_bounds__(NT, ((COLS4 || TT > 0) ? 3 : 2)) void conv_igemm_f1
       const int ko = KK_ * 16 + lh * 8;                                                                     \
       h8 ah[MI], al[MI], bh[NI], bl[NI];                                                                    \
       _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) {                                                   \
-        const int row = (COLS4 || okm_[mi]) ? wm * 64 + mi * 32 + l31 + HALO + dv_ : AROWS;                 \
+        /* TT == 1 (1x1 kernels): no tap shift, nothing to mask -- rows outside the problem only feed accumulator rows \
+           that are never stored (the masks were 75 v_cndmask per 24 MFMAs in the 4-column layout) */       \
+        const int row = (TT == 1 || COLS4 || okm_[mi]) ? wm * 64 + mi * 32 + l31 + HALO + dv_ : AROWS;      \
         ah[mi] = *reinterpret_cast<const h8*>(sAf + (AB_) * (2 * PROWS * RS) + row * RS + ko);             \
         al[mi] = *reinterpret_cast<const h8*>(sAf + (AB_) * (2 * PROWS * RS) + PROWS * RS + row * RS + ko); \
-        if (COLS4 && !okm_[mi]) { ah[mi] = zero_; al[mi] = zero_; }                                         \
+        if (TT != 1 && COLS4 && !okm_[mi]) { ah[mi] = zero_; al[mi] = zero_; }                              \
       }                                                                                                     \
       _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) {                                                   \
         bh[ni] = __builtin_bit_cast(h8, bf[S_][ni][KK_]);                                                   \
@@ -412,7 +414,7 @@ __global__ __launch_bounds__(NT, ((COLS4 || TT > 0) ? 3 : 2)) void conv_igemm_f1
       const int dvr_ = p.dv0 + (T_);                                                                        \
       const int ko = (KK_) * 16 + lh * 8;                                                                   \
       _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) {                                                   \
-        const bool ok_ = static_cast<unsigned>(fv[mi] + dvr_) < static_cast<unsigned>(p.V);                \
+        const bool ok_ = TT == 1 || static_cast<unsigned>(fv[mi] + dvr_) < static_cast<unsigned>(p.V);     \
         const int row = ok_ ? wm * 64 + mi * 32 + l31 + HALO + dvr_ : AROWS;      /* masked tap: the all-zero row */ \
         fa_h[SET_][mi] = *reinterpret_cast<const h8*>(sAf + (AB_) * (2 * PROWS * RS) + row * RS + ko);     \
         fa_l[SET_][mi] = *reinterpret_cast<const h8*>(sAf + (AB_) * (2 * PROWS * RS) + PROWS * RS + row * RS + ko); \
