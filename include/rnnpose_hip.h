@@ -260,6 +260,11 @@ int rnnpose_flow_prep_f32(const float* coords1, int subtract_grid, int B, int h,
                           int motion_c_stride, int motion_c_offset, rnnpose_stream_t stream);
 int rnnpose_flow_conv7x7_relu_f32(const float* flow4, const float* w_t, const float* bias, int B, int h, int w, int c_out,
                                   float* out, int out_c_stride, int out_c_offset, rnnpose_stream_t stream);
+/* flow_prep + flow_conv7x7_relu in one launch: coords1 (B,2,h,w) planar (grid subtracted here when subtract_grid != 0) ->
+ * relu(convf1(flow)) into `out`, and the flow itself into channels [motion_c_offset, +2) of `motion` (update.py:84,91,97). */
+int rnnpose_flow_features_f32(const float* coords1, int subtract_grid, const float* w_t, const float* bias, int B, int h, int w,
+                              int c_out, float* out, int out_c_stride, int out_c_offset, float* motion, int motion_c_stride,
+                              int motion_c_offset, rnnpose_stream_t stream);
 int rnnpose_flow_head_out_f32(const float* x, int x_c_stride, int x_c_offset, int c_in, const float* w_oihw,
                               const float* bias, const float* coords1, int B, int h, int w, float* delta,
                               float* coords1_out, float* flow_lr, rnnpose_stream_t stream);

@@ -73,6 +73,7 @@ PROTOTYPES = {
     "rnnpose_nhwc_to_nchw_f32": (_i, [_p, _i, _i, _i, _i, _i, _p, _p]),
     "rnnpose_flow_prep_f32": (_i, [_p, _i, _i, _i, _i, _p, _p, _i, _i, _p]),
     "rnnpose_flow_conv7x7_relu_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _i, _i, _p]),
+    "rnnpose_flow_features_f32": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _p, _i, _i, _p, _i, _i, _p]),
     "rnnpose_flow_head_out_f32": (_i, [_p, _i, _i, _i, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p]),
     "rnnpose_convex_upsample_nhwc_f32": (_i, [_p, _p, _i, _i, _i, _p, _p]),
     "rnnpose_instnorm_workspace_bytes": (_z, [_i, _i, _i]),

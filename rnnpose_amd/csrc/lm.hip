@@ -113,8 +113,8 @@ __global__ __launch_bounds__(LM_THREADS) void lm_normal_eq_kernel(const float* _
 }
 
 // sums the block partials in fixed order and expands to full H (6x6) and b (6)
-__global__ __launch_bounds__(256) void lm_finalize_kernel(const double* __restrict__ partials, int nblk,
-                                                          double* __restrict__ Hm, double* __restrict__ bv) {
+__device__ __forceinline__ void lm_finalize_block(const double* __restrict__ partials, int nblk, double* __restrict__ Hm,
+                                                  double* __restrict__ bv){
   // 8 groups of 32 lanes walk the partial records with stride 8 (each load is one coalesced 256-byte record), then
   // the 8 group sums are added in fixed order: deterministic, and 8x shorter than one serial chain per value.
   __shared__ double grp[8][PSTRIDE];
@@ -139,6 +139,11 @@ __global__ __launch_bounds__(256) void lm_finalize_kernel(const double* __restri
   } else if (threadIdx.x < 42) {
     bv[b * 6 + (threadIdx.x - 36)] = s[21 + (threadIdx.x - 36)];
   }
+}
+
+__global__ __launch_bounds__(256) void lm_finalize_kernel(const double* __restrict__ partials, int nblk,
+                                                          double* __restrict__ Hm, double* __restrict__ bv) {
+  lm_finalize_block(partials, nblk, Hm, bv);
 }
 
 // ---- SE(3) exponential, fp32, same branch structure as geometry/se3.py:228-281 ----
@@ -191,12 +196,9 @@ __device__ void mat4_mul(const float* A, const float* Bm, float* C) {
 }
 
 // one thread per image: damping, Cholesky, substitutions, guards, exp, left increment
-__global__ __launch_bounds__(64) void lm_solve_update_kernel(const double* __restrict__ Hm, const double* __restrict__ bv,
-                                                             const float* G, int B, double ep, double lm,
-                                                             double max_update, float* G_new /* may alias G */,
-                                                             float* __restrict__ xi_out, int* __restrict__ info) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
+// damping, 6x6 Cholesky solve, NaN -> 0, clamp, SE(3) exponential and left increment of image b (one thread)
+__device__ void lm_solve_one(const double* Hm, const double* bv, const float* G, int b, double ep, double lm,
+                             double max_update, float* G_new /* may alias G */, float* xi_out, int* info) {
   double A[6][6], L[6][6], rhs[6], yv[6], xv[6];
   for (int i = 0; i < 6; ++i) {
     for (int j = 0; j < 6; ++j) {
@@ -249,6 +251,14 @@ __global__ __launch_bounds__(64) void lm_solve_update_kernel(const double* __res
   for (int i = 0; i < 16; ++i) G_new[b * 16 + i] = Gout[i];
 }
 
+__global__ __launch_bounds__(64) void lm_solve_update_kernel(const double* __restrict__ Hm, const double* __restrict__ bv,
+                                                             const float* G, int B, double ep, double lm,
+                                                             double max_update, float* G_new /* may alias G */,
+                                                             float* __restrict__ xi_out, int* __restrict__ info) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) lm_solve_one(Hm, bv, G, b, ep, lm, max_update, G_new, xi_out, info);
+}
+
 __global__ void se3_exp_kernel(const float* __restrict__ xi, int B, float* __restrict__ out) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
@@ -286,15 +296,21 @@ __global__ void se3_inverse_kernel(const float* __restrict__ A, int B, float* __
   for (int i = 0; i < 16; ++i) out[b * 16 + i] = o[i];
 }
 
+// per-workgroup partial sums into `workspace`; -> number of partial records per image
+int launch_normal_eq_partials(const float* target, int target_mode, const float* weight, const float* depth, float eps,
+                              const float* K, const float* G, int B, int H, int W, void* workspace, hipStream_t st) {
+  const long long P = static_cast<long long>(H) * W;
+  const int nblk = lm_blocks_per_image(P);
+  hipLaunchKernelGGL(lm_normal_eq_kernel, dim3(nblk, B), dim3(LM_THREADS), 0, st, target, target_mode, weight, depth, eps,
+                     K, G, H, W, static_cast<double*>(workspace));
+  return nblk;
+}
+
 int launch_normal_eq(const float* target, int target_mode, const float* weight, const float* depth, float eps,
                      const float* K, const float* G, int B, int H, int W, void* workspace, double* Hm, double* bv,
                      hipStream_t st) {
-  const long long P = static_cast<long long>(H) * W;
-  const int nblk = lm_blocks_per_image(P);
-  double* partials = static_cast<double*>(workspace);
-  hipLaunchKernelGGL(lm_normal_eq_kernel, dim3(nblk, B), dim3(LM_THREADS), 0, st, target, target_mode, weight, depth, eps,
-                     K, G, H, W, partials);
-  hipLaunchKernelGGL(lm_finalize_kernel, dim3(B), dim3(256), 0, st, partials, nblk, Hm, bv);
+  const int nblk = launch_normal_eq_partials(target, target_mode, weight, depth, eps, K, G, B, H, W, workspace, st);
+  hipLaunchKernelGGL(lm_finalize_kernel, dim3(B), dim3(256), 0, st, static_cast<const double*>(workspace), nblk, Hm, bv);
   return 0;
 }
 
@@ -342,7 +358,8 @@ static int lm_step_impl(const char* fn, const float* target, int target_mode, co
   for (int it = 0; it < num_iters; ++it) {
     const float* g = it == 0 ? G_in : G_out;            // later iterations continue in place on the output
     launch_normal_eq(target, target_mode, weight, depth, depth_eps, K, g, B, H, W, workspace, Hm, bv, st);
-    // (g may alias G_out: each thread reads its whole pose before writing it)
+    // (g may alias G_out: each thread reads its whole pose before writing it.  A merged finalize + solve kernel was measured
+    //  SLOWER, 26 us vs 7 + 6 us: the solve is a serial fp64 chain that then waits behind the 256-thread reduction's launch)
     hipLaunchKernelGGL(lm_solve_update_kernel, dim3(rp::cdiv(B, 64)), dim3(64), 0, st, Hm, bv, g, B, ep_lambda,
                        lm_lambda, max_update, G_out, xi, info);
   }

@@ -380,10 +380,15 @@ __global__ __launch_bounds__(256) void instnorm_apply_kernel(const float* __rest
 // Direct form: thread = output channel with its 98 weights in registers; a workgroup walks a 20-pixel row segment
 // whose 7 x 26 x 2 flow patch sits in LDS (wave-uniform broadcast reads); each pixel's Cout outputs leave as one
 // contiguous NHWC row.  flow4: (B,h,w,4) [fx,fy,0,0]; wt: weights transposed to (98, Cout) = [(ci*7+ky)*7+kx][c].
+// PLANAR: the input is coords1 / flow (B,2,h,w) planar (the pixel grid is subtracted here when subtract_grid != 0) and the
+// flow is also written into channels [motion_co, +2) of the motion-feature tensor: flow_prep + convf1 in one launch.
 constexpr int F1_TX = 20;
+template <bool PLANAR>
 __global__ __launch_bounds__(128) void conv7x7_cin2_kernel(const float* __restrict__ flow4, const float* __restrict__ wt,
                                                            const float* __restrict__ bias, float* __restrict__ out,
-                                                           int out_cs, int out_co, int Cout, int h, int w) {
+                                                           int out_cs, int out_co, int Cout, int h, int w,
+                                                           int subtract_grid, float* __restrict__ motion, int motion_cs,
+                                                           int motion_co) {
   __shared__ float patch[2][7][F1_TX + 6];
   const int b = blockIdx.z, Y = blockIdx.y, X0 = blockIdx.x * F1_TX;
   const int c = threadIdx.x;
@@ -393,8 +398,15 @@ __global__ __launch_bounds__(128) void conv7x7_cin2_kernel(const float* __restri
     const int yy = Y + ky - 3, x = X0 + xx - 3;
     float2 v = make_float2(0.f, 0.f);
     if (yy >= 0 && yy < h && x >= 0 && x < w) {
-      const float4 f = *reinterpret_cast<const float4*>(flow4 + (static_cast<long long>(b) * n + yy * w + x) * 4);
-      v = make_float2(f.x, f.y);
+      if (PLANAR) {
+        v.x = flow4[(static_cast<long long>(b) * 2 + 0) * n + yy * w + x] - (subtract_grid ? static_cast<float>(x) : 0.f);
+        v.y = flow4[(static_cast<long long>(b) * 2 + 1) * n + yy * w + x] - (subtract_grid ? static_cast<float>(yy) : 0.f);
+        if (ky == 3 && xx >= 3 && xx < 3 + F1_TX)       // this row segment's own pixels: motion[..., co:co+2] = flow (update.py:97)
+          *reinterpret_cast<float2*>(motion + (static_cast<long long>(b) * n + yy * w + x) * motion_cs + motion_co) = v;
+      } else {
+        const float4 f = *reinterpret_cast<const float4*>(flow4 + (static_cast<long long>(b) * n + yy * w + x) * 4);
+        v = make_float2(f.x, f.y);
+      }
     }
     patch[0][ky][xx] = v.x;
     patch[1][ky][xx] = v.y;
@@ -540,8 +552,21 @@ int rnnpose_flow_conv7x7_relu_f32(const float* flow4, const float* w_t, const fl
   RP_REQUIRE(B > 0 && B < 65536 && h > 0 && h < 65536 && w > 0 && c_out > 0 && c_out <= 128, fn, "bad size (c_out <= 128)");
   RP_REQUIRE(out_c_offset >= 0 && out_c_offset + c_out <= out_c_stride && reinterpret_cast<uintptr_t>(flow4) % 16 == 0, fn,
              "bad output window / flow4 alignment");
-  hipLaunchKernelGGL(conv7x7_cin2_kernel, dim3(rp::cdiv(w, F1_TX), h, B), dim3(128), 0, rp::as_stream(stream), flow4, w_t,
-                     bias, out, out_c_stride, out_c_offset, c_out, h, w);
+  hipLaunchKernelGGL(conv7x7_cin2_kernel<false>, dim3(rp::cdiv(w, F1_TX), h, B), dim3(128), 0, rp::as_stream(stream), flow4, w_t,
+                     bias, out, out_c_stride, out_c_offset, c_out, h, w, 0, static_cast<float*>(nullptr), 0, 0);
+  return rp::check_launch(fn);
+}
+
+int rnnpose_flow_features_f32(const float* coords1, int subtract_grid, const float* w_t, const float* bias, int B, int h, int w,
+                              int c_out, float* out, int out_c_stride, int out_c_offset, float* motion, int motion_c_stride,
+                              int motion_c_offset, rnnpose_stream_t stream) {
+  const char* fn = "rnnpose_flow_features_f32";
+  RP_REQUIRE(coords1 && w_t && bias && out && motion, fn, "null pointer");
+  RP_REQUIRE(B > 0 && B < 65536 && h > 0 && h < 65536 && w > 0 && c_out > 0 && c_out <= 128, fn, "bad size (c_out <= 128)");
+  RP_REQUIRE(out_c_offset >= 0 && out_c_offset + c_out <= out_c_stride && motion_c_offset % 2 == 0 && motion_c_stride % 2 == 0 &&
+                 motion_c_offset + 2 <= motion_c_stride, fn, "bad output windows");
+  hipLaunchKernelGGL(conv7x7_cin2_kernel<true>, dim3(rp::cdiv(w, F1_TX), h, B), dim3(128), 0, rp::as_stream(stream), coords1, w_t,
+                     bias, out, out_c_stride, out_c_offset, c_out, h, w, subtract_grid, motion, motion_c_stride, motion_c_offset);
   return rp::check_launch(fn);
 }
 

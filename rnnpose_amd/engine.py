@@ -232,9 +232,8 @@ class UpdateEngine:
         # (convc1 -> convc2) and flow features (flow_prep -> convf1 -> convf2).  With a helper stream the second one runs
         # there (a parallel branch when the step is captured into a hipGraph).  Same for flow_head.conv2 next to mask.2.
         def flow_chain():
-            ops.flow_prep(coords1, b["flow4"], b["motion"], 126, subtract_grid=not flow_is_delta)   # flow -> convf1 input, motion[126:128]
-            yield
-            ops.flow_conv7x7_relu(b["flow4"], W["convf1_wt"], W["convf1_b"], b["flo1"])  # :91 (direct fp32, K = 98)
+            # flow = coords1 - grid -> motion[126:128] (:97) and relu(convf1(flow)) (:91; direct fp32 kernel, K = 98): one launch
+            ops.flow_features(coords1, W["convf1_wt"], W["convf1_b"], b["flo1"], b["motion"], 126, subtract_grid=not flow_is_delta)
             yield
             c(W["convf2"], [(b["flo1"], 0)], (b["corflo"], 192), R)                 # :92
             yield

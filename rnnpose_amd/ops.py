@@ -556,6 +556,16 @@ def flow_conv7x7_relu(flow4, w_t, bias, out, out_c_offset=0):
     return out
 
 
+def flow_features(coords1, w_t, bias, out, motion, motion_c_offset, out_c_offset=0, subtract_grid: bool = True):
+    """flow_prep + flow_conv7x7_relu in one launch: coords1 (B,2,h,w) -> relu(convf1(flow)) into `out` (NHWC), flow into
+    motion[..., co:co+2] (update.py:84,91,97)."""
+    B, _, h, w = coords1.shape
+    c_out = w_t.shape[1]
+    _launch("rnnpose_flow_features_f32", _ptr(coords1), int(subtract_grid), _ptr(w_t), _ptr(bias), B, h, w, c_out, _ptr(out),
+            out.shape[-1], out_c_offset, _ptr(motion), motion.shape[3], motion_c_offset, _stream(), work=2.0 * 98 * c_out * B * h * w)
+    return out
+
+
 def flow_head_out(x, x_c_offset, c_in, weight, bias, coords1, delta, coords1_out, flow_lr):
     B, h, w, cs = x.shape
     _launch("rnnpose_flow_head_out_f32", _ptr(x), cs, x_c_offset, c_in, _ptr(weight), _ptr(bias), _ptr(coords1), B, h, w,

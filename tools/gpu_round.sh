@@ -1,7 +1,8 @@
 #!/bin/bash
-# One GPU-box pass: all -m gpu tests, smoke(), bench.py, rocprofv3 kernel stats + trace.  Run through gpurun:
-#   gpurun --timeout 1500 -- 'bash tools/gpu_round.sh r02a'
-# Everything lands in gpurun_out/<tag>_*; tools/summarize_profiles.py copies the summaries into profiles/.
+# One GPU-box pass for the round's record: all -m gpu tests, smoke(), bench.py (+ two other shapes), rocprofv3 kernel traces,
+# SQ / HBM counter passes, the drift probe.  Run through gpurun:
+#   gpurun --timeout 1800 -- 'bash tools/gpu_round.sh r02 [noprof]'
+# Everything lands in gpurun_out/<tag>_*; tools/summarize_profiles.py <tag> rNN copies the summaries into profiles/.
 TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
@@ -12,10 +13,18 @@ rocminfo 2>/dev/null | grep -m3 -E "Marketing Name|Compute Unit|gfx" > $OUT/${TA
 tail -5 $OUT/${TAG}_pytest_gpu.log
 python __graft_entry__.py smoke > $OUT/${TAG}_smoke.log 2>&1; tail -2 $OUT/${TAG}_smoke.log
 python bench.py --steps 20 --warmup 3 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
-tail -c 600 $OUT/${TAG}_bench.err; head -c 400 $OUT/${TAG}_bench.json; echo
+tail -c 300 $OUT/${TAG}_bench.err; head -c 300 $OUT/${TAG}_bench.json; echo
 if [ "$2" != "noprof" ]; then
-  cd /tmp && export TMPDIR=/tmp
-  rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof -o run -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/${TAG}_prof.log 2>&1
-  rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof_nograph -o run -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph > $OUT/${TAG}_prof_nograph.log 2>&1
-  find $OUT/${TAG}_prof $OUT/${TAG}_prof_nograph -name "*.csv" | head; du -sh $OUT/${TAG}_prof $OUT/${TAG}_prof_nograph
+  python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-graph > $OUT/${TAG}_bench_nograph.json 2>/dev/null
+  python bench.py --steps 20 --warmup 3 --no-cpu-baseline --batch 1 --height 240 --width 240 --inner 4 > $OUT/${TAG}_bench_S1.json 2>/dev/null
+  python bench.py --steps 5 --warmup 2 --no-cpu-baseline --height 960 --width 1280 > $OUT/${TAG}_bench_S5.json 2>/dev/null
+  python bench.py --steps 10 --warmup 2 --no-cpu-baseline --batch 16 > $OUT/${TAG}_bench_B16.json 2>/dev/null
+  python tools/drift_probe.py > $OUT/${TAG}_drift.log 2>&1; cp $OUT/drift_probe.json $OUT/${TAG}_drift.json; tail -1 $OUT/${TAG}_drift.log
+  ( cd /tmp && export TMPDIR=/tmp
+    rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof -o run -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/${TAG}_prof.log 2>&1
+    rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof_unsplit -o run -- env RNNPOSE_SPLIT_BATCH=0 python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph > $OUT/${TAG}_prof_unsplit.log 2>&1
+    rocprofv3 --kernel-trace -d $OUT/${TAG}_prof_convs -o run -- python $R/tools/conv_layers.py 7 > $OUT/${TAG}_prof_convs.log 2>&1 )
+  bash tools/pmc_sq.sh ${TAG}_k python tools/pmc_kernels.py 3 > /dev/null 2>&1
+  bash tools/pmc_sq.sh ${TAG}_c python tools/conv_layers.py 3 > /dev/null 2>&1
+  ls $OUT | grep "^${TAG}_" | tr '\n' ' '
 fi
