@@ -281,9 +281,13 @@ int rnnpose_instnorm_nhwc_f32(const float* x, int B, int HW, int C, float eps, i
                               rnnpose_stream_t stream);
 /* Same normalisation with the statistics taken from the producing convolution's `tile_stats` (tiles_per_image records per
  * image, as the producer laid them out): only the finalize + apply passes run.  out == NULL: statistics only (mean_rstd
- * for a consumer that normalises in its load, rnnpose_conv_desc_t.src0_mean_rstd). */
+ * for a consumer that normalises in its load, rnnpose_conv_desc_t.src0_mean_rstd).
+ * residual_mean_rstd (optional, (B,C,2)): `residual` is itself a RAW convolution output whose instance norm [+ ReLU if
+ * residual_relu] is applied on the fly: out = relu(act_r((residual - mean_r) * rstd_r) + act((x - mean) * rstd)) -- the
+ * stem output / the down-sampling branch of a ResidualBlock are then never written in normalised form (extractor.py:54-58). */
 int rnnpose_instnorm_tiles_nhwc_f32(const float* x, int B, int HW, int C, float eps, int relu, const float* residual,
-                                    const float* tile_stats, int tiles_per_image, float* mean_rstd, float* out,
+                                    const float* residual_mean_rstd, int residual_relu, const float* tile_stats,
+                                    int tiles_per_image, float* mean_rstd, float* out,
                                     rnnpose_stream_t stream);
 
 /* ---- f3 ("next"): brute-force nearest neighbour for ADD-S ------ thirdparty/nn/src/nearest_neighborhood.cu:48-163

@@ -77,7 +77,7 @@ PROTOTYPES = {
     "rnnpose_flow_head_out_f32": (_i, [_p, _i, _i, _i, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p]),
     "rnnpose_convex_upsample_nhwc_f32": (_i, [_p, _p, _i, _i, _i, _p, _p]),
     "rnnpose_instnorm_workspace_bytes": (_z, [_i, _i, _i]),
-    "rnnpose_instnorm_tiles_nhwc_f32": (_i, [_p, _i, _i, _i, _f, _i, _p, _p, _i, _p, _p, _p]),
+    "rnnpose_instnorm_tiles_nhwc_f32": (_i, [_p, _i, _i, _i, _f, _i, _p, _p, _i, _p, _i, _p, _p, _p]),
     "rnnpose_instnorm_nhwc_f32": (_i, [_p, _i, _i, _i, _f, _i, _p, _p, _z, _p, _p, _p]),
     "rnnpose_nn_search_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "findNearestPointIdxLauncher": (None, [_p, _p, _p, _i, _i, _i, _i, _i]),

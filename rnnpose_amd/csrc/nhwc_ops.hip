@@ -354,10 +354,12 @@ __global__ __launch_bounds__(256) void instnorm_finalize_tiles_kernel(const floa
   }
 }
 
-// out = act1((x - mean) * rstd); if residual: out = relu(residual + out)
+// out = act1((x - mean) * rstd); if residual: out = relu(residual' + out), residual' = the residual itself or, with res_mr,
+// its own instance norm [+ ReLU] applied on the fly (the RAW stem / down-sampling convolution output: extractor.py:54-58)
 __global__ __launch_bounds__(256) void instnorm_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean_rstd,
                                                              const float* __restrict__ residual, float* __restrict__ out,
-                                                             int HW, int C, int relu, long long total4) {
+                                                             int HW, int C, int relu, long long total4,
+                                                             const float* __restrict__ res_mr, int res_relu) {
   const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= total4) return;
   const int c4 = static_cast<int>(i % (C >> 2));
@@ -369,7 +371,13 @@ __global__ __launch_bounds__(256) void instnorm_apply_kernel(const float* __rest
   float4 y = make_float4((v.x - m01.x) * m01.y, (v.y - m01.z) * m01.w, (v.z - m23.x) * m23.y, (v.w - m23.z) * m23.w);
   if (relu) y = make_float4(fmaxf(y.x, 0.f), fmaxf(y.y, 0.f), fmaxf(y.z, 0.f), fmaxf(y.w, 0.f));
   if (residual) {
-    const float4 r = reinterpret_cast<const float4*>(residual)[i];
+    float4 r = reinterpret_cast<const float4*>(residual)[i];
+    if (res_mr) {
+      const float4 q01 = *reinterpret_cast<const float4*>(res_mr + (static_cast<long long>(b) * C + c4 * 4) * 2);
+      const float4 q23 = *reinterpret_cast<const float4*>(res_mr + (static_cast<long long>(b) * C + c4 * 4 + 2) * 2);
+      r = make_float4((r.x - q01.x) * q01.y, (r.y - q01.z) * q01.w, (r.z - q23.x) * q23.y, (r.w - q23.z) * q23.w);
+      if (res_relu) r = make_float4(fmaxf(r.x, 0.f), fmaxf(r.y, 0.f), fmaxf(r.z, 0.f), fmaxf(r.w, 0.f));
+    }
     y = make_float4(fmaxf(r.x + y.x, 0.f), fmaxf(r.y + y.y, 0.f), fmaxf(r.z + y.z, 0.f), fmaxf(r.w + y.w, 0.f));
   }
   reinterpret_cast<float4*>(out)[i] = y;
@@ -523,14 +531,14 @@ int rnnpose_instnorm_nhwc_f32(const float* x, int B, int HW, int C, float eps, i
                      nchunk, C, HW, eps);
   const long long total4 = static_cast<long long>(B) * HW * (C >> 2);
   hipLaunchKernelGGL(instnorm_apply_kernel, dim3(rp::cdiv(total4, 256)), dim3(256), 0, st, x, mean_rstd, residual, out, HW,
-                     C, relu, total4);
+                     C, relu, total4, static_cast<const float*>(nullptr), 0);
   return rp::check_launch(fn);
 }
 
 
 int rnnpose_instnorm_tiles_nhwc_f32(const float* x, int B, int HW, int C, float eps, int relu, const float* residual,
-                                    const float* tile_stats, int tiles_per_image, float* mean_rstd, float* out,
-                                    rnnpose_stream_t stream) {
+                                    const float* residual_mean_rstd, int residual_relu, const float* tile_stats,
+                                    int tiles_per_image, float* mean_rstd, float* out, rnnpose_stream_t stream) {
   const char* fn = "rnnpose_instnorm_tiles_nhwc_f32";
   RP_REQUIRE(tile_stats && mean_rstd && (x || !out), fn, "null pointer");
   RP_REQUIRE(B > 0 && B < 65536 && HW > 0 && C > 0 && C % 4 == 0, fn, "bad size (C % 4 == 0)");
@@ -540,7 +548,7 @@ int rnnpose_instnorm_tiles_nhwc_f32(const float* x, int B, int HW, int C, float 
   if (out) {
     const long long total4 = static_cast<long long>(B) * HW * (C >> 2);
     hipLaunchKernelGGL(instnorm_apply_kernel, dim3(rp::cdiv(total4, 256)), dim3(256), 0, st, x, mean_rstd, residual, out, HW,
-                       C, relu, total4);
+                       C, relu, total4, residual ? residual_mean_rstd : nullptr, residual_relu);
   }
   return rp::check_launch(fn);
 }

@@ -344,23 +344,40 @@ class EncoderEngine:
         return out, ts
 
     @staticmethod
-    def _norm(y_ts, relu, residual=None):
-        y, ts = y_ts
-        if ts is None:
-            return ops.instnorm_nhwc(y, relu=relu, residual=residual)
-        return ops.instnorm_tiles_nhwc(y, ts, relu=relu, residual=residual)
+    def _block_gen(W, name, blk, x, x_norm=None):
+        """ResidualBlock (extractor.py:48-58) on an NHWC tensor, as a generator (yields after every launch, returns the block
+        output).  Instance norms are never materialised on their own: norm1 + ReLU happens in conv2's load, the residual's
+        norm (x_norm = (mean_rstd, relu) when `x` is the RAW stem output; norm3 of the down-sampling branch) inside the one
+        pass that forms relu(residual + relu(norm2(conv2 .))) -- the only tensor written per block besides the raw
+        convolution outputs."""
+        E = EncoderEngine
+        st = blk.conv1.stride[0]
+        c1, ts1 = E._conv(W[name + ".c1"], x, st, in_norm=None if x_norm is None else x_norm[0])
+        yield
+        mr1 = ops.instnorm_tiles_nhwc(c1, ts1, stats_only=True)          # relu(norm1(conv1 x)): applied in conv2's load
+        yield
+        res, res_norm = x, x_norm
+        if blk.downsample is not None:
+            assert x_norm is None
+            res, tsd = E._conv(W[name + ".down"], x, st)
+            yield
+            res_norm = (ops.instnorm_tiles_nhwc(res, tsd, stats_only=True), False)            # norm3, no ReLU
+            yield
+        c2, ts2 = E._conv(W[name + ".c2"], c1, in_norm=mr1)
+        yield
+        out = ops.instnorm_tiles_nhwc(c2, ts2, relu=True, residual=res, residual_norm=None if res_norm is None else res_norm[0],
+                                      residual_relu=bool(res_norm and res_norm[1]))               # relu(x + relu(IN(.)))
+        yield
+        return out
 
     @staticmethod
     def _block(W, name, blk, x):
-        """ResidualBlock (extractor.py:48-58) on an NHWC tensor; W[name + ".c1" / ".c2" / ".down"] = packed convolutions."""
-        E = EncoderEngine
-        st = blk.conv1.stride[0]
-        c1, ts1 = E._conv(W[name + ".c1"], x, st)
-        mr1 = ops.instnorm_tiles_nhwc(c1, ts1, stats_only=True)          # relu(norm1(conv1 x)) is applied in conv2's load
-        res = x
-        if blk.downsample is not None:
-            res = E._norm(E._conv(W[name + ".down"], x, st), relu=False)                          # norm3, no ReLU
-        return E._norm(E._conv(W[name + ".c2"], c1, in_norm=mr1), relu=True, residual=res)        # relu(x + relu(IN(.)))
+        g = EncoderEngine._block_gen(W, name, blk, x)
+        try:
+            while True:
+                next(g)
+        except StopIteration as e:
+            return e.value
 
     @torch.no_grad()
     def __call__(self, images, normalize=True):
@@ -428,28 +445,17 @@ class EncoderEngine:
         """One image set through the encoder (extractor.py:187-232); yields after every launch group."""
         E = EncoderEngine
         f = self.fnet
-        t = ops.stem_conv(W["stem"], x_nchw, normalize)                              # extractor.py:197 (+ CFNet.py:42-43)
+        x, ts = ops.stem_conv(W["stem"], x_nchw, normalize)                          # extractor.py:197 (+ CFNet.py:42-43)
         yield
-        x = E._norm(t, relu=True)                                                    # :198-199
+        if ts is not None:             # relu(norm1(conv1 .)) (:198-199) stays lazy: applied where the stem output is consumed
+            x_norm = (ops.instnorm_tiles_nhwc(x, ts, stats_only=True), True)
+        else:                          # (ragged stem tiling: no tile statistics -> one full instance-norm pass)
+            x, x_norm = ops.instnorm_nhwc(x, relu=True), None
         yield
         for li, layer in enumerate((f.layer1, f.layer2, f.layer3), start=1):
             for bi, blk in enumerate(layer):
-                name = f"l{li}.{bi}"
-                st = blk.conv1.stride[0]
-                c1, ts1 = E._conv(W[name + ".c1"], x, st)
-                yield
-                mr1 = ops.instnorm_tiles_nhwc(c1, ts1, stats_only=True)  # relu(norm1(.)) happens in conv2's load (extractor.py:48-52)
-                yield
-                res = x
-                if blk.downsample is not None:
-                    t = E._conv(W[name + ".down"], x, st)
-                    yield
-                    res = E._norm(t, relu=False)                                     # norm3, no ReLU
-                    yield
-                t = E._conv(W[name + ".c2"], c1, in_norm=mr1)
-                yield
-                x = E._norm(t, relu=True, residual=res)                              # relu(x + relu(IN(.)))
-                yield
+                x = yield from E._block_gen(W, f"l{li}.{bi}", blk, x, x_norm)
+                x_norm = None
         o, _ = E._conv(W["out"], x, stats=False)
         yield
         ops.nhwc_to_nchw(o, out=out)

@@ -652,21 +652,24 @@ def instnorm_nhwc(x, relu=True, residual=None, out=None, eps: float = 1e-5):
     return out
 
 
-def instnorm_tiles_nhwc(x, tile_stats, relu=True, residual=None, out=None, eps: float = 1e-5, stats_only: bool = False):
+def instnorm_tiles_nhwc(x, tile_stats, relu=True, residual=None, out=None, eps: float = 1e-5, stats_only: bool = False,
+                        residual_norm=None, residual_relu: bool = False):
     """instnorm_nhwc with the statistics pass replaced by the producing convolution's tile_stats (B * ceil(HW/128) records).
-    stats_only: -> mean_rstd (B,C,2) only (for a consumer that normalises in its load: conv2d_nhwc(in_norm=...))."""
+    stats_only: -> mean_rstd (B,C,2) only (for a consumer that normalises in its load: conv2d_nhwc(in_norm=...)).
+    residual_norm (B,C,2): the residual is a RAW convolution output, normalised [+ ReLU] on the fly with these statistics."""
     _nhwc(x, "x")
     B, H, W, Cc = x.shape
     tpi = -(-(H * W) // 128)
     stats = torch.empty(B, Cc, 2, device=x.device, dtype=F32)
     if stats_only:
-        _launch("rnnpose_instnorm_tiles_nhwc_f32", _ptr(None), B, H * W, Cc, eps, int(bool(relu)), _ptr(None), _ptr(tile_stats), tpi,
-                _ptr(stats), _ptr(None), _stream())
+        _launch("rnnpose_instnorm_tiles_nhwc_f32", _ptr(None), B, H * W, Cc, eps, int(bool(relu)), _ptr(None), _ptr(None), 0,
+                _ptr(tile_stats), tpi, _ptr(stats), _ptr(None), _stream())
         return stats
     if out is None:
         out = torch.empty_like(x)
-    _launch("rnnpose_instnorm_tiles_nhwc_f32", _ptr(x), B, H * W, Cc, eps, int(bool(relu)), _ptr(residual), _ptr(tile_stats), tpi,
-            _ptr(stats), _ptr(out), _stream(), nbytes=4.0 * x.numel() * (2 + (residual is not None)))
+    _launch("rnnpose_instnorm_tiles_nhwc_f32", _ptr(x), B, H * W, Cc, eps, int(bool(relu)), _ptr(residual), _ptr(residual_norm),
+            int(bool(residual_relu)), _ptr(tile_stats), tpi, _ptr(stats), _ptr(out), _stream(),
+            nbytes=4.0 * x.numel() * (2 + (residual is not None)))
     return out
 
 
