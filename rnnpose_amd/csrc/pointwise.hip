@@ -223,6 +223,13 @@ __global__ __launch_bounds__(256) void corr_weight_kernel(const float* __restric
   const long long t = static_cast<long long>(bid - b * bpi) * 256 + threadIdx.x;
   if (t >= P) return;
   const int x = static_cast<int>(t % W), y = static_cast<int>(t / W);
+  // background pixels (rendered depth <= 0) have weight exp(..) * 0 = 0 whatever the descriptors say: skip their 5 * D
+  // loads.  Whole waves of background (the band around the object in a zoomed crop) then cost one depth load.  The only
+  // observable difference to the reference expression is a NaN descriptor AT a background pixel (NaN * 0 = NaN there, 0 here).
+  if (!(depth[b * P + t] > 0.f)) {
+    weight[b * P + t] = 0.f;
+    return;
+  }
   float tx, ty;
   if (target_mode == 0) {
     const float2 tt = *reinterpret_cast<const float2*>(target + (b * P + t) * 2);
@@ -258,8 +265,7 @@ __global__ __launch_bounds__(256) void corr_weight_kernel(const float* __restric
     const float wv = ((qc[o00] * w00 + qc[o10] * w10) + qc[o01] * w01) + qc[o11] * w11;
     s += a[c * P] * wv;
   }
-  const float fg = depth[b * P + t] > 0.f ? 1.f : 0.f;
-  weight[b * P + t] = expf(-fabsf(1.f - s) / sigma[0]) * fg;
+  weight[b * P + t] = expf(-fabsf(1.f - s) / sigma[0]);
 }
 
 // ------------------------------------------------------------------------------------------------

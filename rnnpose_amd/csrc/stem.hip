@@ -40,9 +40,15 @@ __global__ __launch_bounds__(256) void stem_conv7x7_s2_kernel(const float* __res
                                                               int W, int Ho, int Wo, int tiles_x, int tiles_y,
                                                               unsigned long long* sat) {
 #pragma clang fp contract(off)
-  __shared__ float patch[PATCH + 5];
-  __shared__ __attribute__((aligned(16))) float stage[4 * 32 * ES];      // 34.8 KB
+  // the input patch (9.3 KB) and the epilogue's staging tiles (4 waves x 16 rows x 68 floats = 17 KB) share one buffer:
+  // 19.4 KB per workgroup -> 8 workgroups (32 waves) per CU.  The kernel is a chain of latencies per workgroup (patch from
+  // HBM -> LDS -> gather -> MFMA -> LDS -> stores); with the original 46 KB only 3 were resident and it ran at a third
+  // of its HBM bound
+  __shared__ __attribute__((aligned(16))) float smem[4 * 16 * ES];
   __shared__ float tsum[4][16][8];
+  static_assert(4 * 16 * ES >= PATCH + 5, "staging buffer must hold the patch");
+  float* const patch = smem;
+  float* const stage = smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
   int t = blockIdx.x;
@@ -101,28 +107,33 @@ __global__ __launch_bounds__(256) void stem_conv7x7_s2_kernel(const float* __res
     bh0 = nh0; bh1 = nh1; bl0 = nl0; bl1 = nl1;
   }
 
-  // ---- epilogue ----
-  float* S = stage + wave * (32 * ES);
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-    S[row * ES + l31] = acc0[r] * out_scale;
-    S[row * ES + 32 + l31] = acc1[r] * out_scale;
-  }
-  // (wave-private tile: no barrier needed between a wave's own LDS writes and reads)
-  const int cq = (lane & 15) * 4;                          // this lane's column quad, the same for every k below
+  // ---- epilogue: two half-tiles of 16 rows per wave through LDS -> 16-byte row-contiguous stores ----
+  __syncthreads();                                         // every wave is done gathering from the patch (aliased below)
+  float* S = stage + wave * (16 * ES);
+  const int cq = (lane & 15) * 4;                          // this lane's column quad, the same for every row it stores
   const float4 b4 = *reinterpret_cast<const float4*>(bias + cq);
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int rl = (lane >> 4) + 4 * k;                    // tile row of this wave (0..31)
-    const int oy = oy0 + 2 * wave + (rl >> 4), ox = ox0 + (rl & 15);
-    if (oy >= Ho || ox >= Wo) continue;
-    float4 y = *reinterpret_cast<const float4*>(S + rl * ES + cq);
-    y.x += b4.x; y.y += b4.y; y.z += b4.z; y.w += b4.w;
-    s0 += y.x; s1 += y.y; s2 += y.z; s3 += y.w;
-    q0 += y.x * y.x; q1 += y.y * y.y; q2 += y.z * y.z; q3 += y.w * y.w;
-    *reinterpret_cast<float4*>(out + ((static_cast<long long>(n) * Ho + oy) * Wo + ox) * CO + cq) = y;
+  for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {                          // accumulator rows 16 hf .. 16 hf + 15 (C layout of the 32x32 MFMA)
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      S[row * ES + l31] = acc0[8 * hf + r] * out_scale;
+      S[row * ES + 32 + l31] = acc1[8 * hf + r] * out_scale;
+    }
+    __builtin_amdgcn_wave_barrier();                       // wave-private tile: LDS ops of one wave execute in order
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int rl = (lane >> 4) + 4 * k;                  // row within the half-tile (0..15) = output pixel ox0 + rl
+      const int oy = oy0 + 2 * wave + hf, ox = ox0 + rl;
+      if (oy >= Ho || ox >= Wo) continue;
+      float4 y = *reinterpret_cast<const float4*>(S + rl * ES + cq);
+      y.x += b4.x; y.y += b4.y; y.z += b4.z; y.w += b4.w;
+      s0 += y.x; s1 += y.y; s2 += y.z; s3 += y.w;
+      q0 += y.x * y.x; q1 += y.y * y.y; q2 += y.z * y.z; q3 += y.w * y.w;
+      *reinterpret_cast<float4*>(out + ((static_cast<long long>(n) * Ho + oy) * Wo + ox) * CO + cq) = y;
+    }
+    __builtin_amdgcn_wave_barrier();
   }
   if (tstats) {
     // lanes sharing a column quad (same lane & 15): fixed-order butterfly, then the 4 waves through LDS in order

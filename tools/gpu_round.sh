@@ -26,5 +26,6 @@ if [ "$2" != "noprof" ]; then
     rocprofv3 --kernel-trace -d $OUT/${TAG}_prof_convs -o run -- python $R/tools/conv_layers.py 7 > $OUT/${TAG}_prof_convs.log 2>&1 )
   bash tools/pmc_sq.sh ${TAG}_k python tools/pmc_kernels.py 3 > /dev/null 2>&1
   bash tools/pmc_sq.sh ${TAG}_c python tools/conv_layers.py 3 > /dev/null 2>&1
+  PMC_TRAFFIC_ONLY=1 bash tools/pmc_sq.sh ${TAG}_b python bench.py --steps 1 --warmup 1 --no-graph --no-cpu-baseline > /dev/null 2>&1
   ls $OUT | grep "^${TAG}_" | tr '\n' ' '
 fi

@@ -13,9 +13,8 @@ def short(n):
     return m.group(1) if m else n[:48]
 
 
-def main():
-    dbs = [a for a in sys.argv[1:] if a.endswith(".db")]
-    by_grid = "--by-grid" in sys.argv
+def collect(dbs, by_grid=False, verbose=True):
+    """-> {kernel: {launches, counter means, derived ratios}} over the given rocprofv3 databases."""
     acc = {}
     for path in dbs:
         db = sqlite3.connect(path)
@@ -50,10 +49,16 @@ def main():
         if "SQ_VALU_MFMA_BUSY_CYCLES" in row and "SQ_BUSY_CYCLES" in row and row["SQ_BUSY_CYCLES"]:
             row["MFMA_BUSY/BUSY_CYCLES"] = row["SQ_VALU_MFMA_BUSY_CYCLES"] / row["SQ_BUSY_CYCLES"]
         out[name] = dict(launches=n, **{k: (round(v, 4) if v < 100 else round(v, 1)) for k, v in row.items()})
-        print(f"{name[:70]:70s} n={n}")
-        for k, v in out[name].items():
-            if k != "launches":
-                print(f"      {k:34s} {v}")
+        if verbose:
+            print(f"{name[:70]:70s} n={n}")
+            for k, v in out[name].items():
+                if k != "launches":
+                    print(f"      {k:34s} {v}")
+    return out
+
+
+def main():
+    out = collect([a for a in sys.argv[1:] if a.endswith(".db")], "--by-grid" in sys.argv)
     if "--json" in sys.argv:
         json.dump(out, open(sys.argv[sys.argv.index("--json") + 1], "w"), indent=1)
 

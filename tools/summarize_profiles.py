@@ -1,62 +1,115 @@
 #!/usr/bin/env python3
-"""Turns the scratch outputs of tools/gpu_profile.sh (gpurun_out/) into the committed summaries under profiles/:
-r01_bench.json, r01_bench_miopen_convs.json, r01_bench_kernel_stats[_nograph].csv (rocprofv3 --kernel-trace --stats),
-r01_pmc_traffic_bench.json (FETCH_SIZE / WRITE_SIZE per kernel, FETCH_SIZE doubled: gfx950 correction of
-MI355X_MICROARCH.md) and traffic.json (the per-launch HBM bytes bench.py reports as roofline.traffic)."""
-import collections
+"""Turns the scratch outputs of tools/gpu_round.sh (gpurun_out/<tag>_*) into the committed record under profiles/:
+
+    python tools/summarize_profiles.py r02            # gpurun_out/r02_* -> profiles/r02_*
+
+  <tag>_bench*.json            the bench lines (default config, --no-graph, S1 / S5 / B16 shapes)
+  <tag>_kernel_stats*.csv      per-kernel calls / total / mean / min / max of the rocprofv3 --kernel-trace --stats runs of bench.py
+                               (graph replay, two half-batch chains; and RNNPOSE_SPLIT_BATCH=0 --no-graph)
+  <tag>_conv_layers.csv        every convolution of one update step + one encoder pass, one launch each, ALONE on the chip
+  <tag>_pmc_kernels.json       SQ + FETCH/WRITE counters per hand-written kernel (tools/pmc_kernels.py), incl. lm_normal_eq's VALU/LDS
+  <tag>_pmc_convs.json         the same per convolution launch shape (tools/conv_layers.py, keyed by grid size)
+  <tag>_pmc_traffic_bench.json FETCH/WRITE bytes per kernel over one eager bench step
+  <tag>_drift.json             free-running 3x8 drift against the fp64 oracle (tools/drift_probe.py)
+  <tag>_pytest_gpu.txt, <tag>_smoke.txt, <tag>_device.txt
+  traffic.json                 per-launch HBM bytes bench.py reports as roofline.traffic (regenerated here every round)
+
+FETCH_SIZE is doubled (gfx950 tallies 128-byte requests at 64 B: MI355X_MICROARCH.md, HBM/rocprofv3 section)."""
 import csv
 import json
 import os
 import re
 import shutil
+import sqlite3
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import pmc_report  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
 
 
-def kname(s):
-    s = s.replace("void ", "").replace("(anonymous namespace)::", "")
-    m = re.match(r"_ZN12_GLOBAL__N_1\d+([A-Za-z0-9_]+?)I", s)
-    return m.group(1) if m else re.split(r"[(<]", s)[0]
+def have(*parts):
+    p = os.path.join(G, *parts)
+    return p if os.path.exists(p) else None
 
 
-def load(d, counter):
-    acc = collections.defaultdict(lambda: [0, 0.0])
-    for r in csv.DictReader(open(os.path.join(G, d, "k_counter_collection.csv"))):
-        if r["Counter_Name"] == counter:
-            k = kname(r["Kernel_Name"])
-            acc[k][0] += 1
-            acc[k][1] += float(r["Counter_Value"])
-    return acc
+def kernel_stats(db_path, dst, by_grid=False):
+    """rocprofv3's `kernels` view -> csv (name, [grid], calls, total_ms, mean_us, min_us, max_us, pct)."""
+    db = sqlite3.connect(db_path)
+    grp = "name, grid_x" if by_grid else "name"
+    rows = db.execute(f"select {grp}, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels group by {grp} order by 3 desc"
+                      if not by_grid else
+                      f"select {grp}, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels group by {grp} order by 4 desc").fetchall()
+    tot = sum(r[-4] for r in rows) or 1.0
+    with open(dst, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel"] + (["grid_x"] if by_grid else []) + ["calls", "total_ms", "mean_us", "min_us", "max_us", "pct"])
+        for r in rows:
+            name = pmc_report.short(r[0])
+            extra = [r[1]] if by_grid else []
+            n, s, a, lo, hi = r[-5:]
+            w.writerow([name] + extra + [n, round(s / 1e6, 3), round(a / 1e3, 2), round(lo / 1e3, 2), round(hi / 1e3, 2), round(100 * s / tot, 2)])
+    return tot / 1e6
 
 
-for src, dst in (("bench.json", "r01_bench.json"), ("bench_miopen.json", "r01_bench_miopen_convs.json"),
-                 ("prof_stats/bench_kernel_stats.csv", "r01_bench_kernel_stats.csv"),
-                 ("prof_stats_nograph/bench_kernel_stats.csv", "r01_bench_kernel_stats_nograph.csv")):
-    if os.path.exists(os.path.join(G, src)):
-        shutil.copy(os.path.join(G, src), os.path.join(P, dst))
-f, w = load("pmc_fetch", "FETCH_SIZE"), load("pmc_write", "WRITE_SIZE")
-out = {}
-for k in sorted(set(f) | set(w)):
-    nf, vf = f.get(k, [0, 0])
-    nw, vw = w.get(k, [0, 0])
-    fetch, write = vf / max(nf, 1) * 1024 * 2, vw / max(nw, 1) * 1024
-    out[k] = {"launches": nf, "fetch_MB_per_launch": round(fetch / 1e6, 2), "write_MB_per_launch": round(write / 1e6, 2),
-              "hbm_MB_per_launch": round((fetch + write) / 1e6, 2)}
-    print(f"{k[:44]:44s} n={nf:5d} fetch {fetch / 1e6:9.1f} MB  write {write / 1e6:9.1f} MB")
-json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace only) over `bench.py --steps 1 "
-                     "--warmup 1 --no-graph`; FETCH_SIZE doubled (gfx950 correction, MI355X_MICROARCH.md); per-launch means",
-           "per_kernel": out}, open(os.path.join(P, "r01_pmc_traffic_bench.json"), "w"), indent=1)
-tr = {"source": "profiles/r01_pmc_traffic_bench.json (average over all launches of the kernel in one bench step)"}
-for key, kern in (("conv_igemm_bytes_per_launch", "conv_igemm_f16x3_kernel"), ("corr_pyramid_h3_bytes_per_launch", "corr_pyramid_h3_kernel"),
-                  ("corr_pyramid_bytes_per_launch", "corr_pyramid_kernel")):
-    if kern in out:
-        tr[key] = int(out[kern]["hbm_MB_per_launch"] * 1e6)
-old = json.load(open(os.path.join(P, "traffic.json"))) if os.path.exists(os.path.join(P, "traffic.json")) else {}
-for k, v in old.items():
-    tr.setdefault(k, v)
-json.dump(tr, open(os.path.join(P, "traffic.json"), "w"))
-rows = list(csv.DictReader(open(os.path.join(P, "r01_bench_kernel_stats.csv"))))
-print("total kernel ms in the rocprof run:", round(sum(float(r["TotalDurationNs"]) for r in rows) / 1e6, 1))
-for r in rows[:12]:
-    print(f'  {kname(r["Name"])[:44]:44s} n={r["Calls"]:>5s} avg={float(r["AverageNs"]) / 1e3:8.1f} us  {float(r["Percentage"]):5.1f} %')
+def tail(src, dst, n=15):
+    lines = open(src, errors="replace").read().splitlines()
+    open(dst, "w").write("\n".join(lines[-n:]) + "\n")
+
+
+os.makedirs(P, exist_ok=True)
+for suffix in ("bench", "bench_nograph", "bench_S1", "bench_S5", "bench_B16", "drift"):
+    src = have(f"{TAG}_{suffix}.json")
+    if src and os.path.getsize(src):
+        shutil.copy(src, os.path.join(P, f"{TAG}_{suffix}.json"))
+for suffix, n in (("pytest_gpu.log", 12), ("smoke.log", 4), ("device.txt", 5)):
+    src = have(f"{TAG}_{suffix}")
+    if src:
+        tail(src, os.path.join(P, f"{TAG}_{suffix.replace('.log', '.txt')}"), n)
+for d, name, by_grid in ((f"{TAG}_prof", f"{TAG}_kernel_stats.csv", False), (f"{TAG}_prof_unsplit", f"{TAG}_kernel_stats_unsplit_nograph.csv", False),
+                         (f"{TAG}_prof_convs", f"{TAG}_conv_layers.csv", True)):
+    src = have(d, "run_results.db")
+    if src:
+        print(f"{name}: {kernel_stats(src, os.path.join(P, name), by_grid):.1f} ms of kernel time in the run")
+
+traffic = {}
+
+
+def pmc(prefix, dst, by_grid=False):
+    dbs = [p for p in (have(f"{TAG}_{prefix}_pmc{i}", "run_results.db") for i in range(1, 5)) if p]
+    if not dbs:
+        return {}
+    out = pmc_report.collect(dbs, by_grid, verbose=False)
+    for v in out.values():
+        if "FETCH_MB" in v or "WRITE_MB" in v:
+            v["HBM_MB"] = round(v.get("FETCH_MB", 0.0) + v.get("WRITE_MB", 0.0), 2)
+    json.dump({"source": f"tools/pmc_sq.sh over tools/{'conv_layers' if prefix == 'c' else 'pmc_kernels' if prefix == 'k' else 'bench'}.py: "
+                         "rocprofv3 --pmc, one pass per counter set, --kernel-trace only; per-launch means; FETCH doubled (gfx950)",
+               "per_kernel": out}, open(os.path.join(P, dst), "w"), indent=1)
+    print(dst, len(out), "kernels")
+    return out
+
+
+kern = pmc("k", f"{TAG}_pmc_kernels.json")
+pmc("c", f"{TAG}_pmc_convs.json", by_grid=True)
+bench = pmc("b", f"{TAG}_pmc_traffic_bench.json")
+src_of = {}
+for key, pat in (("conv_igemm", r"^conv_igemm_f16x3_kernel"), ("corr_pyramid_h3", r"corr_pyramid_h3_kernel"), ("corr_pyramid", r"corr_pyramid_kernel")):
+    for table, label in ((bench, f"{TAG}_pmc_traffic_bench.json"), (kern, f"{TAG}_pmc_kernels.json")):
+        rows = [v for k, v in table.items() if re.search(pat, k) and "HBM_MB" in v]
+        if rows:
+            n = sum(v["launches"] for v in rows)
+            traffic[key] = {"bytes_per_launch": int(sum(v["HBM_MB"] * v["launches"] for v in rows) / n * 1e6), "launches": n,
+                            "source": f"profiles/{label} (FETCH_SIZE x2 + WRITE_SIZE, mean over the launches of the kernel)"}
+            break
+if traffic:
+    old = {}
+    tp = os.path.join(P, "traffic.json")
+    if os.path.exists(tp):
+        old = {k: v for k, v in json.load(open(tp)).items() if isinstance(v, dict)}
+    old.update(traffic)
+    json.dump(old, open(tp, "w"), indent=1)
+    print("traffic.json:", {k: v["bytes_per_launch"] for k, v in old.items()})
