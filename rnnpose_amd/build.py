@@ -23,7 +23,7 @@ STAMP = os.path.join(LIBDIR, "librnnpose_hip.stamp")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall",
          "-Wno-unused-function", "-Wno-unused-variable", "-DNDEBUG"]
-FLAGS += os.environ.get("RNNPOSE_HIPCC_EXTRA", "").split()     # diagnostics builds (e.g. -DRP_CONV_TS), part of the stamp
+FLAGS += os.environ.get("RNNPOSE_HIPCC_EXTRA", "").split()     # diagnostics builds (e.g. -DRP_ABL=..., tools/conv_ablate.sh), part of the stamp
 
 
 def sources():

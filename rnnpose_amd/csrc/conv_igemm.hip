@@ -98,20 +98,6 @@ __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-
 // the 128-wide tiling would leave the 256 CUs short of workgroups (Cout <= 128 at 300 row tiles) or pad Cout.
 // STRIDED = stride-2 mode (every tap is its own group, general input addressing); a template flag so that the
 // stride-1 instantiations keep their register budget (the 64-wide variant must stay <= 128 VGPRs for 4 waves/SIMD).
-// -DRP_CONV_TS (diagnostics build only): wave 0 of logical tile 0 records s_memtime at the phase boundaries of its
-// first 64 pipeline stages; tools/conv_ts.py prints the per-phase cycle counts.
-#ifdef RP_CONV_TS
-__device__ long long g_conv_ts[64 * 8];
-#define RP_TS(K_)                                                                      \
-  do {                                                                                 \
-    __builtin_amdgcn_sched_barrier(0);                                                 \
-    if (ts_on && ts_i < 64) { const long long t_ = clock64(); if (lane == 0) ts_lds[ts_i * 8 + (K_)] = t_; } /* LDS: a global store would count in vmcnt */ \
-    __builtin_amdgcn_sched_barrier(0);                                                 \
-  } while (0)
-#else
-#define RP_TS(K_) do { } while (0)
-#endif
-
 // COLS4 = wave layout of the 128-wide tile: false = 2 (rows) x 2 (columns) waves of 64 x 32*NI; true = 4 waves side by
 // side, each ALL 128 rows x 32 columns (NI must be 1).  Same MFMA count per wave, but a wave then requests 2 weight
 // fragments per k-slab from L2/L1 instead of 4 (the fragment loads were stalling in the vector-memory queue when two
@@ -326,34 +312,19 @@ __global__ __launch_bounds__(NT, ((COLS4 || TT > 0) ? 3 : 2)) void conv_igemm_f1
   do {                                                                                                      \
     int ncb_ = ccb + 1, ng_ = cg;                                                                           \
     if (ncb_ == p.ncb) { ncb_ = 0; ++ng_; }                                                                 \
-    RP_TS(0);                                                                                               \
     if (ct == 0) RP_LOAD_A(ng_ < p.G ? ng_ : cg, ng_ < p.G ? ncb_ : ccb);                                   \
-    RP_TS(1);                                                                                               \
     RP_MMA(S_, p.dv0 + ct, ab);                                                                             \
-    RP_TS(2);                                                                                               \
     RP_LOAD_B_CLAMPED(S_);                                                                                  \
-    RP_TS(3);                                                                                               \
     if (++pt == p.T) { pt = 0; if (++pcb == p.ncb) { pcb = 0; ++pg; } }                                     \
     if (++ct == p.T) {                                                                                      \
       ct = 0;                                                                                               \
       ccb = ncb_; cg = ng_;                                                                                 \
       RP_STORE_A(ab ^ 1);                                                                                   \
-      RP_TS(4);                                                                                             \
-      __syncthreads();                                                                                      \
+        __syncthreads();                                                                                      \
       ab ^= 1;                                                                                              \
     }                                                                                                       \
-    RP_TS(5);                                                                                               \
-    RP_TS_NEXT;                                                                                             \
   } while (0)
 
-#ifdef RP_CONV_TS
-  __shared__ long long ts_lds[64 * 8];
-  const bool ts_on = (bid == p.n_nt * (p.n_mt / 2)) && wave == 0;     // a tile in the middle of the problem
-  int ts_i = 0;
-#define RP_TS_NEXT ++ts_i
-#else
-#define RP_TS_NEXT do { } while (0)
-#endif
   if (tid < 4 * (RS / 8)) {       // the zero row of each (buffer, hi/lo) plane: 80 bytes = 5 x 16, never overwritten
     const uint4 z = make_uint4(0u, 0u, 0u, 0u);
     *reinterpret_cast<uint4*>(sAf + (tid / (RS / 8)) * (PROWS * RS) + AROWS * RS + (tid % (RS / 8)) * 8) = z;
@@ -510,9 +481,6 @@ __global__ __launch_bounds__(NT, ((COLS4 || TT > 0) ? 3 : 2)) void conv_igemm_f1
   if (total & 1) RP_STAGE(0);
 
   }
-#ifdef RP_CONV_TS
-  if (ts_on) for (int e = lane; e < 64 * 8; e += 64) g_conv_ts[e] = ts_lds[e];
-#endif
   if (p.sat && sat_n) atomicAdd(p.sat, static_cast<unsigned long long>(sat_n));
   // ------------------------------------------- epilogue -------------------------------------------
   // accumulators -> wave-private LDS tile (aliasing the weight staging buffers) -> 16-byte row-contiguous stores:
@@ -857,11 +825,5 @@ int rnnpose_conv2d_nhwc_f16x3(const rnnpose_conv_desc_t* d, rnnpose_stream_t str
 #undef RP_LAUNCH_T
   return rp::check_launch(fn);
 }
-
-#ifdef RP_CONV_TS
-int rnnpose_conv_dbg_timestamps(long long* h_out) {     // 64 x 8 cycle counters of the last launch (diagnostics build)
-  return hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_conv_ts), sizeof(long long) * 64 * 8) == hipSuccess ? 0 : 1;
-}
-#endif
 
 }  // extern "C"

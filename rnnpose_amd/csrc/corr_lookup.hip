@@ -68,21 +68,35 @@ __global__ __launch_bounds__(64) void corr_lookup_kernel(const float* __restrict
   const int ty1 = t1 / FP, tx1 = t1 - ty1 * FP;
   const long long first = static_cast<long long>(blockIdx.x) * PIX;
   const int npix = static_cast<int>(total - first < PIX ? total - first : PIX);
-#pragma unroll 4
-  for (int q = 0; q < npix; ++q) {
-    const int qbx = __shfl(bx, q), qby = __shfl(by, q);
-    const float* src = lvl_base + (p_off + first + q) * img;       // p_off: first pyramid row of this launch's images
-    {
-      const int x = qbx + tx0, y = qby + ty0;
-      float v = 0.f;
-      if (x >= 0 && x < wl && y >= 0 && y < hl) v = src[y * wl + x];
-      foot[q * FS + t0] = v;
+  // Every footprint load is UNCONDITIONAL (texels outside the level read element 0 of the pixel's map and are zeroed on
+  // the way into LDS; pixel slots past the end of the batch repeat the last pixel) and the loads of LB pixels are issued
+  // before the first LDS store: with the bounds test around the load the compiler waited vmcnt(0) after every pixel --
+  // 16 dependent memory round trips per wave (r02: 46 us per half-batch launch, latency-bound).
+  constexpr int LB = 8;
+  const bool has1 = t1 < FP * FP;
+#pragma unroll
+  for (int qb = 0; qb < PIX; qb += LB) {
+    float v0[LB], v1[LB];
+    unsigned ok = 0u;
+#pragma unroll
+    for (int j = 0; j < LB; ++j) {
+      const int q = qb + j;
+      const int qq = q < npix ? q : npix - 1;
+      const int qbx = __shfl(bx, qq), qby = __shfl(by, qq);
+      const float* src = lvl_base + (p_off + first + qq) * img;       // p_off: first pyramid row of this launch's images
+      const int xa = qbx + tx0, ya = qby + ty0, xb = qbx + tx1, yb = qby + ty1;
+      const bool oka = xa >= 0 && xa < wl && ya >= 0 && ya < hl;
+      const bool okb = has1 && xb >= 0 && xb < wl && yb >= 0 && yb < hl;
+      v0[j] = src[oka ? ya * wl + xa : 0];
+      v1[j] = src[okb ? yb * wl + xb : 0];
+      ok |= (oka ? 1u : 0u) << (2 * j) | (okb ? 2u : 0u) << (2 * j);
     }
-    if (t1 < FP * FP) {
-      const int x = qbx + tx1, y = qby + ty1;
-      float v = 0.f;
-      if (x >= 0 && x < wl && y >= 0 && y < hl) v = src[y * wl + x];
-      foot[q * FS + t1] = v;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < LB; ++j) {
+      const int q = qb + j;
+      foot[q * FS + t0] = (ok >> (2 * j)) & 1u ? v0[j] : 0.f;
+      if (has1) foot[q * FS + t1] = (ok >> (2 * j)) & 2u ? v1[j] : 0.f;
     }
   }
   __syncthreads();

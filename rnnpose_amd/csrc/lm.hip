@@ -17,6 +17,7 @@ using rp::Pose;
 constexpr int NACC = 27;        // 21 (upper triangle of H, row-major) + 6 (b)
 constexpr int PSTRIDE = 32;     // doubles per partial record
 constexpr int LM_THREADS = 256;
+constexpr int LM_BATCH = 4;      // pixels per thread whose loads are in flight together
 constexpr int LM_PIX_PER_BLOCK = 2048;   // 150 workgroups per 480x640 image: >4 per CU at B=8 (latency hiding for the fp64 chain)
 constexpr int LM_MAX_BLOCKS = 256;
 
@@ -50,48 +51,70 @@ __global__ __launch_bounds__(LM_THREADS) void lm_normal_eq_kernel(const float* _
 #pragma unroll
   for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
 
-  for (long long t = static_cast<long long>(blockIdx.x) * LM_THREADS + threadIdx.x; t < P;
-       t += static_cast<long long>(nblk) * LM_THREADS) {
-    const int x = static_cast<int>(t % W), y = static_cast<int>(t / W);
-    const float wgt = weight[b * P + t];
-    const float Z = depth[b * P + t] + eps;
-    float tx, ty;
-    if (target_mode == 0) {
-      const float2 tt = *reinterpret_cast<const float2*>(target + (b * P + t) * 2);
-      tx = tt.x;
-      ty = tt.y;
-    } else {
-      tx = target[(static_cast<long long>(b) * 2 + 0) * P + t] + static_cast<float>(x);
-      ty = target[(static_cast<long long>(b) * 2 + 1) * P + t] + static_cast<float>(y);
-    }
-    const rp::Reproj r = rp::reproject(Z, static_cast<float>(x), static_cast<float>(y), k, g);
-    const bool valid = (r.Z0 > rp::kMinDepthValid) && (r.Z1 > rp::kMinDepthValid);   // transformation.py:289
-    const double vw = valid ? static_cast<double>(wgt) : 0.0;
-    // J_pi in fp32 (projective_ops.py:118-124): zeros where clamped Z <= 0.02
-    const bool tiny = r.Zc <= rp::kMinDepthProj + 0.01f;
-    const float zi1 = tiny ? 0.f : 1.0f / r.Zc;
-    const float zi2 = tiny ? 0.f : 1.0f / (r.Zc * r.Zc);
-    const double a = static_cast<double>(k.fx * zi1);
-    const double c = static_cast<double>(-k.fx * r.X1 * zi2);
-    const double d = static_cast<double>(k.fy * zi1);
-    const double e = static_cast<double>(-k.fy * r.Y1 * zi2);
-    const double X1 = r.X1, Y1 = r.Y1, Z1 = r.Z1;
-    // J = J_pi * J_T with J_T = [I | -[X']x] built from the TRANSFORMED point (transformation.py:27-46,85-90)
-    double J0[6], J1[6];
-    J0[0] = a;   J0[1] = 0.0; J0[2] = c; J0[3] = c * Y1;            J0[4] = a * Z1 + c * (-X1); J0[5] = a * (-Y1);
-    J1[0] = 0.0; J1[1] = d;   J1[2] = e; J1[3] = d * (-Z1) + e * Y1; J1[4] = e * (-X1);          J1[5] = d * X1;
-    const double r0 = static_cast<double>(tx) - static_cast<double>(r.u);
-    const double r1 = static_cast<double>(ty) - static_cast<double>(r.v);
-    int idx = 0;
+  // LM_BATCH pixels per trip: their 4-5 loads each are issued (unconditionally, clamped to the last pixel) before the
+  // first fp64 chain starts.  One pixel per trip was 8 dependent memory round trips per thread: 26 us per launch for
+  // 20 MB (r02).  Pixels are accumulated in the same order as before, so the partial sums are bit-identical.
+  const long long stride = static_cast<long long>(nblk) * LM_THREADS;
+  for (long long t0 = static_cast<long long>(blockIdx.x) * LM_THREADS + threadIdx.x; t0 < P; t0 += LM_BATCH * stride) {
+    float wgt_[LM_BATCH], dep_[LM_BATCH], tx_[LM_BATCH], ty_[LM_BATCH];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const double wi0 = vw * J0[i], wi1 = vw * J1[i];
-#pragma unroll
-      for (int j = i; j < 6; ++j) {
-        acc[idx] += wi0 * J0[j] + wi1 * J1[j];
-        ++idx;
+    for (int j = 0; j < LM_BATCH; ++j) {
+      const long long tj = t0 + j * stride;
+      const long long t = tj < P ? tj : P - 1;
+      wgt_[j] = weight[b * P + t];
+      dep_[j] = depth[b * P + t];
+      if (target_mode == 0) {
+        const float2 tt = *reinterpret_cast<const float2*>(target + (b * P + t) * 2);
+        tx_[j] = tt.x;
+        ty_[j] = tt.y;
+      } else {
+        tx_[j] = target[(static_cast<long long>(b) * 2 + 0) * P + t];
+        ty_[j] = target[(static_cast<long long>(b) * 2 + 1) * P + t];
       }
-      acc[21 + i] += wi0 * r0 + wi1 * r1;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < LM_BATCH; ++j) {
+      const long long t = t0 + j * stride;
+      if (t >= P) break;
+      const unsigned tu = static_cast<unsigned>(t);            // t < H*W < 2^31: 32-bit division (64-bit is a software routine)
+      const int y = static_cast<int>(tu / static_cast<unsigned>(W)), x = static_cast<int>(tu - static_cast<unsigned>(y) * static_cast<unsigned>(W));
+      const float wgt = wgt_[j];
+      const float Z = dep_[j] + eps;
+      float tx = tx_[j], ty = ty_[j];
+      if (target_mode != 0) {
+        tx += static_cast<float>(x);
+        ty += static_cast<float>(y);
+      }
+      const rp::Reproj r = rp::reproject(Z, static_cast<float>(x), static_cast<float>(y), k, g);
+      const bool valid = (r.Z0 > rp::kMinDepthValid) && (r.Z1 > rp::kMinDepthValid);   // transformation.py:289
+      const double vw = valid ? static_cast<double>(wgt) : 0.0;
+      // J_pi in fp32 (projective_ops.py:118-124): zeros where clamped Z <= 0.02
+      const bool tiny = r.Zc <= rp::kMinDepthProj + 0.01f;
+      const float zi1 = tiny ? 0.f : 1.0f / r.Zc;
+      const float zi2 = tiny ? 0.f : 1.0f / (r.Zc * r.Zc);
+      const double a = static_cast<double>(k.fx * zi1);
+      const double c = static_cast<double>(-k.fx * r.X1 * zi2);
+      const double d = static_cast<double>(k.fy * zi1);
+      const double e = static_cast<double>(-k.fy * r.Y1 * zi2);
+      const double X1 = r.X1, Y1 = r.Y1, Z1 = r.Z1;
+      // J = J_pi * J_T with J_T = [I | -[X']x] built from the TRANSFORMED point (transformation.py:27-46,85-90)
+      double J0[6], J1[6];
+      J0[0] = a;   J0[1] = 0.0; J0[2] = c; J0[3] = c * Y1;            J0[4] = a * Z1 + c * (-X1); J0[5] = a * (-Y1);
+      J1[0] = 0.0; J1[1] = d;   J1[2] = e; J1[3] = d * (-Z1) + e * Y1; J1[4] = e * (-X1);          J1[5] = d * X1;
+      const double r0 = static_cast<double>(tx) - static_cast<double>(r.u);
+      const double r1 = static_cast<double>(ty) - static_cast<double>(r.v);
+      int idx = 0;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const double wi0 = vw * J0[i], wi1 = vw * J1[i];
+#pragma unroll
+        for (int jj = i; jj < 6; ++jj) {
+          acc[idx] += wi0 * J0[jj] + wi1 * J1[jj];
+          ++idx;
+        }
+        acc[21 + i] += wi0 * r0 + wi1 * r1;
+      }
     }
   }
   // wave reduction (64 lanes), then across the 4 waves through LDS
@@ -329,7 +352,7 @@ int rnnpose_lm_normal_eq_f64(const float* target, int target_mode, const float* 
   const char* fn = "rnnpose_lm_normal_eq_f64";
   RP_REQUIRE(target && weight && depth && K && G && workspace && Hm && bv, fn, "null pointer");
   RP_REQUIRE(target_mode == 0 || target_mode == 1, fn, "target_mode must be 0 or 1");
-  RP_REQUIRE(B > 0 && B < 65536 && H > 0 && W > 0, fn, "bad size");
+  RP_REQUIRE(B > 0 && B < 65536 && H > 0 && W > 0 && static_cast<long long>(H) * W < (1LL << 31), fn, "bad size");
   RP_REQUIRE(workspace_bytes >= rnnpose_lm_workspace_bytes(B, H, W), fn, "workspace too small");
   launch_normal_eq(target, target_mode, weight, depth, depth_eps, K, G, B, H, W, workspace, Hm, bv, rp::as_stream(stream));
   return rp::check_launch(fn);
@@ -352,7 +375,7 @@ static int lm_step_impl(const char* fn, const float* target, int target_mode, co
                         double* Hm, double* bv, float* xi, int* info, rnnpose_stream_t stream) {
   RP_REQUIRE(target && weight && depth && K && G_in && G_out && workspace && Hm && bv && xi, fn, "null pointer");
   RP_REQUIRE(target_mode == 0 || target_mode == 1, fn, "target_mode must be 0 or 1");
-  RP_REQUIRE(B > 0 && B < 65536 && H > 0 && W > 0 && num_iters >= 0, fn, "bad size");
+  RP_REQUIRE(B > 0 && B < 65536 && H > 0 && W > 0 && static_cast<long long>(H) * W < (1LL << 31) && num_iters >= 0, fn, "bad size");
   RP_REQUIRE(workspace_bytes >= rnnpose_lm_workspace_bytes(B, H, W), fn, "workspace too small");
   hipStream_t st = rp::as_stream(stream);
   for (int it = 0; it < num_iters; ++it) {

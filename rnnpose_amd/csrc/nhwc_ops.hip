@@ -150,9 +150,10 @@ __global__ __launch_bounds__(256) void conv3x3_cout2_run4_kernel(const float* __
   const int runs_per_row = (w + 3) >> 2;
   const long long total_runs = static_cast<long long>(B) * h * runs_per_row;
   for (long long r = static_cast<long long>(blockIdx.x) * 4 + wave; r < total_runs; r += static_cast<long long>(gridDim.x) * 4) {
-    const int xr = static_cast<int>(r % runs_per_row);
-    const long long by = r / runs_per_row;
-    const int Y = static_cast<int>(by % h), b = static_cast<int>(by / h);
+    const unsigned ru = static_cast<unsigned>(r);                       // total_runs < 2^31 (host check): 32-bit divisions
+    const unsigned by = ru / static_cast<unsigned>(runs_per_row);
+    const int xr = static_cast<int>(ru - by * runs_per_row);
+    const int b = static_cast<int>(by / static_cast<unsigned>(h)), Y = static_cast<int>(by - static_cast<unsigned>(b) * h);
     const int X0 = xr * 4;
     float4 v[3][6];
 #pragma unroll
@@ -233,12 +234,20 @@ __global__ __launch_bounds__(256) void convex_upsample_nhwc_kernel(const float* 
   if (X >= w) return;
   const int n = h * w;
   const float* m = mask + (static_cast<long long>(b) * n + Y * w + X) * 576 + t;
+  // all 18 loads first, unconditional (neighbours outside the map read the centre pixel and are zeroed afterwards): a load
+  // under its bounds test is followed by a vmcnt(0) wait -- nine dependent round trips per thread before this change
   float mv[9], mx = -INFINITY;
+  float2 fv[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) {
     mv[k] = m[k * 64];
-    mx = fmaxf(mx, mv[k]);
+    const int yy = Y + k / 3 - 1, xx = X + k % 3 - 1;
+    const bool ok = yy >= 0 && yy < h && xx >= 0 && xx < w;
+    fv[k] = *reinterpret_cast<const float2*>(flow + (static_cast<long long>(b) * n + (ok ? yy * w + xx : Y * w + X)) * 2);
   }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) mx = fmaxf(mx, mv[k]);
   float den = 0.f;
 #pragma unroll
   for (int k = 0; k < 9; ++k) {
@@ -249,8 +258,7 @@ __global__ __launch_bounds__(256) void convex_upsample_nhwc_kernel(const float* 
 #pragma unroll
   for (int k = 0; k < 9; ++k) {
     const int yy = Y + k / 3 - 1, xx = X + k % 3 - 1;
-    float2 f = make_float2(0.f, 0.f);
-    if (yy >= 0 && yy < h && xx >= 0 && xx < w) f = *reinterpret_cast<const float2*>(flow + (static_cast<long long>(b) * n + yy * w + xx) * 2);
+    const float2 f = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? fv[k] : make_float2(0.f, 0.f);
     const float wk = mv[k] / den;
     ax += wk * (8.f * f.x);
     ay += wk * (8.f * f.y);
@@ -362,19 +370,26 @@ __global__ __launch_bounds__(256) void instnorm_apply_kernel(const float* __rest
                                                              const float* __restrict__ res_mr, int res_relu) {
   const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= total4) return;
-  const int c4 = static_cast<int>(i % (C >> 2));
-  const long long row = i / (C >> 2);
-  const int b = static_cast<int>(row / HW);
+  // total4 < 2^31 (host check): 32-bit divisions (three 64-bit ones per float4 cost more than the memory traffic)
+  const unsigned iu = static_cast<unsigned>(i), cq = static_cast<unsigned>(C >> 2);
+  const unsigned row = iu / cq;
+  const int c4 = static_cast<int>(iu - row * cq);
+  const int b = static_cast<int>(row / static_cast<unsigned>(HW));
+  // all six loads are issued up front (absent operands alias present ones): a load under `if (residual)` costs a second,
+  // dependent memory round trip per thread
   const float4 v = reinterpret_cast<const float4*>(x)[i];
   const float4 m01 = *reinterpret_cast<const float4*>(mean_rstd + (static_cast<long long>(b) * C + c4 * 4) * 2);
   const float4 m23 = *reinterpret_cast<const float4*>(mean_rstd + (static_cast<long long>(b) * C + c4 * 4 + 2) * 2);
+  const float* rsrc = residual ? residual : x;
+  const float* qsrc = res_mr ? res_mr : mean_rstd;
+  float4 r = reinterpret_cast<const float4*>(rsrc)[i];
+  const float4 q01 = *reinterpret_cast<const float4*>(qsrc + (static_cast<long long>(b) * C + c4 * 4) * 2);
+  const float4 q23 = *reinterpret_cast<const float4*>(qsrc + (static_cast<long long>(b) * C + c4 * 4 + 2) * 2);
+  __builtin_amdgcn_sched_barrier(0);
   float4 y = make_float4((v.x - m01.x) * m01.y, (v.y - m01.z) * m01.w, (v.z - m23.x) * m23.y, (v.w - m23.z) * m23.w);
   if (relu) y = make_float4(fmaxf(y.x, 0.f), fmaxf(y.y, 0.f), fmaxf(y.z, 0.f), fmaxf(y.w, 0.f));
   if (residual) {
-    float4 r = reinterpret_cast<const float4*>(residual)[i];
     if (res_mr) {
-      const float4 q01 = *reinterpret_cast<const float4*>(res_mr + (static_cast<long long>(b) * C + c4 * 4) * 2);
-      const float4 q23 = *reinterpret_cast<const float4*>(res_mr + (static_cast<long long>(b) * C + c4 * 4 + 2) * 2);
       r = make_float4((r.x - q01.x) * q01.y, (r.y - q01.z) * q01.w, (r.z - q23.x) * q23.y, (r.w - q23.z) * q23.w);
       if (res_relu) r = make_float4(fmaxf(r.x, 0.f), fmaxf(r.y, 0.f), fmaxf(r.z, 0.f), fmaxf(r.w, 0.f));
     }
@@ -391,13 +406,15 @@ __global__ __launch_bounds__(256) void instnorm_apply_kernel(const float* __rest
 // PLANAR: the input is coords1 / flow (B,2,h,w) planar (the pixel grid is subtracted here when subtract_grid != 0) and the
 // flow is also written into channels [motion_co, +2) of the motion-feature tensor: flow_prep + convf1 in one launch.
 constexpr int F1_TX = 20;
+constexpr int F1_ROW = 28;     // F1_TX + 6 halo, rounded up to a multiple of 4
 template <bool PLANAR>
-__global__ __launch_bounds__(128) void conv7x7_cin2_kernel(const float* __restrict__ flow4, const float* __restrict__ wt,
+__global__ __launch_bounds__(128, 3) void conv7x7_cin2_kernel(const float* __restrict__ flow4, const float* __restrict__ wt,
                                                            const float* __restrict__ bias, float* __restrict__ out,
                                                            int out_cs, int out_co, int Cout, int h, int w,
                                                            int subtract_grid, float* __restrict__ motion, int motion_cs,
                                                            int motion_co) {
-  __shared__ float patch[2][7][F1_TX + 6];
+  // rows padded to 28 floats (112 bytes): every row is seven aligned 16-byte LDS reads
+  __shared__ __attribute__((aligned(16))) float patch[2][7][F1_ROW];
   const int b = blockIdx.z, Y = blockIdx.y, X0 = blockIdx.x * F1_TX;
   const int c = threadIdx.x;
   const int n = h * w;
@@ -419,26 +436,40 @@ __global__ __launch_bounds__(128) void conv7x7_cin2_kernel(const float* __restri
     patch[0][ky][xx] = v.x;
     patch[1][ky][xx] = v.y;
   }
-  float wreg[98];
-  if (c < Cout) {
-#pragma unroll
-    for (int k = 0; k < 98; ++k) wreg[k] = wt[k * Cout + c];
-  }
   const float bs = c < Cout ? bias[c] : 0.f;
   __syncthreads();
   if (c >= Cout) return;
-#pragma unroll 4
-  for (int x = 0; x < F1_TX; ++x) {
-    if (X0 + x >= w) break;
-    float acc = bs;
+  // Row-outer accumulation: one patch row (7 wave-uniform 16-byte LDS reads) feeds 7 taps x 20 pixels, so the LDS pipe sees
+  // 98 reads per thread instead of one 4-byte read per multiply-add (1960): the kernel was LDS-issue-bound (r02: 23 us per
+  // launch).  The weights are held one input channel (49) at a time: with all 98 (+ their 64-bit addresses) the 20
+  // accumulators did not fit.  Per pixel the products are still added in (ci, ky, kx) order.
+  float acc[F1_TX];
 #pragma unroll
-    for (int ci = 0; ci < 2; ++ci)
+  for (int x = 0; x < F1_TX; ++x) acc[x] = bs;
+#pragma unroll 1
+  for (int ci = 0; ci < 2; ++ci) {
+    float wreg[49];
+    const float* wc = wt + static_cast<long long>(ci) * 49 * Cout + c;
 #pragma unroll
-      for (int ky = 0; ky < 7; ++ky)
+    for (int k = 0; k < 49; ++k) wreg[k] = wc[k * Cout];
 #pragma unroll
-        for (int kx = 0; kx < 7; ++kx) acc += wreg[(ci * 7 + ky) * 7 + kx] * patch[ci][ky][x + kx];
-    out[(static_cast<long long>(b) * n + Y * w + X0 + x) * out_cs + out_co + c] = fmaxf(acc, 0.f);
+    for (int ky = 0; ky < 7; ++ky) {
+      float row[F1_ROW];
+#pragma unroll
+      for (int q = 0; q < F1_ROW / 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(&patch[ci][ky][4 * q]);
+        row[4 * q + 0] = v.x; row[4 * q + 1] = v.y; row[4 * q + 2] = v.z; row[4 * q + 3] = v.w;
+      }
+#pragma unroll
+      for (int x = 0; x < F1_TX; ++x)
+#pragma unroll
+        for (int kx = 0; kx < 7; ++kx) acc[x] += wreg[ky * 7 + kx] * row[x + kx];
+      __builtin_amdgcn_sched_barrier(0);     // one row in registers at a time
+    }
   }
+#pragma unroll
+  for (int x = 0; x < F1_TX; ++x)
+    if (X0 + x < w) out[(static_cast<long long>(b) * n + Y * w + X0 + x) * out_cs + out_co + c] = fmaxf(acc[x], 0.f);
 }
 
 }  // namespace
@@ -488,6 +519,7 @@ int rnnpose_flow_head_out_f32(const float* x, int x_c_stride, int x_c_offset, in
   const long long total = static_cast<long long>(B) * h * w;
   if (c_in <= 256) {
     const long long runs = static_cast<long long>(B) * h * ((w + 3) / 4);
+    RP_REQUIRE(runs < (1LL << 31), fn, "too many pixel runs for 32-bit indices");
     const int nb = static_cast<int>(runs / 4 + 1 < 512 ? runs / 4 + 1 : 512);      // 2 workgroups per CU: a wave keeps its weights for ~5 runs
     hipLaunchKernelGGL(conv3x3_cout2_run4_kernel, dim3(nb), dim3(256), 0, rp::as_stream(stream), x, x_c_stride, x_c_offset, c_in,
                        w_oihw, bias, coords1, delta, coords1_out, flow_lr, B, h, w);
@@ -530,6 +562,7 @@ int rnnpose_instnorm_nhwc_f32(const float* x, int B, int HW, int C, float eps, i
   hipLaunchKernelGGL(instnorm_finalize_kernel, dim3(B), dim3(256), 0, st, static_cast<const double*>(workspace), mean_rstd,
                      nchunk, C, HW, eps);
   const long long total4 = static_cast<long long>(B) * HW * (C >> 2);
+  RP_REQUIRE(total4 < (1LL << 31), fn, "tensor too large for 32-bit float4 indices");
   hipLaunchKernelGGL(instnorm_apply_kernel, dim3(rp::cdiv(total4, 256)), dim3(256), 0, st, x, mean_rstd, residual, out, HW,
                      C, relu, total4, static_cast<const float*>(nullptr), 0);
   return rp::check_launch(fn);
@@ -547,6 +580,7 @@ int rnnpose_instnorm_tiles_nhwc_f32(const float* x, int B, int HW, int C, float 
   hipLaunchKernelGGL(instnorm_finalize_tiles_kernel, dim3(B, rp::cdiv(C, 8)), dim3(256), 0, st, tile_stats, mean_rstd, tiles_per_image, C, HW, eps);
   if (out) {
     const long long total4 = static_cast<long long>(B) * HW * (C >> 2);
+    RP_REQUIRE(total4 < (1LL << 31), fn, "tensor too large for 32-bit float4 indices");
     hipLaunchKernelGGL(instnorm_apply_kernel, dim3(rp::cdiv(total4, 256)), dim3(256), 0, st, x, mean_rstd, residual, out, HW,
                        C, relu, total4, residual ? residual_mean_rstd : nullptr, residual_relu);
   }

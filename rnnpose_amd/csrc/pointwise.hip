@@ -31,13 +31,13 @@ __device__ __forceinline__ AcTap ac_tap(int dst, int in, int out) {
 __global__ __launch_bounds__(256) void context_prep_kernel(const float* __restrict__ ctx, float* __restrict__ net,
                                                            float* __restrict__ inp, int B, int C, int H, int W, int h,
                                                            int w, int hdim) {
-  const long long n = static_cast<long long>(B) * C * h * w;
-  for (long long t = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; t < n;
-       t += static_cast<long long>(gridDim.x) * blockDim.x) {
-    const int X = static_cast<int>(t % w);
-    const int Y = static_cast<int>((t / w) % h);
-    const int c = static_cast<int>((t / (static_cast<long long>(w) * h)) % C);
-    const int b = static_cast<int>(t / (static_cast<long long>(w) * h * C));
+  const unsigned n = static_cast<unsigned>(B) * C * h * w;                 // < 2^31 (host check): 32-bit divisions
+  for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+    const unsigned row = t / static_cast<unsigned>(w), plane = row / static_cast<unsigned>(h);
+    const int X = static_cast<int>(t - row * w);
+    const int Y = static_cast<int>(row - plane * h);
+    const int b = static_cast<int>(plane / static_cast<unsigned>(C));
+    const int c = static_cast<int>(plane - static_cast<unsigned>(b) * C);
     const AcTap ty = ac_tap(Y, H, h), tx = ac_tap(X, W, w);
     const float* p = ctx + (static_cast<long long>(b) * C + c) * H * W;
     const float v00 = p[static_cast<long long>(ty.i0) * W + tx.i0], v01 = p[static_cast<long long>(ty.i0) * W + tx.i1];
@@ -84,7 +84,9 @@ __global__ __launch_bounds__(256) void induced_flow_kernel(const float* __restri
   const long long P = static_cast<long long>(H) * W;
   const long long t = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (t >= P) return;
-  const int x = static_cast<int>(t % W), y = static_cast<int>(t / W);
+  // (32-bit division: t < H*W < 2^31; a 64-bit t % W is a ~200-instruction software routine on this ISA)
+  const unsigned tu = static_cast<unsigned>(t);
+  const int y = static_cast<int>(tu / static_cast<unsigned>(W)), x = static_cast<int>(tu - static_cast<unsigned>(y) * static_cast<unsigned>(W));
   const Intr k = rp::load_intr(K, b);
   const Pose g = rp::load_pose(G, b);
   const float Z = depth[b * P + t] + eps;
@@ -202,6 +204,10 @@ __global__ __launch_bounds__(256) void convex_upsample_kernel(const float* __res
 // ------------------------------------------------------------------------------------------------
 // a8: reliability weight.  One thread per pixel; g1 rows are coalesced, the four g2 taps of neighbouring
 // lanes are neighbouring addresses because the flow is smooth (coalesced in practice).
+#ifndef RP_CW_BATCH
+#define RP_CW_BATCH 4
+#endif
+constexpr int CW_BATCH = RP_CW_BATCH;   // channels whose 5 loads each are in flight together
 __global__ __launch_bounds__(256) void corr_weight_kernel(const float* __restrict__ g1, const float* __restrict__ g2,
                                                           const float* __restrict__ target, int target_mode,
                                                           const float* __restrict__ depth,
@@ -222,11 +228,16 @@ __global__ __launch_bounds__(256) void corr_weight_kernel(const float* __restric
   const int b = bid / bpi;
   const long long t = static_cast<long long>(bid - b * bpi) * 256 + threadIdx.x;
   if (t >= P) return;
-  const int x = static_cast<int>(t % W), y = static_cast<int>(t / W);
-  // background pixels (rendered depth <= 0) have weight exp(..) * 0 = 0 whatever the descriptors say: skip their 5 * D
-  // loads.  Whole waves of background (the band around the object in a zoomed crop) then cost one depth load.  The only
-  // observable difference to the reference expression is a NaN descriptor AT a background pixel (NaN * 0 = NaN there, 0 here).
-  if (!(depth[b * P + t] > 0.f)) {
+  // (32-bit division: t < H*W < 2^31; a 64-bit t % W is a ~200-instruction software routine on this ISA)
+  const unsigned tu = static_cast<unsigned>(t);
+  const int y = static_cast<int>(tu / static_cast<unsigned>(W)), x = static_cast<int>(tu - static_cast<unsigned>(y) * static_cast<unsigned>(W));
+  // background pixels (rendered depth <= 0) have weight exp(..) * 0 = 0 whatever the descriptors say.  A WAVE that is all
+  // background (the band around the object in a zoomed crop) leaves after one depth load instead of 5 * D descriptor
+  // loads.  Wave-uniform exit only: a per-lane `return` put the channel loop under a divergent branch and the compiler
+  // replaced its counted waits by vmcnt(0) -- 104 -> 259 us per launch (r02, same-box A/B).  The only observable
+  // difference to the reference expression is a NaN descriptor inside an all-background wave (NaN * 0 = NaN there, 0 here).
+  const float fg = depth[b * P + t] > 0.f ? 1.f : 0.f;
+  if (__builtin_amdgcn_ballot_w64(fg != 0.f) == 0ull) {
     weight[b * P + t] = 0.f;
     return;
   }
@@ -259,13 +270,33 @@ __global__ __launch_bounds__(256) void corr_weight_kernel(const float* __restric
   const float* a = g1 + static_cast<long long>(b) * D * P + t;
   const float* q = g2 + static_cast<long long>(b) * D * P;
   float s = 0.f;
-#pragma unroll 8
-  for (int c = 0; c < D; ++c) {
+  int c = 0;
+  // CW_BATCH channels per batch: all their loads are issued before the first use (the fence keeps the compiler from serialising
+  // them behind vmcnt(0) waits, which it does as soon as the surrounding control flow changes: 104 vs 259 us per launch)
+  for (; c + CW_BATCH <= D; c += CW_BATCH) {
+    float av[CW_BATCH], v00[CW_BATCH], v10[CW_BATCH], v01[CW_BATCH], v11[CW_BATCH];
+#pragma unroll
+    for (int j = 0; j < CW_BATCH; ++j) {
+      const float* qc = q + (c + j) * P;
+      av[j] = a[(c + j) * P];
+      v00[j] = qc[o00];
+      v10[j] = qc[o10];
+      v01[j] = qc[o01];
+      v11[j] = qc[o11];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < CW_BATCH; ++j) {
+      const float wv = ((v00[j] * w00 + v10[j] * w10) + v01[j] * w01) + v11[j] * w11;
+      s += av[j] * wv;
+    }
+  }
+  for (; c < D; ++c) {
     const float* qc = q + c * P;
     const float wv = ((qc[o00] * w00 + qc[o10] * w10) + qc[o01] * w01) + qc[o11] * w11;
     s += a[c * P] * wv;
   }
-  weight[b * P + t] = expf(-fabsf(1.f - s) / sigma[0]);
+  weight[b * P + t] = expf(-fabsf(1.f - s) / sigma[0]) * fg;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -308,6 +339,7 @@ int rnnpose_context_prep_f32(const float* ctx, int B, int C, int H, int W, int h
   RP_REQUIRE(ctx && net && inp, fn, "null pointer");
   RP_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && h > 0 && w > 0, fn, "non-positive size");
   RP_REQUIRE(hdim > 0 && hdim < C, fn, "hdim must be in (0,C)");
+  RP_REQUIRE(static_cast<long long>(B) * C * h * w < (1LL << 31), fn, "output too large for 32-bit element indices");
   const long long n = static_cast<long long>(B) * C * h * w;
   const int blocks = static_cast<int>(n / 256 + 1 < 65536 ? n / 256 + 1 : 65536);
   hipLaunchKernelGGL(context_prep_kernel, dim3(blocks), dim3(256), 0, rp::as_stream(stream), ctx, net, inp, B, C, H, W, h,
@@ -330,7 +362,7 @@ int rnnpose_induced_flow_f32(const float* depth, const float* K, const float* G,
                              int mode, float* flow, float* vmask, rnnpose_stream_t stream) {
   const char* fn = "rnnpose_induced_flow_f32";
   RP_REQUIRE(depth && K && G && flow, fn, "null pointer");
-  RP_REQUIRE(B > 0 && B < 65536 && H > 0 && W > 0, fn, "bad size");
+  RP_REQUIRE(B > 0 && B < 65536 && H > 0 && W > 0 && static_cast<long long>(H) * W < (1LL << 31), fn, "bad size");
   RP_REQUIRE(mode == 0 || mode == 1, fn, "mode must be 0 or 1");
   const long long P = static_cast<long long>(H) * W;
   hipLaunchKernelGGL(induced_flow_kernel, dim3(rp::cdiv(P, 256), B), dim3(256), 0, rp::as_stream(stream), depth, K, G,
@@ -364,7 +396,7 @@ int rnnpose_corr_weight_f32(const float* g1, const float* g2, const float* targe
   const char* fn = "rnnpose_corr_weight_f32";
   RP_REQUIRE(g1 && g2 && target && depth && sigma && weight, fn, "null pointer");
   RP_REQUIRE(target_mode == 0 || target_mode == 1, fn, "target_mode must be 0 or 1");
-  RP_REQUIRE(B > 0 && B < 65536 && D > 0 && H > 1 && W > 1, fn, "bad size");
+  RP_REQUIRE(B > 0 && B < 65536 && D > 0 && H > 1 && W > 1 && static_cast<long long>(H) * W < (1LL << 31), fn, "bad size");
   const long long P = static_cast<long long>(H) * W;
   RP_REQUIRE(static_cast<long long>(rp::cdiv(P, 256)) * B < (1LL << 31), fn, "grid too large");
   hipLaunchKernelGGL(corr_weight_kernel, dim3(static_cast<unsigned>(rp::cdiv(P, 256) * B)), dim3(256), 0, rp::as_stream(stream), g1, g2, target,

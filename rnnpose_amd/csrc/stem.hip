@@ -60,17 +60,33 @@ __global__ __launch_bounds__(256) void stem_conv7x7_s2_kernel(const float* __res
 
   // ---- patch: global (NCHW) -> LDS, normalised ----
   const float* src = img + static_cast<long long>(n) * 3 * H * W;
-  for (int i = tid; i < PATCH; i += 256) {
+  // all (PATCH + 255) / 256 loads of a thread are issued before the first one is used: unconditional, texels outside the
+  // image read element 0 of the image and become zero below (a load under its bounds test is followed by vmcnt(0):
+  // ten dependent HBM round trips per workgroup before this change)
+  constexpr int NLD = (PATCH + 255) / 256;
+  float pv[NLD];
+  unsigned inside = 0u;
+#pragma unroll
+  for (int j = 0; j < NLD; ++j) {
+    const int i = tid + 256 * j;
     const int c = i / PLANE, r = i - c * PLANE;
     const int py = r / PW, px = r - py * PW;
     const int iy = iy0 + py, ix = ix0 + px;
+    const bool ok = i < PATCH && iy >= 0 && iy < H && ix >= 0 && ix < W;
+    pv[j] = src[ok ? (static_cast<long long>(c) * H + iy) * W + ix : 0];
+    inside |= (ok ? 1u : 0u) << j;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int j = 0; j < NLD; ++j) {
+    const int i = tid + 256 * j;
     float v = 0.f;
-    if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
-      v = src[(static_cast<long long>(c) * H + iy) * W + ix];
+    if ((inside >> j) & 1u) {
+      v = pv[j];
       if (normalize) v = 2.f * (v / 255.f) - 1.f;          // literal operation order of model/CFNet.py:42
     }
     if (sat && !(fabsf(v) * a_scale <= 65504.f)) atomicAdd(sat, 1ull);     // range guard (f16x3.cuh)
-    patch[i] = v;
+    if (i < PATCH) patch[i] = v;
   }
   __syncthreads();
 

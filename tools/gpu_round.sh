@@ -27,5 +27,8 @@ if [ "$2" != "noprof" ]; then
   bash tools/pmc_sq.sh ${TAG}_k python tools/pmc_kernels.py 3 > /dev/null 2>&1
   bash tools/pmc_sq.sh ${TAG}_c python tools/conv_layers.py 3 > /dev/null 2>&1
   PMC_TRAFFIC_ONLY=1 bash tools/pmc_sq.sh ${TAG}_b python bench.py --steps 1 --warmup 1 --no-graph --no-cpu-baseline > /dev/null 2>&1
-  ls $OUT | grep "^${TAG}_" | tr '\n' ' '
+  # summaries on the box (gpurun merges <= 64 MiB back), then drop the databases except the main kernel trace
+  python tools/summarize_profiles.py $TAG $OUT/${TAG}_summary > $OUT/${TAG}_summary.log 2>&1; tail -3 $OUT/${TAG}_summary.log
+  rm -rf $OUT/${TAG}_*_pmc[0-9] $OUT/${TAG}_prof_unsplit $OUT/${TAG}_prof_convs
+  du -sh $OUT | cut -f1
 fi

@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Turns the scratch outputs of tools/gpu_round.sh (gpurun_out/<tag>_*) into the committed record under profiles/:
 
-    python tools/summarize_profiles.py r02            # gpurun_out/r02_* -> profiles/r02_*
+    python tools/summarize_profiles.py r02 [outdir]   # gpurun_out/r02_* -> profiles/r02_* (or outdir/)
+
+tools/gpu_round.sh runs it ON the GPU box with outdir = gpurun_out/<tag>_summary and then deletes the rocprofv3 databases
+(gpurun merges at most 64 MiB back); the summary directory is what gets copied into profiles/.
 
   <tag>_bench*.json            the bench lines (default config, --no-graph, S1 / S5 / B16 shapes)
   <tag>_kernel_stats*.csv      per-kernel calls / total / mean / min / max of the rocprofv3 --kernel-trace --stats runs of bench.py
@@ -27,8 +30,8 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import pmc_report  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
+G, P = os.path.join(ROOT, "gpurun_out"), (os.path.abspath(sys.argv[2]) if len(sys.argv) > 2 else os.path.join(ROOT, "profiles"))
 
 
 def have(*parts):
