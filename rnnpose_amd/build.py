@@ -23,6 +23,8 @@ STAMP = os.path.join(LIBDIR, "librnnpose_hip.stamp")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall",
          "-Wno-unused-function", "-Wno-unused-variable", "-DNDEBUG"]
+# the MFMA kernels keep their fp32 vector ALU work scalar (csrc/f16x3.cuh: packed fp32 ops are slow next to MFMAs)
+PER_FILE_FLAGS = {"conv_igemm.hip": ["-fno-slp-vectorize"], "stem.hip": ["-fno-slp-vectorize"]}
 FLAGS += os.environ.get("RNNPOSE_HIPCC_EXTRA", "").split()     # diagnostics builds (e.g. -DRP_ABL=..., tools/conv_ablate.sh), part of the stamp
 
 
@@ -39,6 +41,7 @@ def _digest() -> str:
         with open(f, "rb") as fh:
             h.update(fh.read())
     h.update(" ".join(FLAGS).encode())
+    h.update(repr(sorted(PER_FILE_FLAGS.items())).encode())
     return h.hexdigest()
 
 
@@ -74,7 +77,7 @@ def _build_locked(dig: str, verbose: bool) -> str:
     for src in sources():
         obj = os.path.join(LIBDIR, os.path.basename(src) + ".o")
         cmd = [hipcc(), "-c", "-x", "hip", src, "-o", obj, "-I", os.path.join(ROOT, "include"), "-I", CSRC] + \
-              [f for f in FLAGS if f != "-shared"]
+              [f for f in FLAGS if f != "-shared"] + PER_FILE_FLAGS.get(os.path.basename(src), [])
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

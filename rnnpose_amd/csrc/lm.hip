@@ -80,6 +80,10 @@ __global__ __launch_bounds__(LM_THREADS) void lm_normal_eq_kernel(const float* _
       const unsigned tu = static_cast<unsigned>(t);            // t < H*W < 2^31: 32-bit division (64-bit is a software routine)
       const int y = static_cast<int>(tu / static_cast<unsigned>(W)), x = static_cast<int>(tu - static_cast<unsigned>(y) * static_cast<unsigned>(W));
       const float wgt = wgt_[j];
+      // zero-weight pixels (the descriptor weight is 0 on the rendered background) add w * (...) = 0 to every sum: a wave
+      // made of such pixels skips the fp64 chain.  Differs from the reference expression only when a zero-weight pixel
+      // carries a non-finite target (0 * NaN = NaN there).
+      if (__builtin_amdgcn_ballot_w64(wgt != 0.f) == 0ull) continue;
       const float Z = dep_[j] + eps;
       float tx = tx_[j], ty = ty_[j];
       if (target_mode != 0) {

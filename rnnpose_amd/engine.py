@@ -114,6 +114,11 @@ class UpdateEngine:
         """Helper stream i (0, 1: the two batch halves; 2: the flow-feature / flow-head side chain of an unsplit step) --
         from the per-device set that is bound to distinct hardware queues (rnnpose_amd/streams.py)."""
         from .streams import reserve
+        if ops.profiling():
+            # per-launch timing (ops.profile): everything on the caller's stream, so that each launch is timed ALONE on the
+            # chip -- the duration a roofline wants (and what rocprofv3's kernel trace, which serialises kernels, reports).
+            # Timed next to its twin on the other stream, a launch's duration includes the sharing.
+            return torch.cuda.current_stream()
         ss = reserve(device)
         return (ss.chain + [ss.aux] + ss.extra)[i]
 
@@ -438,6 +443,8 @@ class EncoderEngine:
     def _second_stream(self, device, i):
         """Stream of image set / batch part i >= 1 (rnnpose_amd/streams.py: distinct hardware queues)."""
         from .streams import reserve
+        if ops.profiling():          # per-launch timing: one stream, every launch alone on the chip (UpdateEngine._stream)
+            return torch.cuda.current_stream()
         ss = reserve(device)
         return (ss.chain + [ss.aux])[(i - 1) % 3]
 

@@ -19,6 +19,7 @@ if [ "$2" != "noprof" ]; then
   python bench.py --steps 20 --warmup 3 --no-cpu-baseline --batch 1 --height 240 --width 240 --inner 4 > $OUT/${TAG}_bench_S1.json 2>/dev/null
   python bench.py --steps 5 --warmup 2 --no-cpu-baseline --height 960 --width 1280 > $OUT/${TAG}_bench_S5.json 2>/dev/null
   python bench.py --steps 10 --warmup 2 --no-cpu-baseline --batch 16 > $OUT/${TAG}_bench_B16.json 2>/dev/null
+  python tools/conv_layers.py > $OUT/${TAG}_conv_layers_alone.txt 2>&1
   python tools/drift_probe.py > $OUT/${TAG}_drift.log 2>&1; cp $OUT/drift_probe.json $OUT/${TAG}_drift.json; tail -1 $OUT/${TAG}_drift.log
   ( cd /tmp && export TMPDIR=/tmp
     rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof -o run -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/${TAG}_prof.log 2>&1

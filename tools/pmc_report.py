@@ -47,7 +47,7 @@ def collect(dbs, by_grid=False, verbose=True):
                 if c in row:
                     row[c + "/WAVE_CYCLES"] = row[c] / wc
         if "SQ_VALU_MFMA_BUSY_CYCLES" in row and "SQ_BUSY_CYCLES" in row and row["SQ_BUSY_CYCLES"]:
-            row["MFMA_BUSY/BUSY_CYCLES"] = row["SQ_VALU_MFMA_BUSY_CYCLES"] / row["SQ_BUSY_CYCLES"]
+            row["MFMA_BUSY/BUSY_CYCLES(raw)"] = row["SQ_VALU_MFMA_BUSY_CYCLES"] / row["SQ_BUSY_CYCLES"]   # NOT a utilisation: the two counters are summed over different numbers of instances (divide by ~44 on this part)
         out[name] = dict(launches=n, **{k: (round(v, 4) if v < 100 else round(v, 1)) for k, v in row.items()})
         if verbose:
             print(f"{name[:70]:70s} n={n}")

@@ -9,7 +9,8 @@ tools/gpu_round.sh runs it ON the GPU box with outdir = gpurun_out/<tag>_summary
   <tag>_bench*.json            the bench lines (default config, --no-graph, S1 / S5 / B16 shapes)
   <tag>_kernel_stats*.csv      per-kernel calls / total / mean / min / max of the rocprofv3 --kernel-trace --stats runs of bench.py
                                (graph replay, two half-batch chains; and RNNPOSE_SPLIT_BATCH=0 --no-graph)
-  <tag>_conv_layers.csv        every convolution of one update step + one encoder pass, one launch each, ALONE on the chip
+  <tag>_conv_layers_alone.txt  tools/conv_layers.py: every update-block convolution shape alone on the chip (us, executed TF, % of peak)
+  <tag>_conv_layers.csv        the same launches in rocprofv3's kernel trace (keyed by grid size)
   <tag>_pmc_kernels.json       SQ + FETCH/WRITE counters per hand-written kernel (tools/pmc_kernels.py), incl. lm_normal_eq's VALU/LDS
   <tag>_pmc_convs.json         the same per convolution launch shape (tools/conv_layers.py, keyed by grid size)
   <tag>_pmc_traffic_bench.json FETCH/WRITE bytes per kernel over one eager bench step
@@ -68,7 +69,7 @@ for suffix in ("bench", "bench_nograph", "bench_S1", "bench_S5", "bench_B16", "d
     src = have(f"{TAG}_{suffix}.json")
     if src and os.path.getsize(src):
         shutil.copy(src, os.path.join(P, f"{TAG}_{suffix}.json"))
-for suffix, n in (("pytest_gpu.log", 12), ("smoke.log", 4), ("device.txt", 5)):
+for suffix, n in (("pytest_gpu.log", 12), ("smoke.log", 4), ("device.txt", 5), ("conv_layers_alone.txt", 40), ("drift.log", 60)):
     src = have(f"{TAG}_{suffix}")
     if src:
         tail(src, os.path.join(P, f"{TAG}_{suffix.replace('.log', '.txt')}"), n)
