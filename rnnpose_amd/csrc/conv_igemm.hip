@@ -77,7 +77,6 @@ struct KParams {
   const float* in_mr;  // NORM variant: (B, seg0.cstride, 2) mean / rstd of source 0, applied with ReLU while staging
   int n_mt, n_nt;
   unsigned long long* sat;   // fp16x3 range guard: counter of clamped / non-finite activation quads (NULL = check off)
-  int dbg;   // tile-shape overrides for A/B timing (RNNPOSE_CONV_DBG: 32 = 64-wide tiles, 64 = 128-wide tiles, 128 = 2x2 wave layout); 0 in production
 };
 
 
@@ -790,7 +789,6 @@ int rnnpose_conv2d_nhwc_f16x3(const rnnpose_conv_desc_t* d, rnnpose_stream_t str
   if (d->src0_mean_rstd)
     RP_REQUIRE(d->n_src == 1 && d->stride == 1 && d->kh == 3 && d->kw == 3 && reinterpret_cast<uintptr_t>(d->src0_mean_rstd) % 16 == 0,
                fn, "src0_mean_rstd (fused instance norm + ReLU of the input) needs one source, a 3x3 stride-1 kernel, 16-byte alignment");
-  p.dbg = 0;
   // tile width: 128 when Cout fills it and there are enough workgroups for 2 per CU, else 64
   const bool wide = !d->src0_mean_rstd && (d->c_out % 128 == 0) && (static_cast<long long>(p.n_mt) * (d->c_out / 128) >= 512);
   const dim3 block(NT);
