@@ -491,35 +491,70 @@ __global__ __launch_bounds__(NT, ((COLS4 || TT > 0) ? 3 : 2)) void conv_igemm_f1
   float ts0 = 0.f, ts1 = 0.f, ts2 = 0.f, ts3 = 0.f, tq0 = 0.f, tq1 = 0.f, tq2 = 0.f, tq3 = 0.f;   // tile statistics of this lane's column quad
   float* S = reinterpret_cast<float*>(&sA[0][0][0]) + wave * (32 * ES);    // 4 x 32 x 68 floats = 34.8 KB <= 43.5 KB
   const int colw = n0 + wn * (32 * NI);
+  // Every lane works on ONE column quad (64 % F4 == 0): its bias is loaded once.  Per 32-row block (mi) the epilogue operands of
+  // all 4*NI row groups -- the additive map, h and z of the GRU forms -- are requested up front, unconditionally (rows /
+  // columns outside the problem read row mend-1 / column 0 and are dropped at the store), and only then are the accumulators
+  // staged through LDS: with the loads under the per-row `continue` the compiler waited vmcnt(0) in every row group, 4*NI*MI
+  // dependent memory round trips per workgroup -- most of the ~10 us launch floor of this kernel (r02).
+  constexpr int KG = 4 * NI;
+  const int colq = colw + (lane % F4) * 4;
+  const bool colok = colq < p.Cout;
+  const int colc = colok ? colq : 0;
+  const int nv = colok ? (p.Cout - colq < 4 ? p.Cout - colq : 4) : 0;     // valid columns of this quad (Cout = 126 -> tail of 2)
+  float bq[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) bq[e] = p.bias[colc + (e < nv ? e : 0)];
+  const int c2 = colc >= p.gru_c ? colc - p.gru_c : 0;                    // epi 2: column inside the r half
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
+    long long pixk[KG];
+    float4 am[KG], hv[KG], zv[KG];
+    unsigned rowok = 0u;
+#pragma unroll
+    for (int k = 0; k < KG; ++k) {
+      const int rl = (lane + 64 * k) / F4;
+      const int m = m0 + wm * 64 + mi * 32 + rl;
+      const int mc = m < mend ? m : mend - 1;
+      rowok |= (m < mend ? 1u : 0u) << k;
+      long long pix = mc;
+      if (p.sv != 1) {
+        const int q = mc / p.V, v = mc - q * p.V;
+        const int b = q / p.U, u = q - b * p.U;
+        pix = static_cast<long long>(b) * UV + u * p.su + v * p.sv;
+      }
+      pixk[k] = pix;
+    }
+    if (p.addm) {                   // (c_out % 4 == 0 checked on the host)
+#pragma unroll
+      for (int k = 0; k < KG; ++k) am[k] = *reinterpret_cast<const float4*>(p.addm + pixk[k] * p.addm_cs + p.addm_co + colc);
+    }
+    if (p.epi == 2) {
+#pragma unroll
+      for (int k = 0; k < KG; ++k) hv[k] = *reinterpret_cast<const float4*>(p.aux0 + pixk[k] * p.aux0_cs + p.aux0_co + c2);
+    } else if (p.epi == 3) {
+#pragma unroll
+      for (int k = 0; k < KG; ++k) {
+        zv[k] = *reinterpret_cast<const float4*>(p.aux1 + pixk[k] * p.aux1_cs + p.aux1_co + colc);
+        hv[k] = *reinterpret_cast<const float4*>(p.aux0 + pixk[k] * p.aux0_cs + p.aux0_co + colc);
+      }
+    }
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
       for (int r = 0; r < 16; ++r) S[((r & 3) + 8 * (r >> 2) + 4 * lh) * ES + ni * 32 + l31] = acc[mi][ni][r] * p.out_scale;
 #pragma unroll
-    for (int k = 0; k < 4 * NI; ++k) {
+    for (int k = 0; k < KG; ++k) {
       const int idx = lane + 64 * k;
       const int rl = idx / F4, c = (idx % F4) * 4;
-      const int m = m0 + wm * 64 + mi * 32 + rl;
-      const int col = colw + c;
-      if (m >= mend || col >= p.Cout) continue;
+      if (!((rowok >> k) & 1u) || !colok) continue;
       if ((RP_ABL & 16) && acc[0][0][0] != 12345.678f) continue;
-      long long pix = m;
-      if (p.sv != 1) {
-        const int q = m / p.V, v = m - q * p.V;
-        const int b = q / p.U, u = q - b * p.U;
-        pix = static_cast<long long>(b) * UV + u * p.su + v * p.sv;
-      }
+      const long long pix = pixk[k];
+      const int col = colq;
       const float4 a4 = *reinterpret_cast<const float4*>(S + rl * ES + c);
       float y[4] = {a4.x, a4.y, a4.z, a4.w};
-      const int nv = p.Cout - col < 4 ? p.Cout - col : 4;      // valid columns of this quad (Cout = 126 -> tail of 2)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) y[e] += (e < nv) ? p.bias[col + e] : 0.f;
-      if (p.addm) {                 // (c_out % 4 == 0 checked on the host: nv == 4 here)
-        const float4 a = *reinterpret_cast<const float4*>(p.addm + pix * p.addm_cs + p.addm_co + col);
-        y[0] += a.x; y[1] += a.y; y[2] += a.z; y[3] += a.w;
-      }
+      for (int e = 0; e < 4; ++e) y[e] += (e < nv) ? bq[e] : 0.f;
+      if (p.addm) { y[0] += am[k].x; y[1] += am[k].y; y[2] += am[k].z; y[3] += am[k].w; }
       float* dptr = p.dst + pix * p.dst_cs + p.dst_co + col;
       if (p.tstats) {              // (column quad of a lane is the same for every k and mi: 64 % F4 == 0)
         if (nv > 0) { ts0 += y[0]; tq0 += y[0] * y[0]; }
@@ -535,17 +570,14 @@ __global__ __launch_bounds__(NT, ((COLS4 || TT > 0) ? 3 : 2)) void conv_igemm_f1
 #pragma unroll
           for (int e = 0; e < 4; ++e) y[e] = sigmoidf_(y[e]);                             // z
         } else {
-          const int c2 = col - p.gru_c;
-          const float4 hv = *reinterpret_cast<const float4*>(p.aux0 + pix * p.aux0_cs + p.aux0_co + c2);
-          y[0] = sigmoidf_(y[0]) * hv.x; y[1] = sigmoidf_(y[1]) * hv.y;                   // r * h
-          y[2] = sigmoidf_(y[2]) * hv.z; y[3] = sigmoidf_(y[3]) * hv.w;
+          y[0] = sigmoidf_(y[0]) * hv[k].x; y[1] = sigmoidf_(y[1]) * hv[k].y;             // r * h
+          y[2] = sigmoidf_(y[2]) * hv[k].z; y[3] = sigmoidf_(y[3]) * hv[k].w;
           dptr = p.dst2 + pix * p.dst2_cs + p.dst2_co + c2;
         }
       } else if (p.epi == 3) {
-        const float4 z = *reinterpret_cast<const float4*>(p.aux1 + pix * p.aux1_cs + p.aux1_co + col);
-        const float4 hv = *reinterpret_cast<const float4*>(p.aux0 + pix * p.aux0_cs + p.aux0_co + col);
-        y[0] = (1.f - z.x) * hv.x + z.x * tanhf(y[0]); y[1] = (1.f - z.y) * hv.y + z.y * tanhf(y[1]);   // h' = (1-z)h + z q
-        y[2] = (1.f - z.z) * hv.z + z.z * tanhf(y[2]); y[3] = (1.f - z.w) * hv.w + z.w * tanhf(y[3]);
+        const float4 z = zv[k], h4 = hv[k];
+        y[0] = (1.f - z.x) * h4.x + z.x * tanhf(y[0]); y[1] = (1.f - z.y) * h4.y + z.y * tanhf(y[1]);   // h' = (1-z)h + z q
+        y[2] = (1.f - z.z) * h4.z + z.z * tanhf(y[2]); y[3] = (1.f - z.w) * h4.w + z.w * tanhf(y[3]);
       }
       if (nv == 4) {
         *reinterpret_cast<float4*>(dptr) = make_float4(y[0], y[1], y[2], y[3]);
