@@ -440,10 +440,12 @@ __global__ __launch_bounds__(NT, ((COLS4 || TT > 0) ? 3 : 2)) void conv_igemm_f1
       if (!(RP_ABL & 4)) RP_STORE_A((PAR_) ^ 1);                                                            \
       if (!(RP_ABL & 8)) __syncthreads();                                                                   \
     }
-    RP_LOAD_A(0, 0);
-    RP_STORE_A(0);
+    // (weight requests first: the activation tile is waited for right away and its wait then covers both; measured neutral)
     RP_LOADB2(0, 0)
     RP_LOADB2(1, 1)
+    RP_LOAD_A(0, 0);
+    RP_SCHED_FENCE();
+    RP_STORE_A(0);
     __syncthreads();
     if (RP_ABL & 2) { RP_READ_A(0, 0, 0, 0) RP_READ_A(1, 0, 1, 0) }
     int cg = 0, ccb = 0, s0 = 0, it = 0;
@@ -495,7 +497,8 @@ __global__ __launch_bounds__(NT, ((COLS4 || TT > 0) ? 3 : 2)) void conv_igemm_f1
   // all 4*NI row groups -- the additive map, h and z of the GRU forms -- are requested up front, unconditionally (rows /
   // columns outside the problem read row mend-1 / column 0 and are dropped at the store), and only then are the accumulators
   // staged through LDS: with the loads under the per-row `continue` the compiler waited vmcnt(0) in every row group, 4*NI*MI
-  // dependent memory round trips per workgroup -- most of the ~10 us launch floor of this kernel (r02).
+  // dependent memory round trips per workgroup -- a large part of the ~10 us launch floor of this kernel (r02: +4.6 % on the
+  // step).  Requesting BOTH row blocks of the 2x2 layout at once (96 operand registers) spilled and was 2 % slower.
   constexpr int KG = 4 * NI;
   const int colq = colw + (lane % F4) * 4;
   const bool colok = colq < p.Cout;
