@@ -155,6 +155,14 @@ __global__ __launch_bounds__(256) void conv3x3_cout2_run4_kernel(const float* __
     const int xr = static_cast<int>(ru - by * runs_per_row);
     const int b = static_cast<int>(by / static_cast<unsigned>(h)), Y = static_cast<int>(by - static_cast<unsigned>(b) * h);
     const int X0 = xr * 4;
+    // the pixel this lane will write (if any) is known from its lane bits: its old coordinates are requested together with
+    // the input quads instead of in a second, dependent round trip after the reduction
+    const int idx = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
+    const int px = idx >> 1, o = idx & 1;
+    const int Xw = X0 + px < w ? X0 + px : w - 1;
+    const int pixw = Y * w + Xw;
+    const float c1x = coords1[(static_cast<long long>(b) * 2 + 0) * n + pixw];
+    const float c1y = coords1[(static_cast<long long>(b) * 2 + 1) * n + pixw];
     float4 v[3][6];
 #pragma unroll
     for (int ry = 0; ry < 3; ++ry)
@@ -202,17 +210,15 @@ __global__ __launch_bounds__(256) void conv3x3_cout2_run4_kernel(const float* __
       s1 += __shfl_xor(s1, 2);
       s1 += __shfl_xor(s1, 1);
     }
-    // lane bits (5,4,3) = (i2, i1, i0): value index = 4*i2 + 2*i1 + i0 = pixel*2 + output
-    const int idx = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
-    const int px = idx >> 1, o = idx & 1;
+    // lane bits (5,4,3) = (i2, i1, i0): value index = 4*i2 + 2*i1 + i0 = pixel*2 + output (idx, px, o above)
     const float other = __shfl_xor(s1, 8);          // the pixel's other output component lives 8 lanes away
     if ((lane & 7) == 0 && o == 0 && X0 + px < w) {
       const int X = X0 + px, pix = Y * w + X;
       const long long p = static_cast<long long>(b) * n + pix;
       const float dx = s1 + bias[0], dy = other + bias[1];
       *reinterpret_cast<float2*>(delta + p * 2) = make_float2(dx, dy);
-      const float cxv = coords1[(static_cast<long long>(b) * 2 + 0) * n + pix] + dx;
-      const float cyv = coords1[(static_cast<long long>(b) * 2 + 1) * n + pix] + dy;
+      const float cxv = c1x + dx;
+      const float cyv = c1y + dy;
       if (coords1_out) {
         coords1_out[(static_cast<long long>(b) * 2 + 0) * n + pix] = cxv;
         coords1_out[(static_cast<long long>(b) * 2 + 1) * n + pix] = cyv;
