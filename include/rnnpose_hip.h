@@ -270,6 +270,17 @@ int rnnpose_flow_head_out_f32(const float* x, int x_c_stride, int x_c_offset, in
                               float* coords1_out, float* flow_lr, rnnpose_stream_t stream);
 int rnnpose_convex_upsample_nhwc_f32(const float* flow_lr, const float* mask, int B, int h, int w, float* flow_up,
                                      rnnpose_stream_t stream);
+/* mask.2 + convex up-sampling in ONE kernel: mask = post_scale * mask.2(x) (1x1, 256 -> 576, thirdparty/raft/update.py:183-187)
+ * is consumed in registers by the softmax / 3x3 convex combination of model/CFNet.py:95-106; the (B,h,w,576) mask tensor is
+ * never written.  pack: weight (576,256) fp32 -> fp16 hi / lo MFMA fragments (rnnpose_mask_upsample_packed_bytes() bytes,
+ * 16-byte aligned) of post_scale * w_scale * weight.  x (B,h,w,x_c_stride): channels [x_c_offset, +256) = relu(mask.0(h));
+ * bias (576) already multiplied by post_scale; flow_lr (B,h,w,2); flow_up (B,2,8h,8w).  The softmax over the 9 taps is
+ * evaluated online (running max / sums): agrees with conv2d + rnnpose_convex_upsample_nhwc_f32 to fp32 round-off. */
+size_t rnnpose_mask_upsample_packed_bytes(void);
+int rnnpose_mask_upsample_pack_f16x3(const float* weight, float post_scale, float w_scale, void* packed, rnnpose_stream_t stream);
+int rnnpose_mask_upsample_f16x3(const float* x, int x_c_stride, int x_c_offset, const void* w_packed, int c_out,
+                                const float* bias, float a_scale, float w_scale, const float* flow_lr, int B, int h, int w,
+                                float* flow_up, rnnpose_stream_t stream);
 
 /* ---- f1 (adjacent): instance norm of the RAFT encoder on NHWC tensors ---- thirdparty/raft/extractor.py:28-31,48-58
  * x (B,HW,C) -> out = act((x - mean_bc) * rsqrt(var_bc + eps)) (biased variance, no affine, as nn.InstanceNorm2d);

@@ -76,6 +76,9 @@ PROTOTYPES = {
     "rnnpose_flow_features_f32": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _p, _i, _i, _p, _i, _i, _p]),
     "rnnpose_flow_head_out_f32": (_i, [_p, _i, _i, _i, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p]),
     "rnnpose_convex_upsample_nhwc_f32": (_i, [_p, _p, _i, _i, _i, _p, _p]),
+    "rnnpose_mask_upsample_f16x3": (_i, [_p, _i, _i, _p, _i, _p, _f, _f, _p, _i, _i, _i, _p, _p]),
+    "rnnpose_mask_upsample_packed_bytes": (_z, []),
+    "rnnpose_mask_upsample_pack_f16x3": (_i, [_p, _f, _f, _p, _p]),
     "rnnpose_instnorm_workspace_bytes": (_z, [_i, _i, _i]),
     "rnnpose_instnorm_tiles_nhwc_f32": (_i, [_p, _i, _i, _i, _f, _i, _p, _p, _i, _p, _i, _p, _p, _p]),
     "rnnpose_instnorm_nhwc_f32": (_i, [_p, _i, _i, _i, _f, _i, _p, _p, _z, _p, _p, _p]),

@@ -28,6 +28,7 @@ class UpdateEngine:
         import os
         self.split_batch = os.environ.get("RNNPOSE_SPLIT_BATCH", "1") != "0"   # concurrent part-batch chains
         self.parts = int(os.environ.get("RNNPOSE_PARTS", "2"))
+        self.fused_mask = os.environ.get("RNNPOSE_FUSED_MASK", "1") != "0"       # mask.2 inside the up-sampling kernel
 
     # ---- weights ---------------------------------------------------------------------------------------------
     def _params(self):
@@ -74,6 +75,7 @@ class UpdateEngine:
             inp2=P(cat(g.convz2.weight, g.convr2.weight, g.convq2.weight)[:, 128:256].contiguous(), zero(384), [128]),
             heads=P(cat(b.flow_head.conv1.weight, b.mask[0].weight), cat(b.flow_head.conv1.bias, b.mask[0].bias), [128]),
             mask2=P(b.mask[2].weight, b.mask[2].bias, [256], post_scale=0.25),            # update.py:187
+            mask2u=ops.PackedMaskHead(b.mask[2].weight, b.mask[2].bias, post_scale=0.25),  # the same layer inside the up-sampling kernel
             flow2_w=b.flow_head.conv2.weight.detach().float().contiguous(),
             flow2_b=b.flow_head.conv2.bias.detach().float().contiguous(),
         )
@@ -150,7 +152,7 @@ class UpdateEngine:
         ops.nchw_to_nhwc(corr, b["corr"])
         self._hoist_inp(W, b)
         flow = flow.float().contiguous()
-        self._chain(W, b, flow, torch.cuda.current_stream(), None, flow_is_delta=True)
+        self._chain(W, b, flow, torch.cuda.current_stream(), None, flow_is_delta=True, want_mask=True)
         return (ops.nhwc_to_nchw(b["hA"]), ops.nhwc_to_nchw(b["mask"]), ops.nhwc_to_nchw(b["delta"]))
 
     def halves(self, B):
@@ -170,7 +172,10 @@ class UpdateEngine:
         ops.corr_lookup_nhwc_part(corr_fn._buf, coords1_part, view["corr"], B, b0, b1, corr_fn.num_levels, corr_fn.radius)
         yield
         yield from self._chain_gen(W, view, coords1_part, st, self._stream(coords1_part.device, 2) if single else None)
-        ops.convex_upsample_nhwc(view["flow_lr"], view["mask"], out=flow_up_part)
+        if self.fused_mask:         # mask.2 + up-sampling in one kernel (the chain skipped its mask.2 launch)
+            ops.mask_upsample(W["mask2u"], view["heads"], 256, view["flow_lr"], out=flow_up_part)
+        else:
+            ops.convex_upsample_nhwc(view["flow_lr"], view["mask"], out=flow_up_part)
         yield
 
     @staticmethod
@@ -223,14 +228,17 @@ class UpdateEngine:
         self.run_interleaved(jobs, main)
         return self._b["coords1"], flow_up
 
-    def _chain(self, W, b, coords1, main, side, flow_is_delta=False):
-        for _ in self._chain_gen(W, b, coords1, main, side, flow_is_delta):
+    def _chain(self, W, b, coords1, main, side, flow_is_delta=False, want_mask=False):
+        for _ in self._chain_gen(W, b, coords1, main, side, flow_is_delta, want_mask):
             pass
 
-    def _chain_gen(self, W, b, coords1, main, side, flow_is_delta=False):
+    def _chain_gen(self, W, b, coords1, main, side, flow_is_delta=False, want_mask=False):
         """The update block on the (sub-)batch views `b`, issued on stream `main` (current) with `side` as helper; yields
         after every launch so that the caller can interleave two chains.
-        flow_is_delta: `coords1` holds the flow itself (facade call) instead of absolute coordinates."""
+        flow_is_delta: `coords1` holds the flow itself (facade call) instead of absolute coordinates.
+        want_mask: write the (B,h,w,576) mask tensor (the facade returns it); the loop's up-sampling kernel computes mask.2
+        itself (ops.mask_upsample) and the chain then ends after the flow head."""
+        mask_here = want_mask or not self.fused_mask
         c = ops.conv2d_nhwc
         R = ops.EPI_RELU
         # Two independent chains feed the motion encoder's last convolution (update.py:89-92): correlation features
@@ -279,8 +287,9 @@ class UpdateEngine:
         if side is None:
             head()
             yield
-            c(W["mask2"], [(b["heads"], 256)], (b["mask"], 0), ops.EPI_LINEAR)      # 0.25 * mask.2(relu(mask.0(h)))
-            yield
+            if mask_here:
+                c(W["mask2"], [(b["heads"], 256)], (b["mask"], 0), ops.EPI_LINEAR)  # 0.25 * mask.2(relu(mask.0(h)))
+                yield
             return
         fork2 = torch.cuda.Event()
         fork2.record(main)
@@ -289,7 +298,8 @@ class UpdateEngine:
             head()
             join2 = torch.cuda.Event()
             join2.record(side)
-        c(W["mask2"], [(b["heads"], 256)], (b["mask"], 0), ops.EPI_LINEAR)          # 0.25 * mask.2(relu(mask.0(h)))
+        if mask_here:
+            c(W["mask2"], [(b["heads"], 256)], (b["mask"], 0), ops.EPI_LINEAR)      # 0.25 * mask.2(relu(mask.0(h)))
         main.wait_event(join2)
         yield
 

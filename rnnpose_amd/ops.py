@@ -581,6 +581,38 @@ def convex_upsample_nhwc(flow_lr, mask, out=None):
     return out
 
 
+class PackedMaskHead:
+    """mask.2 weights (576,256,1,1) + bias, post-scaled (the 0.25 of update.py:187) and split into fp16 hi/lo MFMA fragments
+    for the fused mask + up-sampling kernel (csrc/mask_upsample.hip)."""
+
+    def __init__(self, weight, bias, post_scale: float = 0.25, a_scale: float = A_SCALE):
+        import math
+        w = _chk(weight.detach(), "weight")
+        if tuple(w.shape) != (576, 256, 1, 1):
+            raise ValueError("mask.2 weight must be (576,256,1,1)")
+        wmax = float(w.abs().max()) * post_scale
+        self.w_scale = float(2.0 ** math.floor(math.log2(1024.0 / wmax))) if wmax > 0 else 1.0
+        self.a_scale = float(a_scale)
+        self.bias = (_chk(bias.detach(), "bias") * post_scale).contiguous()
+        n = int(_lib.load().rnnpose_mask_upsample_packed_bytes())
+        self.w_packed = torch.empty(n // 2, device=w.device, dtype=torch.float16)
+        _lib.call("rnnpose_mask_upsample_pack_f16x3", _ptr(w), float(post_scale), self.w_scale, _ptr(self.w_packed), _stream())
+
+
+def mask_upsample(pm: PackedMaskHead, x, x_c_offset, flow_lr, out=None):
+    """mask.2 + convex 8x up-sampling in one kernel (update.py:183-187, CFNet.py:95-106).  x (B,h,w,C) with relu(mask.0(h))
+    in channels [x_c_offset, +256); flow_lr (B,h,w,2) -> (B,2,8h,8w).  Agrees with the 1x1 convolution + convex_upsample_nhwc
+    to fp32 round-off (online softmax); the mask tensor is never materialised."""
+    _nhwc(x, "x")
+    B, h, w, cs = x.shape
+    if out is None:
+        out = torch.empty(B, 2, 8 * h, 8 * w, device=x.device, dtype=F32)
+    _launch("rnnpose_mask_upsample_f16x3", _ptr(x), cs, int(x_c_offset), _ptr(pm.w_packed), 576, _ptr(pm.bias), pm.a_scale,
+            pm.w_scale, _ptr(_chk(flow_lr, "flow_lr")), B, h, w, _ptr(out), _stream(), work=2.0 * B * h * w * 576 * 256,
+            nbytes=4.0 * B * h * w * (256 + 2 + 128))
+    return out
+
+
 # ---- fp16x3 range guard ------------------------------------------------------------------------------------------------
 def saturation_check(enable: bool = True):
     """Switch the fp16x3 range guard on/off (process-global): with it on, every fp16x3 kernel counts the activation quads

@@ -270,3 +270,28 @@ def test_flow_head_out_direct(ops, B, h, w, cin, coff):
     assert float((c1o.double() - (coords1.double() + ref)).abs().max()) < 5e-5
     grid = coords_grid(B, h, w, device="cuda").double()
     assert float((flr.permute(0, 3, 1, 2).double() - (coords1.double() + ref - grid)).abs().max()) < 5e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,h,w", [(1, 16, 20), (3, 17, 19), (2, 9, 80), (1, 5, 13)])
+def test_mask_upsample_fused_equals_conv_plus_upsample(ops, B, h, w):
+    """rnnpose_mask_upsample_f16x3 (mask.2 + convex up-sampling, no mask tensor) against the 1x1 convolution kernel followed
+    by the up-sampling kernel (same logits; online instead of two-pass softmax: fp32 round-off apart), for pixel counts
+    that are not multiples of its 64-pixel tile, and against an fp64 evaluation of update.py:183-187 + CFNet.py:95-106."""
+    x = syn.normal("mu_x", (B, 512, h, w), 11).clip(min=0)                     # relu(heads): mask.0 output in channels 256..511
+    wt = syn.normal("mu_w", (576, 256, 1, 1), 11, std=float(np.sqrt(2.0 / 256)))
+    bs = syn.uniform("mu_b", (576,), 11, -0.5, 0.5)
+    flow = syn.normal("mu_f", (B, 2, h, w), 11, std=2.0)
+    xN = nhwc(D(x))
+    fl = nhwc(D(flow))
+    pc = ops.PackedConv(D(wt), D(bs), [256], post_scale=0.25)
+    mask = torch.empty(B, h, w, 576, device="cuda")
+    ops.conv2d_nhwc(pc, [(xN, 256)], (mask, 0), ops.EPI_LINEAR)
+    want = ops.convex_upsample_nhwc(fl, mask)
+    got = ops.mask_upsample(ops.PackedMaskHead(D(wt), D(bs), post_scale=0.25), xN, 256, fl)
+    assert float((got - want).abs().max()) <= 2e-6 * max(1.0, float(want.abs().max()))
+    m64 = 0.25 * F.conv2d(D(x)[:, 256:].double(), D(wt).double(), D(bs).double())
+    sm = torch.softmax(m64.view(B, 1, 9, 8, 8, h, w), dim=2)
+    upf = F.unfold(8 * D(flow).double(), [3, 3], padding=1).view(B, 2, 9, 1, 1, h, w)
+    ref = torch.sum(sm * upf, dim=2).permute(0, 1, 4, 2, 5, 3).reshape(B, 2, 8 * h, 8 * w)
+    assert float((got.double() - ref).abs().max()) < 2e-5

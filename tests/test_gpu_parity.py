@@ -417,9 +417,11 @@ def test_update_block(ops, golden):
     close(motion[:, 126:], flow, 0.0, what="motion features carry the flow (update.py:97)")
 
 
-def test_update_engine_one_step(ops, golden):
+@pytest.mark.parametrize("fused_mask", [True, False])
+def test_update_engine_one_step(ops, golden, fused_mask):
     """The fused NHWC engine (hand-written fp16x3 implicit-GEMM convs + fused epilogues) against the golden
-    BasicUpdateBlock outputs and the oracle, teacher forced: hidden state, mask, delta flow, upsampled flow."""
+    BasicUpdateBlock outputs and the oracle, teacher forced: hidden state, mask, delta flow, upsampled flow.
+    fused_mask: mask.2 computed inside the up-sampling kernel (the default; no mask tensor) or as its own convolution."""
     from rnnpose_amd.corr import coords_grid
     from rnnpose_amd.engine import UpdateEngine
     g = golden("update_block")
@@ -430,6 +432,7 @@ def test_update_engine_one_step(ops, golden):
     f1, f2 = syn.normal("e_f1", (B, 256, h, w), 3), syn.normal("e_f2", (B, 256, h, w), 3)
     net = _load_update_block()
     eng = UpdateEngine(net.update_block)
+    eng.fused_mask = fused_mask
     from rnnpose_amd.corr import CorrBlock
     cb = CorrBlock(D(f1), D(f2))
     c0 = coords_grid(B, h, w, device="cuda")
@@ -439,7 +442,8 @@ def test_update_engine_one_step(ops, golden):
     corr = orc.corr_lookup(orc.corr_pyramid(f1, f2), c1.cpu())
     wn, wm, wd = orc.update_block(upd_weights(), hid, inp, corr, flow)
     close(eng.hidden_nchw(), wn, 1e-5, what="engine hidden state")
-    close(ops.nhwc_to_nchw(eng._b["mask"]), wm, 2e-5, what="engine mask")
+    if not fused_mask:
+        close(ops.nhwc_to_nchw(eng._b["mask"]), wm, 2e-5, what="engine mask")
     close(ops.nhwc_to_nchw(eng._b["delta"]), wd, 1e-5, what="engine delta flow")
     close(c1n, c1.cpu() + wd, 2e-5, what="engine coords1")
     close(flow_up, orc.convex_upsample(T(flow) + wd, wm), 1e-4, what="engine flow_up")
