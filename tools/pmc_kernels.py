@@ -30,6 +30,8 @@ img = torch.rand(B, 3, H, W, device=dev, generator=g)
 stem = ops.PackedStem(r(64, 3, 7, 7) * 0.1, torch.zeros(64, device=dev))
 x64 = r(B, H // 2, W // 2, 64)
 sigma = torch.ones(1, device=dev)
+heads = r(Bh, h, w, 512).clamp_(min=0)
+mhead = ops.PackedMaskHead(r(576, 256, 1, 1) * 0.09, r(576) * 0.1)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 for _ in range(n):
     buf, _ = ops.corr_pyramid(f1, f2, precision="f16x3")
@@ -37,6 +39,7 @@ for _ in range(n):
     ops.corr_lookup_nhwc_part(buf, c1, corr, B, 0, Bh)
     ops.context_prep(ctx, h, w)
     up = ops.convex_upsample_nhwc(flow_lr, mask)
+    ops.mask_upsample(mhead, heads, 256, flow_lr)
     wm = ops.corr_weight(g1, g2, up, depth[:Bh], sigma)
     ops.lm_step(up, wm, depth[:Bh], K[:Bh], G[:Bh])
     y, ts = ops.stem_conv(stem, img)
