@@ -70,9 +70,10 @@ __global__ __launch_bounds__(512, MU_MINW) void mask_upsample_kernel(const MUPar
     const int e = tid + 512 * q;
     const int px = e / NTAP, k = e - px * NTAP;
     const long long m = m0 + px;
-    const long long mc = (e < MQ * NTAP && m < total) ? m : (m0 < total ? m0 : total - 1);
-    const int b = static_cast<int>(mc / n), pix = static_cast<int>(mc - static_cast<long long>(b) * n);
-    const int Y = pix / p.w, X = pix - Y * p.w;
+    const unsigned mc = static_cast<unsigned>((e < MQ * NTAP && m < total) ? m : (m0 < total ? m0 : total - 1));   // total < 2^31 (host check):
+    const int b = static_cast<int>(mc / static_cast<unsigned>(n));                                                 // 32-bit divisions
+    const int pix = static_cast<int>(mc - static_cast<unsigned>(b) * static_cast<unsigned>(n));
+    const int Y = static_cast<int>(static_cast<unsigned>(pix) / static_cast<unsigned>(p.w)), X = pix - Y * p.w;
     const int yy = Y + k / 3 - 1, xx = X + k % 3 - 1;
     fok[q] = e < MQ * NTAP && m < total && yy >= 0 && yy < p.h && xx >= 0 && xx < p.w;
     fq[q] = *reinterpret_cast<const float2*>(p.flow + (static_cast<long long>(b) * n + (fok[q] ? yy * p.w + xx : pix)) * 2);
@@ -183,8 +184,9 @@ __global__ __launch_bounds__(512, MU_MINW) void mask_upsample_kernel(const MUPar
     const int row = 32 * rh + 16 * (r >> 2) + 4 * lq + (r & 3);
     const long long m = m0 + row;
     if (m < total) {
-      const int b = static_cast<int>(m / n), pix = static_cast<int>(m - static_cast<long long>(b) * n);
-      const int Y = pix / p.w, X = pix - Y * p.w;
+      const unsigned mu = static_cast<unsigned>(m);
+      const int b = static_cast<int>(mu / static_cast<unsigned>(n)), pix = static_cast<int>(mu - static_cast<unsigned>(b) * static_cast<unsigned>(n));
+      const int Y = static_cast<int>(static_cast<unsigned>(pix) / static_cast<unsigned>(p.w)), X = pix - Y * p.w;
       const long long o = (8LL * Y + si) * Wf + 8 * X + sj;
       p.up[(static_cast<long long>(b) * 2 + 0) * Pf + o] = rax[r] / rden[r];
       p.up[(static_cast<long long>(b) * 2 + 1) * Pf + o] = ray[r] / rden[r];
@@ -225,7 +227,8 @@ extern "C" int rnnpose_mask_upsample_f16x3(const float* x, int x_c_stride, int x
   const char* fn = "rnnpose_mask_upsample_f16x3";
   RP_REQUIRE(x && w_packed && bias && flow_lr && flow_up, fn, "null pointer");
   RP_REQUIRE(c_out == 64 * NTAP, fn, "c_out must be 576 (9 taps x 8 x 8 sub-pixels)");
-  RP_REQUIRE(B > 0 && B < 65536 && h > 0 && w > 0 && h < 65536 && static_cast<long long>(h) * w < (1LL << 24), fn, "bad size");
+  RP_REQUIRE(B > 0 && B < 65536 && h > 0 && w > 0 && h < 65536 && static_cast<long long>(h) * w < (1LL << 24) &&
+                 static_cast<long long>(B) * h * w < (1LL << 31), fn, "bad size");
   RP_REQUIRE(x_c_offset >= 0 && x_c_offset % 4 == 0 && x_c_stride % 4 == 0 && x_c_offset + KC <= x_c_stride, fn,
              "the 256 input channels must lie inside the row, 16-byte aligned");
   RP_REQUIRE(reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(w_packed) % 16 == 0 &&
