@@ -5,18 +5,19 @@
 // into fp16 hi / lo ONCE for all 576 output columns: as a stand-alone 1x1 convolution the same layer re-split its input for
 // each of its nine 64-column tiles and ran at 15 % of the matrix peak (r02: 42 us + 15 us for the up-sampling kernel).
 //
-// Workgroup = 64 consecutive low-resolution pixels x all 576 columns, 8 waves: wave (ct, rh) owns the 16 sub-pixel columns
-// [16 ct, 16 ct + 16) of EVERY tap for the 32 pixels of half rh (two 16x16 tiles of v_mfma_f32_16x16x32_f16): the softmax
-// over the taps never leaves the lane, and the two pixel halves read the same weight fragments (L1 hits).  LDS: the whole K = 256 activation tile as fp16
-// hi / lo (64 KB, 16-byte chunks XOR-swizzled instead of padded: a padded tile would not leave room for two workgroups per
-// CU) + the 3x3 flow neighbourhood of every pixel (4.6 KB).  A wave computes the logits of one tap at a time (16
+// Workgroup = 32 consecutive low-resolution pixels x all 576 columns, 4 waves: wave ct owns the 16 sub-pixel columns
+// [16 ct, 16 ct + 16) of EVERY tap for the 32 pixels (two 16x16 tiles of v_mfma_f32_16x16x32_f16): the softmax over the taps
+// never leaves the lane.  32-pixel tiles because of the grid: 4 x 4800 pixels are 600 workgroups, all resident at once at 3
+// per CU (168 VGPRs, 35 KB LDS); with 64-pixel tiles and one workgroup per CU the 300 workgroups needed two rounds on 256
+// CUs and the kernel lasted two workgroup lifetimes.  LDS: the whole K = 256 activation tile as fp16
+// hi / lo (32 KB, 16-byte chunks XOR-swizzled instead of padded) + the 3x3 flow neighbourhood of every pixel (4.6 KB).  A wave computes the logits of one tap at a time (16
 // accumulators) and folds them into running softmax sums; weights arrive as MFMA B fragments straight from their own packed
 // array (rnnpose_mask_upsample_pack_f16x3: [tap][channel block][column tile][hi, lo][lane] x 16 B), four stages ahead.
 // Numerics: fp16x3 split as in csrc/conv_igemm.hip; online softmax (running max / denominator / weighted sums).
 // History (r02, 4 x 4800 pixels): 1x1 convolution + up-sampling kernel 42 + 15 us; first fused version (nine 32x32 logit
 // tiles per wave in registers, one weight stage ahead) 95 us; tap-outer loop + online softmax + 4-stage weight ring 51 us;
 // 16x16x32 tiles with column-split waves 49 us; one exponential per element + the update interleaved with the next tap's
-// MFMAs 44 us; 8 waves per workgroup 45 us (kept: same speed, lower register pressure).
+// MFMAs 44 us; 8 waves per workgroup 45 us; 32-pixel tiles (one round of workgroups instead of two) 35 us.
 #include "common.hpp"
 #include "f16x3.cuh"
 
@@ -24,12 +25,12 @@ namespace {
 
 using rp::f32x16; using rp::h4; using rp::h8; using rp::split4;
 
-constexpr int MQ = 64;          // pixels per workgroup
+constexpr int MQ = 32;          // pixels per workgroup (= threads / 8)
 constexpr int KC = 256;         // input channels (mask.0 output)
 constexpr int NCB = KC / 32;    // 32-channel blocks
 constexpr int NTAP = 9;
 #ifndef MU_MINW
-#define MU_MINW 2          // waves per SIMD the register budget is held to (one 8-wave workgroup per CU: 162 VGPRs; 128 spills)
+#define MU_MINW 3          // waves per SIMD the register budget is held to (168 VGPRs: three 4-wave workgroups per CU; 128 spills)
 #endif
 
 struct MUParams {
@@ -44,7 +45,7 @@ struct MUParams {
   unsigned long long* sat;      // fp16x3 range guard counter (NULL = off)
 };
 
-__global__ __launch_bounds__(512, MU_MINW) void mask_upsample_kernel(const MUParams p) {
+__global__ __launch_bounds__(8 * MQ, MU_MINW) void mask_upsample_kernel(const MUParams p) {
   __shared__ __attribute__((aligned(16))) _Float16 sA[NCB][2][MQ * 32];     // [channel block][hi, lo][row * 32 + swizzled chunk * 8 + e]
   __shared__ float2 sF[MQ][NTAP];                                            // 8 * flow of the 3x3 neighbourhood (0 outside the map)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(512, MU_MINW) void mask_upsample_kernel(const MUPar
   bool fok[2];
 #pragma unroll
   for (int q = 0; q < 2; ++q) {                     // 64 * 9 = 576 table entries, 2 per thread (the second pass is partial)
-    const int e = tid + 512 * q;
+    const int e = tid + 8 * MQ * q;
     const int px = e / NTAP, k = e - px * NTAP;
     const long long m = m0 + px;
     const unsigned mc = static_cast<unsigned>((e < MQ * NTAP && m < total) ? m : (m0 < total ? m0 : total - 1));   // total < 2^31 (host check):
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(512, MU_MINW) void mask_upsample_kernel(const MUPar
   }
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
-    const int e = tid + 512 * q;
+    const int e = tid + 8 * MQ * q;
     if (e < MQ * NTAP) sF[e / NTAP][e % NTAP] = fok[q] ? make_float2(8.f * fq[q].x, 8.f * fq[q].y) : make_float2(0.f, 0.f);
   }
   if (p.sat && sat_n) atomicAdd(p.sat, static_cast<unsigned long long>(sat_n));
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(512, MU_MINW) void mask_upsample_kernel(const MUPar
   //      two-pass form (a few 1e-7 relative).
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   const int l15 = lane & 15, lq = lane >> 4;                          // A/B operand: row / column l15, 8 channels 8 lq ..
-  const int ct = wave & 3, rh = wave >> 2;                           // column tile (16 sub-pixels) / pixel half (32 pixels) of this wave
+  const int ct = wave & 3, rh = wave >> 2;                           // column tile (16 sub-pixels) / 32-pixel block of this wave (MQ = 32: rh = 0)
   const int sub = 16 * ct + l15;
   uint4 bq[4][2];
 #define MU_LOADB(SLOT_, K_, CB_)                                                                  \
@@ -243,6 +244,6 @@ extern "C" int rnnpose_mask_upsample_f16x3(const float* x, int x_c_stride, int x
   p.B = B; p.h = h; p.w = w;
   p.sat = rp::sat_counter();
   const long long total = static_cast<long long>(B) * h * w;
-  hipLaunchKernelGGL(mask_upsample_kernel, dim3(static_cast<unsigned>(rp::cdiv(total, MQ))), dim3(512), 0, rp::as_stream(stream), p);
+  hipLaunchKernelGGL(mask_upsample_kernel, dim3(static_cast<unsigned>(rp::cdiv(total, MQ))), dim3(8 * MQ), 0, rp::as_stream(stream), p);
   return rp::check_launch(fn);
 }
