@@ -29,8 +29,8 @@ constexpr int MQ = 32;          // pixels per workgroup (= threads / 8)
 constexpr int KC = 256;         // input channels (mask.0 output)
 constexpr int NCB = KC / 32;    // 32-channel blocks
 constexpr int NTAP = 9;
-#ifndef MU_MINW
-#define MU_MINW 3          // waves per SIMD the register budget is held to (168 VGPRs: three 4-wave workgroups per CU; 128 spills)
+#ifndef MU_NUM_VGPR
+#define MU_NUM_VGPR 160     // register cap: three 4-wave workgroups per CU (the compiler settles at 148, no spills)
 #endif
 
 struct MUParams {
@@ -45,7 +45,7 @@ struct MUParams {
   unsigned long long* sat;      // fp16x3 range guard counter (NULL = off)
 };
 
-__global__ __launch_bounds__(8 * MQ, MU_MINW) void mask_upsample_kernel(const MUParams p) {
+__global__ __launch_bounds__(8 * MQ) __attribute__((amdgpu_num_vgpr(MU_NUM_VGPR))) void mask_upsample_kernel(const MUParams p) {
   __shared__ __attribute__((aligned(16))) _Float16 sA[NCB][2][MQ * 32];     // [channel block][hi, lo][row * 32 + swizzled chunk * 8 + e]
   __shared__ float2 sF[MQ][NTAP];                                            // 8 * flow of the 3x3 neighbourhood (0 outside the map)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
