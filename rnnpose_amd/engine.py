@@ -3,10 +3,13 @@ thirdparty/raft/update.py:178-188): every convolution of BasicUpdateBlock runs i
 kernel (csrc/conv_igemm.hip) with bias / ReLU / GRU gates fused into its epilogue, reading the concatenations
 [h | inp | motion] and [cor | flo] as virtual concats and writing straight into channel slices.
 
-Per step: lookup (NHWC) -> convc1 -> convc2 | convf1 -> convf2 -> conv -> z|r (1x5) -> q (1x5) -> z|r (5x1) -> q (5x1)
--> flow/mask heads (one 128->512 conv) -> flow_head.conv2 + coords update -> mask.2 (x0.25 folded) -> convex upsample:
-16 launches (the flow-feature chain and the flow head on a side stream = parallel hipGraph branches), no ATen
-elementwise / cat / clone kernels.  The module's parameters stay the single source of truth:
+Per step and batch part: lookup (NHWC) -> convc1 -> convc2 | flow features (coords - grid + 7x7 convf1 in one direct
+kernel) -> convf2 -> conv -> z|r (1x5) -> q (1x5) -> z|r (5x1) -> q (5x1)  [the context input's share of the GRU gates is
+hoisted: computed once per outer iteration and added in the epilogues] -> flow/mask heads (one 128->512 conv) ->
+flow_head.conv2 + coords update -> mask.2 + convex up-sampling in ONE kernel (csrc/mask_upsample.hip; the 576-channel
+mask only exists for the BasicUpdateBlock facade): 14 launches, no ATen elementwise / cat / clone kernels.  The batch is
+cut into parts (default 2) that run their chains on separate streams.  The module's parameters stay the single source of
+truth:
 packed fp16 hi/lo copies are rebuilt whenever a parameter's version or storage changes.
 """
 from __future__ import annotations
