@@ -270,6 +270,18 @@ int rnnpose_flow_head_out_f32(const float* x, int x_c_stride, int x_c_offset, in
                               float* coords1_out, float* flow_lr, rnnpose_stream_t stream);
 int rnnpose_convex_upsample_nhwc_f32(const float* flow_lr, const float* mask, int B, int h, int w, float* flow_up,
                                      rnnpose_stream_t stream);
+/* 1x1 convolution (+ bias, optional ReLU) with the activation tile resident in LDS: 32 pixels x ALL 256 output columns per
+ * workgroup, the tile split into fp16 hi / lo once (the implicit-GEMM kernel re-splits it per 64-column tile).  Used for
+ * BasicMotionEncoder.convc1 (thirdparty/raft/update.py:80,87: 324 -> 256).  pack: weight (256, c_in) fp32 -> MFMA fragments
+ * (rnnpose_conv1x1_resident_packed_bytes(c_in) bytes, 16-byte aligned) of w_scale * weight; c_in % 4 == 0, c_in <= 352.
+ * x: n_pixels rows of x_c_stride floats, channels [x_c_offset, +c_in); dst: rows of dst_c_stride, channels [dst_c_offset, +256).
+ * Agrees with rnnpose_conv2d_nhwc_f16x3 to fp32 round-off (the K sum is grouped differently). */
+size_t rnnpose_conv1x1_resident_packed_bytes(int c_in);
+int rnnpose_conv1x1_resident_pack_f16x3(const float* weight, int c_out, int c_in, float w_scale, void* packed,
+                                        rnnpose_stream_t stream);
+int rnnpose_conv1x1_resident_f16x3(const float* x, int x_c_stride, int x_c_offset, int c_in, const void* w_packed,
+                                   const float* bias, float a_scale, float w_scale, int relu, long long n_pixels, float* dst,
+                                   int dst_c_stride, int dst_c_offset, rnnpose_stream_t stream);
 /* mask.2 + convex up-sampling in ONE kernel: mask = post_scale * mask.2(x) (1x1, 256 -> 576, thirdparty/raft/update.py:183-187)
  * is consumed in registers by the softmax / 3x3 convex combination of model/CFNet.py:95-106; the (B,h,w,576) mask tensor is
  * never written.  pack: weight (576,256) fp32 -> fp16 hi / lo MFMA fragments (rnnpose_mask_upsample_packed_bytes() bytes,

@@ -15,6 +15,7 @@ _i = C.c_int
 _f = C.c_float
 _d = C.c_double
 _z = C.c_size_t
+_ll = C.c_longlong
 
 class ConvSrc(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("c_stride", C.c_int), ("c_offset", C.c_int), ("c_count", C.c_int)]
@@ -78,6 +79,9 @@ PROTOTYPES = {
     "rnnpose_convex_upsample_nhwc_f32": (_i, [_p, _p, _i, _i, _i, _p, _p]),
     "rnnpose_mask_upsample_f16x3": (_i, [_p, _i, _i, _p, _i, _p, _f, _f, _p, _i, _i, _i, _p, _p]),
     "rnnpose_mask_upsample_packed_bytes": (_z, []),
+    "rnnpose_conv1x1_resident_packed_bytes": (_z, [_i]),
+    "rnnpose_conv1x1_resident_pack_f16x3": (_i, [_p, _i, _i, _f, _p, _p]),
+    "rnnpose_conv1x1_resident_f16x3": (_i, [_p, _i, _i, _i, _p, _p, _f, _f, _i, _ll, _p, _i, _i, _p]),
     "rnnpose_mask_upsample_pack_f16x3": (_i, [_p, _f, _f, _p, _p]),
     "rnnpose_instnorm_workspace_bytes": (_z, [_i, _i, _i]),
     "rnnpose_instnorm_tiles_nhwc_f32": (_i, [_p, _i, _i, _i, _f, _i, _p, _p, _i, _p, _i, _p, _p, _p]),

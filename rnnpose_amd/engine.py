@@ -32,6 +32,7 @@ class UpdateEngine:
         self.split_batch = os.environ.get("RNNPOSE_SPLIT_BATCH", "1") != "0"   # concurrent part-batch chains
         self.parts = int(os.environ.get("RNNPOSE_PARTS", "2"))
         self.fused_mask = os.environ.get("RNNPOSE_FUSED_MASK", "1") != "0"       # mask.2 inside the up-sampling kernel
+        self.resident_1x1 = os.environ.get("RNNPOSE_RESIDENT_1X1", "1") != "0"    # convc1 through csrc/conv1x1_resident.hip
 
     # ---- weights ---------------------------------------------------------------------------------------------
     def _params(self):
@@ -61,6 +62,8 @@ class UpdateEngine:
         P = ops.PackedConv
         w = dict(
             convc1=P(e.convc1.weight, e.convc1.bias, [e.convc1.weight.shape[1]]),
+            convc1r=(ops.PackedConv1x1(e.convc1.weight, e.convc1.bias)
+                     if (e.convc1.weight.shape[0] == 256 and e.convc1.weight.shape[1] <= 352 and e.convc1.weight.shape[1] % 4 == 0) else None),
             convc2=P(e.convc2.weight, e.convc2.bias, [256]),
             convf1_wt=e.convf1.weight.detach().float().reshape(e.convf1.weight.shape[0], 98).t().contiguous(),   # (98, 128)
             convf1_b=e.convf1.bias.detach().float().contiguous(),
@@ -266,7 +269,10 @@ class UpdateEngine:
                     pass
                 join = torch.cuda.Event()
                 join.record(side)
-        c(W["convc1"], [(b["corr"], 0)], (b["cor1"], 0), R)                         # update.py:89
+        if self.resident_1x1 and W["convc1r"] is not None:
+            ops.conv1x1_resident(W["convc1r"], (b["corr"], 0), (b["cor1"], 0), relu=True)   # update.py:89 (LDS-resident tile)
+        else:
+            c(W["convc1"], [(b["corr"], 0)], (b["cor1"], 0), R)                     # update.py:89
         yield
         c(W["convc2"], [(b["cor1"], 0)], (b["corflo"], 0), R)                       # :90
         yield

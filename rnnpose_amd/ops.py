@@ -581,6 +581,36 @@ def convex_upsample_nhwc(flow_lr, mask, out=None):
     return out
 
 
+class PackedConv1x1:
+    """Weights of a 1x1 convolution with 256 outputs and <= 352 inputs for the LDS-resident kernel (csrc/conv1x1_resident.hip)."""
+
+    def __init__(self, weight, bias, a_scale: float = A_SCALE):
+        import math
+        w = _chk(weight.detach(), "weight")
+        if w.dim() != 4 or w.shape[0] != 256 or w.shape[2:] != (1, 1) or w.shape[1] % 4 or w.shape[1] > 352:
+            raise ValueError("needs a (256, c_in <= 352, 1, 1) weight with c_in % 4 == 0")
+        self.c_in = int(w.shape[1])
+        wmax = float(w.abs().max())
+        self.w_scale = float(2.0 ** math.floor(math.log2(1024.0 / wmax))) if wmax > 0 else 1.0
+        self.a_scale = float(a_scale)
+        self.bias = _chk(bias.detach(), "bias").contiguous()
+        n = int(_lib.load().rnnpose_conv1x1_resident_packed_bytes(self.c_in))
+        self.w_packed = torch.empty(n // 2, device=w.device, dtype=torch.float16)
+        _lib.call("rnnpose_conv1x1_resident_pack_f16x3", _ptr(w), 256, self.c_in, self.w_scale, _ptr(self.w_packed), _stream())
+
+
+def conv1x1_resident(pc: PackedConv1x1, src, dst, relu: bool = True):
+    """src, dst: (tensor (B,h,w,C), c_offset).  dst[..., off:off+256] = act(conv1x1(src[..., off:off+c_in]))."""
+    x, xo = src
+    y, yo = dst
+    _nhwc(x, "src"); _nhwc(y, "dst")
+    n = x.shape[0] * x.shape[1] * x.shape[2]
+    if y.shape[:3] != x.shape[:3]:
+        raise ValueError("src and dst must share (B,h,w)")
+    _launch("rnnpose_conv1x1_resident_f16x3", _ptr(x), x.shape[3], int(xo), pc.c_in, _ptr(pc.w_packed), _ptr(pc.bias), pc.a_scale,
+            pc.w_scale, int(bool(relu)), n, _ptr(y), y.shape[3], int(yo), _stream(), work=2.0 * n * 256 * pc.c_in)
+
+
 class PackedMaskHead:
     """mask.2 weights (576,256,1,1) + bias, post-scaled (the 0.25 of update.py:187) and split into fp16 hi/lo MFMA fragments
     for the fused mask + up-sampling kernel (csrc/mask_upsample.hip)."""

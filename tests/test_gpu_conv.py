@@ -295,3 +295,23 @@ def test_mask_upsample_fused_equals_conv_plus_upsample(ops, B, h, w):
     upf = F.unfold(8 * D(flow).double(), [3, 3], padding=1).view(B, 2, 9, 1, 1, h, w)
     ref = torch.sum(sm * upf, dim=2).permute(0, 1, 4, 2, 5, 3).reshape(B, 2, 8 * h, 8 * w)
     assert float((got.double() - ref).abs().max()) < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,h,w,cin", [(1, 16, 20, 324), (2, 9, 13, 324), (1, 5, 7, 128), (1, 4, 8, 352)])
+def test_conv1x1_resident_vs_fp64_and_igemm(ops, B, h, w, cin):
+    """rnnpose_conv1x1_resident_f16x3 (activation tile split once, resident in LDS) against fp64 and against the implicit-GEMM
+    kernel on the same layer, incl. the ragged K of convc1 (324 = 10 x 32 + 4) and pixel counts that are not multiples of 32."""
+    x = syn.normal("r1_x", (B, cin, h, w), 13)
+    wt = syn.normal("r1_w", (256, cin, 1, 1), 13, std=float(np.sqrt(2.0 / cin)))
+    bs = syn.uniform("r1_b", (256,), 13, -0.5, 0.5)
+    xN = nhwc(D(x))
+    y64 = F.relu(F.conv2d(D(x).double(), D(wt).double(), D(bs).double()))
+    y32 = F.relu(F.conv2d(D(x), D(wt), D(bs)))
+    out = torch.full((B, h, w, 260), 7.0, device="cuda")                      # channel slice [4, 260) of a wider tensor
+    ops.conv1x1_resident(ops.PackedConv1x1(D(wt), D(bs)), (xN, 0), (out, 4), relu=True)
+    assert float((out[..., :4] - 7.0).abs().max()) == 0.0
+    check(nchw(out[..., 4:].contiguous()), y64, y32, "resident 1x1")
+    ref = torch.empty(B, h, w, 256, device="cuda")
+    ops.conv2d_nhwc(ops.PackedConv(D(wt), D(bs), [cin]), [(xN, 0)], (ref, 0), ops.EPI_RELU)
+    assert float((out[..., 4:] - ref).abs().max()) < 2e-5
