@@ -32,6 +32,8 @@ x64 = r(B, H // 2, W // 2, 64)
 sigma = torch.ones(1, device=dev)
 heads = r(Bh, h, w, 512).clamp_(min=0)
 mhead = ops.PackedMaskHead(r(576, 256, 1, 1) * 0.09, r(576) * 0.1)
+c1r = ops.PackedConv1x1(r(256, 324, 1, 1) * 0.08, r(256) * 0.1)
+cor1 = torch.empty(Bh, h, w, 256, device=dev)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 for _ in range(n):
     buf, _ = ops.corr_pyramid(f1, f2, precision="f16x3")
@@ -40,6 +42,7 @@ for _ in range(n):
     ops.context_prep(ctx, h, w)
     up = ops.convex_upsample_nhwc(flow_lr, mask)
     ops.mask_upsample(mhead, heads, 256, flow_lr)
+    ops.conv1x1_resident(c1r, (corr, 0), (cor1, 0))
     wm = ops.corr_weight(g1, g2, up, depth[:Bh], sigma)
     ops.lm_step(up, wm, depth[:Bh], K[:Bh], G[:Bh])
     y, ts = ops.stem_conv(stem, img)
