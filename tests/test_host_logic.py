@@ -200,3 +200,31 @@ def test_torch_library_ops_registered_with_fake_kernels():
         assert Gn.shape == G.shape and xi.shape == (2, 6) and xi.dtype == torch.float32
     with pytest.raises(NotImplementedError):
         torch.ops.rnnpose.convex_upsample(torch.zeros(1, 2, 4, 4), torch.zeros(1, 576, 4, 4))
+
+
+def test_bench_spawns_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus N` without WORLD_SIZE launches N ranks itself (the driver's invocation measured
+    one GPU): the command is the torchrun contract of the task (one node, 127.0.0.1 rendezvous), arguments passed through."""
+    import importlib.util
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setattr(subprocess, "call", lambda cmd, env=None: seen.update(cmd=cmd, env=env) or 0)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "5", "--warmup", "2"])
+    with pytest.raises(SystemExit) as e:
+        bench.spawn_ranks(4)
+    assert e.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "5", "--warmup", "2"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    with pytest.raises(SystemExit) as e:
+        bench.spawn_ranks(4)
+    assert "only 1 GPU" in str(e.value.code)
