@@ -325,6 +325,7 @@ class EncoderEngine:
         self._key = None
         self._w = None
         self._side = None
+        self.resident_1x1 = os.environ.get("RNNPOSE_RESIDENT_1X1", "1") != "0"
         self.split_batch = os.environ.get("RNNPOSE_SPLIT_ENCODER", "1") != "0"
         self.parts = int(os.environ.get("RNNPOSE_ENCODER_PARTS", "2"))
 
@@ -352,6 +353,9 @@ class EncoderEngine:
             stem = convs.pop("stem")
             self._w = {k: ops.PackedConv(m.weight, m.bias, [m.weight.shape[1]]) for k, m in convs.items()}
             self._w["stem"] = ops.PackedStem(stem.weight, stem.bias)
+            oc = convs["out"]           # the 1x1 output convolution (extractor.py:155: 128 -> 256) in the LDS-resident 1x1 kernel
+            ok = tuple(oc.weight.shape[2:]) == (1, 1) and oc.weight.shape[0] == 256 and oc.weight.shape[1] <= 352 and oc.weight.shape[1] % 4 == 0
+            self._w["outr"] = ops.PackedConv1x1(oc.weight, oc.bias) if ok else None
             self._key = key
         return self._w
 
@@ -482,7 +486,11 @@ class EncoderEngine:
             for bi, blk in enumerate(layer):
                 x = yield from E._block_gen(W, f"l{li}.{bi}", blk, x, x_norm)
                 x_norm = None
-        o, _ = E._conv(W["out"], x, stats=False)
+        if W["outr"] is not None and self.resident_1x1:
+            o = torch.empty(*x.shape[:3], 256, device=x.device, dtype=torch.float32)
+            ops.conv1x1_resident(W["outr"], (x, 0), (o, 0), relu=False)
+        else:
+            o, _ = E._conv(W["out"], x, stats=False)
         yield
         ops.nhwc_to_nchw(o, out=out)
         yield
