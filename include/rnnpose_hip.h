@@ -203,6 +203,22 @@ typedef struct {
                                   the convolution reads relu((x - mean) * rstd) instead of x -- the instance norm + ReLU
                                   between conv1 and conv2 of a ResidualBlock (extractor.py:48-52) applied in the load, so
                                   the normalised tensor is never written.  One source, 3x3, stride 1 only. */
+  /* ---- SPLIT TENSORS (round 3): activations that only feed further convolutions live in HBM already split for the
+   * fp16 matrix cores, written once by their producer's epilogue instead of being re-split by every consumer tile (a 3x3
+   * layer with 256 outputs re-split each input 12 times).  A split tensor has the shape, strides and SIZE of its fp32
+   * NHWC counterpart (4 bytes per element, channel counts / offsets in multiples of 8); every 8-channel group of a pixel
+   * occupies 32 bytes = [hi x 8 | lo x 8] fp16 with  x * a_scale = hi + lo  (hi = x * a_scale truncated to 11 significant
+   * bits, lo = fp16(x * a_scale - hi); |x * a_scale| > 65504 is clamped and counted by the range guard).  a_scale must be
+   * the same for the producer and every consumer of a tensor (the package uses 8). */
+  int src_hl;                  /* != 0: ALL sources are split tensors (stride 1, 1/3/5 taps per group, no src0_mean_rstd) */
+  int dst_hl;                  /* != 0: dst receives the split form (no tile_stats) */
+  int dst2_hl;                 /* != 0: dst2 (r*h of the GRU z|r epilogue) receives the split form */
+  float* dst_split;            /* optional (NULL = off): a second copy of the primary result in split form (GRU state update:
+                                  h' is needed as fp32 by the next gate epilogue AND split by the next convolution); not
+                                  with epilogue 2 */
+  int dst_split_c_stride, dst_split_c_offset;
+  int tile;                    /* 0 = automatic; 1 = 128x64, 2 = 128x128 as 4 column waves, 3 = 128x128 as 2x2 waves (split
+                                  sources only) -- measurement override */
 } rnnpose_conv_desc_t;
 
 /* number of fp16 elements of the packed weight array (hi and lo parts interleaved); -1 on bad arguments */
@@ -264,7 +280,13 @@ int rnnpose_flow_conv7x7_relu_f32(const float* flow4, const float* w_t, const fl
  * relu(convf1(flow)) into `out`, and the flow itself into channels [motion_c_offset, +2) of `motion` (update.py:84,91,97). */
 int rnnpose_flow_features_f32(const float* coords1, int subtract_grid, const float* w_t, const float* bias, int B, int h, int w,
                               int c_out, float* out, int out_c_stride, int out_c_offset, float* motion, int motion_c_stride,
-                              int motion_c_offset, rnnpose_stream_t stream);
+                              int motion_c_offset, int out_split, int motion_split, float a_scale, rnnpose_stream_t stream);
+/* out_split / motion_split != 0: `out` / `motion` are split tensors (rnnpose_conv_desc_t, "SPLIT TENSORS") with scale a_scale.
+ * rnnpose_split_hl_f32: channels [src_c_offset, +c_count) of an fp32 NHWC tensor -> the split form in channels
+ * [dst_c_offset, +c_count) of `dst` (c_count, dst offsets / strides multiples of 8): hidden state / context input once per
+ * outer iteration (model/CFNet.py:131-133 produce them in fp32). */
+int rnnpose_split_hl_f32(const float* src, int src_c_stride, int src_c_offset, long long n_pixels, int c_count, float a_scale,
+                         float* dst, int dst_c_stride, int dst_c_offset, rnnpose_stream_t stream);
 int rnnpose_flow_head_out_f32(const float* x, int x_c_stride, int x_c_offset, int c_in, const float* w_oihw,
                               const float* bias, const float* coords1, int B, int h, int w, float* delta,
                               float* coords1_out, float* flow_lr, rnnpose_stream_t stream);
@@ -275,13 +297,14 @@ int rnnpose_convex_upsample_nhwc_f32(const float* flow_lr, const float* mask, in
  * BasicMotionEncoder.convc1 (thirdparty/raft/update.py:80,87: 324 -> 256).  pack: weight (256, c_in) fp32 -> MFMA fragments
  * (rnnpose_conv1x1_resident_packed_bytes(c_in) bytes, 16-byte aligned) of w_scale * weight; c_in % 4 == 0, c_in <= 352.
  * x: n_pixels rows of x_c_stride floats, channels [x_c_offset, +c_in); dst: rows of dst_c_stride, channels [dst_c_offset, +256).
- * Agrees with rnnpose_conv2d_nhwc_f16x3 to fp32 round-off (the K sum is grouped differently). */
+ * Agrees with rnnpose_conv2d_nhwc_f16x3 to fp32 round-off (the K sum is grouped differently).  dst_split != 0: dst is written
+ * as a split tensor (rnnpose_conv_desc_t, "SPLIT TENSORS") with the launch's a_scale. */
 size_t rnnpose_conv1x1_resident_packed_bytes(int c_in);
 int rnnpose_conv1x1_resident_pack_f16x3(const float* weight, int c_out, int c_in, float w_scale, void* packed,
                                         rnnpose_stream_t stream);
 int rnnpose_conv1x1_resident_f16x3(const float* x, int x_c_stride, int x_c_offset, int c_in, const void* w_packed,
                                    const float* bias, float a_scale, float w_scale, int relu, long long n_pixels, float* dst,
-                                   int dst_c_stride, int dst_c_offset, rnnpose_stream_t stream);
+                                   int dst_c_stride, int dst_c_offset, int dst_split, rnnpose_stream_t stream);
 /* mask.2 + convex up-sampling in ONE kernel: mask = post_scale * mask.2(x) (1x1, 256 -> 576, thirdparty/raft/update.py:183-187)
  * is consumed in registers by the softmax / 3x3 convex combination of model/CFNet.py:95-106; the (B,h,w,576) mask tensor is
  * never written.  pack: weight (576,256) fp32 -> fp16 hi / lo MFMA fragments (rnnpose_mask_upsample_packed_bytes() bytes,

@@ -30,7 +30,8 @@ class ConvDesc(C.Structure):       # rnnpose_conv_desc_t
                 ("aux1", C.c_void_p), ("aux1_c_stride", C.c_int), ("aux1_c_offset", C.c_int),
                 ("dst2", C.c_void_p), ("dst2_c_stride", C.c_int), ("dst2_c_offset", C.c_int), ("gru_c", C.c_int),
                 ("tile_stats", C.c_void_p), ("add_map", C.c_void_p), ("add_c_stride", C.c_int), ("add_c_offset", C.c_int),
-                ("src0_mean_rstd", C.c_void_p)]
+                ("src0_mean_rstd", C.c_void_p), ("src_hl", C.c_int), ("dst_hl", C.c_int), ("dst2_hl", C.c_int),
+                ("dst_split", C.c_void_p), ("dst_split_c_stride", C.c_int), ("dst_split_c_offset", C.c_int), ("tile", C.c_int)]
 
 
 # name -> (restype, argtypes); mirrors include/rnnpose_hip.h one to one
@@ -74,14 +75,15 @@ PROTOTYPES = {
     "rnnpose_nhwc_to_nchw_f32": (_i, [_p, _i, _i, _i, _i, _i, _p, _p]),
     "rnnpose_flow_prep_f32": (_i, [_p, _i, _i, _i, _i, _p, _p, _i, _i, _p]),
     "rnnpose_flow_conv7x7_relu_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _i, _i, _p]),
-    "rnnpose_flow_features_f32": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _p, _i, _i, _p, _i, _i, _p]),
+    "rnnpose_flow_features_f32": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _p, _i, _i, _p, _i, _i, _i, _i, _f, _p]),
+    "rnnpose_split_hl_f32": (_i, [_p, _i, _i, _ll, _i, _f, _p, _i, _i, _p]),
     "rnnpose_flow_head_out_f32": (_i, [_p, _i, _i, _i, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p]),
     "rnnpose_convex_upsample_nhwc_f32": (_i, [_p, _p, _i, _i, _i, _p, _p]),
     "rnnpose_mask_upsample_f16x3": (_i, [_p, _i, _i, _p, _i, _p, _f, _f, _p, _i, _i, _i, _p, _p]),
     "rnnpose_mask_upsample_packed_bytes": (_z, []),
     "rnnpose_conv1x1_resident_packed_bytes": (_z, [_i]),
     "rnnpose_conv1x1_resident_pack_f16x3": (_i, [_p, _i, _i, _f, _p, _p]),
-    "rnnpose_conv1x1_resident_f16x3": (_i, [_p, _i, _i, _i, _p, _p, _f, _f, _i, _ll, _p, _i, _i, _p]),
+    "rnnpose_conv1x1_resident_f16x3": (_i, [_p, _i, _i, _i, _p, _p, _f, _f, _i, _ll, _p, _i, _i, _i, _p]),
     "rnnpose_mask_upsample_pack_f16x3": (_i, [_p, _f, _f, _p, _p]),
     "rnnpose_instnorm_workspace_bytes": (_z, [_i, _i, _i]),
     "rnnpose_instnorm_tiles_nhwc_f32": (_i, [_p, _i, _i, _i, _f, _i, _p, _p, _i, _p, _i, _p, _p, _p]),

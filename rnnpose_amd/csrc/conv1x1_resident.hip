@@ -31,6 +31,7 @@ struct RParams {
   int dcs, dco, relu;
   long long M;
   unsigned long long* sat;
+  int dst_hl;                   // write the output as a SPLIT tensor (fp16 hi|lo per 8-channel group, rnnpose_hip.h) for the next convolution
 };
 
 template <int NCB>
@@ -142,7 +143,19 @@ __global__ __launch_bounds__(8 * MQ) __attribute__((amdgpu_num_vgpr(160))) void 
     const int idx = tid + 256 * k;
     const int row = idx >> 6, cq = (idx & 63) * 4;
     const long long m = m0 + row;
-    if (m < p.M) *reinterpret_cast<float4*>(p.dst + m * p.dcs + p.dco + cq) = *reinterpret_cast<const float4*>(S + row * RSF + cq);
+    if (m >= p.M) continue;
+    const float4 y = *reinterpret_cast<const float4*>(S + row * RSF + cq);
+    if (p.dst_hl) {               // quad cq of the row -> 8 bytes of the hi plane + 8 bytes of the lo plane of its 8-channel group
+      h4 hi, lo;
+      split4(y, p.a_scale, hi, lo);
+      if (p.sat && rp::quad_saturates(y, p.a_scale)) atomicAdd(p.sat, 1ull);
+      const int ch = p.dco + cq;
+      float* ph = p.dst + m * p.dcs + (ch & ~7) + ((ch >> 2) & 1) * 2;
+      *reinterpret_cast<h4*>(ph) = hi;
+      *reinterpret_cast<h4*>(ph + 4) = lo;
+    } else {
+      *reinterpret_cast<float4*>(p.dst + m * p.dcs + p.dco + cq) = y;
+    }
   }
 }
 
@@ -179,8 +192,9 @@ extern "C" int rnnpose_conv1x1_resident_pack_f16x3(const float* weight, int c_ou
 
 extern "C" int rnnpose_conv1x1_resident_f16x3(const float* x, int x_c_stride, int x_c_offset, int c_in, const void* w_packed,
                                               const float* bias, float a_scale, float w_scale, int relu, long long n_pixels,
-                                              float* dst, int dst_c_stride, int dst_c_offset, rnnpose_stream_t stream) {
+                                              float* dst, int dst_c_stride, int dst_c_offset, int dst_split, rnnpose_stream_t stream) {
   const char* fn = "rnnpose_conv1x1_resident_f16x3";
+  if (dst_split) RP_REQUIRE(dst_c_stride % 8 == 0 && reinterpret_cast<uintptr_t>(dst) % 32 == 0, fn, "split-form dst: channel stride multiple of 8, 32-byte aligned");
   RP_REQUIRE(x && w_packed && bias && dst, fn, "null pointer");
   RP_REQUIRE(c_in > 0 && c_in <= 32 * MAX_NCB && c_in % 4 == 0, fn, "c_in must be a multiple of 4, at most 352");
   RP_REQUIRE(n_pixels > 0 && n_pixels < (1LL << 31), fn, "bad pixel count");
@@ -198,6 +212,7 @@ extern "C" int rnnpose_conv1x1_resident_f16x3(const float* x, int x_c_stride, in
   p.dst = dst; p.dcs = dst_c_stride; p.dco = dst_c_offset; p.relu = relu;
   p.M = n_pixels;
   p.sat = rp::sat_counter();
+  p.dst_hl = dst_split;
   const dim3 grid(static_cast<unsigned>(rp::cdiv(n_pixels, MQ))), block(8 * MQ);
   hipStream_t st = rp::as_stream(stream);
   switch (rp::cdiv(c_in, 32)) {

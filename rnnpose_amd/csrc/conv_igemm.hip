@@ -77,7 +77,33 @@ struct KParams {
   const float* in_mr;  // NORM variant: (B, seg0.cstride, 2) mean / rstd of source 0, applied with ReLU while staging
   int n_mt, n_nt;
   unsigned long long* sat;   // fp16x3 range guard: counter of clamped / non-finite activation quads (NULL = check off)
+  int dst_hl, dst2_hl;       // dst / dst2 receive the PRE-SPLIT fp16 hi|lo form (rnnpose_hip.h, "split tensors") instead of fp32
+  float* dsth;               // optional second destination of the primary result, always in split form (GRU: h' as fp32 AND split)
+  int dsth_cs, dsth_co;
 };
+
+// One output quad (4 consecutive channels starting at channel ch of the pixel row `row`) in split form: the 8-channel group
+// g = ch / 8 occupies 32 bytes = [hi x 8 | lo x 8] fp16; a quad is the 8-byte half (ch / 4) & 1 of each plane.  nv < 4 (the
+// ragged tail of a 126-channel layer): only the first nv fp16 of each plane are written -- their neighbours belong to
+// another producer (the flow channels of the motion features).
+__device__ __forceinline__ void store_quad_hl(float* row, int ch, float y0, float y1, float y2, float y3, int nv, float a_scale,
+                                              int& sat_n) {
+  h4 hi, lo;
+  const float4 v = make_float4(y0, nv > 1 ? y1 : 0.f, nv > 2 ? y2 : 0.f, nv > 3 ? y3 : 0.f);
+  split4(v, a_scale, hi, lo);
+  sat_n += rp::quad_saturates(v, a_scale) ? 1 : 0;
+  float* ph = row + (ch & ~7) + ((ch >> 2) & 1) * 2;
+  if (nv == 4) {
+    *reinterpret_cast<h4*>(ph) = hi;
+    *reinterpret_cast<h4*>(ph + 4) = lo;
+  } else {
+    _Float16* hh = reinterpret_cast<_Float16*>(ph);
+    _Float16* ll = reinterpret_cast<_Float16*>(ph + 4);
+    if (nv > 0) { hh[0] = hi.x; ll[0] = lo.x; }
+    if (nv > 1) { hh[1] = hi.y; ll[1] = lo.y; }
+    if (nv > 2) { hh[2] = hi.z; ll[2] = lo.z; }
+  }
+}
 
 
 // Every global load of the main loop is UNCONDITIONAL (out-of-range activation rows read element 0 of their tensor and
@@ -110,9 +136,14 @@ __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-
 // NORM: the (single) source is the RAW output of a convolution whose instance norm + ReLU (extractor.py:48-58: relu(norm1(conv1 x)))
 // is applied here, while the tile is split into LDS -- the normalised tensor never exists in HBM.  Needs per-image tiling
 // (one image per workgroup: the statistics of the staged channel quad are two 16-byte loads per 32-channel block).
-template <int NI, bool STRIDED, bool COLS4 = false, int TT = 0, bool NORM = false>
-__global__ __launch_bounds__(NT, ((COLS4 || TT > 0) ? 3 : 2)) void conv_igemm_f16x3_kernel(const KParams p) {
+// HLIN: the sources are SPLIT tensors (fp16 hi|lo per 8-channel group, written by a producer's epilogue: rnnpose_hip.h): the
+// staging is a 16-byte copy per thread and row -- no conversion, no range test in the loop.  r02 counters: the on-the-fly
+// split was ~3 of the 4.8-6 vector instructions per MFMA of this kernel, on a SIMD whose issue slots (about 8 per MFMA
+// period for all its waves) were the limiter; a 3x3 layer with 256 outputs re-split every activation 12 times.
+template <int NI, bool STRIDED, bool COLS4 = false, int TT = 0, bool NORM = false, bool HLIN = false>
+__global__ __launch_bounds__(NT, (NI == 2 ? 2 : ((COLS4 || TT > 0) ? 3 : 2))) void conv_igemm_f16x3_kernel(const KParams p) {
   static_assert(TT == 0 || (!STRIDED && (TT & 1)), "the unrolled loop is for stride 1 and odd tap counts");
+  static_assert(!HLIN || (!NORM && !STRIDED && TT > 0), "split-tensor sources: stride 1, no fused normalisation");
   static_assert(!COLS4 || NI == 1, "the 4-column layout has one 32-column MFMA tile per wave");
   constexpr int MI = COLS4 ? 4 : 2;                     // 32-row MFMA tiles per wave
   constexpr int BNT = COLS4 ? 128 : 64 * NI;
@@ -202,7 +233,8 @@ __global__ __launch_bounds__(NT, ((COLS4 || TT > 0) ? 3 : 2)) void conv_igemm_f1
     if ((CB_) >= p.cb2) { sg_ = p.seg2; cb0_ = p.cb2; }                                                     \
     if ((CB_) >= p.cb3) { sg_ = p.seg3; cb0_ = p.cb3; }                                                     \
     const int c_ = ((CB_) - cb0_) * BK + c4 * 4;                                                            \
-    const bool cok_ = c_ < sg_.ccount;                                                                      \
+    /* split sources: this thread's 16 bytes are one plane (c4 & 1) of the 8-channel group c4 >> 1 of the block */ \
+    const bool cok_ = (HLIN ? ((CB_) - cb0_) * BK + (c4 >> 1) * 8 : c_) < sg_.ccount;                       \
     const int cc_ = sg_.coff + c_;                                                                          \
     const int du_ = p.du0 + (STRIDED ? (G_) / p.gkw : (G_));                                                \
     const int dvg_ = STRIDED ? p.dvg0 + (G_) % p.gkw : 0;                                                   \
@@ -218,7 +250,14 @@ __global__ __launch_bounds__(NT, ((COLS4 || TT > 0) ? 3 : 2)) void conv_igemm_f1
 #define RP_STORE_A_ROW(R_, AB_)                                                                             \
   {                                                                                                         \
     const int j_ = (tid >> 3) + 32 * R_;                                                                    \
-    if (j_ < AROWS) {                                                                                       \
+    if (HLIN) {                                                                                             \
+      if (j_ < AROWS) {              /* rows outside the image: zeros (bitwise AND: a select of two float4 went through scratch) */ \
+        const unsigned mk_ = 0u - ((amask_n >> R_) & 1u);                                                   \
+        uint4 u_ = __builtin_bit_cast(uint4, av##R_);                                                       \
+        u_.x &= mk_; u_.y &= mk_; u_.z &= mk_; u_.w &= mk_;                                                 \
+        *reinterpret_cast<uint4*>(sAf + (AB_) * (2 * PROWS * RS) + (c4 & 1) * (PROWS * RS) + j_ * RS + (c4 >> 1) * 8) = u_; \
+      }                                                                                                     \
+    } else if (j_ < AROWS) {                                                                                \
       h4 hi_, lo_;                                                                                          \
       const float4 z4_ = make_float4(0.f, 0.f, 0.f, 0.f);                                                   \
       float4 xv_ = av##R_;                                                                                  \
@@ -232,7 +271,7 @@ __global__ __launch_bounds__(NT, ((COLS4 || TT > 0) ? 3 : 2)) void conv_igemm_f1
 #define RP_SAT_ROW(R_) sat_n += (((amask_n >> R_) & 1u) && rp::quad_saturates(av##R_, p.a_scale)) ? 1 : 0;
 #define RP_STORE_A(AB_)                                                                                     \
   do {                                                                                                      \
-    if (p.sat) { RP_SAT_ROW(0) RP_SAT_ROW(1) RP_SAT_ROW(2) RP_SAT_ROW(3) RP_SAT_ROW(4) }   /* uniform branch, VALU only */ \
+    if (!HLIN && p.sat) { RP_SAT_ROW(0) RP_SAT_ROW(1) RP_SAT_ROW(2) RP_SAT_ROW(3) RP_SAT_ROW(4) }   /* uniform branch, VALU only */ \
     RP_STORE_A_ROW(0, AB_) RP_STORE_A_ROW(1, AB_) RP_STORE_A_ROW(2, AB_) RP_STORE_A_ROW(3, AB_) RP_STORE_A_ROW(4, AB_) \
   } while (0)
   // weight fragment registers: two stages (named locals + macros: structs/arrays handed to lambdas end up in LDS or
@@ -482,7 +521,6 @@ __global__ __launch_bounds__(NT, ((COLS4 || TT > 0) ? 3 : 2)) void conv_igemm_f1
   if (total & 1) RP_STAGE(0);
 
   }
-  if (p.sat && sat_n) atomicAdd(p.sat, static_cast<unsigned long long>(sat_n));
   // ------------------------------------------- epilogue -------------------------------------------
   // accumulators -> wave-private LDS tile (aliasing the weight staging buffers) -> 16-byte row-contiguous stores:
   // 16 lanes cover 256 contiguous bytes of one output pixel (the MFMA C layout would give 4-byte stores spread
@@ -558,7 +596,9 @@ __global__ __launch_bounds__(NT, ((COLS4 || TT > 0) ? 3 : 2)) void conv_igemm_f1
 #pragma unroll
       for (int e = 0; e < 4; ++e) y[e] += (e < nv) ? bq[e] : 0.f;
       if (p.addm) { y[0] += am[k].x; y[1] += am[k].y; y[2] += am[k].z; y[3] += am[k].w; }
-      float* dptr = p.dst + pix * p.dst_cs + p.dst_co + col;
+      float* drow = p.dst + pix * p.dst_cs;      // destination pixel row, channel index inside it, fp32 or split form
+      int dch = p.dst_co + col;
+      int dhl = p.dst_hl;
       if (p.tstats) {              // (column quad of a lane is the same for every k and mi: 64 % F4 == 0)
         if (nv > 0) { ts0 += y[0]; tq0 += y[0] * y[0]; }
         if (nv > 1) { ts1 += y[1]; tq1 += y[1] * y[1]; }
@@ -575,22 +615,28 @@ __global__ __launch_bounds__(NT, ((COLS4 || TT > 0) ? 3 : 2)) void conv_igemm_f1
         } else {
           y[0] = sigmoidf_(y[0]) * hv[k].x; y[1] = sigmoidf_(y[1]) * hv[k].y;             // r * h
           y[2] = sigmoidf_(y[2]) * hv[k].z; y[3] = sigmoidf_(y[3]) * hv[k].w;
-          dptr = p.dst2 + pix * p.dst2_cs + p.dst2_co + c2;
+          drow = p.dst2 + pix * p.dst2_cs;
+          dch = p.dst2_co + c2;
+          dhl = p.dst2_hl;
         }
       } else if (p.epi == 3) {
         const float4 z = zv[k], h4 = hv[k];
         y[0] = (1.f - z.x) * h4.x + z.x * tanhf(y[0]); y[1] = (1.f - z.y) * h4.y + z.y * tanhf(y[1]);   // h' = (1-z)h + z q
         y[2] = (1.f - z.z) * h4.z + z.z * tanhf(y[2]); y[3] = (1.f - z.w) * h4.w + z.w * tanhf(y[3]);
       }
-      if (nv == 4) {
-        *reinterpret_cast<float4*>(dptr) = make_float4(y[0], y[1], y[2], y[3]);
+      if (dhl) {
+        store_quad_hl(drow, dch, y[0], y[1], y[2], y[3], nv, p.a_scale, sat_n);
+      } else if (nv == 4) {
+        *reinterpret_cast<float4*>(drow + dch) = make_float4(y[0], y[1], y[2], y[3]);
       } else {
 #pragma unroll
         for (int e = 0; e < 3; ++e)
-          if (e < nv) dptr[e] = y[e];
+          if (e < nv) drow[dch + e] = y[e];
       }
+      if (p.dsth) store_quad_hl(p.dsth + pix * p.dsth_cs, p.dsth_co + col, y[0], y[1], y[2], y[3], nv, p.a_scale, sat_n);
     }
   }
+  if (p.sat && sat_n) atomicAdd(p.sat, static_cast<unsigned long long>(sat_n));
   if (p.tstats) {
     // lanes sharing a column quad (same lane % F4) -> lanes 0..F4-1, fixed order; then rows 0-63 (wm = 0) + rows 64-127
     // (wm = 1) through LDS; one (sum, sum of squares) pair per tile and column: deterministic, no atomics
@@ -812,6 +858,26 @@ int rnnpose_conv2d_nhwc_f16x3(const rnnpose_conv_desc_t* d, rnnpose_stream_t str
   if (d->add_map) RP_REQUIRE(d->c_out % 4 == 0 && d->add_c_stride % 4 == 0 && d->add_c_offset % 4 == 0 &&
                                  reinterpret_cast<uintptr_t>(d->add_map) % 16 == 0, fn, "add_map: c_out % 4 == 0, 16-byte aligned, stride/offset multiples of 4");
   p.sat = rp::sat_counter();
+  // split-tensor sources / destinations (see the header): whole 8-channel groups, 32-byte aligned rows
+  const bool hlin = d->src_hl != 0;
+  if (hlin) {
+    RP_REQUIRE(d->stride == 1 && !d->src0_mean_rstd && (p.T == 1 || p.T == 3 || p.T == 5), fn,
+               "split-tensor sources: stride 1, 1/3/5 taps per group, no fused normalisation");
+    for (int s = 0; s < d->n_src; ++s)
+      RP_REQUIRE(d->src[s].c_count % 8 == 0 && d->src[s].c_offset % 8 == 0 && d->src[s].c_stride % 8 == 0 &&
+                     reinterpret_cast<uintptr_t>(d->src[s].ptr) % 32 == 0, fn,
+                 "split-tensor source: channel stride/offset/count multiples of 8, 32-byte aligned");
+  }
+  p.dst_hl = d->dst_hl; p.dst2_hl = d->dst2_hl;
+  p.dsth = d->dst_split; p.dsth_cs = d->dst_split_c_stride; p.dsth_co = d->dst_split_c_offset;
+  if (d->dst_hl) RP_REQUIRE(d->dst_c_stride % 8 == 0 && reinterpret_cast<uintptr_t>(d->dst) % 32 == 0 && !d->tile_stats, fn,
+                            "split-form dst: channel stride multiple of 8, 32-byte aligned, no tile statistics");
+  if (d->dst2_hl) RP_REQUIRE(d->epilogue == 2 && d->dst2_c_stride % 8 == 0 && reinterpret_cast<uintptr_t>(d->dst2) % 32 == 0, fn,
+                             "split-form dst2: GRU z|r epilogue, channel stride multiple of 8, 32-byte aligned");
+  if (d->dst_split) RP_REQUIRE(d->epilogue != 2 && d->dst_split_c_stride % 8 == 0 && d->dst_split_c_offset % 4 == 0 &&
+                                   reinterpret_cast<uintptr_t>(d->dst_split) % 32 == 0, fn,
+                               "dst_split: not with the GRU z|r epilogue; channel stride multiple of 8, offset of 4, 32-byte aligned");
+  RP_REQUIRE(d->tile >= 0 && d->tile <= 3, fn, "tile must be 0 (auto), 1 (128x64), 2 (128x128, 4 column waves) or 3 (128x128, 2x2 waves)");
   if (d->tile_stats) RP_REQUIRE(d->epilogue == 0, fn, "tile_stats needs the linear epilogue");
   const long long Mtot = static_cast<long long>(d->B) * Ho * Wo;
   RP_REQUIRE(Mtot < (1LL << 31) - 256 && static_cast<long long>(d->B) * d->H * d->W < (1LL << 31) - 256, fn, "too many pixels");
@@ -824,25 +890,37 @@ int rnnpose_conv2d_nhwc_f16x3(const rnnpose_conv_desc_t* d, rnnpose_stream_t str
   if (d->src0_mean_rstd)
     RP_REQUIRE(d->n_src == 1 && d->stride == 1 && d->kh == 3 && d->kw == 3 && reinterpret_cast<uintptr_t>(d->src0_mean_rstd) % 16 == 0,
                fn, "src0_mean_rstd (fused instance norm + ReLU of the input) needs one source, a 3x3 stride-1 kernel, 16-byte alignment");
-  // tile width: 128 when Cout fills it and there are enough workgroups for 2 per CU, else 64
-  const bool wide = !d->src0_mean_rstd && (d->c_out % 128 == 0) && (static_cast<long long>(p.n_mt) * (d->c_out / 128) >= 512);
+  // tile width: 128 when Cout fills it and there are enough workgroups for 2 per CU, else 64.  d->tile overrides (measurement)
+  bool wide = !d->src0_mean_rstd && (d->c_out % 128 == 0) && (static_cast<long long>(p.n_mt) * (d->c_out / 128) >= 512);
+  bool wide22 = false;            // 128x128 as 2x2 waves of 64x64 (NI = 2): stride-1 split-source layers only
+  if (d->tile == 1) wide = false;
+  if (d->tile == 2) wide = !d->src0_mean_rstd;
+  if (d->tile == 3 && hlin) { wide = false; wide22 = true; }
   const dim3 block(NT);
   hipStream_t st = rp::as_stream(stream);
   // stride 1: the main loop unrolled over the taps of a group (T = kw, or kh for vertical kernels); stride 2: generic loop
-#define RP_LAUNCH_T(NI_, COLS4_)                                                                                   \
-  switch (p.T) {                                                                                                    \
-    case 1: hipLaunchKernelGGL((conv_igemm_f16x3_kernel<NI_, false, COLS4_, 1>), grid, block, 0, st, p); break;    \
-    case 3: hipLaunchKernelGGL((conv_igemm_f16x3_kernel<NI_, false, COLS4_, 3>), grid, block, 0, st, p); break;    \
-    case 5: hipLaunchKernelGGL((conv_igemm_f16x3_kernel<NI_, false, COLS4_, 5>), grid, block, 0, st, p); break;    \
-    default: hipLaunchKernelGGL((conv_igemm_f16x3_kernel<NI_, false, COLS4_, 7>), grid, block, 0, st, p); break;   \
+#define RP_LAUNCH_T(NI_, COLS4_, HL_)                                                                                   \
+  switch (p.T) {                                                                                                         \
+    case 1: hipLaunchKernelGGL((conv_igemm_f16x3_kernel<NI_, false, COLS4_, 1, false, HL_>), grid, block, 0, st, p); break;    \
+    case 3: hipLaunchKernelGGL((conv_igemm_f16x3_kernel<NI_, false, COLS4_, 3, false, HL_>), grid, block, 0, st, p); break;    \
+    case 5: hipLaunchKernelGGL((conv_igemm_f16x3_kernel<NI_, false, COLS4_, 5, false, HL_>), grid, block, 0, st, p); break;    \
+    default:                                                                                                             \
+      if constexpr (!(HL_)) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<NI_, false, COLS4_, 7, false, false>), grid, block, 0, st, p); \
+      break;                                                                                                             \
   }
-  if (wide) {
+  if (wide22) {
+    p.n_nt = p.Npad / 128;
+    const dim3 grid(static_cast<unsigned>(p.n_mt) * p.n_nt);
+    RP_LAUNCH_T(2, false, true)
+  } else if (wide) {
     p.n_nt = p.Npad / 128;
     const dim3 grid(static_cast<unsigned>(p.n_mt) * p.n_nt);
     if (p.stride == 2) {
       hipLaunchKernelGGL((conv_igemm_f16x3_kernel<1, true, true>), grid, block, 0, st, p);
+    } else if (hlin) {
+      RP_LAUNCH_T(1, true, true)
     } else {
-      RP_LAUNCH_T(1, true)
+      RP_LAUNCH_T(1, true, false)
     }
   } else {
     p.n_nt = rp::cdiv(d->c_out, 64);
@@ -851,8 +929,10 @@ int rnnpose_conv2d_nhwc_f16x3(const rnnpose_conv_desc_t* d, rnnpose_stream_t str
       hipLaunchKernelGGL((conv_igemm_f16x3_kernel<1, true, false>), grid, block, 0, st, p);
     } else if (d->src0_mean_rstd) {
       hipLaunchKernelGGL((conv_igemm_f16x3_kernel<1, false, false, 3, true>), grid, block, 0, st, p);
+    } else if (hlin) {
+      RP_LAUNCH_T(1, false, true)
     } else {
-      RP_LAUNCH_T(1, false)
+      RP_LAUNCH_T(1, false, false)
     }
   }
 #undef RP_LAUNCH_T

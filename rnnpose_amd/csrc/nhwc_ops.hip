@@ -2,6 +2,7 @@
 // degenerate convolutions of the update block (Cin = 2 is handled by padding in the igemm; Cout = 2 is this
 // file's bandwidth kernel) and the convex upsampling that reads the mask in NHWC.
 #include "common.hpp"
+#include "f16x3.cuh"
 
 namespace {
 
@@ -418,7 +419,8 @@ __global__ __launch_bounds__(128, 3) void conv7x7_cin2_kernel(const float* __res
                                                            const float* __restrict__ bias, float* __restrict__ out,
                                                            int out_cs, int out_co, int Cout, int h, int w,
                                                            int subtract_grid, float* __restrict__ motion, int motion_cs,
-                                                           int motion_co) {
+                                                           int motion_co, int out_hl, int motion_hl, float a_scale,
+                                                           unsigned long long* __restrict__ sat) {
   // rows padded to 28 floats (112 bytes): every row is seven aligned 16-byte LDS reads
   __shared__ __attribute__((aligned(16))) float patch[2][7][F1_ROW];
   const int b = blockIdx.z, Y = blockIdx.y, X0 = blockIdx.x * F1_TX;
@@ -432,8 +434,20 @@ __global__ __launch_bounds__(128, 3) void conv7x7_cin2_kernel(const float* __res
       if (PLANAR) {
         v.x = flow4[(static_cast<long long>(b) * 2 + 0) * n + yy * w + x] - (subtract_grid ? static_cast<float>(x) : 0.f);
         v.y = flow4[(static_cast<long long>(b) * 2 + 1) * n + yy * w + x] - (subtract_grid ? static_cast<float>(yy) : 0.f);
-        if (ky == 3 && xx >= 3 && xx < 3 + F1_TX)       // this row segment's own pixels: motion[..., co:co+2] = flow (update.py:97)
-          *reinterpret_cast<float2*>(motion + (static_cast<long long>(b) * n + yy * w + x) * motion_cs + motion_co) = v;
+        if (ky == 3 && xx >= 3 && xx < 3 + F1_TX) {     // this row segment's own pixels: motion[..., co:co+2] = flow (update.py:97)
+          float* mrow = motion + (static_cast<long long>(b) * n + yy * w + x) * motion_cs;
+          if (motion_hl) {        // split tensor: the two channels are 4 bytes of the hi plane + 4 bytes of the lo plane of their group
+            rp::h4 hi, lo;
+            const float4 q = make_float4(v.x, v.y, 0.f, 0.f);
+            rp::split4(q, a_scale, hi, lo);
+            if (sat && rp::quad_saturates(q, a_scale)) atomicAdd(sat, 1ull);
+            _Float16* ph = reinterpret_cast<_Float16*>(mrow + (motion_co & ~7)) + (motion_co & 7);
+            *reinterpret_cast<rp::h2*>(ph) = rp::h2{hi.x, hi.y};
+            *reinterpret_cast<rp::h2*>(ph + 8) = rp::h2{lo.x, lo.y};
+          } else {
+            *reinterpret_cast<float2*>(mrow + motion_co) = v;
+          }
+        }
       } else {
         const float4 f = *reinterpret_cast<const float4*>(flow4 + (static_cast<long long>(b) * n + yy * w + x) * 4);
         v = make_float2(f.x, f.y);
@@ -444,7 +458,7 @@ __global__ __launch_bounds__(128, 3) void conv7x7_cin2_kernel(const float* __res
   }
   const float bs = c < Cout ? bias[c] : 0.f;
   __syncthreads();
-  if (c >= Cout) return;
+  if (c >= Cout && !out_hl) return;      // (split output: lane pairs exchange their halves below, Cout is even)
   // Row-outer accumulation: one patch row (7 wave-uniform 16-byte LDS reads) feeds 7 taps x 20 pixels, so the LDS pipe sees
   // 98 reads per thread instead of one 4-byte read per multiply-add (1960): the kernel was LDS-issue-bound (r02: 23 us per
   // launch).  The weights are held one input channel (49) at a time: with all 98 (+ their 64-bit addresses) the 20
@@ -455,7 +469,7 @@ __global__ __launch_bounds__(128, 3) void conv7x7_cin2_kernel(const float* __res
 #pragma unroll 1
   for (int ci = 0; ci < 2; ++ci) {
     float wreg[49];
-    const float* wc = wt + static_cast<long long>(ci) * 49 * Cout + c;
+    const float* wc = wt + static_cast<long long>(ci) * 49 * Cout + (c < Cout ? c : 0);
 #pragma unroll
     for (int k = 0; k < 49; ++k) wreg[k] = wc[k * Cout];
 #pragma unroll
@@ -473,9 +487,52 @@ __global__ __launch_bounds__(128, 3) void conv7x7_cin2_kernel(const float* __res
       __builtin_amdgcn_sched_barrier(0);     // one row in registers at a time
     }
   }
+  if (out_hl) {
+    // split tensor: channel ch = out_co + c sits at fp16 index (ch & 7) of the hi plane of its 32-byte group, lo plane 8 fp16
+    // further.  Even lanes store the (hi, hi) pair of channels (ch, ch + 1), odd lanes the (lo, lo) pair: one 4-byte store each.
+    const int ch = out_co + c;
+    const bool odd = c & 1;
+    const long long pbase = (static_cast<long long>(b) * n + Y * w + X0) * out_cs + (ch & ~7);
+    bool sflag = false;
+#pragma unroll
+    for (int x = 0; x < F1_TX; ++x) {
+      const float y = fmaxf(acc[x], 0.f);
+      rp::h4 hi, lo;
+      const float4 q = make_float4(y, 0.f, 0.f, 0.f);
+      rp::split4(q, a_scale, hi, lo);
+      sflag |= rp::quad_saturates(q, a_scale);
+      const unsigned mine = odd ? __builtin_bit_cast(unsigned short, lo.x) : __builtin_bit_cast(unsigned short, hi.x);
+      const unsigned send = odd ? __builtin_bit_cast(unsigned short, hi.x) : __builtin_bit_cast(unsigned short, lo.x);
+      const unsigned got = __shfl_xor(send, 1);          // even lane receives the odd lane's hi, odd lane the even lane's lo
+      const unsigned word = odd ? (got | (mine << 16)) : (mine | (got << 16));
+      if (X0 + x < w && c < Cout)
+        reinterpret_cast<unsigned*>(out + pbase + static_cast<long long>(x) * out_cs)[(odd ? 4 : 0) + ((ch & 7) >> 1)] = word;
+    }
+    if (sat && sflag && c < Cout) atomicAdd(sat, 1ull);
+    return;
+  }
 #pragma unroll
   for (int x = 0; x < F1_TX; ++x)
     if (X0 + x < w) out[(static_cast<long long>(b) * n + Y * w + X0 + x) * out_cs + out_co + c] = fmaxf(acc[x], 0.f);
+}
+
+// fp32 NHWC channels [co, co + C) of `src` -> the same channels of the split tensor `dst` (C % 8 == 0): thread = one 8-channel group
+__global__ __launch_bounds__(256) void split_hl_kernel(const float* __restrict__ src, int scs, int sco, float* __restrict__ dst, int dcs,
+                                                       int dco, int C8, long long total, float a_scale,
+                                                       unsigned long long* __restrict__ sat) {
+  const long long i = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= total) return;
+  const long long m = i / C8;
+  const int g = static_cast<int>(i - m * C8);
+  const float4 a = *reinterpret_cast<const float4*>(src + m * scs + sco + g * 8);
+  const float4 bq = *reinterpret_cast<const float4*>(src + m * scs + sco + g * 8 + 4);
+  rp::h4 h0, l0, h1, l1;
+  rp::split4(a, a_scale, h0, l0);
+  rp::split4(bq, a_scale, h1, l1);
+  if (sat && (rp::quad_saturates(a, a_scale) || rp::quad_saturates(bq, a_scale))) atomicAdd(sat, 1ull);
+  float* o = dst + m * dcs + dco + g * 8;
+  *reinterpret_cast<rp::h8*>(o) = rp::h8{h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+  *reinterpret_cast<rp::h8*>(o + 4) = rp::h8{l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
 }
 
 }  // namespace
@@ -601,20 +658,40 @@ int rnnpose_flow_conv7x7_relu_f32(const float* flow4, const float* w_t, const fl
   RP_REQUIRE(out_c_offset >= 0 && out_c_offset + c_out <= out_c_stride && reinterpret_cast<uintptr_t>(flow4) % 16 == 0, fn,
              "bad output window / flow4 alignment");
   hipLaunchKernelGGL(conv7x7_cin2_kernel<false>, dim3(rp::cdiv(w, F1_TX), h, B), dim3(128), 0, rp::as_stream(stream), flow4, w_t,
-                     bias, out, out_c_stride, out_c_offset, c_out, h, w, 0, static_cast<float*>(nullptr), 0, 0);
+                     bias, out, out_c_stride, out_c_offset, c_out, h, w, 0, static_cast<float*>(nullptr), 0, 0, 0, 0, 1.f,
+                     static_cast<unsigned long long*>(nullptr));
   return rp::check_launch(fn);
 }
 
 int rnnpose_flow_features_f32(const float* coords1, int subtract_grid, const float* w_t, const float* bias, int B, int h, int w,
                               int c_out, float* out, int out_c_stride, int out_c_offset, float* motion, int motion_c_stride,
-                              int motion_c_offset, rnnpose_stream_t stream) {
+                              int motion_c_offset, int out_split, int motion_split, float a_scale, rnnpose_stream_t stream) {
   const char* fn = "rnnpose_flow_features_f32";
+  if (out_split) RP_REQUIRE(c_out % 2 == 0 && out_c_offset % 8 == 0 && out_c_stride % 8 == 0 && reinterpret_cast<uintptr_t>(out) % 32 == 0 && a_scale > 0.f, fn,
+                            "split-form out: even c_out, channel offset/stride multiples of 8, 32-byte aligned");
+  if (motion_split) RP_REQUIRE(motion_c_stride % 8 == 0 && reinterpret_cast<uintptr_t>(motion) % 32 == 0 && a_scale > 0.f, fn,
+                               "split-form motion: channel stride multiple of 8, 32-byte aligned");
   RP_REQUIRE(coords1 && w_t && bias && out && motion, fn, "null pointer");
   RP_REQUIRE(B > 0 && B < 65536 && h > 0 && h < 65536 && w > 0 && c_out > 0 && c_out <= 128, fn, "bad size (c_out <= 128)");
   RP_REQUIRE(out_c_offset >= 0 && out_c_offset + c_out <= out_c_stride && motion_c_offset % 2 == 0 && motion_c_stride % 2 == 0 &&
                  motion_c_offset + 2 <= motion_c_stride, fn, "bad output windows");
   hipLaunchKernelGGL(conv7x7_cin2_kernel<true>, dim3(rp::cdiv(w, F1_TX), h, B), dim3(128), 0, rp::as_stream(stream), coords1, w_t,
-                     bias, out, out_c_stride, out_c_offset, c_out, h, w, subtract_grid, motion, motion_c_stride, motion_c_offset);
+                     bias, out, out_c_stride, out_c_offset, c_out, h, w, subtract_grid, motion, motion_c_stride, motion_c_offset,
+                     out_split, motion_split, a_scale, rp::sat_counter());
+  return rp::check_launch(fn);
+}
+
+int rnnpose_split_hl_f32(const float* src, int src_c_stride, int src_c_offset, long long n_pixels, int c_count, float a_scale,
+                         float* dst, int dst_c_stride, int dst_c_offset, rnnpose_stream_t stream) {
+  const char* fn = "rnnpose_split_hl_f32";
+  RP_REQUIRE(src && dst && n_pixels > 0 && c_count > 0 && a_scale > 0.f, fn, "bad argument");
+  RP_REQUIRE(c_count % 8 == 0 && src_c_offset % 4 == 0 && src_c_stride % 4 == 0 && dst_c_offset % 8 == 0 && dst_c_stride % 8 == 0 &&
+                 src_c_offset + c_count <= src_c_stride && dst_c_offset + c_count <= dst_c_stride &&
+                 reinterpret_cast<uintptr_t>(src) % 16 == 0 && reinterpret_cast<uintptr_t>(dst) % 32 == 0, fn,
+             "whole 8-channel groups, aligned channel windows");
+  const long long total = n_pixels * (c_count / 8);
+  hipLaunchKernelGGL(split_hl_kernel, dim3(rp::cdiv(total, 256)), dim3(256), 0, rp::as_stream(stream), src, src_c_stride, src_c_offset,
+                     dst, dst_c_stride, dst_c_offset, c_count / 8, total, a_scale, rp::sat_counter());
   return rp::check_launch(fn);
 }
 

@@ -33,6 +33,15 @@ class UpdateEngine:
         self.parts = int(os.environ.get("RNNPOSE_PARTS", "2"))
         self.fused_mask = os.environ.get("RNNPOSE_FUSED_MASK", "1") != "0"       # mask.2 inside the up-sampling kernel
         self.resident_1x1 = os.environ.get("RNNPOSE_RESIDENT_1X1", "1") != "0"    # convc1 through csrc/conv1x1_resident.hip
+        # SPLIT TENSORS (include/rnnpose_hip.h): every activation that only feeds further convolutions is written once, by its
+        # producer's epilogue, as fp16 hi|lo pairs and staged by the consumers with a plain 16-byte copy (no per-tile re-split).
+        # RNNPOSE_SPLIT_TENSORS=0 restores fp32 activations + on-the-fly splitting (same-box A/B).
+        self.hl = os.environ.get("RNNPOSE_SPLIT_TENSORS", "1") != "0"
+        # tile-shape override per layer for measurements: RNNPOSE_CONV_TILE="zr=3,q=1,heads=2" (0 auto, see conv2d_nhwc)
+        self.tile = {}
+        for kv in filter(None, os.environ.get("RNNPOSE_CONV_TILE", "").split(",")):
+            k, v = kv.split("=")
+            self.tile[k] = int(v)
 
     # ---- weights ---------------------------------------------------------------------------------------------
     def _params(self):
@@ -73,8 +82,8 @@ class UpdateEngine:
             # iterations, so its share of every GRU convolution is computed ONCE per outer iteration (load_state) into
             # per-pixel bias maps: conv([h|inp|m]) = conv([h|m]) + conv(inp) -- one third of the GRU's multiply-adds leave
             # the loop.  hm(): the weights on [h | motion]; inp1 / inp2: z|r|q weights on `inp` for the 1x5 / 5x1 halves.
-            zr1=P(hm(cat(g.convz1.weight, g.convr1.weight)), cat(g.convz1.bias, g.convr1.bias), [128, 128]),
-            q1=P(hm(g.convq1.weight), g.convq1.bias, [128, 128]),
+            zr=P(hm(cat(g.convz1.weight, g.convr1.weight)), cat(g.convz1.bias, g.convr1.bias), [128, 128]),
+            q=P(hm(g.convq1.weight), g.convq1.bias, [128, 128]),
             zr2=P(hm(cat(g.convz2.weight, g.convr2.weight)), cat(g.convz2.bias, g.convr2.bias), [128, 128]),
             q2=P(hm(g.convq2.weight), g.convq2.bias, [128, 128]),
             inp1=P(cat(g.convz1.weight, g.convr1.weight, g.convq1.weight)[:, 128:256].contiguous(), zero(384), [128]),
@@ -103,6 +112,8 @@ class UpdateEngine:
                 st = dict(corr=z(324), cor1=z(256), corflo=z(256), flow4=z(4), flo1=z(128), motion=z(128), hA=z(128),
                           hB=z(128), inp=z(128), inp1=z(384), inp2=z(384), z=z(128), rh=z(128), heads=z(512), delta=z(2), flow_lr=z(2),
                           mask=z(576), coords1=torch.zeros(B, 2, h, w, device=device))
+                if self.hl:       # split-form copies of the tensors that are needed in fp32 as well (GRU epilogues read h)
+                    st.update(hA_s=z(128), hB_s=z(128), inp_s=z(128))
                 if len(self._sets) >= self.MAX_SETS:
                     self._sets.pop(next(iter(self._sets)))
                     self.epoch += 1
@@ -138,14 +149,26 @@ class UpdateEngine:
         ops.nchw_to_nhwc(inp, b["inp"])
         self._hoist_inp(self._weights(), b)
 
-    @staticmethod
-    def _hoist_inp(W, b):
-        """The `inp` share of the six GRU convolutions (z|r|q x two halves), once per hidden-state load."""
-        ops.conv2d_nhwc(W["inp1"], [(b["inp"], 0)], (b["inp1"], 0), ops.EPI_LINEAR)
-        ops.conv2d_nhwc(W["inp2"], [(b["inp"], 0)], (b["inp2"], 0), ops.EPI_LINEAR)
+    def _hoist_inp(self, W, b):
+        """The `inp` share of the six GRU convolutions (z|r|q x two halves), once per hidden-state load (+ the split forms of
+        the freshly loaded hidden state and context input)."""
+        src = b["inp"]
+        if self.hl:
+            ops.split_hl(b["hA"], b["hA_s"])
+            src = ops.split_hl(b["inp"], b["inp_s"])
+        ops.conv2d_nhwc(W["inp1"], [(src, 0)], (b["inp1"], 0), ops.EPI_LINEAR, src_hl=self.hl, tile=self.tile.get("inp", 0))
+        ops.conv2d_nhwc(W["inp2"], [(src, 0)], (b["inp2"], 0), ops.EPI_LINEAR, src_hl=self.hl, tile=self.tile.get("inp", 0))
 
     def hidden_nchw(self):
         return ops.nhwc_to_nchw(self._b["hA"])
+
+    def state_snapshot(self):
+        """Copies of the recurrent state (graph capture warms up by running the loop, then restores it)."""
+        return {k: self._b[k].clone() for k in ("hA", "hA_s") if k in self._b}
+
+    def state_restore(self, snap):
+        for k, v in snap.items():
+            self._b[k].copy_(v)
 
     def forward_nchw(self, net, inp, corr, flow):
         """The reference boundary `BasicUpdateBlock.forward(net, inp, corr, flow) -> (net, mask, delta_flow)`
@@ -245,16 +268,23 @@ class UpdateEngine:
         want_mask: write the (B,h,w,576) mask tensor (the facade returns it); the loop's up-sampling kernel computes mask.2
         itself (ops.mask_upsample) and the chain then ends after the flow head."""
         mask_here = want_mask or not self.fused_mask
-        c = ops.conv2d_nhwc
+        hl = self.hl
+        tl = self.tile.get
         R = ops.EPI_RELU
+
+        def c(name, srcs, dst, epi, hl_out=False, **kw):
+            """One implicit-GEMM launch; with split tensors every source is in split form and hl_out says the result only
+            feeds further convolutions (written split)."""
+            ops.conv2d_nhwc(W[name], srcs, dst, epi, src_hl=hl, dst_hl=hl and hl_out, tile=tl(name, 0), **kw)
         # Two independent chains feed the motion encoder's last convolution (update.py:89-92): correlation features
         # (convc1 -> convc2) and flow features (flow_prep -> convf1 -> convf2).  With a helper stream the second one runs
         # there (a parallel branch when the step is captured into a hipGraph).  Same for flow_head.conv2 next to mask.2.
         def flow_chain():
             # flow = coords1 - grid -> motion[126:128] (:97) and relu(convf1(flow)) (:91; direct fp32 kernel, K = 98): one launch
-            ops.flow_features(coords1, W["convf1_wt"], W["convf1_b"], b["flo1"], b["motion"], 126, subtract_grid=not flow_is_delta)
+            ops.flow_features(coords1, W["convf1_wt"], W["convf1_b"], b["flo1"], b["motion"], 126, subtract_grid=not flow_is_delta,
+                              out_split=hl, motion_split=hl, a_scale=ops.A_SCALE)
             yield
-            c(W["convf2"], [(b["flo1"], 0)], (b["corflo"], 192), R)                 # :92
+            c("convf2", [(b["flo1"], 0)], (b["corflo"], 192), R, hl_out=True)       # :92
             yield
 
         join = None
@@ -270,26 +300,30 @@ class UpdateEngine:
                 join = torch.cuda.Event()
                 join.record(side)
         if self.resident_1x1 and W["convc1r"] is not None:
-            ops.conv1x1_resident(W["convc1r"], (b["corr"], 0), (b["cor1"], 0), relu=True)   # update.py:89 (LDS-resident tile)
-        else:
-            c(W["convc1"], [(b["corr"], 0)], (b["cor1"], 0), R)                     # update.py:89
+            ops.conv1x1_resident(W["convc1r"], (b["corr"], 0), (b["cor1"], 0), relu=True, dst_split=hl)   # update.py:89 (LDS-resident tile)
+        else:                                                                       # (the looked-up correlation features are fp32)
+            ops.conv2d_nhwc(W["convc1"], [(b["corr"], 0)], (b["cor1"], 0), R, dst_hl=hl)                  # update.py:89
         yield
-        c(W["convc2"], [(b["cor1"], 0)], (b["corflo"], 0), R)                       # :90
+        c("convc2", [(b["cor1"], 0)], (b["corflo"], 0), R, hl_out=True)             # :90
         yield
         if join is not None:
             main.wait_event(join)
-        c(W["conv"], [(b["corflo"], 0)], (b["motion"], 0), R)                       # :95-96 (126 ch; flow already at 126)
+        c("conv", [(b["corflo"], 0)], (b["motion"], 0), R, hl_out=True)             # :95-96 (126 ch; flow already at 126)
         yield
-        hx = lambda hbuf: [(hbuf, 0), (b["motion"], 0)]          # [h | motion]; the `inp` share comes from the hoisted maps
-        c(W["zr1"], hx(b["hA"]), (b["z"], 0), ops.EPI_GRU_ZR, aux0=(b["hA"], 0), dst2=(b["rh"], 0), gru_c=128, add_map=(b["inp1"], 0))
+        # [h | motion]; the `inp` share comes from the hoisted maps.  Split tensors: the convolutions read h from its split copy
+        # (hA_s / hB_s), the gate epilogues read the fp32 one; r*h and the motion features exist in split form only.
+        hs = (lambda k: b[k + "_s"]) if hl else (lambda k: b[k])
+        hx = lambda hbuf: [(hbuf, 0), (b["motion"], 0)]
+        sp = (lambda k: dict(dst_split=(b[k + "_s"], 0))) if hl else (lambda k: {})
+        c("zr", hx(hs("hA")), (b["z"], 0), ops.EPI_GRU_ZR, aux0=(b["hA"], 0), dst2=(b["rh"], 0), dst2_hl=hl, gru_c=128, add_map=(b["inp1"], 0))
         yield
-        c(W["q1"], hx(b["rh"]), (b["hB"], 0), ops.EPI_GRU_Q, aux0=(b["hA"], 0), aux1=(b["z"], 0), add_map=(b["inp1"], 256))
+        c("q", hx(b["rh"]), (b["hB"], 0), ops.EPI_GRU_Q, aux0=(b["hA"], 0), aux1=(b["z"], 0), add_map=(b["inp1"], 256), **sp("hB"))
         yield
-        c(W["zr2"], hx(b["hB"]), (b["z"], 0), ops.EPI_GRU_ZR, aux0=(b["hB"], 0), dst2=(b["rh"], 0), gru_c=128, add_map=(b["inp2"], 0))
+        c("zr2", hx(hs("hB")), (b["z"], 0), ops.EPI_GRU_ZR, aux0=(b["hB"], 0), dst2=(b["rh"], 0), dst2_hl=hl, gru_c=128, add_map=(b["inp2"], 0))
         yield
-        c(W["q2"], hx(b["rh"]), (b["hA"], 0), ops.EPI_GRU_Q, aux0=(b["hB"], 0), aux1=(b["z"], 0), add_map=(b["inp2"], 256))
+        c("q2", hx(b["rh"]), (b["hA"], 0), ops.EPI_GRU_Q, aux0=(b["hB"], 0), aux1=(b["z"], 0), add_map=(b["inp2"], 256), **sp("hA"))
         yield
-        c(W["heads"], [(b["hA"], 0)], (b["heads"], 0), R)                           # flow_head.conv1 | mask.0
+        c("heads", [(hs("hA"), 0)], (b["heads"], 0), R)                             # flow_head.conv1 | mask.0
         yield
         head = lambda: ops.flow_head_out(b["heads"], 0, 256, W["flow2_w"], W["flow2_b"], coords1, b["delta"], b["coords1"],
                                          b["flow_lr"])
@@ -297,7 +331,7 @@ class UpdateEngine:
             head()
             yield
             if mask_here:
-                c(W["mask2"], [(b["heads"], 256)], (b["mask"], 0), ops.EPI_LINEAR)  # 0.25 * mask.2(relu(mask.0(h)))
+                ops.conv2d_nhwc(W["mask2"], [(b["heads"], 256)], (b["mask"], 0), ops.EPI_LINEAR)  # 0.25 * mask.2(relu(mask.0(h)))
                 yield
             return
         fork2 = torch.cuda.Event()
@@ -308,7 +342,7 @@ class UpdateEngine:
             join2 = torch.cuda.Event()
             join2.record(side)
         if mask_here:
-            c(W["mask2"], [(b["heads"], 256)], (b["mask"], 0), ops.EPI_LINEAR)      # 0.25 * mask.2(relu(mask.0(h)))
+            ops.conv2d_nhwc(W["mask2"], [(b["heads"], 256)], (b["mask"], 0), ops.EPI_LINEAR)      # 0.25 * mask.2(relu(mask.0(h)))
         main.wait_event(join2)
         yield
 

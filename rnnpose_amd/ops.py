@@ -416,9 +416,13 @@ def _nhwc(t, name):
 
 
 def conv2d_nhwc(pc: PackedConv, srcs, dst, epilogue: int = EPI_LINEAR, aux0=None, aux1=None, dst2=None, gru_c: int = 0,
-                stride: int = 1, tile_stats=None, add_map=None, in_norm=None):
+                stride: int = 1, tile_stats=None, add_map=None, in_norm=None, src_hl: bool = False, dst_hl: bool = False,
+                dst2_hl: bool = False, dst_split=None, tile: int = 0):
     """srcs: list of (tensor (B,H,W,C), c_offset) matched with pc.seg_counts; dst/aux0/aux1/dst2: (tensor, c_offset).
-    Writes in place into dst (and dst2); returns nothing."""
+    Writes in place into dst (and dst2); returns nothing.
+    src_hl / dst_hl / dst2_hl: the sources / dst / dst2 are SPLIT tensors (fp16 hi|lo per 8-channel group in a buffer of the
+    fp32 tensor's shape: include/rnnpose_hip.h; split_hl / unsplit_hl convert); dst_split = (tensor, c_offset): an additional
+    split-form copy of the primary result; tile: 0 auto, 1..3 tile-shape override (measurement)."""
     d = _lib.ConvDesc()
     if len(srcs) != len(pc.seg_counts):
         raise ValueError("number of sources differs from the packed segment list")
@@ -462,6 +466,11 @@ def conv2d_nhwc(pc: PackedConv, srcs, dst, epilogue: int = EPI_LINEAR, aux0=None
         if not (in_norm.is_cuda and in_norm.dtype == F32 and in_norm.is_contiguous() and tuple(in_norm.shape) == (B, srcs[0][0].shape[3], 2)):
             raise ValueError("in_norm must be a contiguous fp32 CUDA tensor of (B, C_source, 2)")
         d.src0_mean_rstd = in_norm.data_ptr()
+    d.src_hl, d.dst_hl, d.dst2_hl, d.tile = int(bool(src_hl)), int(bool(dst_hl)), int(bool(dst2_hl)), int(tile)
+    if dst_split is not None:
+        t, off = dst_split
+        _nhwc(t, "dst_split")
+        d.dst_split, d.dst_split_c_stride, d.dst_split_c_offset = t.data_ptr(), t.shape[3], off
     _launch("rnnpose_conv2d_nhwc_f16x3", C.byref(d), _stream(),
             work=2.0 * B * (-(-H // stride)) * (-(-W // stride)) * pc.c_out * pc.c_in_real * pc.kh * pc.kw)
 
@@ -479,8 +488,11 @@ def conv2d_nchw(weight, bias, x, relu: bool = False):
     if Cin_w != Cin:
         raise ValueError(f"weight expects {Cin_w} input channels, got {Cin}")
     cin_p, cout_p = -(-Cin // 4) * 4, -(-Cout // 4) * 4
+    # the entry keeps the parameter tensors alive: a freed module's storage could otherwise be handed to a new parameter of the
+    # same shape at the same address and version, and the facade would compute with the previous module's packed weights
     key = (weight.data_ptr(), weight._version, bias.data_ptr(), bias._version, tuple(weight.shape))
-    pc = _nchw_pc.get(key)
+    ent = _nchw_pc.get(key)
+    pc = ent[0] if (ent is not None and ent[1] is weight and ent[2] is bias) else None
     if pc is None:
         w = _chk(weight.detach(), "weight")
         if cin_p != Cin:
@@ -489,7 +501,7 @@ def conv2d_nchw(weight, bias, x, relu: bool = False):
         pc.c_in_real = Cin
         if len(_nchw_pc) >= 64:
             _nchw_pc.pop(next(iter(_nchw_pc)))
-        _nchw_pc[key] = pc
+        _nchw_pc[key] = (pc, weight, bias)
     xn = (torch.zeros if cin_p != Cin else torch.empty)(B, H, W, cin_p, device=x.device, dtype=F32)
     nchw_to_nhwc(x, xn)
     out = torch.empty(B, H, W, cout_p, device=x.device, dtype=F32)
@@ -556,14 +568,37 @@ def flow_conv7x7_relu(flow4, w_t, bias, out, out_c_offset=0):
     return out
 
 
-def flow_features(coords1, w_t, bias, out, motion, motion_c_offset, out_c_offset=0, subtract_grid: bool = True):
+def flow_features(coords1, w_t, bias, out, motion, motion_c_offset, out_c_offset=0, subtract_grid: bool = True,
+                  out_split: bool = False, motion_split: bool = False, a_scale: float = 8.0):
     """flow_prep + flow_conv7x7_relu in one launch: coords1 (B,2,h,w) -> relu(convf1(flow)) into `out` (NHWC), flow into
-    motion[..., co:co+2] (update.py:84,91,97)."""
+    motion[..., co:co+2] (update.py:84,91,97).  out_split / motion_split: the destinations are split tensors."""
     B, _, h, w = coords1.shape
     c_out = w_t.shape[1]
     _launch("rnnpose_flow_features_f32", _ptr(coords1), int(subtract_grid), _ptr(w_t), _ptr(bias), B, h, w, c_out, _ptr(out),
-            out.shape[-1], out_c_offset, _ptr(motion), motion.shape[3], motion_c_offset, _stream(), work=2.0 * 98 * c_out * B * h * w)
+            out.shape[-1], out_c_offset, _ptr(motion), motion.shape[3], motion_c_offset, int(bool(out_split)), int(bool(motion_split)),
+            float(a_scale), _stream(), work=2.0 * 98 * c_out * B * h * w)
     return out
+
+
+# ---- split tensors (fp16 hi|lo per 8-channel group; include/rnnpose_hip.h "SPLIT TENSORS") ------------------------------
+def split_hl(src, dst=None, src_c_offset: int = 0, c_count: int | None = None, dst_c_offset: int = 0, a_scale: float = 8.0):
+    """channels [src_c_offset, +c_count) of the fp32 NHWC tensor `src` -> split form in channels [dst_c_offset, +c_count) of
+    `dst` (allocated with c_count channels if None).  The split tensor is an opaque float32-typed buffer of the same shape."""
+    _nhwc(src, "src")
+    B, H, W, Cs = src.shape
+    c_count = Cs - src_c_offset if c_count is None else c_count
+    if dst is None:
+        dst = torch.empty(B, H, W, c_count, device=src.device, dtype=F32)
+    _lib.call("rnnpose_split_hl_f32", _ptr(src), Cs, int(src_c_offset), B * H * W, int(c_count), float(a_scale), _ptr(dst),
+              dst.shape[3], int(dst_c_offset), _stream())
+    return dst
+
+
+def unsplit_hl(t, a_scale: float = 8.0):
+    """Split tensor (..., C) -> the fp32 values (hi + lo) / a_scale it stands for (torch arithmetic: tests and the NCHW facade)."""
+    sh = t.shape
+    v = t.contiguous().view(torch.float16).view(*sh[:-1], sh[-1] // 8, 2, 8).float()
+    return ((v[..., 0, :] + v[..., 1, :]) / a_scale).reshape(sh)
 
 
 def flow_head_out(x, x_c_offset, c_in, weight, bias, coords1, delta, coords1_out, flow_lr):
@@ -599,8 +634,9 @@ class PackedConv1x1:
         _lib.call("rnnpose_conv1x1_resident_pack_f16x3", _ptr(w), 256, self.c_in, self.w_scale, _ptr(self.w_packed), _stream())
 
 
-def conv1x1_resident(pc: PackedConv1x1, src, dst, relu: bool = True):
-    """src, dst: (tensor (B,h,w,C), c_offset).  dst[..., off:off+256] = act(conv1x1(src[..., off:off+c_in]))."""
+def conv1x1_resident(pc: PackedConv1x1, src, dst, relu: bool = True, dst_split: bool = False):
+    """src, dst: (tensor (B,h,w,C), c_offset).  dst[..., off:off+256] = act(conv1x1(src[..., off:off+c_in])).
+    dst_split: dst is written as a split tensor (for a consuming convolution with src_hl)."""
     x, xo = src
     y, yo = dst
     _nhwc(x, "src"); _nhwc(y, "dst")
@@ -608,7 +644,7 @@ def conv1x1_resident(pc: PackedConv1x1, src, dst, relu: bool = True):
     if y.shape[:3] != x.shape[:3]:
         raise ValueError("src and dst must share (B,h,w)")
     _launch("rnnpose_conv1x1_resident_f16x3", _ptr(x), x.shape[3], int(xo), pc.c_in, _ptr(pc.w_packed), _ptr(pc.bias), pc.a_scale,
-            pc.w_scale, int(bool(relu)), n, _ptr(y), y.shape[3], int(yo), _stream(), work=2.0 * n * 256 * pc.c_in)
+            pc.w_scale, int(bool(relu)), n, _ptr(y), y.shape[3], int(yo), int(bool(dst_split)), _stream(), work=2.0 * n * 256 * pc.c_in)
 
 
 class PackedMaskHead:

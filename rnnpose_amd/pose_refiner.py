@@ -310,8 +310,7 @@ class PoseRefiner(nn.Module):
         ROCm 7.2: r02 timeline, 92 % of the time one kernel in flight).  The warm-up launches advance the GRU hidden
         state; it is restored whatever happens, so an eager retry starts from the right state."""
         eng = self.cf_net.engine()
-        hbuf = eng._b["hA"]
-        hA = hbuf.clone()
+        snap = eng.state_snapshot()
         B, dev = depth.shape[0], depth.device
         try:
             Gs = G.reshape(-1, 4, 4).clone()
@@ -321,7 +320,7 @@ class PoseRefiner(nn.Module):
             with torch.cuda.stream(side):                  # warm-up on a side stream: weight packing, allocator, caches
                 self._loop(depth, K, g1, g2, Gs, h, w, ep_l, lm_l, n)
             main.wait_stream(side)
-            hbuf.copy_(hA)
+            eng.state_restore(snap)
             bufs = self._loop_buffers(B, depth.shape[-2], depth.shape[-1], h, w, n, dev)
             hv = eng.halves(B)
             graphs = []
@@ -349,7 +348,7 @@ class PoseRefiner(nn.Module):
             self._graph = self._graph_static = None
             return None
         finally:
-            hbuf.copy_(hA)
+            eng.state_restore(snap)
 
     @torch.no_grad()
     def forward(self, image, Ts, intrinsics, fea_3d=None, Tj_gt=None, obj_cls=None, geofea_3d=None, geofea_2d=None):

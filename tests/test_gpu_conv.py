@@ -315,3 +315,131 @@ def test_conv1x1_resident_vs_fp64_and_igemm(ops, B, h, w, cin):
     ref = torch.empty(B, h, w, 256, device="cuda")
     ops.conv2d_nhwc(ops.PackedConv(D(wt), D(bs), [cin]), [(xN, 0)], (ref, 0), ops.EPI_RELU)
     assert float((out[..., 4:] - ref).abs().max()) < 2e-5
+
+
+# ---- split tensors (round 3): activations pre-split into fp16 hi|lo by their producer ----------------------------------------
+def test_split_hl_roundtrip_and_layout(ops):
+    """rnnpose_split_hl_f32: layout ([hi x 8 | lo x 8] per 8-channel group) and value (hi + lo = x * a_scale to 2^-21)."""
+    x = torch.randn(2, 5, 7, 48, device="cuda") * 3
+    x[0, 0, 0, :8] = torch.tensor([0.0, 1.0, -1.0, 1e-3, 123.456, -8000.0, 2.0 ** -20, 0.5], device="cuda")
+    wide = torch.full((2, 5, 7, 64), 9.0, device="cuda")
+    ops.split_hl(x, wide, src_c_offset=8, c_count=32, dst_c_offset=16)
+    assert float((wide[..., :16] - 9).abs().max()) == 0 and float((wide[..., 48:] - 9).abs().max()) == 0
+    back = ops.unsplit_hl(wide[..., 16:48].contiguous())
+    ref = x[..., 8:40]
+    assert float(((back - ref).abs() / ref.abs().clamp(min=1e-2)).max()) < 2.0 ** -20
+    s = ops.split_hl(x)
+    v = s.view(torch.float16).view(2, 5, 7, 6, 2, 8)
+    hi = v[..., 0, :].float().reshape(2, 5, 7, 48)
+    t = (x * 8.0).view(torch.int32).bitwise_and(-8192).view(torch.float32)      # mantissa truncated to 11 significant bits
+    assert torch.equal(hi, t)
+    assert torch.equal(v[..., 1, :].float().reshape(2, 5, 7, 48), (x * 8.0 - t).half().float())
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+@pytest.mark.parametrize("B,H,W,segs,cout,kh,kw", [
+    (2, 12, 20, [192, 64], 126, 3, 3),     # ragged output tail (2 valid columns of the last quad)
+    (1, 16, 16, [128, 128], 256, 1, 5),
+    (3, 7, 11, [128, 128], 128, 5, 1),
+    (1, 20, 24, [128], 512, 3, 3),
+    (2, 9, 13, [256], 192, 3, 3),
+    (1, 8, 8, [128], 64, 1, 1),
+])
+def test_conv_split_sources_and_outputs(ops, tile, B, H, W, segs, cout, kh, kw):
+    """Split-tensor sources (src_hl) through every tile shape, fp32 and split-form outputs: same accuracy class as the
+    on-the-fly split (the fp16 operands are bit-identical), and split-form outputs decode to the fp32 ones to 2^-21."""
+    cin = sum(segs)
+    x = syn.normal("x", (B, cin, H, W), 11, std=1.5)
+    w = syn.normal("w", (cout, cin, kh, kw), 11, std=float(np.sqrt(2.0 / (cin * kh * kw))))
+    b = syn.uniform("b", (cout,), 11, -0.5, 0.5)
+    xd, wd, bd = D(x), D(w), D(b)
+    y64 = F.conv2d(xd.double(), wd.double(), bd.double(), padding=(kh // 2, kw // 2))
+    y32 = F.conv2d(xd, wd, bd, padding=(kh // 2, kw // 2))
+    pc = ops.PackedConv(wd, bd, segs)
+    xs, xf, off = [], [], 0
+    for c in segs:                       # sources inside wider split tensors at a channel offset of 8
+        t = torch.zeros(B, H, W, c + 16, device="cuda")
+        t[..., 8:8 + c] = nhwc(xd[:, off:off + c])
+        xf.append((t, 8))
+        xs.append((ops.split_hl(t), 8))
+        off += c
+    cs = (cout + 23) // 8 * 8
+    out = torch.full((B, H, W, cs), 7.0, device="cuda")
+    ops.conv2d_nhwc(pc, xs, (out, 8), ops.EPI_RELU, src_hl=True, tile=tile)
+    check(nchw(out[..., 8:8 + cout]), y64.clamp(min=0), y32.clamp(min=0), f"{kh}x{kw} split sources, tile {tile}")
+    assert float((out[..., :8] - 7).abs().max()) == 0 and float((out[..., 8 + cout:] - 7).abs().max()) == 0
+    ref = torch.full((B, H, W, cs), 7.0, device="cuda")
+    ops.conv2d_nhwc(pc, xf, (ref, 8), ops.EPI_RELU)                 # on-the-fly split of the same values
+    assert float((out - ref).abs().max()) <= 2e-6 * float(y64.abs().max())
+    # split-form destination (+ the extra split copy next to an fp32 destination)
+    outs = torch.zeros(B, H, W, cs, device="cuda")
+    extra = torch.zeros(B, H, W, cs, device="cuda")
+    ops.conv2d_nhwc(pc, xs, (outs, 8), ops.EPI_RELU, src_hl=True, dst_hl=True, tile=tile)
+    ops.conv2d_nhwc(pc, xs, (out, 8), ops.EPI_RELU, src_hl=True, dst_split=(extra, 8), tile=tile)
+    n8 = cout // 8 * 8                                              # whole groups decode; the ragged group is checked per channel
+    for sp in (outs, extra):
+        dec = ops.unsplit_hl(sp)
+        full = out[..., 8:8 + cout]
+        got = dec[..., 8:8 + cout]
+        assert float(((got - full).abs() / full.abs().clamp(min=1e-2)).max()) < 2.0 ** -20
+        if cout % 8:                                                # channels past cout in the last group were left untouched (zeros)
+            assert float(dec[..., 8 + cout:8 + n8 + 8].abs().max()) == 0
+
+
+@pytest.mark.parametrize("kh,kw", [(1, 5), (5, 1)])
+@pytest.mark.parametrize("tile", [0, 3])
+def test_conv_gru_epilogues_split(ops, kh, kw, tile):
+    """The GRU gate / state-update epilogues on split tensors: h from its split copy, r*h written split, h' fp32 + split."""
+    B, H, W, C = 2, 10, 14, 128
+    h = np.tanh(syn.normal("h", (B, C, H, W), 2))
+    x = syn.normal("x", (B, C, H, W), 2)
+    wz, wr, wq = (syn.normal(n, (C, 2 * C, kh, kw), 2, std=0.03) for n in ("wz", "wr", "wq"))
+    bz, br, bq = (syn.uniform(n, (C,), 2, -0.2, 0.2) for n in ("bz", "br", "bq"))
+    hd, xd = D(h), D(x)
+    pad = (kh // 2, kw // 2)
+    hx = torch.cat([hd, xd], 1).double()
+    z64 = torch.sigmoid(F.conv2d(hx, D(wz).double(), D(bz).double(), padding=pad))
+    r64 = torch.sigmoid(F.conv2d(hx, D(wr).double(), D(br).double(), padding=pad))
+    q64 = torch.tanh(F.conv2d(torch.cat([r64 * hd.double(), xd.double()], 1), D(wq).double(), D(bq).double(), padding=pad))
+    h64 = (1 - z64) * hd.double() + z64 * q64
+    pzr = ops.PackedConv(torch.cat([D(wz), D(wr)], 0), torch.cat([D(bz), D(br)], 0), [C, C])
+    pq = ops.PackedConv(D(wq), D(bq), [C, C])
+    hN, xN = nhwc(hd), nhwc(xd)
+    hS, xS = ops.split_hl(hN), ops.split_hl(xN)
+    z = torch.empty(B, H, W, C, device="cuda")
+    rh = torch.empty(B, H, W, C, device="cuda")
+    hnew = torch.empty(B, H, W, C, device="cuda")
+    hnew_s = torch.empty(B, H, W, C, device="cuda")
+    ops.conv2d_nhwc(pzr, [(hS, 0), (xS, 0)], (z, 0), ops.EPI_GRU_ZR, aux0=(hN, 0), dst2=(rh, 0), dst2_hl=True, gru_c=C, src_hl=True,
+                    tile=tile)
+    assert float((nchw(z).double() - z64).abs().max()) < 2e-6
+    assert float((nchw(ops.unsplit_hl(rh)).double() - r64 * hd.double()).abs().max()) < 2e-6
+    ops.conv2d_nhwc(pq, [(rh, 0), (xS, 0)], (hnew, 0), ops.EPI_GRU_Q, aux0=(hN, 0), aux1=(z, 0), src_hl=True, dst_split=(hnew_s, 0),
+                    tile=tile)
+    assert float((nchw(hnew).double() - h64).abs().max()) < 3e-6
+    assert float((ops.unsplit_hl(hnew_s) - hnew).abs().max()) < 2.0 ** -20
+
+
+def test_split_producers(ops):
+    """The two non-GEMM producers of split tensors: the LDS-resident 1x1 convolution and the 7x7 flow-feature kernel."""
+    B, h, w = 2, 11, 23
+    x = torch.randn(B, h, w, 324, device="cuda")
+    wt = torch.randn(256, 324, 1, 1, device="cuda") * 0.08
+    bs = torch.randn(256, device="cuda") * 0.1
+    pr = ops.PackedConv1x1(wt, bs)
+    a = torch.empty(B, h, w, 256, device="cuda")
+    s = torch.empty(B, h, w, 256, device="cuda")
+    ops.conv1x1_resident(pr, (x, 0), (a, 0), relu=True)
+    ops.conv1x1_resident(pr, (x, 0), (s, 0), relu=True, dst_split=True)
+    assert float(((ops.unsplit_hl(s) - a).abs() / a.abs().clamp(min=1e-2)).max()) < 2.0 ** -20
+    coords = torch.randn(B, 2, h, w, device="cuda") * 3 + 10
+    w_t = torch.randn(98, 128, device="cuda") * 0.1
+    fb = torch.randn(128, device="cuda") * 0.1
+    f32o, m32 = torch.zeros(B, h, w, 128, device="cuda"), torch.zeros(B, h, w, 128, device="cuda")
+    fso, mso = torch.zeros(B, h, w, 128, device="cuda"), torch.zeros(B, h, w, 128, device="cuda")
+    ops.flow_features(coords, w_t, fb, f32o, m32, 126)
+    ops.flow_features(coords, w_t, fb, fso, mso, 126, out_split=True, motion_split=True)
+    assert float(((ops.unsplit_hl(fso) - f32o).abs() / f32o.abs().clamp(min=1e-2)).max()) < 2.0 ** -20
+    dm = ops.unsplit_hl(mso)
+    assert float(((dm[..., 126:] - m32[..., 126:]).abs() / m32[..., 126:].abs().clamp(min=1e-2)).max()) < 2.0 ** -20
+    assert float(dm[..., :126].abs().max()) == 0          # the other 6 channels of the group belong to the 126-channel convolution

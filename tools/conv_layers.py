@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """The update-block convolutions as the engine launches them (hoisted GRU input, half batch B=4 and full batch B=8 at
-60x80), each alone: time, executed fp16 TFLOP/s, fraction of the 2.5 PF peak.  Also the target of the SQ counter passes
-(tools/pmc_sq.sh): `python tools/conv_layers.py 3` launches every layer 3 times and prints nothing else."""
+60x80), each alone: time, executed fp16 TFLOP/s, fraction of the 2.5 PF peak -- for fp32 sources (on-the-fly split) and for
+split-tensor sources in every tile shape (1 = 128x64, 2 = 128x128 as 4 column waves, 3 = 128x128 as 2x2 waves).
+Also the target of the SQ counter passes (tools/pmc_sq.sh): `python tools/conv_layers.py 3 [mode]` launches every layer 3
+times in one mode (f32 | hl0 | hl1 | hl2 | hl3) and prints nothing else."""
 import os
 import sys
 import time
@@ -12,34 +14,43 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rnnpose_amd import ops  # noqa: E402
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+only = sys.argv[2] if len(sys.argv) > 2 else None
 h, w = 60, 80
-shapes = [("convc1 1x1 324->256", [324], 256, 1, 1), ("convc2 3x3 256->192", [256], 192, 3, 3),
+shapes = [("convc2 3x3 256->192", [256], 192, 3, 3),
           ("convf2 3x3 128->64", [128], 64, 3, 3), ("conv 3x3 256->126", [192, 64], 126, 3, 3),
           ("gru zr 1x5 256->256", [128, 128], 256, 1, 5), ("gru q 1x5 256->128", [128, 128], 128, 1, 5),
           ("gru zr 5x1 256->256", [128, 128], 256, 5, 1), ("gru q 5x1 256->128", [128, 128], 128, 5, 1),
-          ("heads 3x3 128->512", [128], 512, 3, 3), ("mask2 1x1 256->576", [256], 576, 1, 1),
+          ("heads 3x3 128->512", [128], 512, 3, 3), ("inp 1x5 128->384", [128], 384, 1, 5),
           ("enc l1 3x3 64->64 @240x320", [64], 64, 3, 3)]
-for B in (4, 8):
+modes = [("f32", False, 0), ("hl0", True, 0), ("hl1", True, 1), ("hl2", True, 2), ("hl3", True, 3)]
+for B in (4, 8, 1):
     for name, segs, co, kh, kw in shapes:
-        hh, ww = (240, 320) if "@240" in name else (h, w)
+        hh, ww = (240, 320) if "@240" in name else ((30, 30) if B == 1 else (h, w))
         ci = sum(segs)
         wt = torch.randn(co, ci, kh, kw, device="cuda") * (2.0 / (ci * kh * kw)) ** 0.5
         pc = ops.PackedConv(wt, torch.randn(co, device="cuda"), segs)
-        xs = [(torch.randn(B, hh, ww, c, device="cuda"), 0) for c in segs]
-        out = torch.empty(B, hh, ww, (co + 3) // 4 * 4, device="cuda")
-        run = lambda: ops.conv2d_nhwc(pc, xs, (out, 0), ops.EPI_RELU)
-        if reps:
-            for _ in range(reps):
+        xf = [(torch.randn(B, hh, ww, c, device="cuda"), 0) for c in segs]
+        xs = [(ops.split_hl(t), 0) for t, _ in xf]
+        out = torch.empty(B, hh, ww, (co + 7) // 8 * 8, device="cuda")
+        line = f"B={B} {name:28s}"
+        for mname, hl, tile in modes:
+            if only and mname != only:
+                continue
+            run = lambda: ops.conv2d_nhwc(pc, xs if hl else xf, (out, 0), ops.EPI_RELU, src_hl=hl, dst_hl=hl, tile=tile)
+            if reps:
+                for _ in range(reps):
+                    run()
+                continue
+            for _ in range(3):
                 run()
-            continue
-        for _ in range(3):
-            run()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(30):
-            run()
-        torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / 30 * 1e3
-        fl = 3 * 2.0 * B * hh * ww * co * ci * kh * kw
-        print(f"B={B} {name:28s} {ms*1e3:7.1f} us  {fl/ms/1e9:7.1f} TF executed  {fl/ms/1e9/2500*100:5.1f} % of peak", flush=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(30):
+                run()
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / 30 * 1e3
+            fl = 3 * 2.0 * B * hh * ww * co * ci * kh * kw
+            line += f" | {mname} {ms*1e3:6.1f} us {fl/ms/1e9/2500*100:4.1f}%"
+        if not reps:
+            print(line, flush=True)
 torch.cuda.synchronize()
