@@ -22,7 +22,9 @@ Rank 0 prints ONE JSON line (see the task contract) carrying
   kernels                    every C-ABI launch type: mean duration, share of the step, achieved GB/s from the bytes each
                              launch declared for its own arguments (a half-batch launch declares half the batch);
   cpu_baseline               the CPU oracle on this box's host cores: the full batch, 1 outer x `inner` iterations (the 3x8
-                             schedule repeats that unit, so iterations/s are directly comparable), N=1 only.
+                             schedule repeats that unit, so iterations/s are directly comparable), median of 3 runs, N=1 only;
+  parity                     the GPU refiner's first outer iteration against that oracle run's outputs (identical inputs):
+                             pose within 1e-5 and first-iteration flow within 1e-4, or the line is declared invalid.
 """
 from __future__ import annotations
 
@@ -54,6 +56,7 @@ def parse():
     ap.add_argument("--inner", type=int, default=8)
     ap.add_argument("--optim-iters", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-runs", type=int, default=3, help="timed runs of the CPU baseline (median reported) after one warm-up run")
     ap.add_argument("--no-encoder", action="store_true", help="feed synthetic feature maps (kernel-only runs)")
     ap.add_argument("--unfused", action="store_true", help="literal reference call sequence through the facade")
     ap.add_argument("--no-graph", action="store_true", help="eager launches only (no hipGraph replay; for counter passes)")
@@ -105,7 +108,9 @@ def synth_views(B, H, W, device, seed, with_encoder):
 def cpu_baseline(refiner, rend, K, G0, args):
     """CPU oracle (oracle/rnnpose_oracle.py, kind 'port') on the SAME workload: the full batch, one outer iteration
     (encoder + volume build + context prep) followed by `inner` inner iterations -- the unit the 3x8 schedule repeats
-    three times, so its iterations/s are the schedule's.  One run after a one-image warm-up (thread pools, oneDNN)."""
+    three times, so its iterations/s are the schedule's.  SURVEY 8d: one full warm-up refinement, then the median of 3
+    timed runs.  The warm-up run also captures the oracle's outputs: -> (record, outputs) for the in-run parity check."""
+    import statistics
     import torch
     from oracle import rnnpose_oracle as orc
     v = rend.views
@@ -121,20 +126,62 @@ def cpu_baseline(refiner, rend, K, G0, args):
     else:
         inp["fmap1"], inp["fmap2"] = v["fmap1"], v["fmap2"]
     inp = {k: t.detach().cpu().numpy() for k, t in inp.items()}
-    one = {k: (a[:1] if (a.ndim and a.shape[0] == args.batch and k != "sigma") else a) for k, a in inp.items()}
-    orc.refine(one, W, outer=1, inner=1, optim_iters=args.optim_iters, fast=True)          # warm-up, one image
-    tm = {}
     t0 = time.perf_counter()
-    orc.refine(inp, W, outer=1, inner=args.inner, optim_iters=args.optim_iters, stage_timer=tm, fast=True)
-    wall = time.perf_counter() - t0
-    return {
+    warm = orc.refine(inp, W, outer=1, inner=args.inner, optim_iters=args.optim_iters, fast=True, capture=True)   # warm-up + parity capture
+    t_warm = time.perf_counter() - t0
+    outputs = {"G": warm["G"], "Tij": [tr["Tij"] for tr in warm["trace"]], "flow_first": warm["trace"][0]["flow_up"],
+               "flow_last": warm["flow_up"], "weight_last": warm["weight"]}
+    del warm
+    walls, tm = [], {}
+    for _ in range(max(1, args.cpu_runs)):
+        tm = {}
+        t0 = time.perf_counter()
+        orc.refine(inp, W, outer=1, inner=args.inner, optim_iters=args.optim_iters, stage_timer=tm, fast=True)
+        walls.append(time.perf_counter() - t0)
+    wall = statistics.median(walls)
+    rec = {
         "value": round(args.inner / wall, 4), "unit": "iters/s", "cores": cores, "kind": "port",
+        "runs": len(walls), "min": round(args.inner / max(walls), 4), "max": round(args.inner / min(walls), 4),
         "sample": (f"full batch ({args.batch} x {args.height}x{args.width}), 1 outer x {args.inner} inner iterations of the CPU "
                    f"oracle in its library-call form (grid_sample/unfold as the reference uses on CPU), encoder + volume build "
-                   f"included, {wall:.1f} s wall, single run after a one-image warm-up; torch {torch.__version__} CPU with "
+                   f"included; one full warm-up run ({t_warm:.1f} s, also the parity capture), then the MEDIAN of {len(walls)} timed runs "
+                   f"({', '.join(f'{x:.1f}' for x in walls)} s); torch {torch.__version__} CPU with "
                    f"{cores} threads on {ncpu} logical CPUs.  The 3x8 schedule repeats this unit 3 times: same iterations/s"),
         "stages_s": {k: round(x, 3) for k, x in tm.items()},
     }
+    return rec, outputs
+
+
+POSE_TOL, FLOW_TOL = 1e-5, 1e-4          # north_star: 1e-5 on the 6-DoF pose, 1e-4 on the correspondence field (identical inputs)
+
+
+def parity_block(refiner, rend, K, G0, args, want):
+    """In-run parity of the TIMED configuration: the GPU refiner's first outer iteration (encoder
+    included, `inner` inner iterations, the same weights and device-resident inputs the timed steps used) against the
+    outputs the CPU oracle produced for the cpu_baseline leg on identical inputs.  First-iteration flow and every pose are
+    held to the north-star tolerances; later flows see the pose fed back through the projection (d flow / d pose ~ fx / Z
+    ~ 600 px per unit: DESIGN.md section 2), so the last flow is reported with the free-running drift bound 5e-4."""
+    import torch
+    from rnnpose_amd.pose_refiner import PoseRefiner, default_config
+    from rnnpose_amd.transformation import SE3Sequence
+    cfg = default_config(RENDER_ITER_COUNT=1, ITER_COUNT=args.inner, OPTIM_ITER_COUNT=args.optim_iters)
+    one = PoseRefiner(cfg, renderer=rend, fused=not args.unfused, use_graph=not args.no_graph).to(K.device).eval()
+    one.load_state_dict(refiner.state_dict())
+    out = one(rend.views["image_crop"], SE3Sequence(matrix=G0.clone()), K)
+    torch.cuda.synchronize()
+    T = lambda a: torch.as_tensor(a).to(K.device)
+    dG = float((out["Ti_pred"].G.reshape(-1, 4, 4) - T(want["G"]).reshape(-1, 4, 4)).abs().max())
+    dT = max(float((t.G.reshape(-1, 4, 4) - T(w_).reshape(-1, 4, 4)).abs().max()) for t, w_ in zip(one.residual_pose_history, want["Tij"]))
+    d_first = float((out["flow"][0] - T(want["flow_first"])).abs().max())
+    d_last = float((out["flow_last"] - T(want["flow_last"])).abs().max())
+    d_w = float((out["weight"][:, 0, 0] - T(want["weight_last"])).abs().max())
+    ok = bool(max(dG, dT) <= POSE_TOL and d_first <= FLOW_TOL)
+    return {"max_abs_dpose": max(dG, dT), "max_abs_dpose_final": dG, "max_abs_dflow_first": d_first, "max_abs_dflow_last": d_last,
+            "max_abs_dweight_last": d_w, "tol": {"pose": POSE_TOL, "flow_first_iteration": FLOW_TOL, "flow_last_drift_bound": 5e-4},
+            "ok": ok, "drift_ok": bool(d_last <= 5e-4),
+            "what": (f"GPU refiner vs the CPU oracle on the identical device-generated inputs and weights of the timed run: batch "
+                     f"{args.batch} x {args.height}x{args.width}, encoder in the loop, 1 outer x {args.inner} inner iterations "
+                     f"(the unit the timed schedule repeats {args.outer} times); poses of all {args.inner} iterations and the final pose")}
 
 
 def main():
@@ -195,14 +242,21 @@ def main():
     iters = args.outer * args.inner
     value = world * args.steps * iters / dt
     ms_step = dt / args.steps * 1e3
-    traffic = {}
+    # HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE counter passes over this same command (tools/gpu_round.sh ->
+    # tools/summarize_profiles.py -> profiles/traffic.json).  The file records the digest of the kernel sources it was
+    # measured on: counters of OTHER kernels than the ones timed here are refused (traffic = null), not quoted.
+    traffic, traffic_note = {}, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
             traffic = json.load(open(tpath))
         except Exception:
             traffic = {}
-    tr = lambda k: (traffic.get(k) or {}).get("bytes_per_launch") if isinstance(traffic.get(k), dict) else traffic.get(k)
+        if traffic.get("csrc_digest") != build.source_digest():
+            traffic_note = ("profiles/traffic.json was measured on other kernel sources (digest "
+                            f"{str(traffic.get('csrc_digest'))[:12]} != {build.source_digest()[:12]}): refused")
+            traffic = {}
+    tr = lambda k: (traffic.get(k) or {}).get("bytes_per_launch") if isinstance(traffic.get(k), dict) else None
 
     MFMA3 = ("rnnpose_conv2d_nhwc_f16x3", "rnnpose_stem_conv7x7_s2_f16x3", "rnnpose_corr_pyramid_f16x3")   # 3 fp16 products per multiply-add
     kernels = {}
@@ -232,13 +286,17 @@ def main():
         roofline = {"kernel": "conv_igemm_f16x3_kernel (NHWC implicit-GEMM convolution, fp16x3-split MFMA = fp32-class accuracy; "
                               "all update-block and encoder convolutions but the stem)",
                     "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_F16_MFMA_TFLOPS, 4), "traffic": tr("conv_igemm"),
+                    "frac": round(ach / PEAK_F16_MFMA_TFLOPS, 4), "traffic": tr("conv_igemm"), "traffic_note": traffic_note,
                     "note": "achieved = EXECUTED fp16 MFMA flops (3 products per algorithmic multiply-add: SURVEY 8d's 2*MAC count "
                             "of every launch x 3) / summed HIP-event duration of those launches.  In the event-instrumented outer "
                             "iteration every launch goes to ONE stream, so each is timed alone on the chip (the same durations "
                             "rocprofv3's kernel trace reports: profiles/).  The production schedule runs two half-batch chains "
                             "concurrently on two streams: chip_level is the aggregate over the whole step",
-                    "fp32_equivalent_TFLOPps": round(work / (tot_ms * 1e-3) / 1e12, 1), "launches_timed": n,
+                    "frac_label": "mfma_pipe_util: EXECUTED fp16 flops / fp16 dense peak (3 MFMAs per algorithmic multiply-add)",
+                    "frac_algorithmic": round(work / (tot_ms * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4),
+                    "fp32_equivalent_TFLOPps": round(work / (tot_ms * 1e-3) / 1e12, 1),
+                    "fp32_equivalent_over_f32_mfma_peak": round(work / (tot_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 3),
+                    "launches_timed": n,
                     "mean_ms": round(mean_ms, 4), "share_of_step": round(tot_ms / prof_steps / ms_step, 4),
                     "algorithmic_flops_timed": work}
     elif dom is not None:
@@ -291,11 +349,17 @@ def main():
                         "of the two batch halves overlap on two streams, so the shares add up to more than 1",
     }
     if world == 1 and not args.no_cpu_baseline:
-        res["cpu_baseline"] = cpu_baseline(refiner, rend, K, G0, args)
+        res["cpu_baseline"], want = cpu_baseline(refiner, rend, K, G0, args)
         res["speedup_vs_cpu"] = round(value / res["cpu_baseline"]["value"], 1)
+        res["parity"] = parity_block(refiner, rend, K, G0, args, want)
     else:
         res["cpu_baseline"] = None
+        res["parity"] = None
+    res["f16x3_range_events"] = int(ops.saturation_count(reset=False))     # clamped activation quads over the whole run (sticky counter)
     print(json.dumps(res))
+    if res["parity"] is not None and not res["parity"]["ok"]:
+        raise SystemExit("bench.py: the timed configuration is OUTSIDE the parity tolerances against the CPU oracle "
+                         f"({res['parity']}) -- the line above is invalid")
 
 
 if __name__ == "__main__":

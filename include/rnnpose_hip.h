@@ -207,8 +207,8 @@ typedef struct {
    * fp16 matrix cores, written once by their producer's epilogue instead of being re-split by every consumer tile (a 3x3
    * layer with 256 outputs re-split each input 12 times).  A split tensor has the shape, strides and SIZE of its fp32
    * NHWC counterpart (4 bytes per element, channel counts / offsets in multiples of 8); every 8-channel group of a pixel
-   * occupies 32 bytes = [hi x 8 | lo x 8] fp16 with  x * a_scale = hi + lo  (hi = x * a_scale truncated to 11 significant
-   * bits, lo = fp16(x * a_scale - hi); |x * a_scale| > 65504 is clamped and counted by the range guard).  a_scale must be
+   * occupies 32 bytes = [hi x 8 | lo x 8] fp16 with  x * a_scale = hi + lo  (hi = fp16(x * a_scale) rounded to
+   * nearest, lo = fp16(x * a_scale - hi); |x * a_scale| > 65504 is clamped and counted by the range guard).  a_scale must be
    * the same for the producer and every consumer of a tensor (the package uses 8). */
   int src_hl;                  /* != 0: ALL sources are split tensors (stride 1, 1/3/5 taps per group, no src0_mean_rstd) */
   int dst_hl;                  /* != 0: dst receives the split form (no tile_stats) */
@@ -217,8 +217,8 @@ typedef struct {
                                   h' is needed as fp32 by the next gate epilogue AND split by the next convolution); not
                                   with epilogue 2 */
   int dst_split_c_stride, dst_split_c_offset;
-  int tile;                    /* 0 = automatic; 1 = 128x64, 2 = 128x128 as 4 column waves, 3 = 128x128 as 2x2 waves (split
-                                  sources only) -- measurement override */
+  int tile;                    /* 0 = automatic; 1 = 128x64, 2 = 128x128 as 4 column waves, 3 = 128x128 as 2x2 waves, 4 = 128x64 with
+                                  a block-deep register pipeline (3, 4: split sources only) */
 } rnnpose_conv_desc_t;
 
 /* number of fp16 elements of the packed weight array (hi and lo parts interleaved); -1 on bad arguments */
@@ -235,6 +235,9 @@ int rnnpose_conv2d_nhwc_f16x3(const rnnpose_conv_desc_t* h_desc, rnnpose_stream_
  * ~3 vector instructions per staged float4).  Process-global switch; not meant to be toggled concurrently with launches. */
 int rnnpose_f16x3_saturation_check(int enable);
 int rnnpose_f16x3_saturation_count(unsigned long long* h_count, int reset, rnnpose_stream_t stream);
+/* Device-side read of the same counter: copies it into *d_count (DEVICE memory) on `stream`, no host synchronisation --
+ * callers fold it into their outputs (PoseRefiner returns it as "f16x3_range_events") so that a clamp cannot pass unseen. */
+int rnnpose_f16x3_saturation_peek(unsigned long long* d_count, rnnpose_stream_t stream);
 
 /* ---- f1: RAFT encoder stem -- input normalisation + 7x7 stride-2 convolution 3 -> 64 in one kernel -------------
  *      model/CFNet.py:42-43 (image = 2*(image/255) - 1), thirdparty/raft/extractor.py:131,197 (conv1)

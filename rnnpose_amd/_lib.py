@@ -65,6 +65,7 @@ PROTOTYPES = {
     "rnnpose_conv2d_nhwc_f16x3": (_i, [C.POINTER(ConvDesc), _p]),
     "rnnpose_f16x3_saturation_check": (_i, [_i]),
     "rnnpose_f16x3_saturation_count": (_i, [C.POINTER(C.c_ulonglong), _i, _p]),
+    "rnnpose_f16x3_saturation_peek": (_i, [_p, _p]),
     "rnnpose_stem_packed_halfs": (C.c_longlong, []),
     "rnnpose_stem_pack_weights_f16x3": (_i, [_p, _f, _p, _p, _p]),
     "rnnpose_stem_tiles": (_i, [_i, _i, C.POINTER(_i), C.POINTER(_i)]),

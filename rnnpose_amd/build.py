@@ -32,12 +32,17 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+def source_digest() -> str:
+    """Digest of the kernel sources + flags (what profiles/traffic.json records, so that bench.py can tell stale counters)."""
+    return _digest()
+
+
 def _digest() -> str:
     h = hashlib.sha256()
     files = sources() + sorted(glob.glob(os.path.join(CSRC, "*.hpp"))) + sorted(glob.glob(os.path.join(CSRC, "*.cuh")))
     files.append(os.path.join(ROOT, "include", "rnnpose_hip.h"))
     for f in files:
-        h.update(f.encode())
+        h.update(os.path.relpath(f, ROOT).encode())      # repo-relative: the digest is the same wherever the tree is checked out
         with open(f, "rb") as fh:
             h.update(fh.read())
     h.update(" ".join(FLAGS).encode())

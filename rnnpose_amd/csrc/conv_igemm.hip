@@ -3,10 +3,9 @@
 //
 // Numerics -- "fp16x3 split" fp32 emulation on the fp16 matrix cores.  gfx950 has no TF32/xf32, and its exact
 // fp32 MFMA runs at 1/16 of the fp16 rate.  Every fp32 operand x is split as x*S = hi + lo (S a power of two keeping
-// lo out of the subnormal range; weights: hi = fp16(x*S) rounded, activations: hi = x*S truncated to 11 significant
-// bits -- one v_and --, lo = fp16(x*S - hi)) and
+// lo out of the subnormal range; hi = fp16(x*S) rounded to nearest, lo = fp16(x*S - hi)) and
 //     a*b  ~=  a_hi*b_hi + a_hi*b_lo + a_lo*b_hi          (3 MFMAs, fp32 accumulation)
-// The neglected terms are O(2^-21) relative per product -- fp32 round-off class (measured against an fp64
+// The neglected terms are O(2^-22) relative per product -- fp32 round-off class (measured against an fp64
 // reference in tests/test_gpu_conv.py: within 3x of MIOpen's fp32 error), at 16/3 = 5.3x the fp32-MFMA rate.
 // Weights are split once (rnnpose_conv_pack_weights_f16x3); activations are split on the fly while staging to LDS.
 //
@@ -140,8 +139,15 @@ __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-
 // staging is a 16-byte copy per thread and row -- no conversion, no range test in the loop.  r02 counters: the on-the-fly
 // split was ~3 of the 4.8-6 vector instructions per MFMA of this kernel, on a SIMD whose issue slots (about 8 per MFMA
 // period for all its waves) were the limiter; a 3x3 layer with 256 outputs re-split every activation 12 times.
-template <int NI, bool STRIDED, bool COLS4 = false, int TT = 0, bool NORM = false, bool HLIN = false>
-__global__ __launch_bounds__(NT, (NI == 2 ? 2 : ((COLS4 || TT > 0) ? 3 : 2))) void conv_igemm_f16x3_kernel(const KParams p) {
+// DEEP (split-tensor sources, 2x2 layout): software pipeline one whole channel block deep instead of occupancy.  r03 ablation
+// builds (profiles/r03_conv_ablation.txt): without the weight loads a GRU convolution runs 20 % faster, without the activation
+// staging 15 %, without BOTH LDS traffic and loads 30 % -- the waves wait on the (in-order) vector-memory queue, not on issue
+// slots.  Here the weight fragments of ALL TT taps of a block sit in registers (slot = tap) and are re-requested for the NEXT
+// block right after their MFMAs (a full block = TT taps of latency cover instead of 2 taps), and the activation tile is
+// requested TWO blocks ahead into a second register set.  Costs ~60 registers: 2 waves per SIMD instead of 3.
+template <int NI, bool STRIDED, bool COLS4 = false, int TT = 0, bool NORM = false, bool HLIN = false, bool DEEP = false>
+__global__ __launch_bounds__(NT, ((NI == 2 || DEEP) ? 2 : ((COLS4 || TT > 0) ? 3 : 2))) void conv_igemm_f16x3_kernel(const KParams p) {
+  static_assert(!DEEP || (HLIN && !COLS4 && TT >= 3), "the deep pipeline is for split sources, the 2x2 wave layout, 3 or 5 taps");
   static_assert(TT == 0 || (!STRIDED && (TT & 1)), "the unrolled loop is for stride 1 and odd tap counts");
   static_assert(!HLIN || (!NORM && !STRIDED && TT > 0), "split-tensor sources: stride 1, no fused normalisation");
   static_assert(!COLS4 || NI == 1, "the 4-column layout has one 32-column MFMA tile per wave");
@@ -209,11 +215,12 @@ __global__ __launch_bounds__(NT, (NI == 2 ? 2 : ((COLS4 || TT > 0) ? 3 : 2))) vo
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  float4 av0, av1, av2, av3, av4;
+  float4 av0_0, av0_1, av0_2, av0_3, av0_4;      // staged activation rows in flight: register set 0 ...
+  float4 av1_0, av1_1, av1_2, av1_3, av1_4;      // ... and set 1 (DEEP only: the tile two blocks ahead)
   float4 nrm01 = make_float4(0.f, 1.f, 0.f, 1.f), nrm23 = nrm01;       // NORM: (mean, rstd) x 4 channels of the tile in flight
   int sat_n = 0;                    // range guard (p.sat != NULL): staged quads this thread had to clamp
-  unsigned amask_n = 0u;            // bit r: staged row r of the tile in flight is inside the image (else: zeros)
-#define RP_LOAD_A_ROW(R_)                                                                                   \
+  unsigned amask0 = 0u, amask1 = 0u;   // bit r: staged row r of the tile in flight (set 0 / 1) is inside the image (else: zeros)
+#define RP_LOAD_A_ROW(R_, S_)                                                                                 \
   {                                                                                                         \
     const int uu_ = a_u##R_ + du_, vv_ = a_v##R_ + dvg_;                                                    \
     const bool in_ = cok_ && (STRIDED ? (static_cast<unsigned>(uu_) < static_cast<unsigned>(p.Uin) &&       \
@@ -222,10 +229,10 @@ __global__ __launch_bounds__(NT, (NI == 2 ? 2 : ((COLS4 || TT > 0) ? 3 : 2))) vo
     const unsigned px_ = STRIDED ? static_cast<unsigned>(a_pix##R_) + static_cast<unsigned>(uu_) * p.su + static_cast<unsigned>(vv_) * p.sv \
                                  : static_cast<unsigned>(a_pix##R_ + dpix_);   /* (unsigned: rows outside wrap harmlessly) */ \
     const unsigned off_ = in_ ? px_ * static_cast<unsigned>(sg_.cstride) + cc_ : 0u;   /* < 2^31 (host check) */ \
-    av##R_ = *reinterpret_cast<const float4*>(sg_.ptr + off_);                                              \
-    amask_n |= in_ ? (1u << R_) : 0u;                                                                       \
+    av##S_##_##R_ = *reinterpret_cast<const float4*>(sg_.ptr + off_);                                       \
+    amask##S_ |= in_ ? (1u << R_) : 0u;                                                                     \
   }
-#define RP_LOAD_A(G_, CB_)                                                                                  \
+#define RP_LOAD_A(G_, CB_, S_)                                                                              \
   do {                                                                                                      \
     Seg sg_ = p.seg0;                                                                                       \
     int cb0_ = 0;                                                                                           \
@@ -244,35 +251,35 @@ __global__ __launch_bounds__(NT, (NI == 2 ? 2 : ((COLS4 || TT > 0) ? 3 : 2))) vo
       nrm01 = *reinterpret_cast<const float4*>(mr_);                                                        \
       nrm23 = *reinterpret_cast<const float4*>(mr_ + 4);                                                    \
     }                                                                                                       \
-    amask_n = 0u;                                                                                           \
-    RP_LOAD_A_ROW(0) RP_LOAD_A_ROW(1) RP_LOAD_A_ROW(2) RP_LOAD_A_ROW(3) RP_LOAD_A_ROW(4)                    \
+    amask##S_ = 0u;                                                                                         \
+    RP_LOAD_A_ROW(0, S_) RP_LOAD_A_ROW(1, S_) RP_LOAD_A_ROW(2, S_) RP_LOAD_A_ROW(3, S_) RP_LOAD_A_ROW(4, S_) \
   } while (0)
-#define RP_STORE_A_ROW(R_, AB_)                                                                             \
+#define RP_STORE_A_ROW(R_, AB_, S_)                                                                         \
   {                                                                                                         \
     const int j_ = (tid >> 3) + 32 * R_;                                                                    \
     if (HLIN) {                                                                                             \
       if (j_ < AROWS) {              /* rows outside the image: zeros (bitwise AND: a select of two float4 went through scratch) */ \
-        const unsigned mk_ = 0u - ((amask_n >> R_) & 1u);                                                   \
-        uint4 u_ = __builtin_bit_cast(uint4, av##R_);                                                       \
+        const unsigned mk_ = 0u - ((amask##S_ >> R_) & 1u);                                                 \
+        uint4 u_ = __builtin_bit_cast(uint4, av##S_##_##R_);                                                \
         u_.x &= mk_; u_.y &= mk_; u_.z &= mk_; u_.w &= mk_;                                                 \
         *reinterpret_cast<uint4*>(sAf + (AB_) * (2 * PROWS * RS) + (c4 & 1) * (PROWS * RS) + j_ * RS + (c4 >> 1) * 8) = u_; \
       }                                                                                                     \
     } else if (j_ < AROWS) {                                                                                \
       h4 hi_, lo_;                                                                                          \
       const float4 z4_ = make_float4(0.f, 0.f, 0.f, 0.f);                                                   \
-      float4 xv_ = av##R_;                                                                                  \
+      float4 xv_ = av##S_##_##R_;                                                                           \
       if (NORM) xv_ = make_float4(fmaxf((xv_.x - nrm01.x) * nrm01.y, 0.f), fmaxf((xv_.y - nrm01.z) * nrm01.w, 0.f), \
                                   fmaxf((xv_.z - nrm23.x) * nrm23.y, 0.f), fmaxf((xv_.w - nrm23.z) * nrm23.w, 0.f)); \
-      split4((amask_n >> R_) & 1u ? xv_ : z4_, p.a_scale, hi_, lo_);   /* padding / out-of-range rows: zeros (AFTER the norm) */ \
+      split4((amask##S_ >> R_) & 1u ? xv_ : z4_, p.a_scale, hi_, lo_);   /* padding / out-of-range rows: zeros (AFTER the norm) */ \
       *reinterpret_cast<h4*>(sAf + (AB_) * (2 * PROWS * RS) + j_ * RS + c4 * 4) = hi_;                      \
       *reinterpret_cast<h4*>(sAf + (AB_) * (2 * PROWS * RS) + PROWS * RS + j_ * RS + c4 * 4) = lo_;         \
     }                                                                                                       \
   }
-#define RP_SAT_ROW(R_) sat_n += (((amask_n >> R_) & 1u) && rp::quad_saturates(av##R_, p.a_scale)) ? 1 : 0;
-#define RP_STORE_A(AB_)                                                                                     \
+#define RP_SAT_ROW(R_, S_) sat_n += (((amask##S_ >> R_) & 1u) && rp::quad_saturates(av##S_##_##R_, p.a_scale)) ? 1 : 0;
+#define RP_STORE_A(AB_, S_)                                                                                 \
   do {                                                                                                      \
-    if (!HLIN && p.sat) { RP_SAT_ROW(0) RP_SAT_ROW(1) RP_SAT_ROW(2) RP_SAT_ROW(3) RP_SAT_ROW(4) }   /* uniform branch, VALU only */ \
-    RP_STORE_A_ROW(0, AB_) RP_STORE_A_ROW(1, AB_) RP_STORE_A_ROW(2, AB_) RP_STORE_A_ROW(3, AB_) RP_STORE_A_ROW(4, AB_) \
+    if (!HLIN && p.sat) { RP_SAT_ROW(0, S_) RP_SAT_ROW(1, S_) RP_SAT_ROW(2, S_) RP_SAT_ROW(3, S_) RP_SAT_ROW(4, S_) }   /* uniform branch, VALU only */ \
+    RP_STORE_A_ROW(0, AB_, S_) RP_STORE_A_ROW(1, AB_, S_) RP_STORE_A_ROW(2, AB_, S_) RP_STORE_A_ROW(3, AB_, S_) RP_STORE_A_ROW(4, AB_, S_) \
   } while (0)
   // weight fragment registers: two stages (named locals + macros: structs/arrays handed to lambdas end up in LDS or
   // scratch with this compiler).  Stage S holds, for the tap being consumed, this wave's B fragments
@@ -350,14 +357,14 @@ __global__ __launch_bounds__(NT, (NI == 2 ? 2 : ((COLS4 || TT > 0) ? 3 : 2))) vo
   do {                                                                                                      \
     int ncb_ = ccb + 1, ng_ = cg;                                                                           \
     if (ncb_ == p.ncb) { ncb_ = 0; ++ng_; }                                                                 \
-    if (ct == 0) RP_LOAD_A(ng_ < p.G ? ng_ : cg, ng_ < p.G ? ncb_ : ccb);                                   \
+    if (ct == 0) RP_LOAD_A(ng_ < p.G ? ng_ : cg, ng_ < p.G ? ncb_ : ccb, 0);                                \
     RP_MMA(S_, p.dv0 + ct, ab);                                                                             \
     RP_LOAD_B_CLAMPED(S_);                                                                                  \
     if (++pt == p.T) { pt = 0; if (++pcb == p.ncb) { pcb = 0; ++pg; } }                                     \
     if (++ct == p.T) {                                                                                      \
       ct = 0;                                                                                               \
       ccb = ncb_; cg = ng_;                                                                                 \
-      RP_STORE_A(ab ^ 1);                                                                                   \
+      RP_STORE_A(ab ^ 1, 0);                                                                                \
         __syncthreads();                                                                                      \
       ab ^= 1;                                                                                              \
     }                                                                                                       \
@@ -371,7 +378,8 @@ __global__ __launch_bounds__(NT, (NI == 2 ? 2 : ((COLS4 || TT > 0) ? 3 : 2))) vo
     // ---------------- unrolled main loop (stride 1) ----------------
     // weight fragments: two stages of [ni][hi kk0, hi kk1, lo kk0, lo kk1]; stage s of this wave = 4 (8 for NI = 2) wave
     // loads at fixed offsets from  wp + s * sstride  (packed in consumption order)
-    uint4 bf[2][NI][4];
+    constexpr int NSTG = DEEP ? TT : 2;      // weight-fragment register stages (DEEP: one per tap of a block)
+    uint4 bf[NSTG][NI][4];
     const uint4* wp = p.wpk + static_cast<long long>(ntile0) * 256 + lane;
     const int sstride = ntiles32 * 256;
     const int nit = p.G * p.ncb, nst = nit * TT;
@@ -444,12 +452,19 @@ __global__ __launch_bounds__(NT, (NI == 2 ? 2 : ((COLS4 || TT > 0) ? 3 : 2))) vo
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_h[SET_][mi], bh[ni], acc[mi][ni], 0, 0, 0); \
     }
     // one (group, channel block): PAR_ = parity of its index = LDS buffer it reads = weight stage of its first tap
-#define RP_BODY(PAR_)                                                                                       \
+#define RP_BODY(PAR_, OTH_)                                                                                 \
     {                                                                                                       \
       int ncb_ = ccb + 1, ng_ = cg;                                                                         \
       if (ncb_ == p.ncb) { ncb_ = 0; ++ng_; }                                                               \
       if (!COLS4 && !(RP_ABL & 2)) { RP_READ_A(0, 0, 0, PAR_) }                                             \
-      if (!(RP_ABL & 4)) RP_LOAD_A(ng_ < p.G ? ng_ : cg, ng_ < p.G ? ncb_ : ccb);   /* next tile (the last one re-requests itself) */ \
+      if (DEEP) {                    /* the tile TWO blocks ahead -> register set PAR_ (stored to LDS at the end of the previous block) */ \
+        int ncb2_ = ncb_ + 1, ng2_ = ng_;                                                                   \
+        if (ncb2_ == p.ncb) { ncb2_ = 0; ++ng2_; }                                                          \
+        const bool v2_ = ng2_ < p.G, v1_ = ng_ < p.G;                                                       \
+        RP_LOAD_A(v2_ ? ng2_ : (v1_ ? ng_ : cg), v2_ ? ncb2_ : (v1_ ? ncb_ : ccb), PAR_);                   \
+      } else if (!(RP_ABL & 4)) {                                                                           \
+        RP_LOAD_A(ng_ < p.G ? ng_ : cg, ng_ < p.G ? ncb_ : ccb, 0);   /* next tile (the last one re-requests itself) */ \
+      }                                                                                                     \
       if (!COLS4) RP_SCHED_FENCE();                                                                         \
       _Pragma("unroll") for (int t = 0; t < TT; ++t) {                                                      \
         if (COLS4) {                                                                                        \
@@ -462,41 +477,52 @@ __global__ __launch_bounds__(NT, (NI == 2 ? 2 : ((COLS4 || TT > 0) ? 3 : 2))) vo
           RP_MMA_KK2(((PAR_) + t) & 1, 1, PAR_)                                                             \
           RP_LOADB2(((PAR_) + t) & 1, s0 + t + 2)                                                           \
         } else {                                                                                            \
+          const int slot_ = DEEP ? t : (((PAR_) + t) & 1);                                                  \
           if (!(RP_ABL & 2)) { RP_READ_A(1, t, 1, PAR_) }                                                   \
           RP_SCHED_FENCE();                                                                                 \
-          RP_MFMA6(0, ((PAR_) + t) & 1, 0)                                                                  \
+          RP_MFMA6(0, slot_, 0)                                                                             \
           RP_SCHED_FENCE();                                                                                 \
           if (t + 1 < TT && !(RP_ABL & 2)) { RP_READ_A(0, t + 1, 0, PAR_) }                                 \
           RP_SCHED_FENCE();                                                                                 \
-          RP_MFMA6(1, ((PAR_) + t) & 1, 1)                                                                  \
+          RP_MFMA6(1, slot_, 1)                                                                             \
           RP_SCHED_FENCE();                                                                                 \
-          if (!(RP_ABL & 1)) { RP_LOADB2(((PAR_) + t) & 1, s0 + t + 2) }                                    \
+          if (!(RP_ABL & 1)) { RP_LOADB2(slot_, s0 + t + (DEEP ? TT : 2)) }   /* DEEP: this tap of the NEXT block */ \
           RP_SCHED_FENCE();                                                                                 \
         }                                                                                                   \
       }                                                                                                     \
       s0 += TT;                                                                                             \
       ccb = ncb_; cg = ng_;                                                                                 \
-      if (!(RP_ABL & 4)) RP_STORE_A((PAR_) ^ 1);                                                            \
+      if (DEEP) { RP_STORE_A(OTH_, OTH_); }            /* the NEXT block's tile, requested one block ago */  \
+      else if (!(RP_ABL & 4)) { RP_STORE_A(OTH_, 0); }                                                      \
       if (!(RP_ABL & 8)) __syncthreads();                                                                   \
     }
     // (weight requests first: the activation tile is waited for right away and its wait then covers both; measured neutral)
-    RP_LOADB2(0, 0)
-    RP_LOADB2(1, 1)
-    RP_LOAD_A(0, 0);
+    if constexpr (DEEP) {
+#pragma unroll
+      for (int t = 0; t < TT; ++t) RP_LOADB2(t, t)
+    } else {
+      RP_LOADB2(0, 0)
+      RP_LOADB2(1, 1)
+    }
+    RP_LOAD_A(0, 0, 0);
     RP_SCHED_FENCE();
-    RP_STORE_A(0);
+    RP_STORE_A(0, 0);
+    if constexpr (DEEP) {            // second tile in flight (stored at the end of the first block)
+      const bool v1_ = p.ncb > 1 || p.G > 1;
+      RP_LOAD_A(v1_ ? (p.ncb > 1 ? 0 : 1) : 0, v1_ ? (p.ncb > 1 ? 1 : 0) : 0, 1);
+    }
     __syncthreads();
     if (RP_ABL & 2) { RP_READ_A(0, 0, 0, 0) RP_READ_A(1, 0, 1, 0) }
     int cg = 0, ccb = 0, s0 = 0, it = 0;
     for (; it + 1 < nit; it += 2) {
-      RP_BODY(0)
-      RP_BODY(1)
+      RP_BODY(0, 1)
+      RP_BODY(1, 0)
     }
-    if (it < nit) RP_BODY(0)
+    if (it < nit) RP_BODY(0, 1)
   } else {
     // ---------------- generic stage machine (stride 2) ----------------
-  RP_LOAD_A(0, 0);
-  RP_STORE_A(0);
+ RP_LOAD_A(0, 0, 0);
+  RP_STORE_A(0, 0);
   int ab = 0;                      // LDS buffer holding the activation tile being consumed
   int cg = 0, ccb = 0, ct = 0;     // coordinates of the tap being consumed
   int pg = 0, pcb = 0, pt = 0;     // coordinates of the next weight tile to request
@@ -877,7 +903,7 @@ int rnnpose_conv2d_nhwc_f16x3(const rnnpose_conv_desc_t* d, rnnpose_stream_t str
   if (d->dst_split) RP_REQUIRE(d->epilogue != 2 && d->dst_split_c_stride % 8 == 0 && d->dst_split_c_offset % 4 == 0 &&
                                    reinterpret_cast<uintptr_t>(d->dst_split) % 32 == 0, fn,
                                "dst_split: not with the GRU z|r epilogue; channel stride multiple of 8, offset of 4, 32-byte aligned");
-  RP_REQUIRE(d->tile >= 0 && d->tile <= 3, fn, "tile must be 0 (auto), 1 (128x64), 2 (128x128, 4 column waves) or 3 (128x128, 2x2 waves)");
+  RP_REQUIRE(d->tile >= 0 && d->tile <= 4, fn, "tile must be 0 (auto), 1 (128x64), 2 (128x128, 4 column waves), 3 (128x128, 2x2 waves) or 4 (128x64, deep pipeline)");
   if (d->tile_stats) RP_REQUIRE(d->epilogue == 0, fn, "tile_stats needs the linear epilogue");
   const long long Mtot = static_cast<long long>(d->B) * Ho * Wo;
   RP_REQUIRE(Mtot < (1LL << 31) - 256 && static_cast<long long>(d->B) * d->H * d->W < (1LL << 31) - 256, fn, "too many pixels");
@@ -896,6 +922,8 @@ int rnnpose_conv2d_nhwc_f16x3(const rnnpose_conv_desc_t* d, rnnpose_stream_t str
   if (d->tile == 1) wide = false;
   if (d->tile == 2) wide = !d->src0_mean_rstd;
   if (d->tile == 3 && hlin) { wide = false; wide22 = true; }
+  const bool deep = d->tile == 4 && hlin && (p.T == 3 || p.T == 5);     // 128x64, weights of a whole block + two activation tiles in flight
+  if (d->tile == 4) wide = false;
   const dim3 block(NT);
   hipStream_t st = rp::as_stream(stream);
   // stride 1: the main loop unrolled over the taps of a group (T = kw, or kh for vertical kernels); stride 2: generic loop
@@ -908,7 +936,12 @@ int rnnpose_conv2d_nhwc_f16x3(const rnnpose_conv_desc_t* d, rnnpose_stream_t str
       if constexpr (!(HL_)) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<NI_, false, COLS4_, 7, false, false>), grid, block, 0, st, p); \
       break;                                                                                                             \
   }
-  if (wide22) {
+  if (deep) {
+    p.n_nt = rp::cdiv(d->c_out, 64);
+    const dim3 grid(static_cast<unsigned>(p.n_mt) * p.n_nt);
+    if (p.T == 3) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<1, false, false, 3, false, true, true>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((conv_igemm_f16x3_kernel<1, false, false, 5, false, true, true>), grid, block, 0, st, p);
+  } else if (wide22) {
     p.n_nt = p.Npad / 128;
     const dim3 grid(static_cast<unsigned>(p.n_mt) * p.n_nt);
     RP_LAUNCH_T(2, false, true)

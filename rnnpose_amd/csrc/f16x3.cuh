@@ -1,7 +1,6 @@
 // fp16x3 split: fp32 emulation on the fp16 matrix cores (shared by the implicit-GEMM convolution and the encoder stem).
 //   x * S = hi + lo   (S a power of two), a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi  with fp32 accumulation.
-// hi = x*S with the mantissa TRUNCATED to fp16's 11 significant bits (one v_and; exactly representable, so the packed
-// convert is exact), lo = fp16(x*S - hi) (exact in fp32; 11 more bits) -> 21-22 significant bits.
+// hi = fp16(x*S) rounded to nearest, lo = fp16(x*S - hi) (the difference is exact in fp32; 11 more bits) -> 22 significant bits.
 // Range: |x*S| >= 65520 does not fit fp16.  hi is clamped to +-65504 (never inf/NaN from finite inputs) and the element
 // is COUNTED as saturated: split4 returns the number of saturated elements of its quad so that callers can raise a
 // sticky flag (rnnpose_conv_saturation_count): fp32 in the reference has no such cliff, so it must never pass silently.
@@ -22,18 +21,18 @@ __device__ __forceinline__ void split4(const float4 v, float s, h4& hi, h4& lo) 
   // a v_pk_mul_f32 / v_pk_add_f32 issued next to MFMAs costs ~11 cycles more than its two scalar halves
   // (MI355X_MICROARCH.md, "price of one filler beside MFMAs"), and plain -O3 re-packs adjacent scalar ops.  r02 same-box
   // A/B: +0.7 % on the step.  The fp16 converts and the clamp stay packed (v_cvt_pk*, v_pk_min/max_f16).
+  // hi = x*s ROUNDED to nearest fp16 (round 3; r02 truncated the mantissa with one v_and): the remainder then is at most
+  // half an fp16 ulp, so lo carries one more bit and the neglected lo*lo product halves -- per-product error ~2^-22 instead of
+  // ~2^-21, same instruction count (two packed converts back instead of four ands).  The r03 ablation
+  // showed the split's vector instructions are not what bounds the convolution kernels.
   const float x[4] = {v.x * s, v.y * s, v.z * s, v.w * s};
-  float t[4], l[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    t[i] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x[i]) & 0xffffe000u);   // 11 significant bits: exact in fp16
-    l[i] = x[i] - t[i];                                                                    // exact in fp32
-  }
   const h2 cap = {static_cast<_Float16>(65504.f), static_cast<_Float16>(65504.f)};
-  h2 h01 = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(t[0], t[1]));                 // (exactly representable: any rounding mode)
-  h2 h23 = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(t[2], t[3]));
-  h01 = __builtin_elementwise_max(__builtin_elementwise_min(h01, cap), -cap);
+  h2 h01 = __builtin_convertvector(f32x2{x[0], x[1]}, h2);                                 // round to nearest even; overflow -> inf
+  h2 h23 = __builtin_convertvector(f32x2{x[2], x[3]}, h2);
+  h01 = __builtin_elementwise_max(__builtin_elementwise_min(h01, cap), -cap);              // |x*s| > 65504: clamped (and counted by the callers)
   h23 = __builtin_elementwise_max(__builtin_elementwise_min(h23, cap), -cap);
+  const f32x2 t01 = __builtin_convertvector(h01, f32x2), t23 = __builtin_convertvector(h23, f32x2);
+  const float l[4] = {x[0] - t01.x, x[1] - t01.y, x[2] - t23.x, x[3] - t23.y};             // exact in fp32
   const h2 q01 = __builtin_convertvector(f32x2{l[0], l[1]}, h2), q23 = __builtin_convertvector(f32x2{l[2], l[3]}, h2);
   hi = h4{h01.x, h01.y, h23.x, h23.y};
   lo = h4{q01.x, q01.y, q23.x, q23.y};

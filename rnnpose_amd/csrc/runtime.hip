@@ -79,6 +79,21 @@ int rnnpose_f16x3_saturation_count(unsigned long long* h_count, int reset, rnnpo
   return 0;
 }
 
+int rnnpose_f16x3_saturation_peek(unsigned long long* d_count, rnnpose_stream_t stream) {
+  const char* fn = "rnnpose_f16x3_saturation_peek";
+  RP_REQUIRE(d_count, fn, "null pointer");
+  int dev = 0;
+  RP_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64, fn, "no current device");
+  hipStream_t st = rp::as_stream(stream);
+  hipError_t e = rp::g_sat[dev] ? hipMemcpyAsync(d_count, rp::g_sat[dev], sizeof(unsigned long long), hipMemcpyDeviceToDevice, st)
+                                : hipMemsetAsync(d_count, 0, sizeof(unsigned long long), st);
+  if (e != hipSuccess) {
+    rp::set_error("%s: HIP error %d (%s)", fn, static_cast<int>(e), hipGetErrorString(e));
+    return 2;
+  }
+  return 0;
+}
+
 int rnnpose_abi_version(void) { return RNNPOSE_ABI_VERSION; }
 
 const char* rnnpose_last_error(void) { return rp::g_err; }

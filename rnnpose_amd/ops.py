@@ -140,6 +140,7 @@ def _corr_pyramid_f16x3(f1, f2, layout, B, Cc, h, w, levels, out, a_scale):
     key = (f1.device, n)
     ws = _pyr_ws.get(key)
     if ws is None:
+        range_guard_arm(f1.device)
         ws = _pyr_ws[key] = torch.empty(n // 2, device=f1.device, dtype=torch.float16)
     offs, hl, wl = pyramid_layout(B, h, w, levels)
     buf = out if (out is not None and out.numel() == offs[-1] and out.device == f1.device) else \
@@ -389,6 +390,7 @@ class PackedConv:
 
     def __init__(self, weight, bias, seg_counts=None, post_scale: float = 1.0, a_scale: float = A_SCALE):
         import math
+        range_guard_arm(weight.device)
         w = _chk(weight.detach(), "weight") * post_scale
         b = _chk(bias.detach(), "bias") * post_scale
         self.c_out, self.c_in, self.kh, self.kw = w.shape
@@ -621,6 +623,7 @@ class PackedConv1x1:
 
     def __init__(self, weight, bias, a_scale: float = A_SCALE):
         import math
+        range_guard_arm(weight.device)
         w = _chk(weight.detach(), "weight")
         if w.dim() != 4 or w.shape[0] != 256 or w.shape[2:] != (1, 1) or w.shape[1] % 4 or w.shape[1] > 352:
             raise ValueError("needs a (256, c_in <= 352, 1, 1) weight with c_in % 4 == 0")
@@ -653,6 +656,7 @@ class PackedMaskHead:
 
     def __init__(self, weight, bias, post_scale: float = 0.25, a_scale: float = A_SCALE):
         import math
+        range_guard_arm(weight.device)
         w = _chk(weight.detach(), "weight")
         if tuple(w.shape) != (576, 256, 1, 1):
             raise ValueError("mask.2 weight must be (576,256,1,1)")
@@ -680,10 +684,52 @@ def mask_upsample(pm: PackedMaskHead, x, x_c_offset, flow_lr, out=None):
 
 
 # ---- fp16x3 range guard ------------------------------------------------------------------------------------------------
+# ON BY DEFAULT (round 3): every kernel that splits fp32 values into fp16 hi|lo counts the quads it had to clamp in a sticky
+# device counter; PoseRefiner.forward returns the counter as a device tensor ("f16x3_range_events"), so a silent clamp --
+# something the fp32 reference cannot do -- is visible in the public output without a host synchronisation.
+# RNNPOSE_RANGE_GUARD=0 switches it off (measurement only).
+import os as _os
+_guard_env = _os.environ.get("RNNPOSE_RANGE_GUARD", "1") != "0"
+_guard_on = False
+_guard_devices = set()
+
+
+def range_guard_arm(device=None):
+    """Allocate the current device's counter and switch counting on (idempotent; never called under stream capture: the
+    Packed* constructors and PoseRefiner.forward call it before any launch)."""
+    global _guard_on
+    if not _guard_env:
+        return
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    if dev in _guard_devices and _guard_on:
+        return
+    with torch.cuda.device(dev):
+        _lib.call("rnnpose_f16x3_saturation_check", 1)
+    _guard_devices.add(dev)
+    _guard_on = True
+
+
+def range_guard_state() -> bool:
+    """Part of every captured graph's key: the counter pointer is baked into the captured launches."""
+    return _guard_on
+
+
 def saturation_check(enable: bool = True):
     """Switch the fp16x3 range guard on/off (process-global): with it on, every fp16x3 kernel counts the activation quads
     whose scaled magnitude left the fp16 range (|x * a_scale| > 65504) -- values the fp32 reference would handle."""
+    global _guard_on
     _lib.call("rnnpose_f16x3_saturation_check", int(bool(enable)))
+    _guard_on = bool(enable)
+    if enable:
+        _guard_devices.add(torch.cuda.current_device())
+
+
+def saturation_events(out=None):
+    """-> device tensor (1,) int64 holding the sticky counter NOW in stream order; no host synchronisation."""
+    if out is None:
+        out = torch.zeros(1, device="cuda", dtype=torch.int64)
+    _lib.call("rnnpose_f16x3_saturation_peek", _ptr(out), _stream())
+    return out
 
 
 def saturation_count(reset: bool = True) -> int:
@@ -699,6 +745,7 @@ class PackedStem:
 
     def __init__(self, weight, bias, a_scale: float = 8.0):
         import math
+        range_guard_arm(weight.device)
         w = _chk(weight.detach(), "weight")
         if tuple(w.shape) != (64, 3, 7, 7):
             raise ValueError("the stem kernel is the RAFT encoder's conv1: weight must be (64,3,7,7)")

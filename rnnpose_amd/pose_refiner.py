@@ -128,7 +128,7 @@ class PoseRefiner(nn.Module):
         """Once per forward(): re-pack weights whose parameters changed (load_state_dict, in-place updates, .to()) and
         return the identity every captured graph depends on -- replay never runs the packing code itself."""
         eng = self.cf_net.engine()
-        key = (eng.refresh(), self.image_fea_enc.engine().refresh(), self.sigma[0].data_ptr(), eng.epoch)
+        key = (eng.refresh(), self.image_fea_enc.engine().refresh(), self.sigma[0].data_ptr(), eng.epoch, ops.range_guard_state())
         if key != self._wkey:
             if self._wkey is not None:
                 self._drop_graphs()          # graphs hold pointers to the old packed weights / freed activation buffers
@@ -357,6 +357,7 @@ class PoseRefiner(nn.Module):
         if image is not None and image.is_cuda or intrinsics.is_cuda:
             from .streams import reserve
             reserve(intrinsics.device)        # bind the concurrent streams to distinct hardware queues before anything else
+            ops.range_guard_arm(intrinsics.device)
         self._refresh()
         cfg = self.cfg
         lm_l, ep_l = cfg.get("LM_LMBDA", LM_LMBDA), cfg.get("EP_LMBDA", EP_LMBDA)
@@ -443,4 +444,7 @@ class PoseRefiner(nn.Module):
             "syn_depth": syn_depths,
             "syn_img": syn_imgs,
             "Tij_gt": Tij_gt,
+            # sticky count of activation quads the fp16x3 split had to clamp so far (device tensor, no host sync): nonzero
+            # means some value left the +-8188 range the fp32 reference would have handled
+            "f16x3_range_events": ops.saturation_events(),
         }

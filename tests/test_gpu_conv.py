@@ -134,7 +134,7 @@ def test_conv_range_accuracy(ops, mag):
         ops.conv2d_nhwc(pc, [(nhwc(xd), 0)], (out, 0), ops.EPI_LINEAR)
         assert ops.saturation_count() == 0
     finally:
-        ops.saturation_check(False)
+        ops.saturation_check(True)          # (the guard is on by default since round 3)
     check(nchw(out), y64, y32, f"|x| ~ {mag:g}")
 
 
@@ -169,11 +169,33 @@ def test_conv_range_guard_counts_saturation(ops):
     finally:
         ops.saturation_check(False)
     ops.conv2d_nhwc(pc, [(x, 0)], (out, 0))
-    ops.saturation_check(True)
-    try:
-        assert ops.saturation_count() == 0                      # launches made while the guard was off count nothing
-    finally:
-        ops.saturation_check(False)
+    ops.saturation_check(True)                                  # (back to the default: on)
+    assert ops.saturation_count() == 0                          # launches made while the guard was off count nothing
+
+
+def test_range_guard_is_visible_in_refiner_output(ops):
+    """the clamp event is sticky, on by default and part of the PUBLIC output.  Update-block weights scaled
+    by 1e3 drive activations past +-8188: PoseRefiner's "f16x3_range_events" must be nonzero (and zero for sane weights)."""
+    from rnnpose_amd.pose_refiner import PoseRefiner, SyntheticRenderer, default_config
+    from rnnpose_amd.transformation import SE3Sequence
+    d = syn.make_inputs(1, 64, 96, seed=4)
+    z3 = torch.zeros(1, 3, 64, 96, device="cuda")
+    rend = SyntheticRenderer(syn_img=z3, image_crop=z3, cfea=D(d["ctx"]), geofea1=D(d["g1"]), geofea2_crop=D(d["g2"]), syn_depth=D(d["depth"]),
+                             intrinsics_crop=D(d["K"]), fmap1=D(d["fmap1"]), fmap2=D(d["fmap2"]))
+    cfg = default_config(RENDER_ITER_COUNT=1, ITER_COUNT=2, OPTIM_ITER_COUNT=1)
+    ref = PoseRefiner(cfg, renderer=rend).cuda().eval()
+    ops.saturation_count(reset=True)
+    out = ref(None, SE3Sequence(matrix=D(d["G0"])), D(d["K"]))
+    n0 = int(out["f16x3_range_events"].item())
+    assert n0 == 0, f"{n0} range events with ordinary weights"
+    with torch.no_grad():
+        for prm in ref.cf_net.update_block.parameters():
+            prm.mul_(1.0e3)
+    out = ref(None, SE3Sequence(matrix=D(d["G0"])), D(d["K"]))
+    n = int(out["f16x3_range_events"].item())
+    print("range events with weights x 1e3:", n, "host counter:", ops.saturation_count(reset=False))
+    assert n > 0, "activations beyond the fp16x3 range were clamped silently"
+    ops.saturation_count(reset=True)
 
 
 @pytest.mark.parametrize("B,h,w,cout", [(2, 9, 23, 128), (1, 30, 40, 128), (1, 5, 3, 96)])
@@ -331,12 +353,12 @@ def test_split_hl_roundtrip_and_layout(ops):
     s = ops.split_hl(x)
     v = s.view(torch.float16).view(2, 5, 7, 6, 2, 8)
     hi = v[..., 0, :].float().reshape(2, 5, 7, 48)
-    t = (x * 8.0).view(torch.int32).bitwise_and(-8192).view(torch.float32)      # mantissa truncated to 11 significant bits
+    t = (x * 8.0).half().float()                                                 # rounded to nearest fp16
     assert torch.equal(hi, t)
     assert torch.equal(v[..., 1, :].float().reshape(2, 5, 7, 48), (x * 8.0 - t).half().float())
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("B,H,W,segs,cout,kh,kw", [
     (2, 12, 20, [192, 64], 126, 3, 3),     # ragged output tail (2 valid columns of the last quad)
     (1, 16, 16, [128, 128], 256, 1, 5),
@@ -387,7 +409,7 @@ def test_conv_split_sources_and_outputs(ops, tile, B, H, W, segs, cout, kh, kw):
 
 
 @pytest.mark.parametrize("kh,kw", [(1, 5), (5, 1)])
-@pytest.mark.parametrize("tile", [0, 3])
+@pytest.mark.parametrize("tile", [0, 3, 4])
 def test_conv_gru_epilogues_split(ops, kh, kw, tile):
     """The GRU gate / state-update epilogues on split tensors: h from its split copy, r*h written split, h' fp32 + split."""
     B, H, W, C = 2, 10, 14, 128

@@ -15,6 +15,8 @@ from rnnpose_amd import ops  # noqa: E402
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 only = sys.argv[2] if len(sys.argv) > 2 else None
+flt = [f for f in os.environ.get("CONV_LAYERS_FILTER", "").split(",") if f]      # substrings of layer names to keep
+batches = [int(b) for b in os.environ.get("CONV_LAYERS_B", "4,8,1").split(",")]
 h, w = 60, 80
 shapes = [("convc2 3x3 256->192", [256], 192, 3, 3),
           ("convf2 3x3 128->64", [128], 64, 3, 3), ("conv 3x3 256->126", [192, 64], 126, 3, 3),
@@ -22,9 +24,11 @@ shapes = [("convc2 3x3 256->192", [256], 192, 3, 3),
           ("gru zr 5x1 256->256", [128, 128], 256, 5, 1), ("gru q 5x1 256->128", [128, 128], 128, 5, 1),
           ("heads 3x3 128->512", [128], 512, 3, 3), ("inp 1x5 128->384", [128], 384, 1, 5),
           ("enc l1 3x3 64->64 @240x320", [64], 64, 3, 3)]
-modes = [("f32", False, 0), ("hl0", True, 0), ("hl1", True, 1), ("hl2", True, 2), ("hl3", True, 3)]
-for B in (4, 8, 1):
+modes = [("f32", False, 0), ("hl0", True, 0), ("hl1", True, 1), ("hl2", True, 2), ("hl3", True, 3), ("hl4", True, 4)]
+for B in batches:
     for name, segs, co, kh, kw in shapes:
+        if flt and not any(f in name for f in flt):
+            continue
         hh, ww = (240, 320) if "@240" in name else ((30, 30) if B == 1 else (h, w))
         ci = sum(segs)
         wt = torch.randn(co, ci, kh, kw, device="cuda") * (2.0 / (ci * kh * kw)) ** 0.5
@@ -34,7 +38,7 @@ for B in (4, 8, 1):
         out = torch.empty(B, hh, ww, (co + 7) // 8 * 8, device="cuda")
         line = f"B={B} {name:28s}"
         for mname, hl, tile in modes:
-            if only and mname != only:
+            if only and mname not in only.split(","):
                 continue
             run = lambda: ops.conv2d_nhwc(pc, xs if hl else xf, (out, 0), ops.EPI_RELU, src_hl=hl, dst_hl=hl, tile=tile)
             if reps:
