@@ -452,11 +452,20 @@ __global__ __launch_bounds__(NT, ((NI == 2 || DEEP) ? 2 : ((COLS4 || TT > 0) ? 3
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_h[SET_][mi], bh[ni], acc[mi][ni], 0, 0, 0); \
     }
     // one (group, channel block): PAR_ = parity of its index = LDS buffer it reads = weight stage of its first tap
+    // Block boundary (r03): the next tile is written to the other LDS buffer BEFORE the last tap (its loads have had TT - 1 taps
+    // to land), and the barrier sits in the MIDDLE of the last tap: k-half 0 of the last tap | barrier | first fragment reads of
+    // the NEXT block | k-half 1 of the last tap (its fragments are already in registers).  r02 had store -> barrier -> read ->
+    // wait -> MFMA at every boundary: an LDS write + barrier + LDS read latency chain with an idle matrix pipe per block and wave
+    // (the r03 ablation builds put the staging at 15 % of a GRU convolution although it is 10 instructions per 60 MFMAs).
+#ifndef RP_OVERLAP
+#define RP_OVERLAP 0      // measured neutral on the step (r03: 664.8 vs 666.3 iters/s same-box): off, kept for the record
+#endif
+    constexpr bool OVL = RP_OVERLAP && !COLS4 && TT >= 3;
 #define RP_BODY(PAR_, OTH_)                                                                                 \
     {                                                                                                       \
       int ncb_ = ccb + 1, ng_ = cg;                                                                         \
       if (ncb_ == p.ncb) { ncb_ = 0; ++ng_; }                                                               \
-      if (!COLS4 && !(RP_ABL & 2)) { RP_READ_A(0, 0, 0, PAR_) }                                             \
+      if (!OVL && !COLS4 && !(RP_ABL & 2)) { RP_READ_A(0, 0, 0, PAR_) }   /* (OVL: read at the previous boundary / in the prologue) */ \
       if (DEEP) {                    /* the tile TWO blocks ahead -> register set PAR_ (stored to LDS at the end of the previous block) */ \
         int ncb2_ = ncb_ + 1, ng2_ = ng_;                                                                   \
         if (ncb2_ == p.ncb) { ncb2_ = 0; ++ng2_; }                                                          \
@@ -478,11 +487,19 @@ __global__ __launch_bounds__(NT, ((NI == 2 || DEEP) ? 2 : ((COLS4 || TT > 0) ? 3
           RP_LOADB2(((PAR_) + t) & 1, s0 + t + 2)                                                           \
         } else {                                                                                            \
           const int slot_ = DEEP ? t : (((PAR_) + t) & 1);                                                  \
+          const bool last_ = OVL && t == TT - 1;                                                            \
+          if (last_) {               /* the next block's tile -> the other LDS buffer, before the last tap */ \
+            if (DEEP) { RP_STORE_A(OTH_, OTH_); } else if (!(RP_ABL & 4)) { RP_STORE_A(OTH_, 0); }          \
+            RP_SCHED_FENCE();                                                                               \
+          }                                                                                                 \
           if (!(RP_ABL & 2)) { RP_READ_A(1, t, 1, PAR_) }                                                   \
           RP_SCHED_FENCE();                                                                                 \
           RP_MFMA6(0, slot_, 0)                                                                             \
           RP_SCHED_FENCE();                                                                                 \
-          if (t + 1 < TT && !(RP_ABL & 2)) { RP_READ_A(0, t + 1, 0, PAR_) }                                 \
+          if (last_) {               /* boundary: everybody's stores are in, nobody reads buffer PAR_ any more */ \
+            if (!(RP_ABL & 8)) __syncthreads();                                                             \
+            if (!(RP_ABL & 2)) { RP_READ_A(0, 0, 0, OTH_) }                                                 \
+          } else if (t + 1 < TT && !(RP_ABL & 2)) { RP_READ_A(0, t + 1, 0, PAR_) }                          \
           RP_SCHED_FENCE();                                                                                 \
           RP_MFMA6(1, slot_, 1)                                                                             \
           RP_SCHED_FENCE();                                                                                 \
@@ -492,9 +509,11 @@ __global__ __launch_bounds__(NT, ((NI == 2 || DEEP) ? 2 : ((COLS4 || TT > 0) ? 3
       }                                                                                                     \
       s0 += TT;                                                                                             \
       ccb = ncb_; cg = ng_;                                                                                 \
-      if (DEEP) { RP_STORE_A(OTH_, OTH_); }            /* the NEXT block's tile, requested one block ago */  \
-      else if (!(RP_ABL & 4)) { RP_STORE_A(OTH_, 0); }                                                      \
-      if (!(RP_ABL & 8)) __syncthreads();                                                                   \
+      if (!OVL) {                                                                                           \
+        if (DEEP) { RP_STORE_A(OTH_, OTH_); }            /* the NEXT block's tile, requested one block ago */  \
+        else if (!(RP_ABL & 4)) { RP_STORE_A(OTH_, 0); }                                                    \
+        if (!(RP_ABL & 8)) __syncthreads();                                                                 \
+      }                                                                                                     \
     }
     // (weight requests first: the activation tile is waited for right away and its wait then covers both; measured neutral)
     if constexpr (DEEP) {
@@ -514,6 +533,7 @@ __global__ __launch_bounds__(NT, ((NI == 2 || DEEP) ? 2 : ((COLS4 || TT > 0) ? 3
     __syncthreads();
     if (RP_ABL & 2) { RP_READ_A(0, 0, 0, 0) RP_READ_A(1, 0, 1, 0) }
     int cg = 0, ccb = 0, s0 = 0, it = 0;
+    if (OVL && !(RP_ABL & 2)) { RP_READ_A(0, 0, 0, 0) }      // first fragments of the first block (later blocks: at the boundary)
     for (; it + 1 < nit; it += 2) {
       RP_BODY(0, 1)
       RP_BODY(1, 0)

@@ -81,9 +81,11 @@ __global__ __launch_bounds__(LM_THREADS) void lm_normal_eq_kernel(const float* _
       const int y = static_cast<int>(tu / static_cast<unsigned>(W)), x = static_cast<int>(tu - static_cast<unsigned>(y) * static_cast<unsigned>(W));
       const float wgt = wgt_[j];
       // zero-weight pixels (the descriptor weight is 0 on the rendered background) add w * (...) = 0 to every sum: a wave
-      // made of such pixels skips the fp64 chain.  Differs from the reference expression only when a zero-weight pixel
-      // carries a non-finite target (0 * NaN = NaN there).
-      if (__builtin_amdgcn_ballot_w64(wgt != 0.f) == 0ull) continue;
+      // made of such pixels skips the fp64 chain -- but only pixels whose target and depth are FINITE count as skippable: in the
+      // reference 0 * NaN = NaN poisons the system and the NaN -> zero-update guard fires (geometry/cholesky.py:43-44); a
+      // lane with a non-finite input keeps its wave in the chain, so that happens here too, whatever the wave is made of.
+      const bool skippable = wgt == 0.f && __builtin_isfinite(tx_[j]) && __builtin_isfinite(ty_[j]) && __builtin_isfinite(dep_[j]);
+      if (__builtin_amdgcn_ballot_w64(!skippable) == 0ull) continue;
       const float Z = dep_[j] + eps;
       float tx = tx_[j], ty = ty_[j];
       if (target_mode != 0) {

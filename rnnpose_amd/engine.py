@@ -35,8 +35,10 @@ class UpdateEngine:
         self.resident_1x1 = os.environ.get("RNNPOSE_RESIDENT_1X1", "1") != "0"    # convc1 through csrc/conv1x1_resident.hip
         # SPLIT TENSORS (include/rnnpose_hip.h): every activation that only feeds further convolutions is written once, by its
         # producer's epilogue, as fp16 hi|lo pairs and staged by the consumers with a plain 16-byte copy (no per-tile re-split).
-        # RNNPOSE_SPLIT_TENSORS=0 restores fp32 activations + on-the-fly splitting (same-box A/B).
-        self.hl = os.environ.get("RNNPOSE_SPLIT_TENSORS", "1") != "0"
+        # MEASURED (r03, profiles/r03_conv_ablation.txt): per layer -1..+3 %, on the step -1.3 % (the two extra split launches per
+        # outer iteration and the second copy of h cost more than the staging saves) -- the vector instructions of the split were
+        # not what bounds the kernel.  Therefore OFF by default; RNNPOSE_SPLIT_TENSORS=1 enables it (tests cover both).
+        self.hl = os.environ.get("RNNPOSE_SPLIT_TENSORS", "0") != "0"
         # tile-shape override per layer for measurements: RNNPOSE_CONV_TILE="zr=3,q=1,heads=2" (0 auto, see conv2d_nhwc)
         self.tile = {}
         for kv in filter(None, os.environ.get("RNNPOSE_CONV_TILE", "").split(",")):

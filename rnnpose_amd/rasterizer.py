@@ -25,8 +25,15 @@ from . import _lib, ops
 
 
 class MeshRenderer:
-    def __init__(self, meshes: dict, device="cuda", pixel_center: float = 0.5, shade: bool = True):
-        """meshes: {class name: dict(verts (P,3) float, faces (F,3) int, colors (P,3) float in [0,1] or None)}."""
+    def __init__(self, meshes: dict, device="cuda", pixel_center: float = 0.5, shade: bool = True,
+                 depth_perspective_correct: bool = True):
+        """meshes: {class name: dict(verts (P,3) float, faces (F,3) int, colors (P,3) float in [0,1] or None)}.
+        depth_perspective_correct: barycentrics of render_depth's nearest-vertex choice.  PyTorch3D resolves
+        RasterizationSettings.perspective_correct=None to True for the PerspectiveCameras the reference builds
+        (geometry/diff_render_optim.py:327-367), so True is the default; False = screen-space barycentrics.
+        Faces with a vertex behind `near` are dropped whole (csrc/raster.hip); PyTorch3D clips them at znear / 2 -- objects are
+        ~0.5-1 m from the camera in every LINEMOD / LM-O frame, so no face is near the plane."""
+        self.depth_perspective_correct = bool(depth_perspective_correct)
         self.device = torch.device(device)
         self.pixel_center = float(pixel_center)
         self.shade = bool(shade)
@@ -113,8 +120,9 @@ class MeshRenderer:
         """(B,1,h,w): camera z of the nearest vertex of the visible face, 0 where empty (diff_render_optim.py:327-367)."""
         bt = self._batch(model_names)
         T, K = self._tk(T, K)
-        ws = self._raster(bt, T, K, render_image_size, near, perspective=False)
-        return self._resolve(bt, T, K, render_image_size, near, False, ws, want_vdepth=True)[2]
+        pc = self.depth_perspective_correct
+        ws = self._raster(bt, T, K, render_image_size, near, perspective=pc)
+        return self._resolve(bt, T, K, render_image_size, near, pc, ws, want_vdepth=True)[2]
 
     def __call__(self, model_names, vert_attribute, T, K, render_image_size, near=0.1, far=6, render_tex=False):
         """vert_attribute: (B or 1, P, C) per-vertex rows (or a list of (P_b, C)) -> (maps (B,[3+]C,h,w), depth (B,1,h,w), -1 = empty)."""

@@ -178,8 +178,8 @@ def test_range_guard_is_visible_in_refiner_output(ops):
     by 1e3 drive activations past +-8188: PoseRefiner's "f16x3_range_events" must be nonzero (and zero for sane weights)."""
     from rnnpose_amd.pose_refiner import PoseRefiner, SyntheticRenderer, default_config
     from rnnpose_amd.transformation import SE3Sequence
-    d = syn.make_inputs(1, 64, 96, seed=4)
-    z3 = torch.zeros(1, 3, 64, 96, device="cuda")
+    d = syn.make_inputs(1, 128, 160, seed=4)
+    z3 = torch.zeros(1, 3, 128, 160, device="cuda")
     rend = SyntheticRenderer(syn_img=z3, image_crop=z3, cfea=D(d["ctx"]), geofea1=D(d["g1"]), geofea2_crop=D(d["g2"]), syn_depth=D(d["depth"]),
                              intrinsics_crop=D(d["K"]), fmap1=D(d["fmap1"]), fmap2=D(d["fmap2"]))
     cfg = default_config(RENDER_ITER_COUNT=1, ITER_COUNT=2, OPTIM_ITER_COUNT=1)

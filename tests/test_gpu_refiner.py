@@ -207,3 +207,29 @@ def test_torch_ops_namespace_runs_the_hip_kernels(ops):
     assert torch.equal(Gn.reshape(-1, 4, 4), G1) and torch.equal(xi, x1)
     Gs, xs = R.lm_step(flow, w, depth, K, G, 1, 100.0, 1e-4, 1.0)
     assert torch.equal(Gs.reshape(-1, 4, 4), G1) and torch.equal(xs, x1)
+
+
+def test_split_tensor_schedule_matches_default(ops, monkeypatch):
+    """RNNPOSE_SPLIT_TENSORS=1 (activations pre-split into fp16 hi|lo by their producers, csrc/conv_igemm.hip HLIN) is the same
+    computation as the default schedule: a 2x3 refinement through hipGraph replay agrees to fp32 round-off (the fp16 operands
+    are bit-identical, only the order of the K sum inside the resident 1x1 kernel's consumer differs)."""
+    from rnnpose_amd import synthetic as syn
+    from rnnpose_amd.pose_refiner import PoseRefiner, SyntheticRenderer, default_config
+    from rnnpose_amd.transformation import SE3Sequence
+    from oracle import rnnpose_oracle as orc
+    d = syn.make_inputs(2, 128, 160, seed=12)
+    D = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    z3 = torch.zeros(2, 3, 128, 160, device="cuda")
+    kw = dict(syn_img=z3, image_crop=z3, cfea=D(d["ctx"]), geofea1=D(d["g1"]), geofea2_crop=D(d["g2"]), syn_depth=D(d["depth"]),
+              intrinsics_crop=D(d["K"]), fmap1=D(d["fmap1"]), fmap2=D(d["fmap2"]))
+    outs = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("RNNPOSE_SPLIT_TENSORS", flag)
+        ref = PoseRefiner(default_config(RENDER_ITER_COUNT=2, ITER_COUNT=3, OPTIM_ITER_COUNT=1), renderer=SyntheticRenderer(**kw)).cuda().eval()
+        ref.cf_net.update_block.load_state_dict({k: torch.from_numpy(v) for k, v in syn.make_module_weights(orc.UPDATE_BLOCK_SHAPES, seed=0).items()})
+        assert ref.cf_net.engine().hl == (flag == "1")
+        for _ in range(2):                      # second call replays the captured graphs
+            out = ref(None, SE3Sequence(matrix=D(d["G0"])), D(d["K"]))
+        outs.append((out["Ti_pred"].G.clone(), out["flow_last"].clone()))
+    assert float((outs[0][0] - outs[1][0]).abs().max()) < 1e-6
+    assert float((outs[0][1] - outs[1][1]).abs().max()) < 5e-5

@@ -79,7 +79,7 @@ def test_raster_matches_oracle(ops):
         want = ro.interpolate(f, w, faces, np.concatenate([cols, attr[b]], 1))
         err = np.abs(out[b].cpu().numpy() - want)[:, both]
         assert np.quantile(err, 0.999) < 1e-4                                   # (a face switch at an edge changes a few pixels)
-        f2, _, w2, vz = ro.rasterize(verts, faces, G[b], K[b], H, W, perspective=False)
+        f2, _, w2, vz = ro.rasterize(verts, faces, G[b], K[b], H, W, perspective=True)      # (render_depth: perspective-correct weights)
         vd = vdepth[b, 0].cpu().numpy()
         both2 = (f2 >= 0) & (vd > 0)
         assert (np.abs(vd - vz)[both2] < 1e-5).mean() > 0.995                   # nearest-vertex ties at w_i == w_j may flip
