@@ -34,10 +34,36 @@ MAX_UPDATE = 1.0          # geometry/cholesky.py:32
 MIN_THETA = 1e-4          # geometry/se3.py:10
 
 
-def _t(x, dtype=torch.float32):
+_DTYPE = torch.float32      # working precision of the restatement (the reference's CPU path is fp32 + fp64 LM)
+
+
+def _t(x, dtype=None):
     if isinstance(x, np.ndarray):
         x = torch.from_numpy(x)
-    return x.to(dtype)
+    return x.to(_DTYPE if dtype is None else dtype)
+
+
+class precision:
+    """`with precision(torch.float64): refine(...)` evaluates the SAME arithmetic in fp64: the value that both fp32
+    evaluations -- this oracle's and the GPU's -- approximate.  Used to put a number on the reference's own fp32 round-off
+    (bench.py's parity block, tools/error_budget.py): two implementations cannot be asked to agree more closely than the
+    reference agrees with its exact self."""
+
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def __enter__(self):
+        global _DTYPE
+        self._old, self._old_default = _DTYPE, torch.get_default_dtype()
+        _DTYPE = self.dtype
+        torch.set_default_dtype(self.dtype)
+        return self
+
+    def __exit__(self, *exc):
+        global _DTYPE
+        _DTYPE = self._old
+        torch.set_default_dtype(self._old_default)
+        return False
 
 
 # --------------------------------------------------------------------------------------------------

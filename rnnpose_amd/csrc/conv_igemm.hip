@@ -387,8 +387,12 @@ __global__ __launch_bounds__(NT, ((NI == 2 || DEEP) ? 2 : ((COLS4 || TT > 0) ? 3
     {                                                                                                       \
       const int st_ = (ST_) < nst ? (ST_) : nst - 1;          /* unconditional: past the end re-reads the last record */ \
       const uint4* q_ = wp + static_cast<long long>(st_) * sstride;                                         \
-      _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                                     \
-          _Pragma("unroll") for (int qq = 0; qq < 4; ++qq) bf[S_][ni][qq] = q_[ni * 256 + qq * 64];         \
+      /* ablation bit 32: only the upper row half of the workgroup (wm == 0) requests weights -- HALF the L1 / TA traffic of  \
+         the weight stream at unchanged everything else (results are wrong): is the stream's bandwidth what costs 20 %? */  \
+      if (!((RP_ABL & 32) && wm == 1)) {                                                                    \
+        _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                                   \
+            _Pragma("unroll") for (int qq = 0; qq < 4; ++qq) bf[S_][ni][qq] = q_[ni * 256 + qq * 64];       \
+      }                                                                                                     \
     }
 #define RP_MMA_KK2(S_, KK_, AB_)                                                                            \
     {                                                                                                       \

@@ -25,15 +25,17 @@ __device__ __forceinline__ void split4(const float4 v, float s, h4& hi, h4& lo) 
   // half an fp16 ulp, so lo carries one more bit and the neglected lo*lo product halves -- per-product error ~2^-22 instead of
   // ~2^-21, same instruction count (two packed converts back instead of four ands).  The r03 ablation
   // showed the split's vector instructions are not what bounds the convolution kernels.
-  // |x*s| > 65504 is clamped in fp32 first (one v_med3_f32 per element; hi = +-65504, lo = 0: saturation, never inf / NaN from
-  // finite inputs -- and counted by the callers: quad_saturates)
-  const float x[4] = {__builtin_amdgcn_fmed3f(v.x * s, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(v.y * s, -65504.f, 65504.f),
-                      __builtin_amdgcn_fmed3f(v.z * s, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(v.w * s, -65504.f, 65504.f)};
-  const h2 h01 = __builtin_convertvector(f32x2{x[0], x[1]}, h2);                           // round to nearest even
-  const h2 h23 = __builtin_convertvector(f32x2{x[2], x[3]}, h2);
+  const float x[4] = {v.x * s, v.y * s, v.z * s, v.w * s};
+  const h2 cap = {static_cast<_Float16>(65504.f), static_cast<_Float16>(65504.f)};
+  h2 h01 = __builtin_convertvector(f32x2{x[0], x[1]}, h2);                                 // round to nearest even; overflow -> inf
+  h2 h23 = __builtin_convertvector(f32x2{x[2], x[3]}, h2);
+  h01 = __builtin_elementwise_max(__builtin_elementwise_min(h01, cap), -cap);              // |x*s| > 65504: clamped (and counted by the callers)
+  h23 = __builtin_elementwise_max(__builtin_elementwise_min(h23, cap), -cap);
   const f32x2 t01 = __builtin_convertvector(h01, f32x2), t23 = __builtin_convertvector(h23, f32x2);
-  const float l[4] = {x[0] - t01.x, x[1] - t01.y, x[2] - t23.x, x[3] - t23.y};             // exact in fp32
-  const h2 q01 = __builtin_convertvector(f32x2{l[0], l[1]}, h2), q23 = __builtin_convertvector(f32x2{l[2], l[3]}, h2);
+  const float l[4] = {x[0] - t01.x, x[1] - t01.y, x[2] - t23.x, x[3] - t23.y};             // exact in fp32 (in range)
+  h2 q01 = __builtin_convertvector(f32x2{l[0], l[1]}, h2), q23 = __builtin_convertvector(f32x2{l[2], l[3]}, h2);
+  q01 = __builtin_elementwise_max(__builtin_elementwise_min(q01, cap), -cap);              // (far out of range: the remainder saturates too --
+  q23 = __builtin_elementwise_max(__builtin_elementwise_min(q23, cap), -cap);              //  never inf / NaN from finite inputs)
   hi = h4{h01.x, h01.y, h23.x, h23.y};
   lo = h4{q01.x, q01.y, q23.x, q23.y};
 }
