@@ -132,6 +132,10 @@ int rnnpose_lm_step_io_f32(const float* target, int target_mode, const float* we
                            int num_iters, double ep_lambda, double lm_lambda, double max_update, void* workspace,
                            size_t workspace_bytes, double* Hm, double* bv, float* xi, int* info,
                            rnnpose_stream_t stream);
+/* The fused steps run ONE launch per Gauss-Newton iteration: the workgroup that arrives last for an image (device-scope ticket
+ * in the workspace, which must therefore be ZERO-FILLED when it is allocated) sums the partial records, solves and updates the
+ * pose.  rnnpose_lm_fused_tail(0) restores the three-launch form (normal equations, finalize, solve) for measurements. */
+int rnnpose_lm_fused_tail(int enable);
 
 /* ---- a11/a12 helpers: batched SE(3) ------------------------- geometry/se3.py:194-209,228-306
  * se3_exp: xi (B,6) -> (B,4,4);  se3_compose: out = A*Bm (B,4,4);  se3_inverse: out = A^-1.        */

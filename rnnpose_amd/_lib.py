@@ -55,6 +55,7 @@ PROTOTYPES = {
     "rnnpose_lm_solve_update_f32": (_i, [_p, _p, _p, _i, _d, _d, _d, _p, _p, _p, _p]),
     "rnnpose_lm_step_f32": (_i, [_p, _i, _p, _p, _f, _p, _p, _i, _i, _i, _i, _d, _d, _d, _p, _z, _p, _p, _p, _p, _p]),
     "rnnpose_lm_step_io_f32": (_i, [_p, _i, _p, _p, _f, _p, _p, _p, _i, _i, _i, _i, _d, _d, _d, _p, _z, _p, _p, _p, _p, _p]),
+    "rnnpose_lm_fused_tail": (_i, [_i]),
     "rnnpose_se3_exp_f32": (_i, [_p, _i, _p, _p]),
     "rnnpose_se3_compose_f32": (_i, [_p, _p, _i, _p, _p]),
     "rnnpose_se3_inverse_f32": (_i, [_p, _i, _p, _p]),

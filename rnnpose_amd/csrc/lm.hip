@@ -35,13 +35,36 @@ __device__ __forceinline__ double shfl_down_f64(double v, int d) {
   return __hiloint2double(hi, lo);
 }
 
+// FUSED tail (r03): the workgroup that arrives LAST for its image (device-scope ticket, one counter per image at the end of
+// the workspace) sums the partial records, damps, solves and updates the pose -- lm_finalize + lm_solve_update without their
+// two launches and kernel boundaries (~13 us + 2 x ~1.5 us per LM step, 48 steps per refinement).  r02 tried "finalize + solve
+// as one 256-thread launch" and lost (the serial fp64 solve waited behind the launch); here it runs in a block that is already
+// resident, while the other images' blocks are still computing.  Hand-off = MI355X_MICROARCH.md's counter form: plain stores ->
+// barrier -> lane-0 agent-scope release (+ asm vmcnt(0)) -> relaxed agent fetch_add; the last arriver: agent-scope acquire ->
+// barrier -> plain loads.  The last arriver resets the counter (zero-initialised with the workspace).
+struct LmTail {
+  int* tickets;                 // (B) arrival counters, zero between launches
+  double* Hm;                   // (B,6,6), (B,6): undamped system, as the unfused path returns it
+  double* bv;
+  const float* G_in;            // pose the Jacobians were built with (may alias G_out)
+  float* G_out;
+  float* xi;
+  int* info;
+  double ep, lm, max_update;
+};
+__device__ void lm_finalize_block_one(const double* __restrict__ partials, int nblk, int b, double* __restrict__ Hm, double* __restrict__ bv);
+__device__ void lm_solve_one(const double* Hm, const double* bv, const float* G, int b, double ep, double lm, double max_update,
+                             float* G_new, float* xi_out, int* info);
+
+template <bool FUSED>
 __global__ __launch_bounds__(LM_THREADS) void lm_normal_eq_kernel(const float* __restrict__ target, int target_mode,
                                                                   const float* __restrict__ weight,
                                                                   const float* __restrict__ depth, float eps,
                                                                   const float* __restrict__ K,
                                                                   const float* __restrict__ G, int H, int W,
-                                                                  double* __restrict__ partials) {
+                                                                  double* __restrict__ partials, const LmTail tail) {
   __shared__ double red[LM_THREADS / 64][NACC];
+  __shared__ int is_last;
   const int b = blockIdx.y;
   const int nblk = gridDim.x;
   const long long P = static_cast<long long>(H) * W;
@@ -139,16 +162,34 @@ __global__ __launch_bounds__(LM_THREADS) void lm_normal_eq_kernel(const float* _
     for (int wv = 1; wv < LM_THREADS / 64; ++wv) v += red[wv][threadIdx.x];
     partials[(static_cast<long long>(b) * nblk + blockIdx.x) * PSTRIDE + threadIdx.x] = v;
   }
+  if constexpr (FUSED) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the compiler may drop the wait behind buffer_wbl2: guide, G16 pitfall)
+      const int t = __hip_atomic_fetch_add(&tail.tickets[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      is_last = (t == nblk - 1) ? 1 : 0;
+      if (is_last) {
+        __hip_atomic_store(&tail.tickets[b], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+    }
+    __syncthreads();
+    if (!is_last) return;
+    lm_finalize_block_one(partials, nblk, b, tail.Hm, tail.bv);   // (ends with the values in global memory, written by this block)
+    __syncthreads();
+    if (threadIdx.x == 0) lm_solve_one(tail.Hm, tail.bv, tail.G_in, b, tail.ep, tail.lm, tail.max_update, tail.G_out, tail.xi, tail.info);
+  }
 }
 
 // sums the block partials in fixed order and expands to full H (6x6) and b (6)
-__device__ __forceinline__ void lm_finalize_block(const double* __restrict__ partials, int nblk, double* __restrict__ Hm,
-                                                  double* __restrict__ bv){
+__device__ void lm_finalize_block_one(const double* __restrict__ partials, int nblk, int b, double* __restrict__ Hm,
+                                      double* __restrict__ bv) {
   // 8 groups of 32 lanes walk the partial records with stride 8 (each load is one coalesced 256-byte record), then
   // the 8 group sums are added in fixed order: deterministic, and 8x shorter than one serial chain per value.
   __shared__ double grp[8][PSTRIDE];
   __shared__ double s[NACC];
-  const int b = blockIdx.x;
   const int k = threadIdx.x & 31, g = threadIdx.x >> 5;
   double v = 0.0;
   for (int i = g; i < nblk; i += 8) v += partials[(static_cast<long long>(b) * nblk + i) * PSTRIDE + k];
@@ -172,7 +213,7 @@ __device__ __forceinline__ void lm_finalize_block(const double* __restrict__ par
 
 __global__ __launch_bounds__(256) void lm_finalize_kernel(const double* __restrict__ partials, int nblk,
                                                           double* __restrict__ Hm, double* __restrict__ bv) {
-  lm_finalize_block(partials, nblk, Hm, bv);
+  lm_finalize_block_one(partials, nblk, blockIdx.x, Hm, bv);
 }
 
 // ---- SE(3) exponential, fp32, same branch structure as geometry/se3.py:228-281 ----
@@ -228,6 +269,7 @@ __device__ void mat4_mul(const float* A, const float* Bm, float* C) {
 // damping, 6x6 Cholesky solve, NaN -> 0, clamp, SE(3) exponential and left increment of image b (one thread)
 __device__ void lm_solve_one(const double* Hm, const double* bv, const float* G, int b, double ep, double lm,
                              double max_update, float* G_new /* may alias G */, float* xi_out, int* info) {
+  // (the fused tail reads H, b that this very thread's block wrote a barrier ago: same CU, same L1 -- plain loads are current)
   double A[6][6], L[6][6], rhs[6], yv[6], xv[6];
   for (int i = 0; i < 6; ++i) {
     for (int j = 0; j < 6; ++j) {
@@ -330,9 +372,23 @@ int launch_normal_eq_partials(const float* target, int target_mode, const float*
                               const float* K, const float* G, int B, int H, int W, void* workspace, hipStream_t st) {
   const long long P = static_cast<long long>(H) * W;
   const int nblk = lm_blocks_per_image(P);
-  hipLaunchKernelGGL(lm_normal_eq_kernel, dim3(nblk, B), dim3(LM_THREADS), 0, st, target, target_mode, weight, depth, eps,
-                     K, G, H, W, static_cast<double*>(workspace));
+  hipLaunchKernelGGL(lm_normal_eq_kernel<false>, dim3(nblk, B), dim3(LM_THREADS), 0, st, target, target_mode, weight, depth, eps,
+                     K, G, H, W, static_cast<double*>(workspace), LmTail{});
   return nblk;
+}
+
+// partial sums + (in the last-arriving workgroup of every image) finalize, damped solve, pose update: ONE launch per LM step
+void launch_lm_step_fused(const float* target, int target_mode, const float* weight, const float* depth, float eps, const float* K,
+                          const float* G_in, float* G_out, int B, int H, int W, double ep, double lm, double max_update,
+                          void* workspace, double* Hm, double* bv, float* xi, int* info, hipStream_t st) {
+  const long long P = static_cast<long long>(H) * W;
+  const int nblk = lm_blocks_per_image(P);
+  LmTail tail{};
+  tail.tickets = reinterpret_cast<int*>(static_cast<double*>(workspace) + static_cast<size_t>(B) * nblk * PSTRIDE);
+  tail.Hm = Hm; tail.bv = bv; tail.G_in = G_in; tail.G_out = G_out; tail.xi = xi; tail.info = info;
+  tail.ep = ep; tail.lm = lm; tail.max_update = max_update;
+  hipLaunchKernelGGL(lm_normal_eq_kernel<true>, dim3(nblk, B), dim3(LM_THREADS), 0, st, target, target_mode, weight, depth, eps,
+                     K, G_in, H, W, static_cast<double*>(workspace), tail);
 }
 
 int launch_normal_eq(const float* target, int target_mode, const float* weight, const float* depth, float eps,
@@ -349,7 +405,16 @@ extern "C" {
 
 size_t rnnpose_lm_workspace_bytes(int B, int H, int W) {
   if (B <= 0 || H <= 0 || W <= 0) return 0;
-  return static_cast<size_t>(B) * lm_blocks_per_image(static_cast<long long>(H) * W) * PSTRIDE * sizeof(double);
+  // partial records + one arrival counter per image (padded to 8 bytes each); the counters must be ZERO before the first fused
+  // step (rnnpose_lm_step_*): allocate the workspace zero-filled.  Every fused launch leaves them at zero.
+  return static_cast<size_t>(B) * lm_blocks_per_image(static_cast<long long>(H) * W) * PSTRIDE * sizeof(double) +
+         static_cast<size_t>(B) * sizeof(double);
+}
+
+static bool g_lm_fused = true;
+int rnnpose_lm_fused_tail(int enable) {          // measurement switch: 0 = three launches per LM step (r02), 1 = one (default)
+  g_lm_fused = enable != 0;
+  return 0;
 }
 
 int rnnpose_lm_normal_eq_f64(const float* target, int target_mode, const float* weight, const float* depth,
@@ -386,6 +451,11 @@ static int lm_step_impl(const char* fn, const float* target, int target_mode, co
   hipStream_t st = rp::as_stream(stream);
   for (int it = 0; it < num_iters; ++it) {
     const float* g = it == 0 ? G_in : G_out;            // later iterations continue in place on the output
+    if (g_lm_fused && info) {
+      launch_lm_step_fused(target, target_mode, weight, depth, depth_eps, K, g, G_out, B, H, W, ep_lambda, lm_lambda, max_update,
+                           workspace, Hm, bv, xi, info, st);
+      continue;
+    }
     launch_normal_eq(target, target_mode, weight, depth, depth_eps, K, g, B, H, W, workspace, Hm, bv, st);
     // (g may alias G_out: each thread reads its whole pose before writing it.  A merged finalize + solve kernel was measured
     //  SLOWER, 26 us vs 7 + 6 us: the solve is a serial fp64 chain that then waits behind the 256-thread reduction's launch)

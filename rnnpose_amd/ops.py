@@ -266,7 +266,7 @@ def _workspace(B, H, W, device, slot=0):
     key = (device, n, slot)
     ws = _ws_cache.get(key)
     if ws is None:
-        ws = torch.empty(n // 8, device=device, dtype=F64)
+        ws = torch.zeros(n // 8, device=device, dtype=F64)      # (zero: the arrival counters of the fused LM step live at its end)
         _ws_cache[key] = ws
     return ws, n
 
@@ -331,6 +331,11 @@ def lm_step(target, weight, depth, K, G, num_iters=1, ep_lambda=100.0, lm_lambda
             int(num_iters), float(ep_lambda), float(lm_lambda), float(max_update), _ptr(ws), n, _ptr(Hm), _ptr(bv),
             _ptr(xi), _ptr(info), _stream(), nbytes=16.0 * B * H * W * int(num_iters), work=200.0 * B * H * W * int(num_iters))
     return G, Hm, bv, xi, info
+
+
+def lm_fused_tail(enable: bool = True):
+    """One launch per LM step (default) or the r02 three-launch form (measurement switch; drop captured graphs when toggling)."""
+    _lib.call("rnnpose_lm_fused_tail", int(bool(enable)))
 
 
 def se3_exp(xi):

@@ -84,10 +84,11 @@ class PoseRefiner(nn.Module):
         # 240x240) the loop is launch-bound, not GPU-bound.  Falls back to eager launches if capture is refused.
         self.use_graph = use_graph
         self.profile_rec = None           # set by profile_first_outer(): record of the instrumented first outer iteration
-        self._graph = None                # inner-iteration graph captured on the caller's tensors (keyed by their addresses)
-        self._graph_static = None         # ... and the one over persistent input copies, once the addresses keep changing
-        self._static_buf = None
-        self._ptr_captures = 0
+        # inner-iteration graphs, one record PER INPUT SHAPE (a partial last evaluation batch followed by a full one must not
+        # evict each other: ADVICE r02): {"gr": graph captured on the caller's tensors (keyed by their addresses), "captures":
+        # how often this shape was re-captured because the addresses moved, "static": the graph over persistent input copies
+        # that takes over once they keep moving, "sbuf": those copies}
+        self._shapes = {}
         self._outer_graphs = {}
         self._outer_captures = 0
         self.loop_timing = None           # set to [] to collect HIP events around the per-half graph replays
@@ -119,10 +120,22 @@ class PoseRefiner(nn.Module):
         return feats1, feats2
 
     def _drop_graphs(self):
-        self._graph = self._graph_static = None
+        self._shapes = {}
         self._outer_graphs = {}
-        self._ptr_captures = 0
         self._outer_captures = 0
+
+    # (compatibility views for tests / tools: the record of the most recently used shape)
+    @property
+    def _ptr_captures(self):
+        return self._last_shape["captures"] if getattr(self, "_last_shape", None) else 0
+
+    @property
+    def _graph_static(self):
+        return self._last_shape["static"] if getattr(self, "_last_shape", None) else None
+
+    @property
+    def _graph(self):
+        return self._last_shape["gr"] if getattr(self, "_last_shape", None) else None
 
     def _refresh(self):
         """Once per forward(): re-pack weights whose parameters changed (load_state_dict, in-place updates, .to()) and
@@ -247,20 +260,27 @@ class PoseRefiner(nn.Module):
         eng = self.cf_net.engine()
         key = (depth.data_ptr(), K.data_ptr(), g1.data_ptr(), g2.data_ptr(), self.cf_net.corr_fn._buf.data_ptr(),
                tuple(depth.shape), n, self.cfg.OPTIM_ITER_COUNT, float(ep_l), float(lm_l), eng.buffer_key(), self._wkey)
-        gr = self._graph
+        skey = key[5:]                          # everything but the addresses: one record per shape
+        rec = self._shapes.get(skey)
+        if rec is None:
+            if len(self._shapes) >= eng.MAX_SETS:      # as many shapes as the engine keeps activation buffer sets for
+                self._shapes.pop(next(iter(self._shapes)))
+            rec = self._shapes[skey] = dict(gr=None, captures=0, static=None, sbuf=None)
+        self._last_shape = rec
+        gr = rec["gr"]
         if gr is None or gr["key"] != key:
-            if self._ptr_captures >= 2:
+            if rec["captures"] >= 2:
                 # the views keep moving (a renderer that allocates fresh tensors every outer iteration): re-capturing per
                 # pointer set would cost more than it saves.  Switch to ONE graph set over persistent input buffers and pay
                 # a device copy of depth / K / descriptors (~0.65 GB at 480x640, B=8: ~0.25 ms) per outer iteration.
-                sb = self._static_inputs(depth, K, g1, g2)
-                skey = ("static",) + key[4:]
-                gr = self._graph_static
-                if gr is None or gr["key"] != skey:
-                    gr = self._capture(skey, sb["depth"], sb["K"], sb["g1"], sb["g2"], G, h, w, ep_l, lm_l, n, static=True)
+                sb = self._static_inputs(rec, depth, K, g1, g2)
+                stkey = ("static",) + key[4:]
+                gr = rec["static"]
+                if gr is None or gr["key"] != stkey:
+                    gr = rec["static"] = self._capture(stkey, sb["depth"], sb["K"], sb["g1"], sb["g2"], G, h, w, ep_l, lm_l, n)
             else:
-                self._ptr_captures += 1
-                gr = self._capture(key, depth, K, g1, g2, G, h, w, ep_l, lm_l, n)
+                rec["captures"] += 1
+                gr = rec["gr"] = self._capture(key, depth, K, g1, g2, G, h, w, ep_l, lm_l, n)
         if gr is None:                         # capture refused: eager launches from now on (use_graph is off)
             return unpack(*self._loop(depth, K, g1, g2, G, h, w, ep_l, lm_l, n))
         gr["G"].copy_(G.reshape(-1, 4, 4))
@@ -289,21 +309,21 @@ class PoseRefiner(nn.Module):
         # copies (the reference returns distinct tensors per iteration): two device copies per OUTER iteration
         return unpack(gr["bufs"]["big"].clone(), gr["bufs"]["small"].clone())
 
-    def _static_inputs(self, depth, K, g1, g2):
-        """Persistent copies of the per-outer-iteration inputs of the inner graph; refreshed when the sources change."""
+    def _static_inputs(self, rec, depth, K, g1, g2):
+        """Persistent copies (per shape record) of the per-outer-iteration inputs of the inner graph; refreshed when the sources change."""
         shapes = (tuple(depth.shape), tuple(K.shape), tuple(g1.shape), tuple(g2.shape))
-        sb = self._static_buf
+        sb = rec["sbuf"]
         if sb is None or sb["shapes"] != shapes:
-            sb = self._static_buf = dict(shapes=shapes, depth=torch.empty_like(depth), K=torch.empty_like(K),
-                                         g1=torch.empty_like(g1), g2=torch.empty_like(g2), src=None)
-            self._graph_static = None
+            sb = rec["sbuf"] = dict(shapes=shapes, depth=torch.empty_like(depth), K=torch.empty_like(K),
+                                    g1=torch.empty_like(g1), g2=torch.empty_like(g2), src=None)
+            rec["static"] = None
         src = (depth.data_ptr(), K.data_ptr(), g1.data_ptr(), g2.data_ptr(), depth._version, K._version, g1._version, g2._version)
         if sb["src"] != src:
             sb["depth"].copy_(depth); sb["K"].copy_(K); sb["g1"].copy_(g1); sb["g2"].copy_(g2)
             sb["src"] = src
         return sb
 
-    def _capture(self, key, depth, K, g1, g2, G, h, w, ep_l, lm_l, n, static=False):
+    def _capture(self, key, depth, K, g1, g2, G, h, w, ep_l, lm_l, n):
         """-> graph record, or None when capture is refused (the caller then runs eager launches).  One hipGraph per batch
         half, each a LINEAR chain captured on the stream it will be replayed on: concurrency between the halves comes from
         the two streams, not from branches inside a graph (a two-branch graph of this length replayed almost serially on
@@ -335,17 +355,12 @@ class PoseRefiner(nn.Module):
                     for _ in self._half_loop(bufs, b0, b1, cap, depth, K, g1, g2, Gs, h, w, ep_l, lm_l, n, len(hv) == 1):
                         pass
                 graphs.append((graph, st))
-            gr = dict(key=key, graphs=graphs, G=Gs, bufs=bufs)
-            if static:
-                self._graph_static = gr
-            else:
-                self._graph = gr
-            return gr
+            return dict(key=key, graphs=graphs, G=Gs, bufs=bufs)
         except Exception as e:                             # noqa: BLE001 -- any capture failure means "run eagerly"
             import warnings
             warnings.warn(f"hipGraph capture of the refinement iterations failed ({e!r}); running eager launches")
             self.use_graph = False
-            self._graph = self._graph_static = None
+            self._shapes = {}
             return None
         finally:
             eng.state_restore(snap)

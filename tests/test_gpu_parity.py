@@ -323,8 +323,18 @@ def test_lm(ops, golden, pat):
     close(G1[:, None], g[f"lm_{pat}_G1"], 1e-5, what="G after 1 step")
     assert int(info.abs().sum()) == 0
     close(xi, orc.lm_solve(N(oH), N(ob)), 1e-6, what="xi oracle")
-    G2, _, _, _, _ = ops.lm_step(D(tgt), D(wgt), depth, K, G, num_iters=2)
+    G2, H2, b2, xi2, info2 = ops.lm_step(D(tgt), D(wgt), depth, K, G, num_iters=2)
     close(G2[:, None], g[f"lm_{pat}_G"], 1e-5, what="G after 2 fused steps")
+    # one launch per step (the last-arriving workgroup of an image finalizes + solves) == the three-launch form, bit for bit,
+    # and the arrival counters are back at zero (a third call gives the same again)
+    ops.lm_fused_tail(False)
+    try:
+        G2u, H2u, b2u, xi2u, info2u = ops.lm_step(D(tgt), D(wgt), depth, K, G, num_iters=2)
+    finally:
+        ops.lm_fused_tail(True)
+    G2b = ops.lm_step(D(tgt), D(wgt), depth, K, G, num_iters=2)[0]
+    assert torch.equal(G2, G2u) and torch.equal(H2, H2u) and torch.equal(b2, b2u) and torch.equal(xi2, xi2u) and torch.equal(info2, info2u)
+    assert torch.equal(G2, G2b)
     if pat == "zero":
         close(G1[:, None], g["G"], 1e-7, what="zero weight leaves the pose unchanged")
     # determinism: two launches give bit-identical sums (fixed-order reduction, no atomics)

@@ -169,6 +169,8 @@ def test_graph_replay_with_alternating_batch_shapes(ops):
             seq.append((out["Ti_pred"].G.clone(), out["flow_last"].clone()))
         res[mode] = seq
         assert torch.equal(seq[0][0], seq[2][0]) and torch.equal(seq[0][1], seq[4][1]) and torch.equal(seq[1][1], seq[3][1])
+        if mode:        # one graph record PER SHAPE -- alternating shapes neither re-capture nor fall back to input copies
+            assert len(ref._shapes) == 2 and all(r["captures"] == 1 and r["static"] is None for r in ref._shapes.values())
     for (Gg, fg), (Ge, fe) in zip(res[True], res[False]):
         assert torch.equal(Gg, Ge) and torch.equal(fg, fe)
     # the single-image result equals image 0 of the batch (images are independent)

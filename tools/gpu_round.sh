@@ -19,6 +19,17 @@ if [ "$2" != "noprof" ]; then
   python bench.py --steps 20 --warmup 3 --no-cpu-baseline --batch 1 --height 240 --width 240 --inner 4 > $OUT/${TAG}_bench_S1.json 2>/dev/null
   python bench.py --steps 5 --warmup 2 --no-cpu-baseline --height 960 --width 1280 > $OUT/${TAG}_bench_S5.json 2>/dev/null
   python bench.py --steps 10 --warmup 2 --no-cpu-baseline --batch 16 > $OUT/${TAG}_bench_B16.json 2>/dev/null
+  python bench.py --steps 10 --warmup 2 --no-cpu-baseline --batch 16 --height 240 --width 240 --inner 4 > $OUT/${TAG}_bench_B16_240.json 2>/dev/null   # configs[2] shape
+  python bench.py --steps 10 --warmup 2 --no-cpu-baseline --batch 32 --height 240 --width 240 --inner 4 > $OUT/${TAG}_bench_B32_240.json 2>/dev/null   # configs[3] shape
+  RNNPOSE_SPLIT_TENSORS=1 python bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/${TAG}_bench_split_tensors.json 2>/dev/null
+  timeout 600 python tools/error_budget.py > $OUT/${TAG}_error_budget.log 2>&1; cp $OUT/error_budget.json $OUT/${TAG}_error_budget.json
+  timeout 900 python tools/parity_probe.py > $OUT/${TAG}_parity_probe.log 2>&1; cp $OUT/parity_probe.json $OUT/${TAG}_parity_probe.json
+  if ls rnnpose_amd/lib/abl_*.so > /dev/null 2>&1; then     # ablation builds (bash tools/conv_ablate.sh 1 2 4 8 16 32 7 31 in the build container)
+    for lib in librnnpose_hip $(ls rnnpose_amd/lib | grep -E '^abl_[0-9]+\.so$' | sed 's/\.so//' | sort -t_ -k2 -n); do
+      echo "== $lib  (RP_ABL bits: 1 no weight loads, 2 no LDS fragment reads, 4 no activation staging, 8 no barrier, 16 no epilogue stores, 32 half the waves request weights)"
+      CONV_LAYERS_FILTER="zr 1x5,q 1x5,heads,convc2,enc l1" CONV_LAYERS_B=4,8,1 RNNPOSE_LIB=$R/rnnpose_amd/lib/$lib.so timeout 200 python tools/conv_layers.py 0 f32,hl1 2>&1 | grep -v amdgpu.ids
+    done > $OUT/${TAG}_conv_ablation.txt
+  fi
   python tools/conv_layers.py > $OUT/${TAG}_conv_layers_alone.txt 2>&1
   python tools/drift_probe.py > $OUT/${TAG}_drift.log 2>&1; cp $OUT/drift_probe.json $OUT/${TAG}_drift.json; tail -1 $OUT/${TAG}_drift.log
   ( cd /tmp && export TMPDIR=/tmp

@@ -59,7 +59,7 @@ torch.cuda.synchronize()
 ref._outer, ref._inner_loop = orig_outer, orig_inner
 ms = [marks[i][1].elapsed_time(marks[i + 1][1]) for i in range(len(marks) - 1)]
 print("in-situ segments (ms):", " ".join(f"{marks[i][0]}>{marks[i+1][0]}:{m:.2f}" for i, m in enumerate(ms[-9:])))
-gr = ref._graph
+gr = ref._graph            # (record of the most recently used shape)
 print("graphs:", [(str(st)) for _, st in gr["graphs"]])
 g0, s0 = gr["graphs"][0]
 g1, s1 = gr["graphs"][1]

@@ -15,6 +15,9 @@ tools/gpu_round.sh runs it ON the GPU box with outdir = gpurun_out/<tag>_summary
   <tag>_pmc_convs.json         the same per convolution launch shape (tools/conv_layers.py, keyed by grid size)
   <tag>_pmc_traffic_bench.json FETCH/WRITE bytes per kernel over one eager bench step
   <tag>_drift.json             free-running 3x8 drift against the fp64 oracle (tools/drift_probe.py)
+  <tag>_conv_ablation.txt      ablation builds of the convolution kernel (tools/conv_ablate.sh): time without weight loads / LDS reads / staging / ...
+  <tag>_error_budget.json      fp64 evaluation vs the fp32 CPU oracle vs the GPU as the feature magnitude grows (tools/error_budget.py)
+  <tag>_parity_probe.json      first-iteration flow of the timed configuration: GPU vs both oracle forms, encoder in / out (tools/parity_probe.py)
   <tag>_pytest_gpu.txt, <tag>_smoke.txt, <tag>_device.txt
   traffic.json                 per-launch HBM bytes bench.py reports as roofline.traffic (regenerated here every round)
 
@@ -65,11 +68,13 @@ def tail(src, dst, n=15):
 
 
 os.makedirs(P, exist_ok=True)
-for suffix in ("bench", "bench_nograph", "bench_S1", "bench_S5", "bench_B16", "drift"):
+for suffix in ("bench", "bench_nograph", "bench_S1", "bench_S5", "bench_B16", "bench_B16_240", "bench_B32_240", "bench_split_tensors", "drift",
+               "error_budget", "parity_probe"):
     src = have(f"{TAG}_{suffix}.json")
     if src and os.path.getsize(src):
         shutil.copy(src, os.path.join(P, f"{TAG}_{suffix}.json"))
-for suffix, n in (("pytest_gpu.log", 12), ("smoke.log", 4), ("device.txt", 5), ("conv_layers_alone.txt", 40), ("drift.log", 60)):
+for suffix, n in (("pytest_gpu.log", 12), ("smoke.log", 4), ("device.txt", 5), ("conv_layers_alone.txt", 40), ("drift.log", 60),
+                  ("conv_ablation.txt", 200)):
     src = have(f"{TAG}_{suffix}")
     if src:
         tail(src, os.path.join(P, f"{TAG}_{suffix.replace('.log', '.txt')}"), n)
@@ -110,10 +115,11 @@ for key, pat in (("conv_igemm", r"^conv_igemm_f16x3_kernel"), ("corr_pyramid_h3"
                             "source": f"profiles/{label} (FETCH_SIZE x2 + WRITE_SIZE, mean over the launches of the kernel)"}
             break
 if traffic:
-    old = {}
+    # the counters describe THESE kernel sources: bench.py refuses the file when the digest differs from the tree it runs on
+    sys.path.insert(0, ROOT)
+    from rnnpose_amd import build as _build
+    traffic["csrc_digest"] = _build.source_digest()
+    traffic["round"] = TAG
     tp = os.path.join(P, "traffic.json")
-    if os.path.exists(tp):
-        old = {k: v for k, v in json.load(open(tp)).items() if isinstance(v, dict)}
-    old.update(traffic)
-    json.dump(old, open(tp, "w"), indent=1)
-    print("traffic.json:", {k: v["bytes_per_launch"] for k, v in old.items()})
+    json.dump(traffic, open(tp, "w"), indent=1)
+    print("traffic.json:", {k: v["bytes_per_launch"] for k, v in traffic.items() if isinstance(v, dict)})
