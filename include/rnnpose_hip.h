@@ -191,7 +191,7 @@ typedef struct {
   float* dst2;
   int dst2_c_stride, dst2_c_offset;
   int gru_c;
-  float* tile_stats;           /* optional (NULL = off), linear epilogue only: (B * tiles_per_image, c_out, 2) fp32 receives, per
+  double* tile_stats;          /* optional (NULL = off), linear epilogue only: (B * tiles_per_image, c_out, 2) FP64 receives, per
                                   128-row output tile, the column sums and sums of squares of the outputs (bias included)
                                   -- the instance-norm statistics pass of the encoder without re-reading the tensor
                                   (rnnpose_instnorm_tiles_nhwc_f32).  With tile_stats (or src0_mean_rstd) the output rows
@@ -254,7 +254,7 @@ int rnnpose_stem_pack_weights_f16x3(const float* w_oihw, float w_scale, void* w_
 int rnnpose_stem_tiles(int H, int W, int* h_tiles_per_image, int* h_exact);
 int rnnpose_stem_conv7x7_s2_f16x3(const float* img_nchw, int N, int H, int W, int normalize, const void* w_hi,
                                   const void* w_lo, const float* bias, float a_scale, float w_scale, float* out_nhwc,
-                                  float* tile_stats, rnnpose_stream_t stream);
+                                  double* tile_stats, rnnpose_stream_t stream);
 
 /* ---- NHWC companions of the fused update-block engine ----------------------------------------------------
  * corr_lookup_nhwc: a3 with the output laid out (B,h,w,levels*81) (thirdparty/raft/corr.py:36-57).
@@ -339,7 +339,7 @@ int rnnpose_instnorm_nhwc_f32(const float* x, int B, int HW, int C, float eps, i
  * residual_relu] is applied on the fly: out = relu(act_r((residual - mean_r) * rstd_r) + act((x - mean) * rstd)) -- the
  * stem output / the down-sampling branch of a ResidualBlock are then never written in normalised form (extractor.py:54-58). */
 int rnnpose_instnorm_tiles_nhwc_f32(const float* x, int B, int HW, int C, float eps, int relu, const float* residual,
-                                    const float* residual_mean_rstd, int residual_relu, const float* tile_stats,
+                                    const float* residual_mean_rstd, int residual_relu, const double* tile_stats,
                                     int tiles_per_image, float* mean_rstd, float* out,
                                     rnnpose_stream_t stream);
 

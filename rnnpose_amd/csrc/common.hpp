@@ -31,6 +31,13 @@ constexpr float kMinDepthValid = 0.1f;   // geometry/transformation.py:16
 constexpr float kMinDepthProj = 0.01f;   // geometry/projective_ops.py:9
 constexpr float kMinTheta = 1e-4f;       // geometry/se3.py:10
 
+__device__ __forceinline__ double shfl_xor_f64(double v, int o) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __shfl_xor(lo, o);
+  hi = __shfl_xor(hi, o);
+  return __hiloint2double(hi, lo);
+}
+
 struct Intr {
   float fx, fy, cx, cy;
 };

@@ -69,7 +69,7 @@ struct KParams {
   float* dst2;
   int dst2_cs, dst2_co;
   int gru_c;
-  float* tstats;   // optional per-tile column statistics (linear epilogue)
+  double* tstats;  // optional per-tile column statistics (linear epilogue), fp64: sum, sum of squares
   const float* addm;   // optional per-pixel bias map (NHWC), added before the epilogue
   int addm_cs, addm_co;
   int tpi;             // > 0: M is tiled PER IMAGE (tpi tiles of 128 rows each, the last one ragged): no tile straddles two images
@@ -578,7 +578,10 @@ __global__ __launch_bounds__(NT, ((NI == 2 || DEEP) ? 2 : ((COLS4 || TT > 0) ? 3
   __syncthreads();
   constexpr int ES = 32 * NI + 4;                       // row stride (floats) of the staging tile
   constexpr int F4 = 8 * NI;                            // float4 per tile row
-  float ts0 = 0.f, ts1 = 0.f, ts2 = 0.f, ts3 = 0.f, tq0 = 0.f, tq1 = 0.f, tq2 = 0.f, tq3 = 0.f;   // tile statistics of this lane's column quad
+  // tile statistics of this lane's column quad, in fp64 (r03): the instance norm takes var = E[x^2] - mean^2, and the encoder's
+  // first layers see an almost constant image (2 (x / 255) - 1 of a [0,1] image: model/CFNet.py:42-43), mean^2 / var up to 2e3 --
+  // fp32 sums lost 4-5 digits of the variance there and were the largest single source of the GPU's distance to the oracle
+  double ts0 = 0., ts1 = 0., ts2 = 0., ts3 = 0., tq0 = 0., tq1 = 0., tq2 = 0., tq3 = 0.;
   float* S = reinterpret_cast<float*>(&sA[0][0][0]) + wave * (32 * ES);    // 4 x 32 x 68 floats = 34.8 KB <= 43.5 KB
   const int colw = n0 + wn * (32 * NI);
   // Every lane works on ONE column quad (64 % F4 == 0): its bias is loaded once.  Per 32-row block (mi) the epilogue operands of
@@ -650,10 +653,11 @@ __global__ __launch_bounds__(NT, ((NI == 2 || DEEP) ? 2 : ((COLS4 || TT > 0) ? 3
       int dch = p.dst_co + col;
       int dhl = p.dst_hl;
       if (p.tstats) {              // (column quad of a lane is the same for every k and mi: 64 % F4 == 0)
-        if (nv > 0) { ts0 += y[0]; tq0 += y[0] * y[0]; }
-        if (nv > 1) { ts1 += y[1]; tq1 += y[1] * y[1]; }
-        if (nv > 2) { ts2 += y[2]; tq2 += y[2] * y[2]; }
-        if (nv > 3) { ts3 += y[3]; tq3 += y[3] * y[3]; }
+        const double y0 = y[0], y1 = y[1], y2 = y[2], y3 = y[3];
+        if (nv > 0) { ts0 += y0; tq0 += y0 * y0; }
+        if (nv > 1) { ts1 += y1; tq1 += y1 * y1; }
+        if (nv > 2) { ts2 += y2; tq2 += y2 * y2; }
+        if (nv > 3) { ts3 += y3; tq3 += y3 * y3; }
       }
       if (p.epi == 1) {
 #pragma unroll
@@ -692,37 +696,37 @@ __global__ __launch_bounds__(NT, ((NI == 2 || DEEP) ? 2 : ((COLS4 || TT > 0) ? 3
     // (wm = 1) through LDS; one (sum, sum of squares) pair per tile and column: deterministic, no atomics
 #pragma unroll
     for (int o = F4; o < 64; o <<= 1) {
-      ts0 += __shfl_xor(ts0, o); ts1 += __shfl_xor(ts1, o); ts2 += __shfl_xor(ts2, o); ts3 += __shfl_xor(ts3, o);
-      tq0 += __shfl_xor(tq0, o); tq1 += __shfl_xor(tq1, o); tq2 += __shfl_xor(tq2, o); tq3 += __shfl_xor(tq3, o);
+      ts0 += rp::shfl_xor_f64(ts0, o); ts1 += rp::shfl_xor_f64(ts1, o); ts2 += rp::shfl_xor_f64(ts2, o); ts3 += rp::shfl_xor_f64(ts3, o);
+      tq0 += rp::shfl_xor_f64(tq0, o); tq1 += rp::shfl_xor_f64(tq1, o); tq2 += rp::shfl_xor_f64(tq2, o); tq3 += rp::shfl_xor_f64(tq3, o);
     }
     if (COLS4) {                       // a wave owns all 128 rows of its 32 columns: nothing to combine
       if (lane < F4) {
         const int col = colw + lane * 4;
-        const float ts[4] = {ts0, ts1, ts2, ts3}, tq[4] = {tq0, tq1, tq2, tq3};
+        const double ts[4] = {ts0, ts1, ts2, ts3}, tq[4] = {tq0, tq1, tq2, tq3};
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           if (col + e < p.Cout) {
-            float* o = p.tstats + (static_cast<long long>(mt_i) * p.Cout + col + e) * 2;
+            double* o = p.tstats + (static_cast<long long>(mt_i) * p.Cout + col + e) * 2;
             o[0] = ts[e];
             o[1] = tq[e];
           }
       }
     } else {
-      float* TS = reinterpret_cast<float*>(&sA[0][0][0]) + 4 * (32 * ES);      // behind the four staging tiles
+      double* TS = reinterpret_cast<double*>(reinterpret_cast<float*>(&sA[0][0][0]) + 4 * (32 * ES));      // behind the four staging tiles (8-byte aligned: 32 * ES is even)
       __syncthreads();
       if (lane < F4) {
-        float* t = TS + (wave * F4 + lane) * 8;
+        double* t = TS + (wave * F4 + lane) * 8;
         t[0] = ts0; t[1] = ts1; t[2] = ts2; t[3] = ts3; t[4] = tq0; t[5] = tq1; t[6] = tq2; t[7] = tq3;
       }
       __syncthreads();
       if (wm == 0 && lane < F4) {
-        const float* t0 = TS + (wave * F4 + lane) * 8;
-        const float* t1 = TS + ((wave + 2) * F4 + lane) * 8;
+        const double* t0 = TS + (wave * F4 + lane) * 8;
+        const double* t1 = TS + ((wave + 2) * F4 + lane) * 8;
         const int col = colw + lane * 4;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           if (col + e < p.Cout) {
-            float* o = p.tstats + (static_cast<long long>(mt_i) * p.Cout + col + e) * 2;
+            double* o = p.tstats + (static_cast<long long>(mt_i) * p.Cout + col + e) * 2;
             o[0] = t0[e] + t1[e];
             o[1] = t0[4 + e] + t1[4 + e];
           }

@@ -337,7 +337,7 @@ __global__ void instnorm_finalize_kernel(const double* __restrict__ part, float*
 }
 
 // statistics from the producing convolution's per-tile (sum, sum of squares) pairs: tile_stats (B * tiles_per_image, C, 2)
-__global__ __launch_bounds__(256) void instnorm_finalize_tiles_kernel(const float* __restrict__ tile_stats,
+__global__ __launch_bounds__(256) void instnorm_finalize_tiles_kernel(const double* __restrict__ tile_stats,
                                                                       float* __restrict__ mean_rstd, int tiles_per_image,
                                                                       int C, int HW, float eps) {
   // grid (B, ceil(C/8)): 8 channels x 32 tile groups per workgroup; group g sums tiles g, g+32, ... (fixed order), the
@@ -347,10 +347,10 @@ __global__ __launch_bounds__(256) void instnorm_finalize_tiles_kernel(const floa
   const int b = blockIdx.x, cl = threadIdx.x & 7, c = blockIdx.y * 8 + cl, g = threadIdx.x >> 3;
   double t1 = 0, t2 = 0;
   if (c < C) {
-    const float* p = tile_stats + (static_cast<long long>(b) * tiles_per_image * C + c) * 2;
+    const double* p = tile_stats + (static_cast<long long>(b) * tiles_per_image * C + c) * 2;
 #pragma unroll 4
     for (int k = g; k < tiles_per_image; k += 32) {
-      const float2 v = *reinterpret_cast<const float2*>(p + static_cast<long long>(k) * C * 2);
+      const double2 v = *reinterpret_cast<const double2*>(p + static_cast<long long>(k) * C * 2);
       t1 += v.x;
       t2 += v.y;
     }
@@ -633,7 +633,7 @@ int rnnpose_instnorm_nhwc_f32(const float* x, int B, int HW, int C, float eps, i
 
 
 int rnnpose_instnorm_tiles_nhwc_f32(const float* x, int B, int HW, int C, float eps, int relu, const float* residual,
-                                    const float* residual_mean_rstd, int residual_relu, const float* tile_stats,
+                                    const float* residual_mean_rstd, int residual_relu, const double* tile_stats,
                                     int tiles_per_image, float* mean_rstd, float* out, rnnpose_stream_t stream) {
   const char* fn = "rnnpose_instnorm_tiles_nhwc_f32";
   RP_REQUIRE(tile_stats && mean_rstd && (x || !out), fn, "null pointer");

@@ -36,7 +36,7 @@ __host__ __device__ constexpr int koff(int k) {    // patch offset of GEMM-k ind
 __global__ __launch_bounds__(256) void stem_conv7x7_s2_kernel(const float* __restrict__ img, int normalize,
                                                               const uint4* __restrict__ whi, const uint4* __restrict__ wlo,
                                                               const float* __restrict__ bias, float a_scale, float out_scale,
-                                                              float* __restrict__ out, float* __restrict__ tstats, int H,
+                                                              float* __restrict__ out, double* __restrict__ tstats, int H,
                                                               int W, int Ho, int Wo, int tiles_x, int tiles_y,
                                                               unsigned long long* sat) {
 #pragma clang fp contract(off)
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void stem_conv7x7_s2_kernel(const float* __res
   // HBM -> LDS -> gather -> MFMA -> LDS -> stores); with the original 46 KB only 3 were resident and it ran at a third
   // of its HBM bound
   __shared__ __attribute__((aligned(16))) float smem[4 * 16 * ES];
-  __shared__ float tsum[4][16][8];
+  __shared__ double tsum[4][16][8];
   static_assert(4 * 16 * ES >= PATCH + 5, "staging buffer must hold the patch");
   float* const patch = smem;
   float* const stage = smem;
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void stem_conv7x7_s2_kernel(const float* __res
   float* S = stage + wave * (16 * ES);
   const int cq = (lane & 15) * 4;                          // this lane's column quad, the same for every row it stores
   const float4 b4 = *reinterpret_cast<const float4*>(bias + cq);
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
+  double s0 = 0., s1 = 0., s2 = 0., s3 = 0., q0 = 0., q1 = 0., q2 = 0., q3 = 0.;
 #pragma unroll
   for (int hf = 0; hf < 2; ++hf) {
 #pragma unroll
@@ -145,8 +145,9 @@ __global__ __launch_bounds__(256) void stem_conv7x7_s2_kernel(const float* __res
       if (oy >= Ho || ox >= Wo) continue;
       float4 y = *reinterpret_cast<const float4*>(S + rl * ES + cq);
       y.x += b4.x; y.y += b4.y; y.z += b4.z; y.w += b4.w;
-      s0 += y.x; s1 += y.y; s2 += y.z; s3 += y.w;
-      q0 += y.x * y.x; q1 += y.y * y.y; q2 += y.z * y.z; q3 += y.w * y.w;
+      const double d0 = y.x, d1 = y.y, d2 = y.z, d3 = y.w;         // fp64 statistics (csrc/conv_igemm.hip: the stem sees an almost constant image)
+      s0 += d0; s1 += d1; s2 += d2; s3 += d3;
+      q0 += d0 * d0; q1 += d1 * d1; q2 += d2 * d2; q3 += d3 * d3;
       *reinterpret_cast<float4*>(out + ((static_cast<long long>(n) * Ho + oy) * Wo + ox) * CO + cq) = y;
     }
     __builtin_amdgcn_wave_barrier();
@@ -155,16 +156,16 @@ __global__ __launch_bounds__(256) void stem_conv7x7_s2_kernel(const float* __res
     // lanes sharing a column quad (same lane & 15): fixed-order butterfly, then the 4 waves through LDS in order
 #pragma unroll
     for (int o = 16; o < 64; o <<= 1) {
-      s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); s3 += __shfl_xor(s3, o);
-      q0 += __shfl_xor(q0, o); q1 += __shfl_xor(q1, o); q2 += __shfl_xor(q2, o); q3 += __shfl_xor(q3, o);
+      s0 += rp::shfl_xor_f64(s0, o); s1 += rp::shfl_xor_f64(s1, o); s2 += rp::shfl_xor_f64(s2, o); s3 += rp::shfl_xor_f64(s3, o);
+      q0 += rp::shfl_xor_f64(q0, o); q1 += rp::shfl_xor_f64(q1, o); q2 += rp::shfl_xor_f64(q2, o); q3 += rp::shfl_xor_f64(q3, o);
     }
     if (lane < 16) {
-      float* p = tsum[wave][lane];
+      double* p = tsum[wave][lane];
       p[0] = s0; p[1] = s1; p[2] = s2; p[3] = s3; p[4] = q0; p[5] = q1; p[6] = q2; p[7] = q3;
     }
     __syncthreads();
     if (tid < 16) {
-      float* o = tstats + (static_cast<long long>(blockIdx.x) * CO + tid * 4) * 2;
+      double* o = tstats + (static_cast<long long>(blockIdx.x) * CO + tid * 4) * 2;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         o[2 * e + 0] = ((tsum[0][tid][e] + tsum[1][tid][e]) + tsum[2][tid][e]) + tsum[3][tid][e];
@@ -212,7 +213,7 @@ int rnnpose_stem_tiles(int H, int W, int* tiles_per_image, int* exact) {
 
 int rnnpose_stem_conv7x7_s2_f16x3(const float* img_nchw, int N, int H, int W, int normalize, const void* w_hi,
                                   const void* w_lo, const float* bias, float a_scale, float w_scale, float* out_nhwc,
-                                  float* tile_stats, rnnpose_stream_t stream) {
+                                  double* tile_stats, rnnpose_stream_t stream) {
   const char* fn = "rnnpose_stem_conv7x7_s2_f16x3";
   RP_REQUIRE(img_nchw && w_hi && w_lo && bias && out_nhwc, fn, "null pointer");
   RP_REQUIRE(N > 0 && H > 0 && W > 0 && a_scale > 0.f && w_scale > 0.f, fn, "bad size / scale");

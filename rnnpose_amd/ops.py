@@ -465,9 +465,9 @@ def conv2d_nhwc(pc: PackedConv, srcs, dst, epilogue: int = EPI_LINEAR, aux0=None
     if tile_stats is not None:
         # (B * ceil(HWout/128), c_out, 2) fp32: per-tile column sums / sums of squares for instnorm_tiles_nhwc
         tpi = -(-((-(-H // stride)) * (-(-W // stride))) // 128)
-        if not (tile_stats.is_cuda and tile_stats.dtype == F32 and tile_stats.is_contiguous()
+        if not (tile_stats.is_cuda and tile_stats.dtype == F64 and tile_stats.is_contiguous()
                 and tile_stats.numel() >= B * tpi * pc.c_out * 2):
-            raise ValueError("tile_stats must be a contiguous fp32 CUDA tensor of (B * ceil(H_out*W_out/128), c_out, 2)")
+            raise ValueError("tile_stats must be a contiguous FP64 CUDA tensor of (B * ceil(H_out*W_out/128), c_out, 2)")
         d.tile_stats = tile_stats.data_ptr()
     if in_norm is not None:          # (B, C_src, 2) mean / rstd of source 0: read relu((x - mean) * rstd) instead of x
         if not (in_norm.is_cuda and in_norm.dtype == F32 and in_norm.is_contiguous() and tuple(in_norm.shape) == (B, srcs[0][0].shape[3], 2)):
@@ -775,7 +775,7 @@ def stem_conv(ps: PackedStem, img, normalize: bool = True):
     tiles, exact = C.c_int(0), C.c_int(0)
     _lib.call("rnnpose_stem_tiles", H, W, C.byref(tiles), C.byref(exact))
     out = torch.empty(N, Ho, Wo, 64, device=img.device, dtype=F32)
-    ts = torch.empty(N * tiles.value, 64, 2, device=img.device, dtype=F32) if exact.value else None
+    ts = torch.empty(N * tiles.value, 64, 2, device=img.device, dtype=F64) if exact.value else None      # fp64 sums (cancellation in E[x^2] - mean^2)
     _launch("rnnpose_stem_conv7x7_s2_f16x3", _ptr(img), N, H, W, int(bool(normalize)), _ptr(ps.w_hi), _ptr(ps.w_lo),
             _ptr(ps.bias), ps.a_scale, ps.w_scale, _ptr(out), _ptr(ts), _stream(), work=2.0 * N * Ho * Wo * 64 * 147)
     return out, ts

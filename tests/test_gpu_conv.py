@@ -227,7 +227,7 @@ def test_conv_tile_stats_feed_instnorm(ops, B, H, W, cin, cout, k, stride):
     Ho, Wo = -(-H // stride), -(-W // stride)
     assert (Ho * Wo) % 128 == 0
     out = torch.empty(B, Ho, Wo, cout, device="cuda")
-    ts = torch.full((B * Ho * Wo // 128, cout, 2), -1.0, device="cuda")
+    ts = torch.full((B * Ho * Wo // 128, cout, 2), -1.0, device="cuda", dtype=torch.float64)      # fp64 tile statistics
     ops.conv2d_nhwc(pc, [(nhwc(D(x)), 0)], (out, 0), ops.EPI_LINEAR, stride=stride, tile_stats=ts)
     y64 = F.conv2d(D(x).double(), D(w).double(), D(b).double(), stride=stride, padding=k // 2)
     rows = y64.permute(0, 2, 3, 1).reshape(-1, 128, cout)                       # tiles of 128 consecutive pixels
@@ -252,7 +252,7 @@ def test_conv_per_image_tiles_and_fused_input_norm(ops, B, H, W, cin, cout):
     p1, p2 = ops.PackedConv(D(w1), D(b1), [cin]), ops.PackedConv(D(w2), D(b2), [cout if False else cin])
     tpi = -(-(H * W) // 128)
     c1 = torch.empty(B, H, W, cin, device="cuda")
-    ts = torch.full((B * tpi, cin, 2), -1.0, device="cuda")
+    ts = torch.full((B * tpi, cin, 2), -1.0, device="cuda", dtype=torch.float64)
     ops.conv2d_nhwc(p1, [(nhwc(D(x)), 0)], (c1, 0), ops.EPI_LINEAR, tile_stats=ts)
     y64 = F.conv2d(D(x).double(), D(w1).double(), D(b1).double(), padding=1)
     n64 = F.relu(F.instance_norm(y64, eps=1e-5))

@@ -562,6 +562,29 @@ def test_encoder_stem_kernel(ops, N, H, W):
             assert ((H + 1) // 2) % 8 or ((W + 1) // 2) % 16
 
 
+def test_stem_statistics_on_a_nearly_constant_image(ops):
+    """The reference feeds [0,1] images through 2 (x / 255) - 1 (model/CFNet.py:42-43): the stem sees an almost constant -1
+    image, its outputs have mean^2 / var up to ~2e3, and instance norm's var = E[x^2] - mean^2 cancels 3-4 digits.  With fp64
+    tile sums (r03) the normalised stem output stays at fp32 round-off of the fp64 reference."""
+    import torch.nn.functional as F
+    N, H, W = 2, 128, 192
+    img = D(syn.uniform("img01", (N, 3, H, W), 13, 0.0, 1.0))
+    wt = D(syn.normal("w", (64, 3, 7, 7), 13, std=0.08) + 0.02)              # weights with a non-zero sum: large output mean
+    bias = D(syn.uniform("b", (64,), 13, -0.5, 0.5))
+    out, ts = ops.stem_conv(ops.PackedStem(wt, bias), img, normalize=True)
+    assert ts is not None and ts.dtype == torch.float64
+    y64 = F.conv2d(2 * (img.double() / 255.0) - 1.0, wt.double(), bias.double(), stride=2, padding=3)
+    ratio = float((y64.mean((2, 3)) ** 2 / y64.var((2, 3), unbiased=False)).max())
+    assert ratio > 1e3, ratio                                               # the regime this test is about
+    got = ops.instnorm_tiles_nhwc(out, ts, relu=False)
+    want = F.instance_norm(y64, eps=1e-5).permute(0, 2, 3, 1)
+    # the convolution's own fp32-class error (~1e-7 of |y|) is amplified by rstd ~ 1/sqrt(var) exactly as in the fp32 reference
+    ref32 = F.instance_norm(F.conv2d(2 * (img / 255.0) - 1.0, wt, bias, stride=2, padding=3).double(), eps=1e-5).permute(0, 2, 3, 1)
+    err, err32 = float((got.double() - want).abs().max()), float((ref32 - want).abs().max())
+    print(f"mean^2/var {ratio:.0f}: normalised stem output error {err:.2e} (fp32 convolution + exact statistics: {err32:.2e})")
+    assert err <= max(4 * err32, 5e-6), (err, err32)
+
+
 # ------------------------------------------------------------------------------------------------ a5/a12
 def _renderer(d):
     from rnnpose_amd.pose_refiner import SyntheticRenderer
