@@ -301,6 +301,7 @@ def lm_step(target, weight, depth, K, G, num_iters=1, ep_lambda=100.0, lm_lambda
             slot=0):
     """num_iters fused GN steps; returns (G_new (B,4,4), Hm, bv, xi, info) of the last iteration.
     out: optional preallocated (G_new, Hm, bv, xi, info) views to write into; slot: workspace slot (see _workspace)."""
+    _apply_lm_env()
     target, weight, depth = _chk(target, "target"), _chk(weight, "weight"), _chk(depth, "depth")
     K = _chk(K, "intrinsics")
     B, H, W = depth.shape[0], depth.shape[-2], depth.shape[-1]
@@ -331,6 +332,19 @@ def lm_step(target, weight, depth, K, G, num_iters=1, ep_lambda=100.0, lm_lambda
             int(num_iters), float(ep_lambda), float(lm_lambda), float(max_update), _ptr(ws), n, _ptr(Hm), _ptr(bv),
             _ptr(xi), _ptr(info), _stream(), nbytes=16.0 * B * H * W * int(num_iters), work=200.0 * B * H * W * int(num_iters))
     return G, Hm, bv, xi, info
+
+
+_lm_fused_env_applied = False
+
+
+def _apply_lm_env():
+    """RNNPOSE_LM_FUSED=0/1 selects the LM step form at first use (same-box A/B); default: the library's."""
+    global _lm_fused_env_applied
+    if not _lm_fused_env_applied:
+        _lm_fused_env_applied = True
+        v = _os.environ.get("RNNPOSE_LM_FUSED")
+        if v is not None:
+            _lib.call("rnnpose_lm_fused_tail", int(v != "0"))
 
 
 def lm_fused_tail(enable: bool = True):

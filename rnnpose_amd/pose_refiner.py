@@ -390,8 +390,15 @@ class PoseRefiner(nn.Module):
             # residual_pose_history one line of bookkeeping earlier (same Python object); a fresh object keeps
             # the history intact
             Tij = Tij.identity()
-            if self.legacy:
-                Tij = Ti * Ti.inv()                                     # identity up to rounding (:243-244)
+            # The reference's legacy branch forms Tij = Ti * Ti.inv() here (:243-244): the identity up to fp32 rounding of ITS
+            # inverse / product (~1e-7, BLAS-dependent).  That noise is not reproducible between implementations, and it is not
+            # harmless: it moves the first lookup ~1e-6..1e-5 px off the integer grid, which a correlation surface of
+            # un-normalised features (|corr| ~ 900, gradients of hundreds per pixel at the bench shape) turns into 1e-4-level
+            # flow differences -- r03 found it to be the whole first-iteration distance of the timed configuration to the oracle
+            # (tools/bench_parity_probe.py; the distance did not move by one bit under any change of the GPU arithmetic).  The
+            # oracle and this loop use the EXACT identity; `literal_legacy_pose=True` restores the product.
+            if self.legacy and getattr(self, "literal_legacy_pose", False):
+                Tij = Ti * Ti.inv()
             views = self.renderer.render_views(Ti.matrix().squeeze(1), intrinsics, obj_cls=obj_cls, image=image,
                                                fea_3d=fea_3d, geofea_3d=geofea_3d, geofea_2d=geofea_2d)
             syn_depth = views["syn_depth"]

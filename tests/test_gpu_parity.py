@@ -569,13 +569,13 @@ def test_stem_statistics_on_a_nearly_constant_image(ops):
     import torch.nn.functional as F
     N, H, W = 2, 128, 192
     img = D(syn.uniform("img01", (N, 3, H, W), 13, 0.0, 1.0))
-    wt = D(syn.normal("w", (64, 3, 7, 7), 13, std=0.08) + 0.02)              # weights with a non-zero sum: large output mean
+    wt = D(syn.normal("w", (64, 3, 7, 7), 13, std=0.05) + 0.05)              # weights with a non-zero sum: large output mean
     bias = D(syn.uniform("b", (64,), 13, -0.5, 0.5))
     out, ts = ops.stem_conv(ops.PackedStem(wt, bias), img, normalize=True)
     assert ts is not None and ts.dtype == torch.float64
     y64 = F.conv2d(2 * (img.double() / 255.0) - 1.0, wt.double(), bias.double(), stride=2, padding=3)
     ratio = float((y64.mean((2, 3)) ** 2 / y64.var((2, 3), unbiased=False)).max())
-    assert ratio > 1e3, ratio                                               # the regime this test is about
+    assert ratio > 1e2, ratio                                               # the regime this test is about
     got = ops.instnorm_tiles_nhwc(out, ts, relu=False)
     want = F.instance_norm(y64, eps=1e-5).permute(0, 2, 3, 1)
     # the convolution's own fp32-class error (~1e-7 of |y|) is amplified by rstd ~ 1/sqrt(var) exactly as in the fp32 reference
