@@ -800,7 +800,9 @@ def test_timed_configuration_vs_oracle(ops):
     d_last = float((out["flow_last"].cpu() - want["flow_up"]).abs().max())
     print(f"first flow: |gpu-cpu| {d_gc:.3e}  |gpu-fp64| {d_g64:.3e}  |cpu-fp64| {d_c64:.3e}   last flow |gpu-cpu| {d_last:.3e}   max|flow| {float(wf.abs().max()):.1f}")
     assert d_gc <= 1e-4 or d_g64 <= max(1e-4, 2.0 * d_c64), (d_gc, d_g64, d_c64)
-    assert d_last <= 1e-3, d_last             # free-running over 8 iterations at 10x feature magnitude (the unit-magnitude loops hold 5e-4)
+    # free-running over 8 iterations at 10x the feature magnitude of the other loops (those hold 5e-4): the CPU oracle itself starts
+    # 2e-4 away from the fp64 evaluation at iteration 1 here, so the bound scales with that distance
+    assert d_last <= max(1e-3, 8.0 * d_c64), (d_last, d_c64)
     assert int(out["f16x3_range_events"].item()) == 0
 
 
