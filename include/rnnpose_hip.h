@@ -195,7 +195,7 @@ typedef struct {
                                   128-row output tile, the column sums and sums of squares of the outputs (bias included)
                                   -- the instance-norm statistics pass of the encoder without re-reading the tensor
                                   (rnnpose_instnorm_tiles_nhwc_f32).  With tile_stats (or src0_mean_rstd) the output rows
-                                  are tiled PER IMAGE: tiles_per_image = ceil(H_out*W_out / 128), the last tile of an
+                                  are tiled PER IMAGE: tiles_per_image = rnnpose_conv_tiles_per_image(...), the last tile of an
                                   image ragged, so no tile straddles two images. */
   const float* add_map;        /* optional (NULL = off): NHWC tensor added to y before the epilogue, y += add_map[pixel,
                                   add_c_offset + n] -- a per-pixel bias.  Used to hoist the part of a convolution whose input
@@ -225,6 +225,12 @@ typedef struct {
                                   a block-deep register pipeline (3, 4: split sources only) */
 } rnnpose_conv_desc_t;
 
+/* Output tiles per image of a convolution launch = records per image of its `tile_stats`: 3x3 stride-1 layers run on 8 x 16
+ * image PATCHES (ceil(W/16) * ceil(H/8) tiles per image, nine taps on one staged halo tile), everything else on runs of 128
+ * output pixels (ceil(H_out*W_out/128) when tiled per image).  rnnpose_conv_spatial_tiles(0) switches the patch tiling off
+ * (measurement: the r02 row-major tiling for 3x3 layers too). */
+int rnnpose_conv_tiles_per_image(int H, int W, int kh, int kw, int stride);
+int rnnpose_conv_spatial_tiles(int enable);
 /* number of fp16 elements of the packed weight array (hi and lo parts interleaved); -1 on bad arguments */
 long long rnnpose_conv_packed_halfs(int c_out, int kh, int kw, const int* h_seg_counts, int n_seg);
 int rnnpose_conv_pack_weights_f16x3(const float* w_oihw, int c_out, int c_in, int kh, int kw, const int* h_seg_counts,

@@ -61,6 +61,8 @@ PROTOTYPES = {
     "rnnpose_se3_inverse_f32": (_i, [_p, _i, _p, _p]),
     "rnnpose_gru_gate_f32": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p]),
     "rnnpose_gru_update_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _i, _p]),
+    "rnnpose_conv_tiles_per_image": (_i, [_i, _i, _i, _i, _i]),
+    "rnnpose_conv_spatial_tiles": (_i, [_i]),
     "rnnpose_conv_packed_halfs": (C.c_longlong, [_i, _i, _i, C.POINTER(_i), _i]),
     "rnnpose_conv_pack_weights_f16x3": (_i, [_p, _i, _i, _i, _i, C.POINTER(_i), _i, _f, _p, _p]),
     "rnnpose_conv2d_nhwc_f16x3": (_i, [C.POINTER(ConvDesc), _p]),

@@ -76,6 +76,7 @@ struct KParams {
   const float* in_mr;  // NORM variant: (B, seg0.cstride, 2) mean / rstd of source 0, applied with ReLU while staging
   int n_mt, n_nt;
   unsigned long long* sat;   // fp16x3 range guard: counter of clamped / non-finite activation quads (NULL = check off)
+  int sp_tx, sp_ty;          // SPATIAL kernels: 16-pixel-wide / 8-pixel-high patches per image row / column
   int dst_hl, dst2_hl;       // dst / dst2 receive the PRE-SPLIT fp16 hi|lo form (rnnpose_hip.h, "split tensors") instead of fp32
   float* dsth;               // optional second destination of the primary result, always in split form (GRU: h' as fp32 AND split)
   int dsth_cs, dsth_co;
@@ -145,9 +146,22 @@ __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-
 // slots.  Here the weight fragments of ALL TT taps of a block sit in registers (slot = tap) and are re-requested for the NEXT
 // block right after their MFMAs (a full block = TT taps of latency cover instead of 2 taps), and the activation tile is
 // requested TWO blocks ahead into a second register set.  Costs ~60 registers: 2 waves per SIMD instead of 3.
-template <int NI, bool STRIDED, bool COLS4 = false, int TT = 0, bool NORM = false, bool HLIN = false, bool DEEP = false>
-__global__ __launch_bounds__(NT, ((NI == 2 || DEEP) ? 2 : ((COLS4 || TT > 0) ? 3 : 2))) void conv_igemm_f16x3_kernel(const KParams p) {
+// SPATIAL (r03, 3x3 stride 1): the 128 output rows of a workgroup are an 8 x 16 PATCH of one image instead of 128 consecutive
+// pixels, and the staged activation tile is the patch with a one-pixel halo (10 x 18 = 180 rows, zeros outside the image).  All
+// NINE taps then read one staged tile at a constant row offset ((dy-1) * 18 + (dx-1)): one staging + one barrier per 32-channel
+// block instead of three (the row-major tiling staged a separate tile per kernel row), a third of the activation traffic, and
+// no tap masks at all.  r03 ablation: the staging is 20-25 % of a 3x3 layer (17 % of a 1x5 one, which already stages once).
+constexpr int SPR = 180, SPW = 18;      // halo tile rows, halo tile width
+template <int NI, bool STRIDED, bool COLS4 = false, int TT = 0, bool NORM = false, bool HLIN = false, bool DEEP = false,
+          bool SPATIAL = false>
+#ifndef RP_COLS4_WAVES
+#define RP_COLS4_WAVES 2      // waves per SIMD the 4-column layout is compiled for (3: 168 VGPRs with 60-90 spilled once the statistics are fp64; 2: none; measured equal)
+#endif
+__global__ __launch_bounds__(NT, ((NI == 2 || DEEP || SPATIAL) ? 2 : (COLS4 ? RP_COLS4_WAVES : (TT > 0 ? 3 : 2)))) void conv_igemm_f16x3_kernel(const KParams p) {
   static_assert(!DEEP || (HLIN && !COLS4 && TT >= 3), "the deep pipeline is for split sources, the 2x2 wave layout, 3 or 5 taps");
+  static_assert(!SPATIAL || (TT == 9 && !STRIDED && !DEEP), "patch tiling is the 3x3 stride-1 form: nine taps on one staged tile");
+  constexpr int ARW = SPATIAL ? SPR : AROWS;            // staged rows
+  constexpr int PRW = ARW + 1;                          // + the all-zero row
   static_assert(TT == 0 || (!STRIDED && (TT & 1)), "the unrolled loop is for stride 1 and odd tap counts");
   static_assert(!HLIN || (!NORM && !STRIDED && TT > 0), "split-tensor sources: stride 1, no fused normalisation");
   static_assert(!COLS4 || NI == 1, "the 4-column layout has one 32-column MFMA tile per wave");
@@ -157,7 +171,7 @@ __global__ __launch_bounds__(NT, ((NI == 2 || DEEP) ? 2 : ((COLS4 || TT > 0) ? 3
   // wave loads its own MFMA B fragments straight from the fragment-ordered packed array (two waves of a workgroup read
   // the same lines; the second hits L1).  r01 ablation: staging weights through LDS cost 16 % in ds_write alone, made
   // the LDS pipe a co-bottleneck with the matrix pipe, and needed a barrier per tap (now: one per 32-channel block).
-  __shared__ __attribute__((aligned(16))) _Float16 sA[2][2][PROWS * RS];
+  __shared__ __attribute__((aligned(16))) _Float16 sA[2][2][PRW * RS];
   _Float16* const sAf = &sA[0][0][0];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = COLS4 ? 0 : wave >> 1, wn = COLS4 ? wave : wave & 1;
@@ -177,6 +191,9 @@ __global__ __launch_bounds__(NT, ((NI == 2 || DEEP) ? 2 : ((COLS4 || TT > 0) ? 3
   // rows [128 (t % tpi), ...) of that image, output rows end with the image (halo rows of a neighbour image are never used:
   // they could only serve taps across an image line boundary, which the fast-axis masks already zero)
   const int img_ = p.tpi > 0 ? mt_i / p.tpi : 0;
+  // SPATIAL: patch (py_, px_) of image img_: output row r of the tile = pixel (8 py_ + (r >> 4), 16 px_ + (r & 15))
+  const int pt_ = SPATIAL ? mt_i - img_ * p.tpi : 0;
+  const int py0_ = SPATIAL ? (pt_ / p.sp_tx) * 8 : 0, px0_ = SPATIAL ? (pt_ % p.sp_tx) * 16 : 0;
   const int m0 = p.tpi > 0 ? img_ * (p.U * p.V) + (mt_i - img_ * p.tpi) * BM : mt_i * BM;
   const int mend = p.tpi > 0 ? (img_ + 1) * (p.U * p.V) : Mtot;
   const int n0 = nt_i * BNT;
@@ -189,6 +206,14 @@ __global__ __launch_bounds__(NT, ((NI == 2 || DEEP) ? 2 : ((COLS4 || TT > 0) ? 3
   int a_pix##R_, a_u##R_, a_v##R_;   /* rows outside the problem carry a_u = -2^20: every range test fails */ \
   {                                                                                                         \
     const int j_ = (tid >> 3) + 32 * R_;                                                                    \
+    if (SPATIAL) {                   /* halo row j_ = pixel (py0 - 1 + j_ / 18, px0 - 1 + j_ % 18) of image img_ */ \
+      const int hy_ = j_ / SPW, y_ = py0_ - 1 + hy_, x_ = px0_ - 1 + (j_ - hy_ * SPW);                      \
+      const bool okr_ = (j_ < SPR) && static_cast<unsigned>(y_) < static_cast<unsigned>(p.U) &&             \
+                        static_cast<unsigned>(x_) < static_cast<unsigned>(p.V);                             \
+      a_u##R_ = okr_ ? 0 : -(1 << 20);                                                                      \
+      a_v##R_ = 0;                                                                                          \
+      a_pix##R_ = okr_ ? img_ * UV + y_ * p.V + x_ : 0;                                                     \
+    } else {                                                                                                \
     const int m_ = m0 - HALO + j_;                                                                          \
     const bool okr_ = (j_ < AROWS) && m_ >= 0 && m_ < Mtot;                                                 \
     const int mm_ = okr_ ? m_ : 0;                                                                          \
@@ -197,14 +222,19 @@ __global__ __launch_bounds__(NT, ((NI == 2 || DEEP) ? 2 : ((COLS4 || TT > 0) ? 3
     a_u##R_ = okr_ ? (STRIDED ? u_ * 2 : u_) : -(1 << 20);                                                  \
     a_v##R_ = STRIDED ? v_ * 2 : 0;                                                                         \
     a_pix##R_ = STRIDED ? b_ * (p.Uin * p.Vin) : b_ * UV + u_ * p.su + v_ * p.sv;                           \
+    }                                                                                                       \
   }
-  RP_ROW_INIT(0) RP_ROW_INIT(1) RP_ROW_INIT(2) RP_ROW_INIT(3) RP_ROW_INIT(4)
+  RP_ROW_INIT(0) RP_ROW_INIT(1) RP_ROW_INIT(2) RP_ROW_INIT(3) RP_ROW_INIT(4) RP_ROW_INIT(5)
   // ---- per-lane fragment rows: fast-axis coordinate for the tap masks ----
   int fv[MI];
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     const int m = m0 + wm * 64 + mi * 32 + l31;
     fv[mi] = (m < mend) ? m % p.V : -1000;
+    if (SPATIAL) {                   // (re-used as the lane's halo-tile row of the CENTRE tap: ((r >> 4) + 1) * 18 + (r & 15) + 1)
+      const int r = wm * 64 + mi * 32 + l31;
+      fv[mi] = ((r >> 4) + 1) * SPW + (r & 15) + 1;
+    }
   }
 
   f32x16 acc[MI][NI];
@@ -215,8 +245,8 @@ __global__ __launch_bounds__(NT, ((NI == 2 || DEEP) ? 2 : ((COLS4 || TT > 0) ? 3
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  float4 av0_0, av0_1, av0_2, av0_3, av0_4;      // staged activation rows in flight: register set 0 ...
-  float4 av1_0, av1_1, av1_2, av1_3, av1_4;      // ... and set 1 (DEEP only: the tile two blocks ahead)
+  float4 av0_0, av0_1, av0_2, av0_3, av0_4, av0_5;   // staged activation rows in flight: register set 0 (row 5: SPATIAL) ...
+  float4 av1_0, av1_1, av1_2, av1_3, av1_4, av1_5;   // ... and set 1 (DEEP only: the tile two blocks ahead)
   float4 nrm01 = make_float4(0.f, 1.f, 0.f, 1.f), nrm23 = nrm01;       // NORM: (mean, rstd) x 4 channels of the tile in flight
   int sat_n = 0;                    // range guard (p.sat != NULL): staged quads this thread had to clamp
   unsigned amask0 = 0u, amask1 = 0u;   // bit r: staged row r of the tile in flight (set 0 / 1) is inside the image (else: zeros)
@@ -253,33 +283,35 @@ __global__ __launch_bounds__(NT, ((NI == 2 || DEEP) ? 2 : ((COLS4 || TT > 0) ? 3
     }                                                                                                       \
     amask##S_ = 0u;                                                                                         \
     RP_LOAD_A_ROW(0, S_) RP_LOAD_A_ROW(1, S_) RP_LOAD_A_ROW(2, S_) RP_LOAD_A_ROW(3, S_) RP_LOAD_A_ROW(4, S_) \
+    if (SPATIAL) RP_LOAD_A_ROW(5, S_)                                                                       \
   } while (0)
 #define RP_STORE_A_ROW(R_, AB_, S_)                                                                         \
   {                                                                                                         \
     const int j_ = (tid >> 3) + 32 * R_;                                                                    \
     if (HLIN) {                                                                                             \
-      if (j_ < AROWS) {              /* rows outside the image: zeros (bitwise AND: a select of two float4 went through scratch) */ \
+      if (j_ < ARW) {                /* rows outside the image: zeros (bitwise AND: a select of two float4 went through scratch) */ \
         const unsigned mk_ = 0u - ((amask##S_ >> R_) & 1u);                                                 \
         uint4 u_ = __builtin_bit_cast(uint4, av##S_##_##R_);                                                \
         u_.x &= mk_; u_.y &= mk_; u_.z &= mk_; u_.w &= mk_;                                                 \
-        *reinterpret_cast<uint4*>(sAf + (AB_) * (2 * PROWS * RS) + (c4 & 1) * (PROWS * RS) + j_ * RS + (c4 >> 1) * 8) = u_; \
+        *reinterpret_cast<uint4*>(sAf + (AB_) * (2 * PRW * RS) + (c4 & 1) * (PRW * RS) + j_ * RS + (c4 >> 1) * 8) = u_; \
       }                                                                                                     \
-    } else if (j_ < AROWS) {                                                                                \
+    } else if (j_ < ARW) {                                                                                  \
       h4 hi_, lo_;                                                                                          \
       const float4 z4_ = make_float4(0.f, 0.f, 0.f, 0.f);                                                   \
       float4 xv_ = av##S_##_##R_;                                                                           \
       if (NORM) xv_ = make_float4(fmaxf((xv_.x - nrm01.x) * nrm01.y, 0.f), fmaxf((xv_.y - nrm01.z) * nrm01.w, 0.f), \
                                   fmaxf((xv_.z - nrm23.x) * nrm23.y, 0.f), fmaxf((xv_.w - nrm23.z) * nrm23.w, 0.f)); \
       split4((amask##S_ >> R_) & 1u ? xv_ : z4_, p.a_scale, hi_, lo_);   /* padding / out-of-range rows: zeros (AFTER the norm) */ \
-      *reinterpret_cast<h4*>(sAf + (AB_) * (2 * PROWS * RS) + j_ * RS + c4 * 4) = hi_;                      \
-      *reinterpret_cast<h4*>(sAf + (AB_) * (2 * PROWS * RS) + PROWS * RS + j_ * RS + c4 * 4) = lo_;         \
+      *reinterpret_cast<h4*>(sAf + (AB_) * (2 * PRW * RS) + j_ * RS + c4 * 4) = hi_;                        \
+      *reinterpret_cast<h4*>(sAf + (AB_) * (2 * PRW * RS) + PRW * RS + j_ * RS + c4 * 4) = lo_;             \
     }                                                                                                       \
   }
 #define RP_SAT_ROW(R_, S_) sat_n += (((amask##S_ >> R_) & 1u) && rp::quad_saturates(av##S_##_##R_, p.a_scale)) ? 1 : 0;
 #define RP_STORE_A(AB_, S_)                                                                                 \
   do {                                                                                                      \
-    if (!HLIN && p.sat) { RP_SAT_ROW(0, S_) RP_SAT_ROW(1, S_) RP_SAT_ROW(2, S_) RP_SAT_ROW(3, S_) RP_SAT_ROW(4, S_) }   /* uniform branch, VALU only */ \
+    if (!HLIN && p.sat) { RP_SAT_ROW(0, S_) RP_SAT_ROW(1, S_) RP_SAT_ROW(2, S_) RP_SAT_ROW(3, S_) RP_SAT_ROW(4, S_) if (SPATIAL) RP_SAT_ROW(5, S_) }   /* uniform branch, VALU only */ \
     RP_STORE_A_ROW(0, AB_, S_) RP_STORE_A_ROW(1, AB_, S_) RP_STORE_A_ROW(2, AB_, S_) RP_STORE_A_ROW(3, AB_, S_) RP_STORE_A_ROW(4, AB_, S_) \
+    if (SPATIAL) RP_STORE_A_ROW(5, AB_, S_)                                                                 \
   } while (0)
   // weight fragment registers: two stages (named locals + macros: structs/arrays handed to lambdas end up in LDS or
   // scratch with this compiler).  Stage S holds, for the tap being consumed, this wave's B fragments
@@ -320,8 +352,8 @@ __global__ __launch_bounds__(NT, ((NI == 2 || DEEP) ? 2 : ((COLS4 || TT > 0) ? 3
          of 8 v_cndmask per fragment; -4 % on the 64-wide kernels); the 4-column layout sits at its 168-VGPR cap, where \
          the extra address registers spilled (measured slower), so it masks the loaded fragments instead */ \
       const int row = (COLS4 || okm_[mi]) ? wm * 64 + mi * 32 + l31 + HALO + dv_ : AROWS;                   \
-      ah[mi] = *reinterpret_cast<const h8*>(sAf + (AB_) * (2 * PROWS * RS) + row * RS + ko);               \
-      al[mi] = *reinterpret_cast<const h8*>(sAf + (AB_) * (2 * PROWS * RS) + PROWS * RS + row * RS + ko);  \
+      ah[mi] = *reinterpret_cast<const h8*>(sAf + (AB_) * (2 * PRW * RS) + row * RS + ko);                 \
+      al[mi] = *reinterpret_cast<const h8*>(sAf + (AB_) * (2 * PRW * RS) + PRW * RS + row * RS + ko);      \
       if (COLS4 && !okm_[mi]) { ah[mi] = zero_; al[mi] = zero_; }                                           \
     }                                                                                                       \
     bh[0] = __builtin_bit_cast(h8, b##S_##h0##KK_);                                                         \
@@ -372,7 +404,7 @@ __global__ __launch_bounds__(NT, ((NI == 2 || DEEP) ? 2 : ((COLS4 || TT > 0) ? 3
 
   if (tid < 4 * (RS / 8)) {       // the zero row of each (buffer, hi/lo) plane: 80 bytes = 5 x 16, never overwritten
     const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-    *reinterpret_cast<uint4*>(sAf + (tid / (RS / 8)) * (PROWS * RS) + AROWS * RS + (tid % (RS / 8)) * 8) = z;
+    *reinterpret_cast<uint4*>(sAf + (tid / (RS / 8)) * (PRW * RS) + ARW * RS + (tid % (RS / 8)) * 8) = z;
   }
   if constexpr (TT > 0) {
     // ---------------- unrolled main loop (stride 1) ----------------
@@ -382,10 +414,14 @@ __global__ __launch_bounds__(NT, ((NI == 2 || DEEP) ? 2 : ((COLS4 || TT > 0) ? 3
     uint4 bf[NSTG][NI][4];
     const uint4* wp = p.wpk + static_cast<long long>(ntile0) * 256 + lane;
     const int sstride = ntiles32 * 256;
-    const int nit = p.G * p.ncb, nst = nit * TT;
+    const int nit = SPATIAL ? p.ncb : p.G * p.ncb, nst = nit * TT;     // (SPATIAL: all nine taps belong to one channel block)
 #define RP_LOADB2(S_, ST_)                                                                                  \
     {                                                                                                       \
-      const int st_ = (ST_) < nst ? (ST_) : nst - 1;          /* unconditional: past the end re-reads the last record */ \
+      int st_ = (ST_) < nst ? (ST_) : nst - 1;                /* unconditional: past the end re-reads the last record */ \
+      if (SPATIAL) {                 /* stage = 9 cb + (3 ky + kx); the records are packed [ky][cb][kx] */  \
+        const int cbq_ = st_ / 9, tq_ = st_ - cbq_ * 9, kyq_ = tq_ / 3;                                     \
+        st_ = (kyq_ * p.ncb + cbq_) * 3 + (tq_ - kyq_ * 3);                                                 \
+      }                                                                                                     \
       const uint4* q_ = wp + static_cast<long long>(st_) * sstride;                                         \
       /* ablation bit 32: only the upper row half of the workgroup (wm == 0) requests weights -- HALF the L1 / TA traffic of  \
          the weight stream at unchanged everything else (results are wrong): is the stream's bandwidth what costs 20 %? */  \
@@ -401,10 +437,12 @@ __global__ __launch_bounds__(NT, ((NI == 2 || DEEP) ? 2 : ((COLS4 || TT > 0) ? 3
       _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) {                                                   \
         /* TT == 1 (1x1 kernels): no tap shift, nothing to mask -- rows outside the problem only feed accumulator rows \
            that are never stored (the masks were 75 v_cndmask per 24 MFMAs in the 4-column layout) */       \
-        const int row = (TT == 1 || COLS4 || okm_[mi]) ? wm * 64 + mi * 32 + l31 + HALO + dv_ : AROWS;      \
-        ah[mi] = *reinterpret_cast<const h8*>(sAf + (AB_) * (2 * PROWS * RS) + row * RS + ko);             \
-        al[mi] = *reinterpret_cast<const h8*>(sAf + (AB_) * (2 * PROWS * RS) + PROWS * RS + row * RS + ko); \
-        if (TT != 1 && COLS4 && !okm_[mi]) { ah[mi] = zero_; al[mi] = zero_; }                              \
+        /* SPATIAL: the lane's halo-tile row of the centre tap + the tap's constant offset; nothing to mask */ \
+        const int row = SPATIAL ? fv[mi] + dv_                                                              \
+                                : ((TT == 1 || COLS4 || okm_[mi]) ? wm * 64 + mi * 32 + l31 + HALO + dv_ : AROWS); \
+        ah[mi] = *reinterpret_cast<const h8*>(sAf + (AB_) * (2 * PRW * RS) + row * RS + ko);               \
+        al[mi] = *reinterpret_cast<const h8*>(sAf + (AB_) * (2 * PRW * RS) + PRW * RS + row * RS + ko);    \
+        if (!SPATIAL && TT != 1 && COLS4 && !okm_[mi]) { ah[mi] = zero_; al[mi] = zero_; }                  \
       }                                                                                                     \
       _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) {                                                   \
         bh[ni] = __builtin_bit_cast(h8, bf[S_][ni][KK_]);                                                   \
@@ -432,13 +470,14 @@ __global__ __launch_bounds__(NT, ((NI == 2 || DEEP) ? 2 : ((COLS4 || TT > 0) ? 3
 #define RP_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define RP_READ_A(SET_, T_, KK_, AB_)                                                                       \
     {                                                                                                       \
-      const int dvr_ = p.dv0 + (T_);                                                                        \
+      /* SPATIAL: tap T_ = 3 dy + dx reads the halo tile at the constant offset (dy - 1) * 18 + (dx - 1) */  \
+      const int dvr_ = SPATIAL ? (((T_) / 3) - 1) * SPW + ((T_) % 3) - 1 : p.dv0 + (T_);                    \
       const int ko = (KK_) * 16 + lh * 8;                                                                   \
       _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) {                                                   \
-        const bool ok_ = TT == 1 || static_cast<unsigned>(fv[mi] + dvr_) < static_cast<unsigned>(p.V);     \
-        const int row = ok_ ? wm * 64 + mi * 32 + l31 + HALO + dvr_ : AROWS;      /* masked tap: the all-zero row */ \
-        fa_h[SET_][mi] = *reinterpret_cast<const h8*>(sAf + (AB_) * (2 * PROWS * RS) + row * RS + ko);     \
-        fa_l[SET_][mi] = *reinterpret_cast<const h8*>(sAf + (AB_) * (2 * PROWS * RS) + PROWS * RS + row * RS + ko); \
+        const bool ok_ = SPATIAL || TT == 1 || static_cast<unsigned>(fv[mi] + dvr_) < static_cast<unsigned>(p.V); \
+        const int row = SPATIAL ? fv[mi] + dvr_ : (ok_ ? wm * 64 + mi * 32 + l31 + HALO + dvr_ : AROWS);    /* masked tap: the all-zero row */ \
+        fa_h[SET_][mi] = *reinterpret_cast<const h8*>(sAf + (AB_) * (2 * PRW * RS) + row * RS + ko);       \
+        fa_l[SET_][mi] = *reinterpret_cast<const h8*>(sAf + (AB_) * (2 * PRW * RS) + PRW * RS + row * RS + ko); \
       }                                                                                                     \
     }
 #define RP_MFMA6(SET_, S_, KK_)                                                                             \
@@ -481,11 +520,11 @@ __global__ __launch_bounds__(NT, ((NI == 2 || DEEP) ? 2 : ((COLS4 || TT > 0) ? 3
       if (!COLS4) RP_SCHED_FENCE();                                                                         \
       _Pragma("unroll") for (int t = 0; t < TT; ++t) {                                                      \
         if (COLS4) {                                                                                        \
-          const int dv_ = p.dv0 + t;                                                                        \
+          const int dv_ = SPATIAL ? ((t / 3) - 1) * SPW + (t % 3) - 1 : p.dv0 + t;                          \
           const h8 zero_ = {0, 0, 0, 0, 0, 0, 0, 0};                                                        \
           bool okm_[MI];                                                                                    \
           _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                                 \
-              okm_[mi] = static_cast<unsigned>(fv[mi] + dv_) < static_cast<unsigned>(p.V);                  \
+              okm_[mi] = SPATIAL || static_cast<unsigned>(fv[mi] + dv_) < static_cast<unsigned>(p.V);       \
           RP_MMA_KK2(((PAR_) + t) & 1, 0, PAR_)                                                             \
           RP_MMA_KK2(((PAR_) + t) & 1, 1, PAR_)                                                             \
           RP_LOADB2(((PAR_) + t) & 1, s0 + t + 2)                                                           \
@@ -609,9 +648,16 @@ __global__ __launch_bounds__(NT, ((NI == 2 || DEEP) ? 2 : ((COLS4 || TT > 0) ? 3
       const int rl = (lane + 64 * k) / F4;
       const int m = m0 + wm * 64 + mi * 32 + rl;
       const int mc = m < mend ? m : mend - 1;
-      rowok |= (m < mend ? 1u : 0u) << k;
       long long pix = mc;
-      if (p.sv != 1) {
+      if (SPATIAL) {                 // tile row r -> pixel (py0 + (r >> 4), px0 + (r & 15)) of image img_; partial patches at the border
+        const int r = wm * 64 + mi * 32 + rl;
+        const int y = py0_ + (r >> 4), x = px0_ + (r & 15);
+        rowok |= ((y < p.U && x < p.V) ? 1u : 0u) << k;
+        pix = static_cast<long long>(img_) * UV + (y < p.U ? y : p.U - 1) * p.V + (x < p.V ? x : p.V - 1);
+      } else {
+        rowok |= (m < mend ? 1u : 0u) << k;
+      }
+      if (!SPATIAL && p.sv != 1) {
         const int q = mc / p.V, v = mc - q * p.V;
         const int b = q / p.U, u = q - b * p.U;
         pix = static_cast<long long>(b) * UV + u * p.su + v * p.sv;
@@ -792,7 +838,21 @@ int fill_cb_tables(const int* counts, int n, unsigned char* cb_seg, short* cb_c0
 
 }  // namespace
 
+static bool g_conv_spatial = true;      // 3x3 stride-1 convolutions on 8 x 16 image patches (rnnpose_conv_spatial_tiles)
+
 extern "C" {
+
+int rnnpose_conv_spatial_tiles(int enable) {     // measurement switch: 0 = the r02 row-major tiling for 3x3 layers too
+  g_conv_spatial = enable != 0;
+  return 0;
+}
+
+int rnnpose_conv_tiles_per_image(int H, int W, int kh, int kw, int stride) {
+  if (H <= 0 || W <= 0 || (stride != 1 && stride != 2)) return -1;
+  const int Ho = stride == 2 ? (H + 1) / 2 : H, Wo = stride == 2 ? (W + 1) / 2 : W;
+  if (g_conv_spatial && kh == 3 && kw == 3 && stride == 1) return rp::cdiv(W, 16) * rp::cdiv(H, 8);
+  return rp::cdiv(static_cast<long long>(Ho) * Wo, BM);
+}
 
 long long rnnpose_conv_packed_halfs(int c_out, int kh, int kw, const int* h_seg_counts, int n_seg) {
   if (c_out <= 0 || kh <= 0 || kw <= 0 || !h_seg_counts || n_seg < 1 || n_seg > 4) return -1;
@@ -886,6 +946,8 @@ int rnnpose_conv2d_nhwc_f16x3(const rnnpose_conv_desc_t* d, rnnpose_stream_t str
     p.U = d->H; p.V = d->W; p.su = d->W; p.sv = 1;
     p.G = d->kh; p.T = d->kw; p.du0 = -(d->kh / 2); p.dv0 = -(d->kw / 2);
   }
+  const bool spatial = g_conv_spatial && d->kh == 3 && d->kw == 3 && d->stride == 1;      // 8 x 16 patches, nine taps on one staged tile
+  if (spatial) { p.G = 1; p.T = 9; p.du0 = 0; p.dv0 = 0; }
   p.stride = 1; p.Uin = p.U; p.Vin = p.V; p.gkw = 0; p.dvg0 = 0;
   int Ho = d->H, Wo = d->W;
   if (d->stride == 2) {      // strided: every tap is its own group (no tap sharing), row-major tiling over the OUTPUT
@@ -894,7 +956,7 @@ int rnnpose_conv2d_nhwc_f16x3(const rnnpose_conv_desc_t* d, rnnpose_stream_t str
     p.U = Ho; p.V = Wo;
     p.G = d->kh * d->kw; p.T = 1; p.gkw = d->kw; p.du0 = -(d->kh / 2); p.dvg0 = -(d->kw / 2); p.dv0 = 0;
   }
-  RP_REQUIRE(p.T / 2 <= HALO && (p.stride == 2 || p.T == 1 || p.T == 3 || p.T == 5 || p.T == 7), fn, "kernel too wide for the staged halo");
+  RP_REQUIRE(spatial || (p.T / 2 <= HALO && (p.stride == 2 || p.T == 1 || p.T == 3 || p.T == 5 || p.T == 7)), fn, "kernel too wide for the staged halo");
   p.wpk = static_cast<const uint4*>(d->w_packed);
   p.Npad = rp::cdiv(d->c_out, BN) * BN;
   p.bias = d->bias; p.Cout = d->c_out;
@@ -915,7 +977,7 @@ int rnnpose_conv2d_nhwc_f16x3(const rnnpose_conv_desc_t* d, rnnpose_stream_t str
   // split-tensor sources / destinations (see the header): whole 8-channel groups, 32-byte aligned rows
   const bool hlin = d->src_hl != 0;
   if (hlin) {
-    RP_REQUIRE(d->stride == 1 && !d->src0_mean_rstd && (p.T == 1 || p.T == 3 || p.T == 5), fn,
+    RP_REQUIRE(d->stride == 1 && !d->src0_mean_rstd && (p.T == 1 || p.T == 3 || p.T == 5 || spatial), fn,
                "split-tensor sources: stride 1, 1/3/5 taps per group, no fused normalisation");
     for (int s = 0; s < d->n_src; ++s)
       RP_REQUIRE(d->src[s].c_count % 8 == 0 && d->src[s].c_offset % 8 == 0 && d->src[s].c_stride % 8 == 0 &&
@@ -941,6 +1003,11 @@ int rnnpose_conv2d_nhwc_f16x3(const rnnpose_conv_desc_t* d, rnnpose_stream_t str
     p.tpi = rp::cdiv(static_cast<long long>(Ho) * Wo, BM);
     p.n_mt = d->B * p.tpi;
   }
+  if (spatial) {                                 // patches never straddle images: always per-image tiling
+    p.sp_tx = rp::cdiv(d->W, 16); p.sp_ty = rp::cdiv(d->H, 8);
+    p.tpi = p.sp_tx * p.sp_ty;
+    p.n_mt = d->B * p.tpi;
+  }
   if (d->src0_mean_rstd)
     RP_REQUIRE(d->n_src == 1 && d->stride == 1 && d->kh == 3 && d->kw == 3 && reinterpret_cast<uintptr_t>(d->src0_mean_rstd) % 16 == 0,
                fn, "src0_mean_rstd (fused instance norm + ReLU of the input) needs one source, a 3x3 stride-1 kernel, 16-byte alignment");
@@ -949,8 +1016,8 @@ int rnnpose_conv2d_nhwc_f16x3(const rnnpose_conv_desc_t* d, rnnpose_stream_t str
   bool wide22 = false;            // 128x128 as 2x2 waves of 64x64 (NI = 2): stride-1 split-source layers only
   if (d->tile == 1) wide = false;
   if (d->tile == 2) wide = !d->src0_mean_rstd;
-  if (d->tile == 3 && hlin) { wide = false; wide22 = true; }
-  const bool deep = d->tile == 4 && hlin && (p.T == 3 || p.T == 5);     // 128x64, weights of a whole block + two activation tiles in flight
+  if (d->tile == 3 && hlin && !spatial) { wide = false; wide22 = true; }
+  const bool deep = d->tile == 4 && hlin && !spatial && (p.T == 3 || p.T == 5);     // 128x64, weights of a whole block + two activation tiles in flight
   if (d->tile == 4) wide = false;
   const dim3 block(NT);
   hipStream_t st = rp::as_stream(stream);
@@ -964,7 +1031,20 @@ int rnnpose_conv2d_nhwc_f16x3(const rnnpose_conv_desc_t* d, rnnpose_stream_t str
       if constexpr (!(HL_)) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<NI_, false, COLS4_, 7, false, false>), grid, block, 0, st, p); \
       break;                                                                                                             \
   }
-  if (deep) {
+  if (spatial) {                  // 3x3 stride 1: 8 x 16 patches, nine taps per staged tile (tile shapes 3 / 4 do not apply)
+    if (wide) {
+      p.n_nt = p.Npad / 128;
+      const dim3 grid(static_cast<unsigned>(p.n_mt) * p.n_nt);
+      if (hlin) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<1, false, true, 9, false, true, false, true>), grid, block, 0, st, p);
+      else hipLaunchKernelGGL((conv_igemm_f16x3_kernel<1, false, true, 9, false, false, false, true>), grid, block, 0, st, p);
+    } else {
+      p.n_nt = rp::cdiv(d->c_out, 64);
+      const dim3 grid(static_cast<unsigned>(p.n_mt) * p.n_nt);
+      if (d->src0_mean_rstd) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<1, false, false, 9, true, false, false, true>), grid, block, 0, st, p);
+      else if (hlin) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<1, false, false, 9, false, true, false, true>), grid, block, 0, st, p);
+      else hipLaunchKernelGGL((conv_igemm_f16x3_kernel<1, false, false, 9, false, false, false, true>), grid, block, 0, st, p);
+    }
+  } else if (deep) {
     p.n_nt = rp::cdiv(d->c_out, 64);
     const dim3 grid(static_cast<unsigned>(p.n_mt) * p.n_nt);
     if (p.T == 3) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<1, false, false, 3, false, true, true>), grid, block, 0, st, p);

@@ -403,7 +403,7 @@ class EncoderEngine:
         B, H, W, _ = x.shape
         Ho, Wo = -(-H // stride), -(-W // stride)
         out = torch.empty(B, Ho, Wo, pc.c_out, device=x.device, dtype=torch.float32)
-        ts = torch.empty(B * (-(-(Ho * Wo) // 128)), pc.c_out, 2, device=x.device, dtype=torch.float64) if stats else None
+        ts = torch.empty(B * ops.conv_tiles_per_image(H, W, pc.kh, pc.kw, stride), pc.c_out, 2, device=x.device, dtype=torch.float64) if stats else None
         ops.conv2d_nhwc(pc, [(x, 0)], (out, 0), ops.EPI_LINEAR, stride=stride, tile_stats=ts, in_norm=in_norm)
         return out, ts
 

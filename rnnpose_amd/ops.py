@@ -444,6 +444,7 @@ def conv2d_nhwc(pc: PackedConv, srcs, dst, epilogue: int = EPI_LINEAR, aux0=None
     src_hl / dst_hl / dst2_hl: the sources / dst / dst2 are SPLIT tensors (fp16 hi|lo per 8-channel group in a buffer of the
     fp32 tensor's shape: include/rnnpose_hip.h; split_hl / unsplit_hl convert); dst_split = (tensor, c_offset): an additional
     split-form copy of the primary result; tile: 0 auto, 1..3 tile-shape override (measurement)."""
+    _apply_conv_env()
     d = _lib.ConvDesc()
     if len(srcs) != len(pc.seg_counts):
         raise ValueError("number of sources differs from the packed segment list")
@@ -478,10 +479,10 @@ def conv2d_nhwc(pc: PackedConv, srcs, dst, epilogue: int = EPI_LINEAR, aux0=None
     d.gru_c = gru_c
     if tile_stats is not None:
         # (B * ceil(HWout/128), c_out, 2) fp32: per-tile column sums / sums of squares for instnorm_tiles_nhwc
-        tpi = -(-((-(-H // stride)) * (-(-W // stride))) // 128)
+        tpi = conv_tiles_per_image(H, W, pc.kh, pc.kw, stride)
         if not (tile_stats.is_cuda and tile_stats.dtype == F64 and tile_stats.is_contiguous()
                 and tile_stats.numel() >= B * tpi * pc.c_out * 2):
-            raise ValueError("tile_stats must be a contiguous FP64 CUDA tensor of (B * ceil(H_out*W_out/128), c_out, 2)")
+            raise ValueError("tile_stats must be a contiguous FP64 CUDA tensor of (B * conv_tiles_per_image(...), c_out, 2)")
         d.tile_stats = tile_stats.data_ptr()
     if in_norm is not None:          # (B, C_src, 2) mean / rstd of source 0: read relu((x - mean) * rstd) instead of x
         if not (in_norm.is_cuda and in_norm.dtype == F32 and in_norm.is_contiguous() and tuple(in_norm.shape) == (B, srcs[0][0].shape[3], 2)):
@@ -494,6 +495,29 @@ def conv2d_nhwc(pc: PackedConv, srcs, dst, epilogue: int = EPI_LINEAR, aux0=None
         d.dst_split, d.dst_split_c_stride, d.dst_split_c_offset = t.data_ptr(), t.shape[3], off
     _launch("rnnpose_conv2d_nhwc_f16x3", C.byref(d), _stream(),
             work=2.0 * B * (-(-H // stride)) * (-(-W // stride)) * pc.c_out * pc.c_in_real * pc.kh * pc.kw)
+
+
+def conv_tiles_per_image(H, W, kh, kw, stride=1) -> int:
+    """Records per image of a convolution's tile_stats (3x3 stride 1: 8 x 16 patches; else runs of 128 output pixels)."""
+    _apply_conv_env()
+    return int(_lib.load().rnnpose_conv_tiles_per_image(int(H), int(W), int(kh), int(kw), int(stride)))
+
+
+_conv_env_applied = False
+
+
+def _apply_conv_env():
+    """RNNPOSE_SPATIAL_TILES=0 restores the row-major tiling of 3x3 layers (same-box A/B)."""
+    global _conv_env_applied
+    if not _conv_env_applied:
+        _conv_env_applied = True
+        v = _os.environ.get("RNNPOSE_SPATIAL_TILES")
+        if v is not None:
+            _lib.call("rnnpose_conv_spatial_tiles", int(v != "0"))
+
+
+def conv_spatial_tiles(enable: bool = True):
+    _lib.call("rnnpose_conv_spatial_tiles", int(bool(enable)))
 
 
 _nchw_pc = {}
@@ -823,7 +847,7 @@ def instnorm_tiles_nhwc(x, tile_stats, relu=True, residual=None, out=None, eps: 
     residual_norm (B,C,2): the residual is a RAW convolution output, normalised [+ ReLU] on the fly with these statistics."""
     _nhwc(x, "x")
     B, H, W, Cc = x.shape
-    tpi = -(-(H * W) // 128)
+    tpi = tile_stats.shape[0] // B              # records per image, as the producing convolution tiled it
     stats = torch.empty(B, Cc, 2, device=x.device, dtype=F32)
     if stats_only:
         _launch("rnnpose_instnorm_tiles_nhwc_f32", _ptr(None), B, H * W, Cc, eps, int(bool(relu)), _ptr(None), _ptr(None), 0,

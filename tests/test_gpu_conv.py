@@ -465,3 +465,40 @@ def test_split_producers(ops):
     dm = ops.unsplit_hl(mso)
     assert float(((dm[..., 126:] - m32[..., 126:]).abs() / m32[..., 126:].abs().clamp(min=1e-2)).max()) < 2.0 ** -20
     assert float(dm[..., :126].abs().max()) == 0          # the other 6 channels of the group belong to the 126-channel convolution
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout,hl", [(2, 60, 80, 256, 192, False), (1, 30, 30, 128, 512, False), (3, 13, 21, 64, 64, False),
+                                               (2, 60, 80, 256, 126, True), (1, 17, 33, 128, 512, True)])
+def test_conv3x3_patch_tiling_equals_row_major(ops, B, H, W, cin, cout, hl):
+    """3x3 stride-1 layers run on 8 x 16 image patches (nine taps on one staged halo tile, csrc/conv_igemm.hip SPATIAL) by
+    default; rnnpose_conv_spatial_tiles(0) restores the row-major tiling.  Same products, same fp16 operands: the outputs agree
+    to fp32 summation order, the per-image statistics too, at sizes whose patches are ragged in both directions."""
+    x = syn.normal("sp.x", (B, cin, H, W), 21, std=1.5)
+    w = syn.normal("sp.w", (cout, cin, 3, 3), 21, std=float(np.sqrt(2.0 / (cin * 9))))
+    b = syn.uniform("sp.b", (cout,), 21, -0.5, 0.5)
+    pc = ops.PackedConv(D(w), D(b), [cin])
+    xn = nhwc(D(x))
+    src = [(ops.split_hl(xn) if hl else xn, 0)]
+    cs = (cout + 7) // 8 * 8
+    outs, stats = [], []
+    try:
+        for sp in (True, False):
+            ops.conv_spatial_tiles(sp)
+            tpi = ops.conv_tiles_per_image(H, W, 3, 3, 1)
+            assert tpi == ((-(-W // 16)) * (-(-H // 8)) if sp else -(-(H * W) // 128))
+            out = torch.full((B, H, W, cs), 3.0, device="cuda")
+            ts = torch.zeros(B * tpi, cout, 2, device="cuda", dtype=torch.float64) if not hl else None
+            ops.conv2d_nhwc(pc, src, (out, 0), ops.EPI_LINEAR, src_hl=hl, tile_stats=ts)
+            outs.append(out)
+            stats.append(None if ts is None else ts.view(B, tpi, cout, 2).sum(1))
+    finally:
+        ops.conv_spatial_tiles(True)
+    y64 = F.conv2d(D(x).double(), D(w).double(), D(b).double(), padding=1)
+    y32 = F.conv2d(D(x), D(w), D(b), padding=1)
+    check(nchw(outs[0][..., :cout]), y64, y32, "3x3 on patches")
+    assert float((outs[0] - outs[1]).abs().max()) <= 3e-6 * float(y64.abs().max())
+    assert float((outs[0][..., cout:] - 3).abs().max()) == 0 if cs > cout else True
+    if stats[0] is not None:
+        want = torch.stack([y64.sum((2, 3)), (y64 * y64).sum((2, 3))], -1)
+        for st in stats:
+            assert float(((st - want).abs() / want.abs().clamp(min=1.0)).max()) < 1e-5
