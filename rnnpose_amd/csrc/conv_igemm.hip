@@ -157,7 +157,7 @@ template <int NI, bool STRIDED, bool COLS4 = false, int TT = 0, bool NORM = fals
 #ifndef RP_COLS4_WAVES
 #define RP_COLS4_WAVES 2      // waves per SIMD the 4-column layout is compiled for (3: 168 VGPRs with 60-90 spilled once the statistics are fp64; 2: none; measured equal)
 #endif
-__global__ __launch_bounds__(NT, ((NI == 2 || DEEP || SPATIAL) ? 2 : (COLS4 ? RP_COLS4_WAVES : (TT > 0 ? 3 : 2)))) void conv_igemm_f16x3_kernel(const KParams p) {
+__global__ __launch_bounds__(NT, ((NI == 2 || DEEP || SPATIAL) ? 2 : (COLS4 ? (TT == 3 ? 3 : RP_COLS4_WAVES) : (TT > 0 ? 3 : 2)))) void conv_igemm_f16x3_kernel(const KParams p) {
   static_assert(!DEEP || (HLIN && !COLS4 && TT >= 3), "the deep pipeline is for split sources, the 2x2 wave layout, 3 or 5 taps");
   static_assert(!SPATIAL || (TT == 9 && !STRIDED && !DEEP), "patch tiling is the 3x3 stride-1 form: nine taps on one staged tile");
   constexpr int ARW = SPATIAL ? SPR : AROWS;            // staged rows
@@ -1032,7 +1032,9 @@ int rnnpose_conv2d_nhwc_f16x3(const rnnpose_conv_desc_t* d, rnnpose_stream_t str
       break;                                                                                                             \
   }
   if (spatial) {                  // 3x3 stride 1: 8 x 16 patches, nine taps per staged tile (tile shapes 3 / 4 do not apply)
-    if (wide) {
+    // 128x64 as 2x2 waves unless the 4-column layout is asked for: at 2 workgroups per CU (58 KB of LDS) the 128x128 tile's
+    // 600-odd workgroups need a second round (heads, half batch: 100 vs 80 us); at the full batch the two are equal
+    if (d->tile == 2 && d->c_out % 128 == 0 && !d->src0_mean_rstd) {
       p.n_nt = p.Npad / 128;
       const dim3 grid(static_cast<unsigned>(p.n_mt) * p.n_nt);
       if (hlin) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<1, false, true, 9, false, true, false, true>), grid, block, 0, st, p);

@@ -227,12 +227,18 @@ def test_conv_tile_stats_feed_instnorm(ops, B, H, W, cin, cout, k, stride):
     Ho, Wo = -(-H // stride), -(-W // stride)
     assert (Ho * Wo) % 128 == 0
     out = torch.empty(B, Ho, Wo, cout, device="cuda")
-    ts = torch.full((B * Ho * Wo // 128, cout, 2), -1.0, device="cuda", dtype=torch.float64)      # fp64 tile statistics
+    tpi = ops.conv_tiles_per_image(H, W, k, k, stride)         # 3x3 stride 1: 8 x 16 patches; else runs of 128 output pixels
+    ts = torch.full((B * tpi, cout, 2), -1.0, device="cuda", dtype=torch.float64)      # fp64 tile statistics
     ops.conv2d_nhwc(pc, [(nhwc(D(x)), 0)], (out, 0), ops.EPI_LINEAR, stride=stride, tile_stats=ts)
     y64 = F.conv2d(D(x).double(), D(w).double(), D(b).double(), stride=stride, padding=k // 2)
-    rows = y64.permute(0, 2, 3, 1).reshape(-1, 128, cout)                       # tiles of 128 consecutive pixels
-    want = torch.stack([rows.sum(1), (rows * rows).sum(1)], -1)
-    err = float((ts.double() - want).abs().max())
+    if k == 3 and stride == 1:                                                  # tiles = 8 x 16 patches (ragged at the border): compare per image
+        got_s = ts.view(B, tpi, cout, 2).sum(1)
+        want = torch.stack([y64.sum((2, 3)), (y64 * y64).sum((2, 3))], -1)
+        err = float((got_s - want).abs().max())
+    else:
+        rows = y64.permute(0, 2, 3, 1).reshape(-1, 128, cout)                   # tiles of 128 consecutive pixels
+        want = torch.stack([rows.sum(1), (rows * rows).sum(1)], -1)
+        err = float((ts.double() - want).abs().max())
     print(f"tile stats err {err:.3e} (max {float(want.abs().max()):.1f})")
     assert err <= 2e-5 * float(want.abs().max())
     got = ops.instnorm_tiles_nhwc(out, ts, relu=True)
@@ -250,7 +256,7 @@ def test_conv_per_image_tiles_and_fused_input_norm(ops, B, H, W, cin, cout):
     w2 = syn.normal("pn.w2", (cout, cin, 3, 3), 5, std=float(np.sqrt(2.0 / (cin * 9))))
     b1, b2 = syn.uniform("pn.b1", (cin,), 4, -0.5, 0.5), syn.uniform("pn.b2", (cout,), 5, -0.5, 0.5)
     p1, p2 = ops.PackedConv(D(w1), D(b1), [cin]), ops.PackedConv(D(w2), D(b2), [cout if False else cin])
-    tpi = -(-(H * W) // 128)
+    tpi = ops.conv_tiles_per_image(H, W, 3, 3, 1)
     c1 = torch.empty(B, H, W, cin, device="cuda")
     ts = torch.full((B * tpi, cin, 2), -1.0, device="cuda", dtype=torch.float64)
     ops.conv2d_nhwc(p1, [(nhwc(D(x)), 0)], (c1, 0), ops.EPI_LINEAR, tile_stats=ts)

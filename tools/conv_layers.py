@@ -24,7 +24,7 @@ shapes = [("convc2 3x3 256->192", [256], 192, 3, 3),
           ("gru zr 5x1 256->256", [128, 128], 256, 5, 1), ("gru q 5x1 256->128", [128, 128], 128, 5, 1),
           ("heads 3x3 128->512", [128], 512, 3, 3), ("inp 1x5 128->384", [128], 384, 1, 5),
           ("enc l1 3x3 64->64 @240x320", [64], 64, 3, 3)]
-modes = [("f32", False, 0), ("hl0", True, 0), ("hl1", True, 1), ("hl2", True, 2), ("hl3", True, 3), ("hl4", True, 4)]
+modes = [("f32", False, 0), ("f32t1", False, 1), ("f32t2", False, 2), ("hl0", True, 0), ("hl1", True, 1), ("hl2", True, 2), ("hl3", True, 3), ("hl4", True, 4)]
 for B in batches:
     for name, segs, co, kh, kw in shapes:
         if flt and not any(f in name for f in flt):
