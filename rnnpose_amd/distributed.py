@@ -29,7 +29,9 @@ def init_from_env(backend: str | None = None):
     if world <= 1:
         return 0, 1, 0
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        # RNNPOSE_DIST_BACKEND=gloo: several ranks on ONE GPU (RCCL refuses duplicate devices) -- how the multi-rank path of
+        # bench.py / eval_epoch is exercised on a single-GPU box
+        backend = os.environ.get("RNNPOSE_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if torch.cuda.is_available():
