@@ -221,6 +221,9 @@ typedef struct {
                                   h' is needed as fp32 by the next gate epilogue AND split by the next convolution); not
                                   with epilogue 2 */
   int dst_split_c_stride, dst_split_c_offset;
+  int src_bounded;             /* != 0: the caller guarantees |source| < 65504 / a_scale, the range guard skips this launch.  The
+                                  encoder sets it: every convolution input there is an instance-normalised map or a ReLU sum of a few
+                                  (|(x - mean) * rstd| <= sqrt(H*W); extractor.py:48-58), two orders below the fp16x3 range */
   int tile;                    /* 0 = automatic; 1 = 128x64, 2 = 128x128 as 4 column waves, 3 = 128x128 as 2x2 waves, 4 = 128x64 with
                                   a block-deep register pipeline (3, 4: split sources only) */
 } rnnpose_conv_desc_t;

@@ -438,7 +438,7 @@ def _nhwc(t, name):
 
 def conv2d_nhwc(pc: PackedConv, srcs, dst, epilogue: int = EPI_LINEAR, aux0=None, aux1=None, dst2=None, gru_c: int = 0,
                 stride: int = 1, tile_stats=None, add_map=None, in_norm=None, src_hl: bool = False, dst_hl: bool = False,
-                dst2_hl: bool = False, dst_split=None, tile: int = 0):
+                dst2_hl: bool = False, dst_split=None, tile: int = 0, src_bounded: bool = False):
     """srcs: list of (tensor (B,H,W,C), c_offset) matched with pc.seg_counts; dst/aux0/aux1/dst2: (tensor, c_offset).
     Writes in place into dst (and dst2); returns nothing.
     src_hl / dst_hl / dst2_hl: the sources / dst / dst2 are SPLIT tensors (fp16 hi|lo per 8-channel group in a buffer of the
@@ -489,6 +489,7 @@ def conv2d_nhwc(pc: PackedConv, srcs, dst, epilogue: int = EPI_LINEAR, aux0=None
             raise ValueError("in_norm must be a contiguous fp32 CUDA tensor of (B, C_source, 2)")
         d.src0_mean_rstd = in_norm.data_ptr()
     d.src_hl, d.dst_hl, d.dst2_hl, d.tile = int(bool(src_hl)), int(bool(dst_hl)), int(bool(dst2_hl)), int(tile)
+    d.src_bounded = int(bool(src_bounded))      # caller's guarantee that the sources cannot leave the fp16x3 range: no range check
     if dst_split is not None:
         t, off = dst_split
         _nhwc(t, "dst_split")
