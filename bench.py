@@ -281,7 +281,7 @@ def main():
             traffic = {}
     tr = lambda k: (traffic.get(k) or {}).get("bytes_per_launch") if isinstance(traffic.get(k), dict) else None
 
-    MFMA3 = ("rnnpose_conv2d_nhwc_f16x3", "rnnpose_stem_conv7x7_s2_f16x3", "rnnpose_corr_pyramid_f16x3")   # 3 fp16 products per multiply-add
+    MFMA3 = ("rnnpose_conv2d_nhwc_f16x3", "rnnpose_stem_conv7x7_s2_f16x3", "rnnpose_corr_pyramid_f16x3", "rnnpose_corr_pyramid_split")   # 3 fp16 products per multiply-add
     kernels = {}
     exec_flops_step = 0.0
     for name, (n, mean_ms, tot_ms, work, nbytes) in prof.items():
@@ -334,14 +334,16 @@ def main():
                     "of the step -- includes every memory-bound kernel and launch gap of the step"}
     # north_star's named kernel
     corr_vol = None
-    for nm, label in (("rnnpose_corr_pyramid_f16x3", "corr_pyramid_h3_kernel (+ the two split_features_kernel pre-passes of the same C-ABI call)"),
+    for nm, label in (("rnnpose_corr_pyramid_split", "corr_pyramid_h3_kernel (operands written as fp16 hi|lo split tensors by the encoder's "
+                                                    "output convolution: the C-ABI call is this one kernel)"),
+                      ("rnnpose_corr_pyramid_f16x3", "corr_pyramid_h3_kernel (+ the split_features_kernel pre-pass of the same C-ABI call)"),
                       ("rnnpose_corr_pyramid_f32", "corr_pyramid_kernel (exact fp32 MFMA)")):
         if nm in prof:
             n, mean_ms, tot_ms, work, nbytes = prof[nm]
             gbs = nbytes / (tot_ms * 1e-3) / 1e9
-            corr_vol = {"kernel": label, "bound": "hbm" if nm.endswith("f16x3") else "mfma (fp32, 96 flop/B)",
+            corr_vol = {"kernel": label, "bound": "hbm" if not nm.endswith("f32") else "mfma (fp32, 96 flop/B)",
                         "achieved_GBps": round(gbs, 1), "peak_GBps": PEAK_HBM_GBS, "frac": round(gbs / PEAK_HBM_GBS, 4),
-                        "algorithmic_bytes_per_launch": nbytes / n, "traffic": tr("corr_pyramid_h3" if nm.endswith("f16x3") else "corr_pyramid"),
+                        "algorithmic_bytes_per_launch": nbytes / n, "traffic": tr("corr_pyramid_h3" if not nm.endswith("f32") else "corr_pyramid"),
                         "mean_ms": round(mean_ms, 4), "launches_timed": n}
             if nm.endswith("f32"):
                 corr_vol["TFLOPps"] = round(work / (tot_ms * 1e-3) / 1e12, 2)

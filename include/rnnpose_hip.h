@@ -44,14 +44,18 @@ int rnnpose_corr_pyramid_layout(int B, int h, int w, int levels, int64_t* h_offs
 int rnnpose_corr_pyramid_f32(const float* fmap1, const float* fmap2, int B, int C, int h, int w,
                              int levels, float* pyramid, rnnpose_stream_t stream);
 /* Same volume + pyramid with the operands split into fp16 hi/lo halves and multiplied on the fp16 matrix cores with
- * fp32 accumulation (3 MFMAs per k-slab; the dropped lo*lo term is 2^-22 relative: fp32-class accuracy).  A pre-pass
- * writes the scaled, split, pixel-major operands into `workspace`.  layout 0: fmaps are (B,C,h,w) as above; layout 1:
- * (B,h,w,C) (what the encoder engine produces).  a_scale (a power of two, 64 in the host code) scales both operands
- * before the split; |x| * a_scale beyond 65504 saturates.  C % 32 == 0. */
+ * fp32 accumulation (3 MFMAs per k-slab; the dropped lo*lo term is 2^-22 relative: fp32-class accuracy).  One pre-pass
+ * launch writes both operands, scaled and split, as pixel-major SPLIT TENSORS (see rnnpose_conv_desc_t) into `workspace`.
+ * layout 0: fmaps are (B,C,h,w) as above; layout 1: (B,h,w,C).  a_scale (a power of two, 8 in the host code) scales both
+ * operands before the split; |x| * a_scale beyond 65504 saturates (range guard).  C % 32 == 0.
+ * rnnpose_corr_pyramid_split: the operands ARE split tensors already ((B,h,w,C), 4*C bytes per pixel, scale a_scale), e.g.
+ * written by the encoder's output convolution (rnnpose_conv1x1_resident_f16x3, dst_split): no pre-pass, no workspace. */
 size_t rnnpose_corr_pyramid_f16x3_workspace_bytes(int B, int C, int h, int w);
 int rnnpose_corr_pyramid_f16x3(const float* fmap1, const float* fmap2, int layout, int B, int C, int h, int w, int levels,
                                float a_scale, void* workspace, size_t workspace_bytes, float* pyramid,
                                rnnpose_stream_t stream);
+int rnnpose_corr_pyramid_split(const void* fmap1_split, const void* fmap2_split, int B, int C, int h, int w, int levels,
+                               float a_scale, float* pyramid, rnnpose_stream_t stream);
 
 /* ---- a3: pyramid lookup -------- thirdparty/raft/corr.py:36-57, thirdparty/raft/utils/utils.py:57-71
  * coords (B,2,h,w) (ch0 = x, ch1 = y) -> out (B, levels*(2r+1)^2, h, w); channel

@@ -59,6 +59,16 @@ class ImageFeaEncoder(nn.Module):
         f = self.engine()([image1, image2], normalize=True)
         return f[:B], f[B:]
 
+    @torch.no_grad()
+    def forward_split(self, image1, image2):
+        """Same features as ops.SplitTensor pairs (pixel-major fp16 hi|lo written by the output convolution): the operand
+        format of the fp16x3 volume build (GRU_CFUpdator.prepare accepts them in place of the NCHW maps)."""
+        if not image1.is_cuda:
+            raise RuntimeError("ImageFeaEncoder runs on the GPU only (no CPU path in rnnpose_amd)")
+        B = image1.shape[0]
+        f = self.engine()([image1, image2], normalize=True, split_out=True)
+        return f[:B], f[B:]
+
 
 class GRU_CFUpdator(nn.Module):
     def __init__(self, args=None):
@@ -115,7 +125,7 @@ class GRU_CFUpdator(nn.Module):
 
     def prepare(self, fmap1, fmap2, context_fea):
         """The update_corr_fn=True branch (CFNet.py:115-133): volume + pyramid, hidden state, context input."""
-        self.fmap1 = fmap1.float()
+        self.fmap1 = fmap1.float()           # (NCHW tensors, or ops.SplitTensor pairs from ImageFeaEncoder.forward_split)
         self.fmap2 = fmap2.float()
         self.corr_fn = CorrBlock(self.fmap1, self.fmap2, radius=self.args.corr_radius, reuse=self.corr_fn,
                                  precision=self.corr_precision)

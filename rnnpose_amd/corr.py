@@ -31,8 +31,13 @@ class CorrBlock:
         # reuse: a previous CorrBlock whose device buffer may be overwritten (same shapes) -- keeps addresses stable
         # precision: "f32" = fp32 MFMA kernel; "f16x3" = fp16 hi/lo split on the fp16 matrix cores (fp32-class accuracy,
         # ~3x faster build: HBM-write-bound instead of MFMA-bound)
-        self._buf, self.corr_pyramid = ops.corr_pyramid(fmap1.float(), fmap2.float(), num_levels,
-                                                        out=None if reuse is None else reuse._buf, precision=precision)
+        out = None if reuse is None else reuse._buf
+        if isinstance(fmap1, ops.SplitTensor):      # operands already split by their producer (encoder output convolution)
+            if precision != "f16x3":
+                raise ValueError("split feature maps feed the fp16x3 volume kernel only")
+            self._buf, self.corr_pyramid = ops.corr_pyramid_split(fmap1, fmap2, num_levels, out=out)
+        else:
+            self._buf, self.corr_pyramid = ops.corr_pyramid(fmap1.float(), fmap2.float(), num_levels, out=out, precision=precision)
 
     def __call__(self, coords):
         return ops.corr_lookup(self._buf, coords, self.num_levels, self.radius)

@@ -33,6 +33,18 @@ constexpr int BK = 16;
 constexpr int NT = 256;
 constexpr int ST = 8;     // supertile side (tiles)
 
+// Diagnostics builds only (tools/corr_ablate.sh): RPC_ABL bits 1 = the K loop requests no operands after the first slab,
+// 2 = the epilogue stores nothing, 4 = no K loop at all, 8 = no epilogue (one value per lane leaves), 16 = the K loop does not
+// refill LDS.  0 in the product.
+#ifndef RPC_ABL
+#define RPC_ABL 0
+#endif
+#ifndef RPC_NT
+#define RPC_NT 1          // 1: level-0 rows leave with non-temporal stores (they are never re-read by this kernel: -13 %);
+                          // 2: the pooled levels too (their 8-32 byte pieces then miss L2's merging: +30 %)
+#endif
+typedef float f4v __attribute__((ext_vector_type(4)));
+
 struct PyrInfo {
   long long off[RNNPOSE_MAX_LEVELS];
   int hl[RNNPOSE_MAX_LEVELS];
@@ -111,6 +123,9 @@ __device__ __forceinline__ void pyramid_epilogue(const f32x16& acc0, const f32x1
                                                  float scale, int wave, int lane) {
   const int kh = lane >> 5, l31 = lane & 31;
   const f32x16 acc[4] = {acc0, acc1, acc2, acc3};
+  const int Nm = ((RPC_ABL & 2) && scale != 1234.5f) ? 0 : N;      // diagnostics: every store below is masked by i < Nm
+  const int Nm0 = ((RPC_ABL & 32) && scale != 1234.5f) ? 0 : Nm;   // 32: no level-0 stores, 64: no pooled stores
+  const int NmP = ((RPC_ABL & 64) && scale != 1234.5f) ? 0 : Nm;
   float* S = smem + wave * 2304;    // [32 i][32 j]   j = yy*16 + xx within sub-tile s (patch rows 2s, 2s+1)
   float* L1 = S + 1024;             // [32 i][4 Y1][8 X1]
   float* L2 = S + 2048;             // [32 i][2 Y2][4 X2]
@@ -136,11 +151,16 @@ __device__ __forceinline__ void pyramid_epilogue(const f32x16& acc0, const f32x1
       const int c = (f & 7) << 2;
       const int yy = c >> 4, xx = c & 15;
       const int i = iw + row, y = y0 + 2 * s + yy, x = x0 + xx;
-      if (i < N && y < h) {
+      if (i < Nm0 && y < h) {
         const float4 v = *reinterpret_cast<const float4*>(S + row * 32 + c);
         float* dst = p0 + static_cast<long long>(i) * N + static_cast<long long>(y) * w + x;
         if (ALIGNED && x + 3 < w) {
-          *reinterpret_cast<float4*>(dst) = v;
+          if (RPC_NT) {
+            const f4v vv = {v.x, v.y, v.z, v.w};
+            __builtin_nontemporal_store(vv, reinterpret_cast<f4v*>(dst));
+          } else {
+            *reinterpret_cast<float4*>(dst) = v;
+          }
         } else {
           if (x + 0 < w) dst[0] = v.x;
           if (x + 1 < w) dst[1] = v.y;
@@ -161,7 +181,10 @@ __device__ __forceinline__ void pyramid_epilogue(const f32x16& acc0, const f32x1
         const float v = (((top.x + top.y) + bot.x) + bot.y) * 0.25f;
         L1[row * 32 + s * 8 + X] = v;
         const int i = iw + row, Y1 = (y0 >> 1) + s, X1 = (x0 >> 1) + X;
-        if (i < N && Y1 < h1 && X1 < w1) p1[(static_cast<long long>(i) * h1 + Y1) * w1 + X1] = v;
+        if (i < NmP && Y1 < h1 && X1 < w1) {
+          if (RPC_NT >= 2) __builtin_nontemporal_store(v, p1 + (static_cast<long long>(i) * h1 + Y1) * w1 + X1);
+          else p1[(static_cast<long long>(i) * h1 + Y1) * w1 + X1] = v;
+        }
       }
     }
     __builtin_amdgcn_wave_barrier();   // S / L1 / L2 are wave-private: LDS ops of one wave execute in order
@@ -178,7 +201,10 @@ __device__ __forceinline__ void pyramid_epilogue(const f32x16& acc0, const f32x1
       const float v = (((q[0] + q[1]) + q[8]) + q[9]) * 0.25f;
       L2[row * 8 + Y * 4 + X] = v;
       const int i = iw + row, Y2 = (y0 >> 2) + Y, X2 = (x0 >> 2) + X;
-      if (i < N && Y2 < h2 && X2 < w2) p2[(static_cast<long long>(i) * h2 + Y2) * w2 + X2] = v;
+      if (i < NmP && Y2 < h2 && X2 < w2) {
+        if (RPC_NT >= 2) __builtin_nontemporal_store(v, p2 + (static_cast<long long>(i) * h2 + Y2) * w2 + X2);
+        else p2[(static_cast<long long>(i) * h2 + Y2) * w2 + X2] = v;
+      }
     }
     __builtin_amdgcn_wave_barrier();   // S / L1 / L2 are wave-private: LDS ops of one wave execute in order
     if (info.levels > 3) {
@@ -188,7 +214,7 @@ __device__ __forceinline__ void pyramid_epilogue(const f32x16& acc0, const f32x1
       const float* q = L2 + row * 8 + 2 * X;
       const float v = (((q[0] + q[1]) + q[4]) + q[5]) * 0.25f;
       const int i = iw + row, Y3 = (y0 >> 3), X3 = (x0 >> 3) + X;
-      if (i < N && Y3 < h3 && X3 < w3) p3[(static_cast<long long>(i) * h3 + Y3) * w3 + X3] = v;
+      if (i < NmP && Y3 < h3 && X3 < w3) p3[(static_cast<long long>(i) * h3 + Y3) * w3 + X3] = v;
     }
   }
 }
@@ -295,22 +321,27 @@ __device__ __forceinline__ void split4_h3(const float4 v, float s, h4& hi, h4& l
   }
 }
 
-// pre-pass: fp32 features -> pixel-major fp16 hi / lo planes ((B*N, C) halfs each), scaled by a_scale, saturated.
-// layout 0: source is (B, C, N) (NCHW, transposed through a 32 x 33 LDS tile); layout 1: source is (B, N, C).
-__global__ __launch_bounds__(256) void split_features_kernel(const float* __restrict__ src, _Float16* __restrict__ hi,
-                                                             _Float16* __restrict__ lo, int C, int N, int layout,
-                                                             float a_scale, unsigned long long* sat) {
-  const int b = blockIdx.z;
+// pre-pass: fp32 features -> SPLIT tensors (rnnpose_hip.h: per 8-channel group 16 bytes of fp16 hi then 16 bytes of fp16 lo,
+// pixel-major, the same 4*C bytes per pixel as the fp32 map), scaled by a_scale, saturated.  Both maps in one launch
+// (blockIdx.z = map * B + b).  layout 0: source is (B, C, N) (NCHW, transposed through a 32 x 33 LDS tile); 1: (B, N, C).
+__global__ __launch_bounds__(256) void split_features_kernel(const float* __restrict__ src1, const float* __restrict__ src2,
+                                                             _Float16* __restrict__ dst1, _Float16* __restrict__ dst2, int B,
+                                                             int C, int N, int layout, float a_scale, unsigned long long* sat) {
+  const int which = blockIdx.z / B, b = blockIdx.z - which * B;
+  const float* src = which ? src2 : src1;
+  _Float16* dst = which ? dst2 : dst1;
   if (layout == 1) {
-    const long long total4 = static_cast<long long>(N) * C / 4;
+    const long long total8 = static_cast<long long>(N) * C / 8;
     const long long i = (static_cast<long long>(blockIdx.y) * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
-    if (i >= total4) return;
-    const float4 v = reinterpret_cast<const float4*>(src + static_cast<long long>(b) * N * C)[i];
-    h4 h, l;
-    split4_h3(v, a_scale, h, l);
-    if (sat && rp::quad_saturates(v, a_scale)) atomicAdd(sat, 1ull);       // range guard (f16x3.cuh)
-    reinterpret_cast<h4*>(hi + static_cast<long long>(b) * N * C)[i] = h;
-    reinterpret_cast<h4*>(lo + static_cast<long long>(b) * N * C)[i] = l;
+    if (i >= total8) return;
+    const float4* s4 = reinterpret_cast<const float4*>(src + static_cast<long long>(b) * N * C) + 2 * i;
+    const float4 v0 = s4[0], v1 = s4[1];
+    h4 h0, l0, h1, l1;
+    split4_h3(v0, a_scale, h0, l0);
+    split4_h3(v1, a_scale, h1, l1);
+    if (sat && (rp::quad_saturates(v0, a_scale) || rp::quad_saturates(v1, a_scale))) atomicAdd(sat, 1ull);   // range guard
+    h4* d = reinterpret_cast<h4*>(dst + (static_cast<long long>(b) * N * C) * 2) + 4 * i;
+    d[0] = h0; d[1] = h1; d[2] = l0; d[3] = l1;
     return;
   }
   __shared__ float tile[32][33];
@@ -330,17 +361,33 @@ __global__ __launch_bounds__(256) void split_features_kernel(const float* __rest
       if (sat && !(fabsf(raw) <= 65504.f)) atomicAdd(sat, 1ull);           // range guard (f16x3.cuh)
       const float x = fminf(fmaxf(raw, -65504.f), 65504.f);
       const _Float16 h = static_cast<_Float16>(x);
-      hi[(static_cast<long long>(b) * N + n) * C + c] = h;
-      lo[(static_cast<long long>(b) * N + n) * C + c] = static_cast<_Float16>(x - static_cast<float>(h));
+      _Float16* row = dst + (static_cast<long long>(b) * N + n) * C * 2 + (c >> 3) * 16 + (c & 7);
+      row[0] = h;
+      row[8] = static_cast<_Float16>(x - static_cast<float>(h));
     }
   }
 }
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+// Operands are SPLIT tensors: a pixel's k-slab of 32 channels is 128 contiguous bytes (4 groups x [hi 16 B | lo 16 B]).
+//
+// What bounds it (profiles/r03_corr_ablation.txt, r03_corr_store_patterns.txt, r03_corr_variants_not_kept.txt; B = 8, 60 x 80,
+// C = 256: 475-490 us per launch): an empty pass (no K loop, no stores) 70 us, the stores alone +160 us, the K loop alone +270 us
+// (fragment reads + MFMA + two barriers per slab 150 -- 75 % of the matrix pipe --, refilling LDS +30, requesting operands +60,
+// the epilogue's transposes +25), and the SUM is what is measured.  The K loop reaches that rate only with all four resident
+// workgroups of a CU in it (they hide each other's LDS latencies and barriers); a workgroup sitting in its epilogue until the
+// memory system has taken its stores is one fewer, so the two phases hardly overlap.  The store phase itself: 978 MB as 64-byte
+// row pieces (128 rows x 8 image rows per tile) go at 3.6-4.3 TB/s whatever the instruction shape, also as 128- or 256-byte
+// pieces; one workgroup writing a whole 8-row stripe of an i row (2560 contiguous bytes) 5.2-6.0, a linear fill 5.9-6.5.
+// Tried, measured slower or equal, not kept: a second register set (requests two slabs ahead: equal, costs a workgroup per CU);
+// non-temporal stores for the pooled levels too (+30 %: their 8-32 byte pieces then miss L2's merging); workgroups walking a
+// contiguous range of the tile list so that one workgroup writes whole stripes (+45 %: a tile's first operands cannot be
+// consumed before the previous tile's stores are acknowledged -- gfx9 counts both on vmcnt).  Kept: non-temporal level-0 stores
+// (-13 %), operands pre-split by their producer (no pre-pass).  Next: a K loop that is fast on its own (double-buffered LDS,
+// one barrier per slab), then stripe-wide tiles.
 template <bool ALIGNED>
-__global__ __launch_bounds__(NT, 2) void corr_pyramid_h3_kernel(const _Float16* __restrict__ f1h, const _Float16* __restrict__ f1l,
-                                                                const _Float16* __restrict__ f2h, const _Float16* __restrict__ f2l,
+__global__ __launch_bounds__(NT, 2) void corr_pyramid_h3_kernel(const _Float16* __restrict__ f1, const _Float16* __restrict__ f2,
                                                                 float* __restrict__ pyr, int B, int C, int h, int w, int n_it,
                                                                 int n_py, int n_px, float scale, PyrInfo info) {
   // [A | B][hi | lo][128 rows x HRS] halfs = 40 KiB (single buffer, the next slab waits in registers);
@@ -371,19 +418,20 @@ __global__ __launch_bounds__(NT, 2) void corr_pyramid_h3_kernel(const _Float16* 
   const int y0 = (patch / n_px) * PY;
   const int x0 = (patch % n_px) * PX;
 
-  // per-thread staging: rows (tid >> 2) + 64 r (r = 0, 1), 16-byte chunk q = tid & 3 of the 64-byte k-slab of a row.
+  // per-thread staging: rows (tid >> 2) + 64 r (r = 0, 1), channel group q = tid & 3 of the slab (32 bytes: hi then lo).
   // Offsets in halfs (< 2^31, host check); rows outside the problem read element 0 and are masked to zero.
   const int q = tid & 3;
+  const unsigned rs = 2u * C;                       // halfs per pixel
   unsigned offa0, offa1, offb0, offb1, ma0, ma1, mb0, mb1;
   {
     const int r0 = tid >> 2, r1 = r0 + 64;
     const bool va0 = i0 + r0 < N, va1 = i0 + r1 < N;
-    offa0 = va0 ? (static_cast<unsigned>(b) * N + i0 + r0) * C + q * 8 : 0u;
-    offa1 = va1 ? (static_cast<unsigned>(b) * N + i0 + r1) * C + q * 8 : 0u;
+    offa0 = va0 ? (static_cast<unsigned>(b) * N + i0 + r0) * rs + q * 16 : 0u;
+    offa1 = va1 ? (static_cast<unsigned>(b) * N + i0 + r1) * rs + q * 16 : 0u;
     const int ya = y0 + (r0 >> 4), xa = x0 + (r0 & 15), yb = y0 + (r1 >> 4), xb = x0 + (r1 & 15);
     const bool vb0 = ya < h && xa < w, vb1 = yb < h && xb < w;
-    offb0 = vb0 ? (static_cast<unsigned>(b) * N + ya * w + xa) * C + q * 8 : 0u;
-    offb1 = vb1 ? (static_cast<unsigned>(b) * N + yb * w + xb) * C + q * 8 : 0u;
+    offb0 = vb0 ? (static_cast<unsigned>(b) * N + ya * w + xa) * rs + q * 16 : 0u;
+    offb1 = vb1 ? (static_cast<unsigned>(b) * N + yb * w + xb) * rs + q * 16 : 0u;
     ma0 = va0 ? 0xffffffffu : 0u; ma1 = va1 ? 0xffffffffu : 0u;
     mb0 = vb0 ? 0xffffffffu : 0u; mb1 = vb1 ? 0xffffffffu : 0u;
   }
@@ -395,14 +443,14 @@ __global__ __launch_bounds__(NT, 2) void corr_pyramid_h3_kernel(const _Float16* 
   u32x4 rah0, rah1, ral0, ral1, rbh0, rbh1, rbl0, rbl1;
 #define RPH_LOAD(K0_)                                                                          \
   do {                                                                                         \
-    rah0 = *reinterpret_cast<const u32x4*>(f1h + offa0 + (K0_));                               \
-    rah1 = *reinterpret_cast<const u32x4*>(f1h + offa1 + (K0_));                               \
-    ral0 = *reinterpret_cast<const u32x4*>(f1l + offa0 + (K0_));                               \
-    ral1 = *reinterpret_cast<const u32x4*>(f1l + offa1 + (K0_));                               \
-    rbh0 = *reinterpret_cast<const u32x4*>(f2h + offb0 + (K0_));                               \
-    rbh1 = *reinterpret_cast<const u32x4*>(f2h + offb1 + (K0_));                               \
-    rbl0 = *reinterpret_cast<const u32x4*>(f2l + offb0 + (K0_));                               \
-    rbl1 = *reinterpret_cast<const u32x4*>(f2l + offb1 + (K0_));                               \
+    rah0 = *reinterpret_cast<const u32x4*>(f1 + offa0 + (K0_));                                \
+    ral0 = *reinterpret_cast<const u32x4*>(f1 + offa0 + (K0_) + 8);                            \
+    rah1 = *reinterpret_cast<const u32x4*>(f1 + offa1 + (K0_));                                \
+    ral1 = *reinterpret_cast<const u32x4*>(f1 + offa1 + (K0_) + 8);                            \
+    rbh0 = *reinterpret_cast<const u32x4*>(f2 + offb0 + (K0_));                                \
+    rbl0 = *reinterpret_cast<const u32x4*>(f2 + offb0 + (K0_) + 8);                            \
+    rbh1 = *reinterpret_cast<const u32x4*>(f2 + offb1 + (K0_));                                \
+    rbl1 = *reinterpret_cast<const u32x4*>(f2 + offb1 + (K0_) + 8);                            \
   } while (0)
   // plane p (0 = A hi, 1 = A lo, 2 = B hi, 3 = B lo) x 128 rows x HRS halfs
 #define RPH_ST(V_, M_, P_, R_) *reinterpret_cast<u32x4*>(sT + (P_) * (128 * HRS) + ((tid >> 2) + 64 * (R_)) * HRS + q * 8) = (V_) & (M_)
@@ -411,43 +459,51 @@ __global__ __launch_bounds__(NT, 2) void corr_pyramid_h3_kernel(const _Float16* 
     RPH_ST(rah0, ma0, 0, 0); RPH_ST(rah1, ma1, 0, 1); RPH_ST(ral0, ma0, 1, 0); RPH_ST(ral1, ma1, 1, 1); \
     RPH_ST(rbh0, mb0, 2, 0); RPH_ST(rbh1, mb1, 2, 1); RPH_ST(rbl0, mb0, 3, 0); RPH_ST(rbl1, mb1, 3, 1); \
   } while (0)
+#define RPH_MFMA                                                                               \
+  _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                           \
+    const h8 ah = *reinterpret_cast<const h8*>(sAh + kk * 16);                                 \
+    const h8 al = *reinterpret_cast<const h8*>(sAh + 128 * HRS + kk * 16);                     \
+    h8 bh[4], bl[4];                                                                           \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                            \
+      bh[s] = *reinterpret_cast<const h8*>(sBh + s * 32 * HRS + kk * 16);                      \
+      bl[s] = *reinterpret_cast<const h8*>(sBh + 128 * HRS + s * 32 * HRS + kk * 16);          \
+    }                                                                                          \
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[0], acc0, 0, 0, 0);                   \
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[1], acc1, 0, 0, 0);                   \
+    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[2], acc2, 0, 0, 0);                   \
+    acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[3], acc3, 0, 0, 0);                   \
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[0], acc0, 0, 0, 0);                   \
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[1], acc1, 0, 0, 0);                   \
+    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[2], acc2, 0, 0, 0);                   \
+    acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[3], acc3, 0, 0, 0);                   \
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[0], acc0, 0, 0, 0);                   \
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[1], acc1, 0, 0, 0);                   \
+    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[2], acc2, 0, 0, 0);                   \
+    acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[3], acc3, 0, 0, 0);                   \
+  }
 
   RPH_LOAD(0);
   RPH_STORE;
   __syncthreads();
-  const int nk = C / HBK;
+  const int nk = (RPC_ABL & 4) ? 0 : C / HBK;
   const _Float16* sAh = sT + (wave * 32 + l31) * HRS + lh * 8;
   const _Float16* sBh = sT + 2 * 128 * HRS + l31 * HRS + lh * 8;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int knext = (kt + 1 < nk ? kt + 1 : kt) * HBK;          // (the last slab is re-requested: loads stay unconditional)
-    RPH_LOAD(knext);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const h8 ah = *reinterpret_cast<const h8*>(sAh + kk * 16);
-      const h8 al = *reinterpret_cast<const h8*>(sAh + 128 * HRS + kk * 16);
-      h8 bh[4], bl[4];
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        bh[s] = *reinterpret_cast<const h8*>(sBh + s * 32 * HRS + kk * 16);
-        bl[s] = *reinterpret_cast<const h8*>(sBh + 128 * HRS + s * 32 * HRS + kk * 16);
-      }
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[0], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[1], acc1, 0, 0, 0);
-      acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[2], acc2, 0, 0, 0);
-      acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[3], acc3, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[0], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[1], acc1, 0, 0, 0);
-      acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[2], acc2, 0, 0, 0);
-      acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[3], acc3, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[0], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[1], acc1, 0, 0, 0);
-      acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[2], acc2, 0, 0, 0);
-      acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[3], acc3, 0, 0, 0);
-    }
+  for (int kt = 1; kt < nk; ++kt) {                  // slab kt travels while slab kt - 1 is multiplied
+    if (!(RPC_ABL & 1)) RPH_LOAD(kt * (2 * HBK));
+    RPH_MFMA
     __syncthreads();
-    RPH_STORE;
+    if (!(RPC_ABL & 16)) RPH_STORE;
     __syncthreads();
   }
+  if (nk > 0) {
+    RPH_MFMA
+    __syncthreads();                                 // every wave is done with the operands: the epilogue re-uses their LDS
+  }
+  if (RPC_ABL & 8) {
+    if (scale == 1234.5f) pyr[tid] = acc0[0] + acc1[1] + acc2[2] + acc3[3];
+    return;
+  }
+#undef RPH_MFMA
 #undef RPH_LOAD
 #undef RPH_STORE
 #undef RPH_ST
@@ -506,8 +562,35 @@ int rnnpose_corr_pyramid_f32(const float* fmap1, const float* fmap2, int B, int 
 
 size_t rnnpose_corr_pyramid_f16x3_workspace_bytes(int B, int C, int h, int w) {
   if (B <= 0 || C <= 0 || h <= 0 || w <= 0) return 0;
-  return static_cast<size_t>(B) * h * w * C * sizeof(_Float16) * 4;      // (hi, lo) x (fmap1, fmap2)
+  return static_cast<size_t>(B) * h * w * C * sizeof(_Float16) * 4;      // two split tensors (fmap1, fmap2)
 }
+
+namespace {
+int launch_h3(const char* fn, const _Float16* f1, const _Float16* f2, int B, int C, int h, int w, int levels, float a_scale,
+              float* pyramid, hipStream_t st) {
+  RP_REQUIRE(C > 0 && C % HBK == 0, fn, "C must be a positive multiple of 32");
+  RP_REQUIRE(a_scale > 0.f, fn, "a_scale must be positive");
+  int64_t offs[RNNPOSE_MAX_LEVELS + 1];
+  PyrInfo info{};
+  if (int e = rnnpose_corr_pyramid_layout(B, h, w, levels, offs, info.hl, info.wl)) return e;
+  for (int l = 0; l < levels; ++l) info.off[l] = offs[l];
+  info.levels = levels;
+  const int N = h * w;
+  RP_REQUIRE(B < 65536 && 2LL * B * N * C < (1LL << 31), fn, "feature maps too large for 32-bit element offsets");
+  const int n_it = rp::cdiv(N, BM), n_py = rp::cdiv(h, PY), n_px = rp::cdiv(w, PX);
+  const long long ntiles = static_cast<long long>(B) * rp::cdiv(n_it, ST) * rp::cdiv(n_py * n_px, ST) * ST * ST;
+  RP_REQUIRE(ntiles < (1LL << 31), fn, "grid too large");
+  const float scale = 1.0f / (sqrtf(static_cast<float>(C)) * a_scale * a_scale);
+  const bool aligned = (N % 4 == 0) && (w % 4 == 0) && (reinterpret_cast<uintptr_t>(pyramid) % 16 == 0);
+  dim3 grid(static_cast<unsigned>(ntiles)), block(NT);
+  if (aligned) {
+    hipLaunchKernelGGL(corr_pyramid_h3_kernel<true>, grid, block, 0, st, f1, f2, pyramid, B, C, h, w, n_it, n_py, n_px, scale, info);
+  } else {
+    hipLaunchKernelGGL(corr_pyramid_h3_kernel<false>, grid, block, 0, st, f1, f2, pyramid, B, C, h, w, n_it, n_py, n_px, scale, info);
+  }
+  return rp::check_launch(fn);
+}
+}  // namespace
 
 int rnnpose_corr_pyramid_f16x3(const float* fmap1, const float* fmap2, int layout, int B, int C, int h, int w, int levels,
                                float a_scale, void* workspace, size_t workspace_bytes, float* pyramid,
@@ -517,39 +600,30 @@ int rnnpose_corr_pyramid_f16x3(const float* fmap1, const float* fmap2, int layou
   RP_REQUIRE(layout == 0 || layout == 1, fn, "layout must be 0 (B,C,h,w) or 1 (B,h,w,C)");
   RP_REQUIRE(C > 0 && C % HBK == 0, fn, "C must be a positive multiple of 32");
   RP_REQUIRE(a_scale > 0.f, fn, "a_scale must be positive");
+  RP_REQUIRE(B > 0 && 2 * B < 65536, fn, "B out of range");
   RP_REQUIRE(workspace_bytes >= rnnpose_corr_pyramid_f16x3_workspace_bytes(B, C, h, w) &&
                  reinterpret_cast<uintptr_t>(workspace) % 16 == 0, fn, "workspace too small or not 16-byte aligned");
   RP_REQUIRE(layout == 0 || (reinterpret_cast<uintptr_t>(fmap1) % 16 == 0 && reinterpret_cast<uintptr_t>(fmap2) % 16 == 0), fn,
              "pixel-major feature maps must be 16-byte aligned");
-  int64_t offs[RNNPOSE_MAX_LEVELS + 1];
-  PyrInfo info{};
-  if (int e = rnnpose_corr_pyramid_layout(B, h, w, levels, offs, info.hl, info.wl)) return e;
-  for (int l = 0; l < levels; ++l) info.off[l] = offs[l];
-  info.levels = levels;
   const int N = h * w;
-  RP_REQUIRE(B < 65536 && static_cast<long long>(B) * N * C < (1LL << 31), fn, "feature maps too large for 32-bit element offsets");
   hipStream_t st = rp::as_stream(stream);
-  const size_t plane = static_cast<size_t>(B) * N * C;
+  const size_t plane = static_cast<size_t>(B) * N * C * 2;             // halfs per split tensor
   _Float16* ws = static_cast<_Float16*>(workspace);
-  _Float16 *f1h = ws, *f1l = ws + plane, *f2h = ws + 2 * plane, *f2l = ws + 3 * plane;
-  dim3 sg = layout == 1 ? dim3(1024, static_cast<unsigned>(rp::cdiv(static_cast<long long>(N) * C / 4, 256 * 1024)), B)
-                        : dim3(rp::cdiv(N, 32), rp::cdiv(C, 32), B);
-  hipLaunchKernelGGL(split_features_kernel, sg, dim3(256), 0, st, fmap1, f1h, f1l, C, N, layout, a_scale, rp::sat_counter());
-  hipLaunchKernelGGL(split_features_kernel, sg, dim3(256), 0, st, fmap2, f2h, f2l, C, N, layout, a_scale, rp::sat_counter());
-  const int n_it = rp::cdiv(N, BM), n_py = rp::cdiv(h, PY), n_px = rp::cdiv(w, PX);
-  const long long ntiles = static_cast<long long>(B) * rp::cdiv(n_it, ST) * rp::cdiv(n_py * n_px, ST) * ST * ST;
-  RP_REQUIRE(ntiles < (1LL << 31), fn, "grid too large");
-  const float scale = 1.0f / (sqrtf(static_cast<float>(C)) * a_scale * a_scale);
-  const bool aligned = (N % 4 == 0) && (w % 4 == 0) && (reinterpret_cast<uintptr_t>(pyramid) % 16 == 0);
-  dim3 grid(static_cast<unsigned>(ntiles)), block(NT);
-  if (aligned) {
-    hipLaunchKernelGGL(corr_pyramid_h3_kernel<true>, grid, block, 0, st, f1h, f1l, f2h, f2l, pyramid, B, C, h, w, n_it, n_py,
-                       n_px, scale, info);
-  } else {
-    hipLaunchKernelGGL(corr_pyramid_h3_kernel<false>, grid, block, 0, st, f1h, f1l, f2h, f2l, pyramid, B, C, h, w, n_it, n_py,
-                       n_px, scale, info);
-  }
-  return rp::check_launch(fn);
+  dim3 sg = layout == 1 ? dim3(1024, static_cast<unsigned>(rp::cdiv(static_cast<long long>(N) * C / 8, 256 * 1024)), 2 * B)
+                        : dim3(rp::cdiv(N, 32), rp::cdiv(C, 32), 2 * B);
+  hipLaunchKernelGGL(split_features_kernel, sg, dim3(256), 0, st, fmap1, fmap2, ws, ws + plane, B, C, N, layout, a_scale,
+                     rp::sat_counter());
+  return launch_h3(fn, ws, ws + plane, B, C, h, w, levels, a_scale, pyramid, st);
+}
+
+int rnnpose_corr_pyramid_split(const void* fmap1_split, const void* fmap2_split, int B, int C, int h, int w, int levels,
+                               float a_scale, float* pyramid, rnnpose_stream_t stream) {
+  const char* fn = "rnnpose_corr_pyramid_split";
+  RP_REQUIRE(fmap1_split && fmap2_split && pyramid, fn, "null pointer");
+  RP_REQUIRE(reinterpret_cast<uintptr_t>(fmap1_split) % 16 == 0 && reinterpret_cast<uintptr_t>(fmap2_split) % 16 == 0, fn,
+             "split feature maps must be 16-byte aligned");
+  return launch_h3(fn, static_cast<const _Float16*>(fmap1_split), static_cast<const _Float16*>(fmap2_split), B, C, h, w, levels,
+                   a_scale, pyramid, rp::as_stream(stream));
 }
 
 }  // extern "C"

@@ -447,9 +447,11 @@ class EncoderEngine:
             return e.value
 
     @torch.no_grad()
-    def __call__(self, images, normalize=True):
+    def __call__(self, images, normalize=True, split_out=False):
         """images: one (N,3,H,W) tensor or a list of them (rendered, observed: processed as one batch, no concatenation)
-        -> (sum N, 256, H/8, W/8) NCHW.  normalize: apply 2*(x/255)-1 in the stem's load (model/CFNet.py:42-43)."""
+        -> (sum N, 256, H/8, W/8) NCHW.  normalize: apply 2*(x/255)-1 in the stem's load (model/CFNet.py:42-43).
+        split_out: return an ops.SplitTensor instead (pixel-major fp16 hi|lo, written by the output convolution itself) --
+        the operand format of the volume build, which then needs neither the NCHW transposition nor its split pre-pass."""
         W = self._weights()
         imgs = [images] if torch.is_tensor(images) else list(images)
         imgs = [ops._chk(t, "image") for t in imgs]
@@ -458,7 +460,10 @@ class EncoderEngine:
         dev = imgs[0].device
         H8, W8 = ((H + 1) // 2 + 1) // 2, ((Wd + 1) // 2 + 1) // 2
         H8, W8 = (H8 + 1) // 2, (W8 + 1) // 2
-        out = torch.empty(N, self.fnet.conv2.out_channels, H8, W8, device=dev, dtype=torch.float32)
+        if split_out:
+            out = torch.empty(N, H8, W8, self.fnet.conv2.out_channels, device=dev, dtype=torch.float32)
+        else:
+            out = torch.empty(N, self.fnet.conv2.out_channels, H8, W8, device=dev, dtype=torch.float32)
         # Two halves of the image batch (rendered | observed) as two independent streams = two hipGraph branches with a
         # single join at the end: the chains drift apart, so one half's HBM-bound instance-norm passes and latency-bound
         # finalize launches run under the other half's convolutions.  Bit-identical (instance norm is per image).
@@ -479,7 +484,7 @@ class EncoderEngine:
         def job(x_part, b0, b1, st):
             if st is not main:
                 st.wait_event(fork)
-            yield from self._forward_gen(W, x_part, out[b0:b1], normalize)
+            yield from self._forward_gen(W, x_part, out[b0:b1], normalize, split_out)
             if st is not main:
                 j = torch.cuda.Event()
                 j.record(st)
@@ -500,7 +505,7 @@ class EncoderEngine:
                         active.remove(item)
         for j in joins:
             main.wait_event(j)
-        return out
+        return ops.SplitTensor(out, ops.A_SCALE) if split_out else out
 
     def _second_stream(self, device, i):
         """Stream of image set / batch part i >= 1 (rnnpose_amd/streams.py: distinct hardware queues)."""
@@ -510,7 +515,7 @@ class EncoderEngine:
         ss = reserve(device)
         return (ss.chain + [ss.aux])[(i - 1) % 3]
 
-    def _forward_gen(self, W, x_nchw, out, normalize):
+    def _forward_gen(self, W, x_nchw, out, normalize, split_out=False):
         """One image set through the encoder (extractor.py:187-232); yields after every launch group."""
         E = EncoderEngine
         f = self.fnet
@@ -526,10 +531,17 @@ class EncoderEngine:
                 x = yield from E._block_gen(W, f"l{li}.{bi}", blk, x, x_norm)
                 x_norm = None
         if W["outr"] is not None and self.resident_1x1:
+            if split_out:                # the volume build's operand, written in place (a batch slice of NHWC is contiguous)
+                ops.conv1x1_resident(W["outr"], (x, 0), (out, 0), relu=False, dst_split=True)
+                yield
+                return
             o = torch.empty(*x.shape[:3], 256, device=x.device, dtype=torch.float32)
             ops.conv1x1_resident(W["outr"], (x, 0), (o, 0), relu=False)
         else:
             o, _ = E._conv(W["out"], x, stats=False)
         yield
-        ops.nhwc_to_nchw(o, out=out)
+        if split_out:
+            ops.split_hl(o, dst=out, a_scale=ops.A_SCALE)
+        else:
+            ops.nhwc_to_nchw(o, out=out)
         yield

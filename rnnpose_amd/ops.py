@@ -160,6 +160,50 @@ def corr_pyramid_nhwc(f1, f2, levels: int = 4, out=None, a_scale: float = 8.0):
     return _corr_pyramid_f16x3(f1, f2, 1, B, Cc, h, w, levels, out, a_scale)
 
 
+class SplitTensor:
+    """A (B,C,h,w) feature map held as a pixel-major split tensor (rnnpose_hip.h "SPLIT TENSORS": per 8-channel group fp16
+    hi x 8 | fp16 lo x 8 of a_scale * x, in a float32-typed (B,h,w,C) buffer): what the encoder's output convolution writes
+    for the volume build.  `shape` is the NCHW shape of the map it stands for; dense() converts back (tests, facade)."""
+
+    def __init__(self, data, a_scale: float = 8.0):
+        self.data = _nhwc(data, "split tensor")
+        self.a_scale = float(a_scale)
+
+    @property
+    def shape(self):
+        B, h, w, Cc = self.data.shape
+        return torch.Size((B, Cc, h, w))
+
+    @property
+    def device(self):
+        return self.data.device
+
+    def float(self):
+        return self
+
+    def __getitem__(self, sl):
+        if not isinstance(sl, slice):
+            raise TypeError("SplitTensor supports batch slices only")
+        return SplitTensor(self.data[sl], self.a_scale)
+
+    def dense(self):
+        return unsplit_hl(self.data, self.a_scale).permute(0, 3, 1, 2).contiguous()
+
+
+def corr_pyramid_split(f1: SplitTensor, f2: SplitTensor, levels: int = 4, out=None):
+    """Volume + pyramid from operands that are split tensors already (no pre-pass): (buffer, views) as corr_pyramid."""
+    if f1.shape != f2.shape or f1.a_scale != f2.a_scale:
+        raise ValueError("f1/f2 must have the same shape and scale")
+    B, Cc, h, w = f1.shape
+    offs, hl, wl = pyramid_layout(B, h, w, levels)
+    dev = f1.device
+    buf = out if (out is not None and out.numel() == offs[-1] and out.device == dev) else torch.empty(offs[-1], device=dev, dtype=F32)
+    _launch("rnnpose_corr_pyramid_split", _ptr(f1.data), _ptr(f2.data), B, Cc, h, w, levels, f1.a_scale, _ptr(buf), _stream(),
+            work=2.0 * B * (h * w) ** 2 * Cc, nbytes=4.0 * (2 * B * h * w * Cc + offs[-1]))
+    views = [buf[offs[l]:offs[l + 1]].view(B * h * w, 1, hl[l], wl[l]) for l in range(levels)]
+    return buf, views
+
+
 # ---- a3 ------------------------------------------------------------------------------------------------
 def _lookup_bytes(B, h, w, levels, radius):
     """per pixel and level a (2r+2)^2 texel footprint read + (2r+1)^2 outputs written, + 2 coords."""

@@ -19,6 +19,8 @@ What is different, on purpose (DESIGN.md section "Batched semantics"):
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -83,6 +85,7 @@ class PoseRefiner(nn.Module):
         # hipGraph replay of the inner-iteration body (~25 launches): at the reference's own working size (B=1,
         # 240x240) the loop is launch-bound, not GPU-bound.  Falls back to eager launches if capture is refused.
         self.use_graph = use_graph
+        self.split_fmaps = os.environ.get("RNNPOSE_SPLIT_FMAPS", "1") != "0"
         self.profile_rec = None           # set by profile_first_outer(): record of the instrumented first outer iteration
         # inner-iteration graphs, one record PER INPUT SHAPE (a partial last evaluation batch followed by a full one must not
         # evict each other: ADVICE r02): {"gr": graph captured on the caller's tensors (keyed by their addresses), "captures":
@@ -115,7 +118,12 @@ class PoseRefiner(nn.Module):
         if views.get("fmap1") is not None:
             feats1, feats2 = views["fmap1"], views["fmap2"]
         else:
-            feats1, feats2 = self.image_fea_enc(views["syn_img"], views["image_crop"])
+            # the encoder's output convolution writes the volume build's operand format directly (fp16 hi|lo, pixel-major):
+            # no NCHW transposition, no split pre-pass.  RNNPOSE_SPLIT_FMAPS=0: fp32 NCHW maps as the reference hands over.
+            if self.split_fmaps and self.cf_net.corr_precision == "f16x3":
+                feats1, feats2 = self.image_fea_enc.forward_split(views["syn_img"], views["image_crop"])
+            else:
+                feats1, feats2 = self.image_fea_enc(views["syn_img"], views["image_crop"])
         self.cf_net.prepare(feats1, feats2, views["cfea"])
         return feats1, feats2
 

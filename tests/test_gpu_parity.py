@@ -83,6 +83,54 @@ def test_corr_pyramid_f16x3_vs_oracle(ops, B, C, h, w, levels):
     close(v2[0][:, 0] / (37.0 * 11.0), want[0], 1e-5, what="f16x3 scaled inputs")
 
 
+@pytest.mark.parametrize("B,C,h,w,levels", [(2, 256, 16, 24, 4), (1, 256, 30, 30, 4), (2, 64, 17, 19, 4), (1, 96, 9, 21, 3),
+                                            (1, 32, 40, 23, 3)])
+def test_corr_pyramid_split_operands(ops, B, C, h, w, levels):
+    """rnnpose_corr_pyramid_split: operands handed over as split tensors (what the encoder's output convolution writes) give the
+    same volume, bit for bit, as the fp32 entry with its own pre-pass, in both source layouts; odd slab counts (C = 32, 96)
+    and ragged tiles included; and the oracle's volume within the fp16x3 tolerance."""
+    f1 = syn.normal("fmap1", (B, C, h, w), 11)
+    f2 = syn.normal("fmap2", (B, C, h, w), 11)
+    want = orc.corr_pyramid(f1, f2, levels)
+    n1, n2 = D(f1).permute(0, 2, 3, 1).contiguous(), D(f2).permute(0, 2, 3, 1).contiguous()
+    s1, s2 = ops.SplitTensor(ops.split_hl(n1), 8.0), ops.SplitTensor(ops.split_hl(n2), 8.0)
+    assert tuple(s1.shape) == (B, C, h, w)
+    close(s1.dense(), f1, 1e-6, what="split tensor round trip")
+    buf, views = ops.corr_pyramid_split(s1, s2, levels)
+    for l in range(levels):
+        close(views[l][:, 0], want[l], 1e-5, what=f"split operands level {l}")
+    buf_n, _ = ops.corr_pyramid_nhwc(n1, n2, levels, a_scale=8.0)
+    buf_c, _ = ops.corr_pyramid(D(f1), D(f2), levels, precision="f16x3")
+    assert torch.equal(buf, buf_n), "pixel-major fp32 entry differs from the split-operand entry"
+    assert torch.equal(buf, buf_c), "NCHW fp32 entry differs from the split-operand entry"
+    with pytest.raises(ValueError):
+        ops.corr_pyramid_split(s1, ops.SplitTensor(s2.data, 4.0), levels)
+
+
+def test_encoder_split_output(ops):
+    """ImageFeaEncoder.forward_split: the output convolution writes the volume operands itself; they stand for the same maps
+    (to the 2^-22 of the split) and the volume built from them equals the one built from the NCHW maps to fp32 round-off."""
+    from rnnpose_amd.cfnet import ImageFeaEncoder
+    from rnnpose_amd.corr import CorrBlock
+    enc = ImageFeaEncoder().cuda().eval()
+    W = syn.make_module_weights(orc.encoder_shapes(), seed=2)
+    enc.fnet.load_state_dict({k: T(v) for k, v in W.items()}, strict=True)
+    a, b = D(syn.uniform("img_render", (2, 3, 64, 96), 2)), D(syn.uniform("img_target", (2, 3, 64, 96), 2))
+    with torch.no_grad():
+        f1, f2 = enc(a, b)
+        s1, s2 = enc.forward_split(a, b)
+    assert isinstance(s1, ops.SplitTensor) and tuple(s1.shape) == tuple(f1.shape)
+    scale = float(f1.abs().max())
+    close(s1.dense(), f1, 2e-6 * max(1.0, scale), what="split fmap1")
+    close(s2.dense(), f2, 2e-6 * max(1.0, scale), what="split fmap2")
+    c_split = CorrBlock(s1, s2, precision="f16x3")
+    c_dense = CorrBlock(f1, f2, precision="f16x3")
+    for l in range(4):
+        close(c_split.corr_pyramid[l], c_dense.corr_pyramid[l], 2e-5 * max(1.0, scale * scale), what=f"volume level {l}")
+    with pytest.raises(ValueError):
+        CorrBlock(s1, s2, precision="f32")
+
+
 @pytest.mark.parametrize("precision", ["f32", "f16x3"])
 def test_corr_pyramid_golden(ops, golden, precision):
     g = golden("corr")

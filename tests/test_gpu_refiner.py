@@ -235,3 +235,33 @@ def test_split_tensor_schedule_matches_default(ops, monkeypatch):
         outs.append((out["Ti_pred"].G.clone(), out["flow_last"].clone()))
     assert float((outs[0][0] - outs[1][0]).abs().max()) < 1e-6
     assert float((outs[0][1] - outs[1][1]).abs().max()) < 5e-5
+
+
+def test_split_feature_maps_match_nchw_hand_over(ops, monkeypatch):
+    """Default: the encoder's output convolution writes the volume build's operands (fp16 hi|lo split tensors) itself;
+    RNNPOSE_SPLIT_FMAPS=0 hands fp32 NCHW maps over as the reference does (thirdparty/raft/corr.py:13-17 takes fmap1 / fmap2).
+    Same refinement: the fp16 operands of the volume are the same numbers, the encoder output is split once instead of
+    converted twice."""
+    from rnnpose_amd import synthetic as syn
+    from rnnpose_amd.pose_refiner import PoseRefiner, SyntheticRenderer, default_config
+    from rnnpose_amd.transformation import SE3Sequence
+    from oracle import rnnpose_oracle as orc
+    d = syn.make_inputs(2, 128, 160, seed=14)
+    D = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    img1 = D(syn.uniform("img_render", (2, 3, 128, 160), 3, 0.0, 255.0))
+    img2 = D(syn.uniform("img_target", (2, 3, 128, 160), 4, 0.0, 255.0))
+    kw = dict(syn_img=img1, image_crop=img2, cfea=D(d["ctx"]), geofea1=D(d["g1"]), geofea2_crop=D(d["g2"]), syn_depth=D(d["depth"]),
+              intrinsics_crop=D(d["K"]))
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("RNNPOSE_SPLIT_FMAPS", flag)
+        ref = PoseRefiner(default_config(RENDER_ITER_COUNT=2, ITER_COUNT=3, OPTIM_ITER_COUNT=1), renderer=SyntheticRenderer(**kw)).cuda().eval()
+        ref.cf_net.update_block.load_state_dict({k: torch.from_numpy(v) for k, v in syn.make_module_weights(orc.UPDATE_BLOCK_SHAPES, seed=0).items()})
+        ref.image_fea_enc.fnet.load_state_dict({k: torch.from_numpy(v) for k, v in syn.make_module_weights(orc.encoder_shapes(), seed=2).items()})
+        assert ref.split_fmaps == (flag == "1")
+        for _ in range(2):                      # second call replays the captured graphs
+            out = ref(None, SE3Sequence(matrix=D(d["G0"])), D(d["K"]))
+        assert isinstance(ref.cf_net.fmap1, ops.SplitTensor) == (flag == "1")
+        outs.append((out["Ti_pred"].G.clone(), out["flow_last"].clone()))
+    assert float((outs[0][0] - outs[1][0]).abs().max()) < 1e-6
+    assert float((outs[0][1] - outs[1][1]).abs().max()) < 5e-5

@@ -1,0 +1,8 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R
+python -m pytest tests/test_gpu_parity.py tests/test_gpu_refiner.py -x -q -p no:cacheprovider --tb=short -k "corr or encoder or split or lookup" 2>&1 | tail -3
+bash tools/corr_ablate_run.sh r03
+ab() { env "$@" python bench.py --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); c=d['correlation_volume_kernel']; print('$*', d['value'], 'iters/s', d['ms_per_step'], 'ms | corr', c['mean_ms'], 'ms frac', c['frac'])"; }
+for i in 1 2; do ab RNNPOSE_SPLIT_FMAPS=1; ab RNNPOSE_SPLIT_FMAPS=0; done
