@@ -230,7 +230,19 @@ typedef struct {
                                   (|(x - mean) * rstd| <= sqrt(H*W); extractor.py:48-58), two orders below the fp16x3 range */
   int tile;                    /* 0 = automatic; 1 = 128x64, 2 = 128x128 as 4 column waves, 3 = 128x128 as 2x2 waves, 4 = 128x64 with
                                   a block-deep register pipeline (3, 4: split sources only) */
+  void* ksplit_ws;             /* optional (NULL = off): workspace of rnnpose_conv_ksplit_workspace_bytes() bytes, 16-byte aligned,
+                                  its first 1024 bytes ZERO before the first launch (the kernel leaves them zero).  With it, a
+                                  stride-1 launch of few tiles (B = 1 crops: 8-64 workgroups on 256 CUs) splits its K loop over up
+                                  to 8 workgroups per tile; the last one to arrive sums the partial accumulators in split order
+                                  (deterministic) and runs the epilogue.  Launches that may run CONCURRENTLY (two streams) need
+                                  separate workspaces. */
+  size_t ksplit_ws_bytes;
 } rnnpose_conv_desc_t;
+
+size_t rnnpose_conv_ksplit_workspace_bytes(void);
+int rnnpose_conv_ksplit(int enable);       /* measurement switch (default 1): 0 = never split K */
+int rnnpose_conv_ksplit_limits(int max_tiles, int max_splits);   /* measurement: launches of <= max_tiles (default 24, <= 96) tiles
+                                                                     split into <= max_splits (default 4, 2..8) ranges */
 
 /* Output tiles per image of a convolution launch = records per image of its `tile_stats`: 3x3 stride-1 layers run on 8 x 16
  * image PATCHES (ceil(W/16) * ceil(H/8) tiles per image, nine taps on one staged halo tile), everything else on runs of 128

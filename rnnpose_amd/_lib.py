@@ -32,7 +32,7 @@ class ConvDesc(C.Structure):       # rnnpose_conv_desc_t
                 ("tile_stats", C.c_void_p), ("add_map", C.c_void_p), ("add_c_stride", C.c_int), ("add_c_offset", C.c_int),
                 ("src0_mean_rstd", C.c_void_p), ("src_hl", C.c_int), ("dst_hl", C.c_int), ("dst2_hl", C.c_int),
                 ("dst_split", C.c_void_p), ("dst_split_c_stride", C.c_int), ("dst_split_c_offset", C.c_int), ("src_bounded", C.c_int),
-                ("tile", C.c_int)]
+                ("tile", C.c_int), ("ksplit_ws", C.c_void_p), ("ksplit_ws_bytes", C.c_size_t)]
 
 
 # name -> (restype, argtypes); mirrors include/rnnpose_hip.h one to one
@@ -65,6 +65,9 @@ PROTOTYPES = {
     "rnnpose_gru_update_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _i, _p]),
     "rnnpose_conv_tiles_per_image": (_i, [_i, _i, _i, _i, _i]),
     "rnnpose_conv_spatial_tiles": (_i, [_i]),
+    "rnnpose_conv_ksplit": (_i, [_i]),
+    "rnnpose_conv_ksplit_limits": (_i, [_i, _i]),
+    "rnnpose_conv_ksplit_workspace_bytes": (_z, []),
     "rnnpose_conv_packed_halfs": (C.c_longlong, [_i, _i, _i, C.POINTER(_i), _i]),
     "rnnpose_conv_pack_weights_f16x3": (_i, [_p, _i, _i, _i, _i, C.POINTER(_i), _i, _f, _p, _p]),
     "rnnpose_conv2d_nhwc_f16x3": (_i, [C.POINTER(ConvDesc), _p]),

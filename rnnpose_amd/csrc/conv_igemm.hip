@@ -80,6 +80,9 @@ struct KParams {
   int dst_hl, dst2_hl;       // dst / dst2 receive the PRE-SPLIT fp16 hi|lo form (rnnpose_hip.h, "split tensors") instead of fp32
   float* dsth;               // optional second destination of the primary result, always in split form (GRU: h' as fp32 AND split)
   int dsth_cs, dsth_co;
+  int ksplit;                // > 1: gridDim.x = tiles * ksplit, workgroup (tile, s) multiplies channel blocks [nit s / ksplit, nit (s + 1) / ksplit)
+  float* ks_ws;              // ksplit partial accumulators: [tile][split][acc register][thread] floats
+  unsigned* ks_cnt;          // per-tile arrival counters (zero between launches)
 };
 
 // One output quad (4 consecutive channels starting at channel ch of the pixel row `row`) in split form: the 8-channel group
@@ -178,8 +181,14 @@ __global__ __launch_bounds__(NT, ((NI == 2 || DEEP || SPATIAL) ? 2 : (COLS4 ? (T
   const int l31 = lane & 31, lh = lane >> 5;
 
   // ---- tile id: XCD-contiguous chunks, n fastest (the n tiles of one m tile share the activation tile) ----
-  const int ntiles = gridDim.x;
-  int bid = blockIdx.x;
+  // K split (launches of a few dozen tiles: B = 1 crops): the `ks` workgroups of a tile each multiply a contiguous range of the
+  // channel blocks, leave their accumulators in a workspace, and the one that arrives last adds them up IN SPLIT ORDER (the
+  // result does not depend on who is last) and runs the epilogue.  A 3x3 256-channel layer of a 30 x 30 map is 8-24 tiles whose
+  // 72-stage serial chain is what the launch takes (25 us); four splits of 18 stages take half.
+  const int ks = p.ksplit;
+  const int ntiles = ks > 1 ? static_cast<int>(gridDim.x) / ks : static_cast<int>(gridDim.x);
+  const int split = ks > 1 ? static_cast<int>(blockIdx.x) / ntiles : 0;
+  int bid = ks > 1 ? static_cast<int>(blockIdx.x) - split * ntiles : static_cast<int>(blockIdx.x);
   {
     const int per = ntiles >> 3, rem = ntiles & 7;
     const int xcd = bid & 7, idx = bid >> 3;
@@ -561,15 +570,18 @@ __global__ __launch_bounds__(NT, ((NI == 2 || DEEP || SPATIAL) ? 2 : (COLS4 ? (T
         if (!(RP_ABL & 8)) __syncthreads();                                                                 \
       }                                                                                                     \
     }
+    // this workgroup's range of (group, channel block) iterations (all of them unless the launch splits K)
+    const int it0 = ks > 1 ? nit * split / ks : 0, it1 = ks > 1 ? nit * (split + 1) / ks : nit;
+    const int ksg0 = SPATIAL ? 0 : it0 / p.ncb, kscb0 = SPATIAL ? it0 : it0 - ksg0 * p.ncb;
     // (weight requests first: the activation tile is waited for right away and its wait then covers both; measured neutral)
     if constexpr (DEEP) {
 #pragma unroll
       for (int t = 0; t < TT; ++t) RP_LOADB2(t, t)
     } else {
-      RP_LOADB2(0, 0)
-      RP_LOADB2(1, 1)
+      RP_LOADB2(0, it0 * TT)
+      RP_LOADB2(1, it0 * TT + 1)
     }
-    RP_LOAD_A(0, 0, 0);
+    RP_LOAD_A(ksg0, kscb0, 0);
     RP_SCHED_FENCE();
     RP_STORE_A(0, 0);
     if constexpr (DEEP) {            // second tile in flight (stored at the end of the first block)
@@ -578,13 +590,13 @@ __global__ __launch_bounds__(NT, ((NI == 2 || DEEP || SPATIAL) ? 2 : (COLS4 ? (T
     }
     __syncthreads();
     if (RP_ABL & 2) { RP_READ_A(0, 0, 0, 0) RP_READ_A(1, 0, 1, 0) }
-    int cg = 0, ccb = 0, s0 = 0, it = 0;
+    int cg = ksg0, ccb = kscb0, s0 = it0 * TT, it = it0;
     if (OVL && !(RP_ABL & 2)) { RP_READ_A(0, 0, 0, 0) }      // first fragments of the first block (later blocks: at the boundary)
-    for (; it + 1 < nit; it += 2) {
+    for (; it + 1 < it1; it += 2) {
       RP_BODY(0, 1)
       RP_BODY(1, 0)
     }
-    if (it < nit) RP_BODY(0, 1)
+    if (it < it1) RP_BODY(0, 1)
   } else {
     // ---------------- generic stage machine (stride 2) ----------------
  RP_LOAD_A(0, 0, 0);
@@ -612,6 +624,45 @@ __global__ __launch_bounds__(NT, ((NI == 2 || DEEP || SPATIAL) ? 2 : (COLS4 ? (T
   }
   if (total & 1) RP_STAGE(0);
 
+  }
+  if (ks > 1) {                      // K split: partial accumulators -> workspace; the last arrival of the tile sums them in split order
+    constexpr int ACCN = MI * NI * 16;
+    const int tile_lin = mt_i * p.n_nt + nt_i;
+    float* wsb = p.ks_ws + (static_cast<long long>(tile_lin) * ks + split) * (NT * ACCN) + tid;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) wsb[((i * NI + j) * 16 + r) * NT] = acc[i][j][r];
+    __shared__ int ks_last;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned prev = __hip_atomic_fetch_add(p.ks_cnt + tile_lin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = prev == static_cast<unsigned>(ks - 1);
+      if (last) __hip_atomic_store(p.ks_cnt + tile_lin, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+      ks_last = last;
+    }
+    __syncthreads();
+    if (!ks_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const float* wsr = p.ks_ws + static_cast<long long>(tile_lin) * ks * (NT * ACCN) + tid;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = wsr[((i * NI + j) * 16 + r) * NT];
+    for (int sp = 1; sp < ks; ++sp) {
+      const float* wq = wsr + static_cast<long long>(sp) * (NT * ACCN);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] += wq[((i * NI + j) * 16 + r) * NT];
+    }
   }
   // ------------------------------------------- epilogue -------------------------------------------
   // accumulators -> wave-private LDS tile (aliasing the weight staging buffers) -> 16-byte row-contiguous stores:
@@ -842,12 +893,34 @@ int fill_cb_tables(const int* counts, int n, unsigned char* cb_seg, short* cb_c0
 }  // namespace
 
 static bool g_conv_spatial = true;      // 3x3 stride-1 convolutions on 8 x 16 image patches (rnnpose_conv_spatial_tiles)
+static bool g_conv_ksplit = true;       // K split of launches with few tiles when the caller provides a workspace (rnnpose_conv_ksplit)
+static int g_ks_max_tiles = 24, g_ks_max_splits = 4;      // (rnnpose_conv_ksplit_limits: measurement)
+constexpr int KS_MAX_WG = 192;          // tiles x splits of a split launch
+constexpr size_t KS_CNT_BYTES = 1024;   // arrival counters (<= 96 tiles) at the head of the workspace
 
 extern "C" {
 
 int rnnpose_conv_spatial_tiles(int enable) {     // measurement switch: 0 = the r02 row-major tiling for 3x3 layers too
   g_conv_spatial = enable != 0;
   return 0;
+}
+
+int rnnpose_conv_ksplit(int enable) {            // measurement switch: 0 = never split K
+  g_conv_ksplit = enable != 0;
+  return 0;
+}
+
+int rnnpose_conv_ksplit_limits(int max_tiles, int max_splits) {      // measurement: which launches split (default 24 tiles, 4 splits)
+  if (max_tiles < 1 || max_tiles > 96 || max_splits < 2 || max_splits > 8) {
+    rp::set_error("rnnpose_conv_ksplit_limits: max_tiles 1..96, max_splits 2..8");
+    return 1;
+  }
+  g_ks_max_tiles = max_tiles; g_ks_max_splits = max_splits;
+  return 0;
+}
+
+size_t rnnpose_conv_ksplit_workspace_bytes(void) {
+  return KS_CNT_BYTES + static_cast<size_t>(KS_MAX_WG) * (NT * 32) * sizeof(float);
 }
 
 int rnnpose_conv_tiles_per_image(int H, int W, int kh, int kw, int stride) {
@@ -977,6 +1050,7 @@ int rnnpose_conv2d_nhwc_f16x3(const rnnpose_conv_desc_t* d, rnnpose_stream_t str
   if (d->add_map) RP_REQUIRE(d->c_out % 4 == 0 && d->add_c_stride % 4 == 0 && d->add_c_offset % 4 == 0 &&
                                  reinterpret_cast<uintptr_t>(d->add_map) % 16 == 0, fn, "add_map: c_out % 4 == 0, 16-byte aligned, stride/offset multiples of 4");
   p.sat = d->src_bounded ? nullptr : rp::sat_counter();        // (split-form outputs of such a launch are not range-checked either)
+  p.ksplit = 1; p.ks_ws = nullptr; p.ks_cnt = nullptr;
   // split-tensor sources / destinations (see the header): whole 8-channel groups, 32-byte aligned rows
   const bool hlin = d->src_hl != 0;
   if (hlin) {
@@ -1024,6 +1098,23 @@ int rnnpose_conv2d_nhwc_f16x3(const rnnpose_conv_desc_t* d, rnnpose_stream_t str
   if (d->tile == 4) wide = false;
   const dim3 block(NT);
   hipStream_t st = rp::as_stream(stream);
+  // K split of small launches (128x64 tiles, 2x2 waves, stride 1): only with a caller-provided workspace (two chains on two
+  // streams must not share one), tiles * splits <= KS_MAX_WG, at least two channel-block iterations per split
+  auto choose_ksplit = [&](int tiles, int nit) {
+    // (measured per layer at B = 1, 30 x 30, profiles/r03_conv_ksplit_layers.txt: 8-24 tiles gain 15-35 %; 32-64 tiles -- GRU z|r,
+    //  heads, the hoisted inp convolutions -- lose 5-30 % to the reduction pass: not split)
+    if (!g_conv_ksplit || !d->ksplit_ws || tiles > g_ks_max_tiles || nit < 4) return 1;
+    int ksn = g_ks_max_splits;
+    if (ksn > nit / 2) ksn = nit / 2;
+    if (ksn * tiles > KS_MAX_WG) ksn = KS_MAX_WG / tiles;
+    if (ksn < 2) return 1;
+    const size_t need = KS_CNT_BYTES + static_cast<size_t>(tiles) * ksn * (NT * 32) * sizeof(float);     // 2 x 1 MFMA tiles of 16 registers per lane
+    if (d->ksplit_ws_bytes < need || reinterpret_cast<uintptr_t>(d->ksplit_ws) % 16 != 0) return 1;
+    p.ksplit = ksn;
+    p.ks_cnt = static_cast<unsigned*>(d->ksplit_ws);
+    p.ks_ws = reinterpret_cast<float*>(static_cast<char*>(d->ksplit_ws) + KS_CNT_BYTES);
+    return ksn;
+  };
   // stride 1: the main loop unrolled over the taps of a group (T = kw, or kh for vertical kernels); stride 2: generic loop
 #define RP_LAUNCH_T(NI_, COLS4_, HL_)                                                                                   \
   switch (p.T) {                                                                                                         \
@@ -1044,7 +1135,8 @@ int rnnpose_conv2d_nhwc_f16x3(const rnnpose_conv_desc_t* d, rnnpose_stream_t str
       else hipLaunchKernelGGL((conv_igemm_f16x3_kernel<1, false, true, 9, false, false, false, true>), grid, block, 0, st, p);
     } else {
       p.n_nt = rp::cdiv(d->c_out, 64);
-      const dim3 grid(static_cast<unsigned>(p.n_mt) * p.n_nt);
+      const int ksn = choose_ksplit(p.n_mt * p.n_nt, p.ncb);
+      const dim3 grid(static_cast<unsigned>(p.n_mt) * p.n_nt * ksn);
       if (d->src0_mean_rstd) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<1, false, false, 9, true, false, false, true>), grid, block, 0, st, p);
       else if (hlin) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<1, false, false, 9, false, true, false, true>), grid, block, 0, st, p);
       else hipLaunchKernelGGL((conv_igemm_f16x3_kernel<1, false, false, 9, false, false, false, true>), grid, block, 0, st, p);
@@ -1070,7 +1162,8 @@ int rnnpose_conv2d_nhwc_f16x3(const rnnpose_conv_desc_t* d, rnnpose_stream_t str
     }
   } else {
     p.n_nt = rp::cdiv(d->c_out, 64);
-    const dim3 grid(static_cast<unsigned>(p.n_mt) * p.n_nt);
+    const int ksn = p.stride == 2 ? 1 : choose_ksplit(p.n_mt * p.n_nt, p.G * p.ncb);
+    const dim3 grid(static_cast<unsigned>(p.n_mt) * p.n_nt * ksn);
     if (p.stride == 2) {
       hipLaunchKernelGGL((conv_igemm_f16x3_kernel<1, true, false>), grid, block, 0, st, p);
     } else if (d->src0_mean_rstd) {

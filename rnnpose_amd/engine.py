@@ -33,6 +33,7 @@ class UpdateEngine:
         self.parts = int(os.environ.get("RNNPOSE_PARTS", "2"))
         self.fused_mask = os.environ.get("RNNPOSE_FUSED_MASK", "1") != "0"       # mask.2 inside the up-sampling kernel
         self.resident_1x1 = os.environ.get("RNNPOSE_RESIDENT_1X1", "1") != "0"    # convc1 through csrc/conv1x1_resident.hip
+        self.ksplit = os.environ.get("RNNPOSE_KSPLIT", "1") != "0"                # small launches (B = 1 crops) split their K loop
         # SPLIT TENSORS (include/rnnpose_hip.h): every activation that only feeds further convolutions is written once, by its
         # producer's epilogue, as fp16 hi|lo pairs and staged by the consumers with a plain 16-byte copy (no per-tile re-split).
         # MEASURED (r03, profiles/r03_conv_ablation.txt): per layer -1..+3 %, on the step -1.3 % (the two extra split launches per
@@ -126,6 +127,23 @@ class UpdateEngine:
     def buffer_key(self):
         return (self._buf_key, self.epoch)
 
+    def _ksplit_ws(self, b0, b1, which):
+        """K-split workspace (ops.conv_ksplit_workspace) of the chain of images [b0, b1) -- `which` 0: its main stream, 1: its
+        helper stream (launches that can run concurrently must not share one).  None when the chain has too many pixels for
+        any of its convolutions to split (the library splits launches of <= 96 tiles).  Allocated on first use, i.e. in the
+        eager warm-up runs before a hipGraph capture."""
+        B, h, w, dev = self._buf_key
+        if not self.ksplit or (b1 - b0) * h * w > 96 * 128:
+            return None
+        reg = self.__dict__.setdefault("_ksws", {})
+        key = (self._buf_key, self.epoch, b0, which)
+        ws = reg.get(key)
+        if ws is None:
+            for k in [k for k in reg if k[1] != self.epoch]:
+                del reg[k]
+            ws = reg[key] = ops.conv_ksplit_workspace(self._b["hA"].device)
+        return ws
+
     def select(self, buf_key):
         """Make the buffer set a captured graph was recorded on the current one (graph replay path)."""
         (B, h, w, dev), _ = buf_key
@@ -200,6 +218,7 @@ class UpdateEngine:
         concurrent chains segfault hipStreamEndCapture on ROCm 7.2)."""
         W = self._weights()
         view = {k: v[b0:b1] for k, v in self._b.items()}
+        view["_ksws"], view["_ksws_side"] = self._ksplit_ws(b0, b1, 0), self._ksplit_ws(b0, b1, 1)
         ops.corr_lookup_nhwc_part(corr_fn._buf, coords1_part, view["corr"], B, b0, b1, corr_fn.num_levels, corr_fn.radius)
         yield
         yield from self._chain_gen(W, view, coords1_part, st, self._stream(coords1_part.device, 2) if single else None)
@@ -274,10 +293,14 @@ class UpdateEngine:
         tl = self.tile.get
         R = ops.EPI_RELU
 
-        def c(name, srcs, dst, epi, hl_out=False, **kw):
+        ks_main = b.get("_ksws")
+        ks_side = b.get("_ksws_side") if side is not None else ks_main
+
+        def c(name, srcs, dst, epi, hl_out=False, ks=None, **kw):
             """One implicit-GEMM launch; with split tensors every source is in split form and hl_out says the result only
-            feeds further convolutions (written split)."""
-            ops.conv2d_nhwc(W[name], srcs, dst, epi, src_hl=hl, dst_hl=hl and hl_out, tile=tl(name, 0), **kw)
+            feeds further convolutions (written split).  ks: K-split workspace of the stream the launch goes to."""
+            ops.conv2d_nhwc(W[name], srcs, dst, epi, src_hl=hl, dst_hl=hl and hl_out, tile=tl(name, 0),
+                            ksplit_ws=ks_main if ks is None else ks, **kw)
         # Two independent chains feed the motion encoder's last convolution (update.py:89-92): correlation features
         # (convc1 -> convc2) and flow features (flow_prep -> convf1 -> convf2).  With a helper stream the second one runs
         # there (a parallel branch when the step is captured into a hipGraph).  Same for flow_head.conv2 next to mask.2.
@@ -286,7 +309,7 @@ class UpdateEngine:
             ops.flow_features(coords1, W["convf1_wt"], W["convf1_b"], b["flo1"], b["motion"], 126, subtract_grid=not flow_is_delta,
                               out_split=hl, motion_split=hl, a_scale=ops.A_SCALE)
             yield
-            c("convf2", [(b["flo1"], 0)], (b["corflo"], 192), R, hl_out=True)       # :92
+            c("convf2", [(b["flo1"], 0)], (b["corflo"], 192), R, hl_out=True, ks=ks_side)       # :92
             yield
 
         join = None
@@ -362,6 +385,7 @@ class EncoderEngine:
         self._w = None
         self._side = None
         self.resident_1x1 = os.environ.get("RNNPOSE_RESIDENT_1X1", "1") != "0"
+        self.ksplit = os.environ.get("RNNPOSE_KSPLIT", "1") != "0"
         self.split_batch = os.environ.get("RNNPOSE_SPLIT_ENCODER", "1") != "0"
         self.parts = int(os.environ.get("RNNPOSE_ENCODER_PARTS", "2"))
 
@@ -396,7 +420,7 @@ class EncoderEngine:
         return self._w
 
     @staticmethod
-    def _conv(pc, x, stride=1, stats=True, in_norm=None):
+    def _conv(pc, x, stride=1, stats=True, in_norm=None, ks=None):
         """-> (out, tile_stats or None): the convolution's epilogue also emits the per-tile column statistics the following
         instance norm needs (saves re-reading the tensor once; output rows are tiled per image for that).
         in_norm: mean / rstd of `x`, which is then a RAW convolution output normalised (+ ReLU) in this convolution's load."""
@@ -407,11 +431,12 @@ class EncoderEngine:
         # src_bounded: every convolution input of the encoder is an instance-normalised map (|.| <= sqrt(H*W)) or a ReLU sum of a
         # few of them (extractor.py:48-58): two orders of magnitude inside the fp16x3 range, so the in-loop range check is skipped
         # (the stem, which sees the raw image, and the update block keep theirs)
-        ops.conv2d_nhwc(pc, [(x, 0)], (out, 0), ops.EPI_LINEAR, stride=stride, tile_stats=ts, in_norm=in_norm, src_bounded=True)
+        ops.conv2d_nhwc(pc, [(x, 0)], (out, 0), ops.EPI_LINEAR, stride=stride, tile_stats=ts, in_norm=in_norm, src_bounded=True,
+                        ksplit_ws=ks)
         return out, ts
 
     @staticmethod
-    def _block_gen(W, name, blk, x, x_norm=None):
+    def _block_gen(W, name, blk, x, x_norm=None, ks=None):
         """ResidualBlock (extractor.py:48-58) on an NHWC tensor, as a generator (yields after every launch, returns the block
         output).  Instance norms are never materialised on their own: norm1 + ReLU happens in conv2's load, the residual's
         norm (x_norm = (mean_rstd, relu) when `x` is the RAW stem output; norm3 of the down-sampling branch) inside the one
@@ -419,18 +444,18 @@ class EncoderEngine:
         convolution outputs."""
         E = EncoderEngine
         st = blk.conv1.stride[0]
-        c1, ts1 = E._conv(W[name + ".c1"], x, st, in_norm=None if x_norm is None else x_norm[0])
+        c1, ts1 = E._conv(W[name + ".c1"], x, st, in_norm=None if x_norm is None else x_norm[0], ks=ks)
         yield
         mr1 = ops.instnorm_tiles_nhwc(c1, ts1, stats_only=True)          # relu(norm1(conv1 x)): applied in conv2's load
         yield
         res, res_norm = x, x_norm
         if blk.downsample is not None:
             assert x_norm is None
-            res, tsd = E._conv(W[name + ".down"], x, st)
+            res, tsd = E._conv(W[name + ".down"], x, st, ks=ks)
             yield
             res_norm = (ops.instnorm_tiles_nhwc(res, tsd, stats_only=True), False)            # norm3, no ReLU
             yield
-        c2, ts2 = E._conv(W[name + ".c2"], c1, in_norm=mr1)
+        c2, ts2 = E._conv(W[name + ".c2"], c1, in_norm=mr1, ks=ks)
         yield
         out = ops.instnorm_tiles_nhwc(c2, ts2, relu=True, residual=res, residual_norm=None if res_norm is None else res_norm[0],
                                       residual_relu=bool(res_norm and res_norm[1]))               # relu(x + relu(IN(.)))
@@ -481,10 +506,10 @@ class EncoderEngine:
         fork.record(main)
         joins = []
 
-        def job(x_part, b0, b1, st):
+        def job(x_part, b0, b1, st, ji):
             if st is not main:
                 st.wait_event(fork)
-            yield from self._forward_gen(W, x_part, out[b0:b1], normalize, split_out)
+            yield from self._forward_gen(W, x_part, out[b0:b1], normalize, split_out, ks=self._ksplit_ws(ji, x_part))
             if st is not main:
                 j = torch.cuda.Event()
                 j.record(st)
@@ -494,7 +519,7 @@ class EncoderEngine:
         active = []
         for hi_, (x_part, b0, b1) in enumerate(jobs):
             st = main if hi_ == 0 else self._second_stream(dev, hi_)
-            active.append((job(x_part, b0, b1, st), st))
+            active.append((job(x_part, b0, b1, st, hi_), st))
         while active:
             for item in list(active):
                 g, st = item
@@ -507,6 +532,17 @@ class EncoderEngine:
             main.wait_event(j)
         return ops.SplitTensor(out, ops.A_SCALE) if split_out else out
 
+    def _ksplit_ws(self, ji, x_part):
+        """K-split workspace of job (stream) ji, or None when even the 1/8-resolution layers have too many tiles to split."""
+        n, _, H, Wd = x_part.shape
+        if not self.ksplit or n * ((H + 7) // 8) * ((Wd + 7) // 8) > 96 * 128:
+            return None
+        reg = self.__dict__.setdefault("_ksws", {})
+        key = (ji, str(x_part.device))
+        if key not in reg:
+            reg[key] = ops.conv_ksplit_workspace(x_part.device)
+        return reg[key]
+
     def _second_stream(self, device, i):
         """Stream of image set / batch part i >= 1 (rnnpose_amd/streams.py: distinct hardware queues)."""
         from .streams import reserve
@@ -515,7 +551,7 @@ class EncoderEngine:
         ss = reserve(device)
         return (ss.chain + [ss.aux])[(i - 1) % 3]
 
-    def _forward_gen(self, W, x_nchw, out, normalize, split_out=False):
+    def _forward_gen(self, W, x_nchw, out, normalize, split_out=False, ks=None):
         """One image set through the encoder (extractor.py:187-232); yields after every launch group."""
         E = EncoderEngine
         f = self.fnet
@@ -528,7 +564,7 @@ class EncoderEngine:
         yield
         for li, layer in enumerate((f.layer1, f.layer2, f.layer3), start=1):
             for bi, blk in enumerate(layer):
-                x = yield from E._block_gen(W, f"l{li}.{bi}", blk, x, x_norm)
+                x = yield from E._block_gen(W, f"l{li}.{bi}", blk, x, x_norm, ks=ks)
                 x_norm = None
         if W["outr"] is not None and self.resident_1x1:
             if split_out:                # the volume build's operand, written in place (a batch slice of NHWC is contiguous)
@@ -538,7 +574,7 @@ class EncoderEngine:
             o = torch.empty(*x.shape[:3], 256, device=x.device, dtype=torch.float32)
             ops.conv1x1_resident(W["outr"], (x, 0), (o, 0), relu=False)
         else:
-            o, _ = E._conv(W["out"], x, stats=False)
+            o, _ = E._conv(W["out"], x, stats=False, ks=ks)
         yield
         if split_out:
             ops.split_hl(o, dst=out, a_scale=ops.A_SCALE)

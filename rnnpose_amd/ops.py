@@ -482,8 +482,10 @@ def _nhwc(t, name):
 
 def conv2d_nhwc(pc: PackedConv, srcs, dst, epilogue: int = EPI_LINEAR, aux0=None, aux1=None, dst2=None, gru_c: int = 0,
                 stride: int = 1, tile_stats=None, add_map=None, in_norm=None, src_hl: bool = False, dst_hl: bool = False,
-                dst2_hl: bool = False, dst_split=None, tile: int = 0, src_bounded: bool = False):
+                dst2_hl: bool = False, dst_split=None, tile: int = 0, src_bounded: bool = False, ksplit_ws=None):
     """srcs: list of (tensor (B,H,W,C), c_offset) matched with pc.seg_counts; dst/aux0/aux1/dst2: (tensor, c_offset).
+    ksplit_ws: a conv_ksplit_workspace() buffer -- lets a launch of few tiles (B = 1 crops) split its K loop over several
+    workgroups per tile; launches that may run concurrently (two streams) need separate buffers.
     Writes in place into dst (and dst2); returns nothing.
     src_hl / dst_hl / dst2_hl: the sources / dst / dst2 are SPLIT tensors (fp16 hi|lo per 8-channel group in a buffer of the
     fp32 tensor's shape: include/rnnpose_hip.h; split_hl / unsplit_hl convert); dst_split = (tensor, c_offset): an additional
@@ -538,6 +540,8 @@ def conv2d_nhwc(pc: PackedConv, srcs, dst, epilogue: int = EPI_LINEAR, aux0=None
         t, off = dst_split
         _nhwc(t, "dst_split")
         d.dst_split, d.dst_split_c_stride, d.dst_split_c_offset = t.data_ptr(), t.shape[3], off
+    if ksplit_ws is not None:
+        d.ksplit_ws, d.ksplit_ws_bytes = ksplit_ws.data_ptr(), ksplit_ws.numel() * ksplit_ws.element_size()
     _launch("rnnpose_conv2d_nhwc_f16x3", C.byref(d), _stream(),
             work=2.0 * B * (-(-H // stride)) * (-(-W // stride)) * pc.c_out * pc.c_in_real * pc.kh * pc.kw)
 
@@ -559,10 +563,28 @@ def _apply_conv_env():
         v = _os.environ.get("RNNPOSE_SPATIAL_TILES")
         if v is not None:
             _lib.call("rnnpose_conv_spatial_tiles", int(v != "0"))
+        v = _os.environ.get("RNNPOSE_KSPLIT")
+        if v is not None:
+            _lib.call("rnnpose_conv_ksplit", int(v != "0"))
+        v = _os.environ.get("RNNPOSE_KSPLIT_LIMITS")          # "max_tiles,max_splits" (measurement)
+        if v:
+            a, b = (int(t) for t in v.split(","))
+            _lib.call("rnnpose_conv_ksplit_limits", a, b)
 
 
 def conv_spatial_tiles(enable: bool = True):
     _lib.call("rnnpose_conv_spatial_tiles", int(bool(enable)))
+
+
+def conv_ksplit(enable: bool = True):
+    """Measurement switch: False = launches never split K even when a workspace is passed (RNNPOSE_KSPLIT=0)."""
+    _lib.call("rnnpose_conv_ksplit", int(bool(enable)))
+
+
+def conv_ksplit_workspace(device):
+    """Zeroed workspace for conv2d_nhwc(ksplit_ws=...): one per chain of launches that can run concurrently with another."""
+    n = int(_lib.load().rnnpose_conv_ksplit_workspace_bytes())
+    return torch.zeros((n + 3) // 4, device=device, dtype=torch.int32)
 
 
 _nchw_pc = {}

@@ -510,3 +510,114 @@ def test_conv3x3_patch_tiling_equals_row_major(ops, B, H, W, cin, cout, hl):
         for st in stats:
             assert float(((st - want).abs() / scale).max()) < 1e-5
         assert float(((stats[0] - stats[1]).abs() / scale).max()) < 1e-6               # patches vs runs: same values, regrouped
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,segs,cout,kh,kw", [
+    (1, 30, 30, [256], 192, 3, 3),         # convc2 at the 240 x 240 crop: 8 patches x 3 column tiles, 8 channel blocks -> 4 splits
+    (1, 30, 30, [128, 128, 128], 256, 1, 5),
+    (1, 30, 30, [128, 128, 128], 256, 5, 1),
+    (1, 30, 30, [128], 512, 3, 3),         # 64 tiles: 2-3 splits
+    (1, 16, 20, [256], 126, 3, 3),         # ragged columns
+    (2, 9, 13, [324], 256, 1, 1),          # 1x1, K tail (11 blocks)
+    (1, 7, 9, [96], 64, 3, 3),             # 3 channel blocks: too few to split (>= 2 per split needs 4)
+])
+def test_conv_k_split_matches_single_pass(ops, B, H, W, segs, cout, kh, kw):
+    """conv2d_nhwc(ksplit_ws=...): launches of few tiles split their K loop over several workgroups per tile; the last arrival
+    sums the partial accumulators in split order.  Same result as the single pass to fp32 round-off (the K sum is grouped per
+    split), fp32-class against fp64, bit-identical from run to run, counters left at zero, outputs outside the slice untouched."""
+    cin = sum(segs)
+    x = syn.normal("ks.x", (B, cin, H, W), 3, std=1.5)
+    w = syn.normal("ks.w", (cout, cin, kh, kw), 3, std=float(np.sqrt(2.0 / (cin * kh * kw))))
+    b = syn.uniform("ks.b", (cout,), 3, -0.5, 0.5)
+    xd, wd, bd = D(x), D(w), D(b)
+    y64 = F.conv2d(xd.double(), wd.double(), bd.double(), padding=(kh // 2, kw // 2))
+    y32 = F.conv2d(xd, wd, bd, padding=(kh // 2, kw // 2))
+    pc = ops.PackedConv(wd, bd, segs)
+    xs, off = [], 0
+    for c in segs:
+        xs.append((nhwc(xd[:, off:off + c]), 0))
+        off += c
+    cs = (cout + 15) // 4 * 4
+    single = torch.full((B, H, W, cs), 7.0, device="cuda")
+    ops.conv2d_nhwc(pc, xs, (single, 8), ops.EPI_RELU)
+    ws = ops.conv_ksplit_workspace("cuda")
+    outs = []
+    for _ in range(3):
+        o = torch.full((B, H, W, cs), 7.0, device="cuda")
+        ops.conv2d_nhwc(pc, xs, (o, 8), ops.EPI_RELU, ksplit_ws=ws)
+        outs.append(o)
+    torch.cuda.synchronize()
+    assert int(ws[:256].abs().max()) == 0, "arrival counters not restored"
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), "K-split result differs between runs"
+    check(nchw(outs[0][..., 8:8 + cout]), y64.clamp(min=0), y32.clamp(min=0), f"{kh}x{kw} K split")
+    scale = float(y64.abs().max())
+    assert float((outs[0] - single).abs().max()) <= 3e-6 * scale
+    assert float((outs[0][..., :8] - 7).abs().max()) == 0 and float((outs[0][..., 8 + cout:] - 7).abs().max()) == 0
+    # the measurement switch and a workspace that is too small both give the single pass, bit for bit
+    ops.conv_ksplit(False)
+    try:
+        o2 = torch.full((B, H, W, cs), 7.0, device="cuda")
+        ops.conv2d_nhwc(pc, xs, (o2, 8), ops.EPI_RELU, ksplit_ws=ws)
+    finally:
+        ops.conv_ksplit(True)
+    assert torch.equal(o2, single)
+    o3 = torch.full((B, H, W, cs), 7.0, device="cuda")
+    ops.conv2d_nhwc(pc, xs, (o3, 8), ops.EPI_RELU, ksplit_ws=ws[:512])
+    assert torch.equal(o3, single)
+
+
+@pytest.mark.gpu
+def test_conv_k_split_with_statistics_norm_and_gru_epilogues(ops):
+    """The epilogue variants behind a K split: per-tile statistics + fused input normalisation (encoder layers at 30 x 30) and
+    the GRU gate epilogues (1 x 5) -- all computed by the last-arriving workgroup from the summed accumulators."""
+    B, H, W, cin, cout = 1, 30, 30, 128, 128
+    x = syn.normal("ks2.x", (B, cin, H, W), 4, std=2.0) + 0.7
+    w1 = syn.normal("ks2.w1", (cin, cin, 3, 3), 4, std=float(np.sqrt(2.0 / (cin * 9))))
+    w2 = syn.normal("ks2.w2", (cout, cin, 3, 3), 5, std=float(np.sqrt(2.0 / (cin * 9))))
+    b1, b2 = syn.uniform("ks2.b1", (cin,), 4, -0.5, 0.5), syn.uniform("ks2.b2", (cout,), 5, -0.5, 0.5)
+    p1, p2 = ops.PackedConv(D(w1), D(b1), [cin]), ops.PackedConv(D(w2), D(b2), [cin])
+    tpi = ops.conv_tiles_per_image(H, W, 3, 3, 1)
+    ws = ops.conv_ksplit_workspace("cuda")
+    res = []
+    for k in (None, ws):
+        c1 = torch.empty(B, H, W, cin, device="cuda")
+        ts = torch.full((B * tpi, cin, 2), -1.0, device="cuda", dtype=torch.float64)
+        ops.conv2d_nhwc(p1, [(nhwc(D(x)), 0)], (c1, 0), ops.EPI_LINEAR, tile_stats=ts, ksplit_ws=k)
+        mr = ops.instnorm_tiles_nhwc(c1, ts, stats_only=True)
+        c2 = torch.empty(B, H, W, cout, device="cuda")
+        ts2 = torch.full((B * tpi, cout, 2), -1.0, device="cuda", dtype=torch.float64)
+        ops.conv2d_nhwc(p2, [(c1, 0)], (c2, 0), ops.EPI_LINEAR, in_norm=mr, tile_stats=ts2, ksplit_ws=k)
+        res.append((c1, ts, c2, ts2))
+    for a, bb in zip(res[0], res[1]):
+        sc = float(a.abs().max())
+        assert float((a.double() - bb.double()).abs().max()) <= 1e-5 * sc
+    y64 = F.conv2d(D(x).double(), D(w1).double(), D(b1).double(), padding=1)
+    z64 = F.conv2d(F.relu(F.instance_norm(y64, eps=1e-5)), D(w2).double(), D(b2).double(), padding=1)
+    assert float((nchw(res[1][2]).double() - z64).abs().max()) < 3e-5 * float(z64.abs().max())
+    # GRU epilogues
+    C, kh, kw = 128, 1, 5
+    h = np.tanh(syn.normal("ks2.h", (B, C, H, W), 2))
+    xx = syn.normal("ks2.xx", (B, 2 * C, H, W), 2)
+    wz, wr, wq = (syn.normal("ks2." + n, (C, 3 * C, kh, kw), 2, std=0.03) for n in ("wz", "wr", "wq"))
+    bz, br, bq = (syn.uniform("ks2." + n, (C,), 2, -0.2, 0.2) for n in ("bz", "br", "bq"))
+    hd, xd = D(h), D(xx)
+    pad = (kh // 2, kw // 2)
+    hx = torch.cat([hd, xd], 1).double()
+    z64 = torch.sigmoid(F.conv2d(hx, D(wz).double(), D(bz).double(), padding=pad))
+    r64 = torch.sigmoid(F.conv2d(hx, D(wr).double(), D(br).double(), padding=pad))
+    q64 = torch.tanh(F.conv2d(torch.cat([r64 * hd.double(), xd.double()], 1), D(wq).double(), D(bq).double(), padding=pad))
+    h64 = (1 - z64) * hd.double() + z64 * q64
+    pzr = ops.PackedConv(torch.cat([D(wz), D(wr)], 0), torch.cat([D(bz), D(br)], 0), [C, C, C])
+    pq = ops.PackedConv(D(wq), D(bq), [C, C, C])
+    hN, xN = nhwc(hd), nhwc(xd)
+    z = torch.empty(B, H, W, C, device="cuda")
+    rh = torch.empty(B, H, W, C, device="cuda")
+    hnew = torch.empty(B, H, W, C, device="cuda")
+    ops.conv2d_nhwc(pzr, [(hN, 0), (xN, 0), (xN, C)], (z, 0), ops.EPI_GRU_ZR, aux0=(hN, 0), dst2=(rh, 0), gru_c=C, ksplit_ws=ws)
+    assert float((nchw(z).double() - z64).abs().max()) < 2e-6
+    assert float((nchw(rh).double() - r64 * hd.double()).abs().max()) < 2e-6
+    ops.conv2d_nhwc(pq, [(rh, 0), (xN, 0), (xN, C)], (hnew, 0), ops.EPI_GRU_Q, aux0=(hN, 0), aux1=(z, 0), ksplit_ws=ws)
+    assert float((nchw(hnew).double() - h64).abs().max()) < 3e-6
+    torch.cuda.synchronize()
+    assert int(ws[:256].abs().max()) == 0

@@ -265,3 +265,34 @@ def test_split_feature_maps_match_nchw_hand_over(ops, monkeypatch):
         outs.append((out["Ti_pred"].G.clone(), out["flow_last"].clone()))
     assert float((outs[0][0] - outs[1][0]).abs().max()) < 1e-6
     assert float((outs[0][1] - outs[1][1]).abs().max()) < 5e-5
+
+
+def test_k_split_schedule_matches_single_pass(ops, monkeypatch):
+    """Single-image refinement (the reference's own working size is B = 1): the small convolutions of the encoder and the update
+    block split their K loop over several workgroups per tile (RNNPOSE_KSPLIT=0: never).  Same refinement to fp32 round-off, through
+    hipGraph replay, and identical from call to call."""
+    from rnnpose_amd import synthetic as syn
+    from rnnpose_amd.pose_refiner import PoseRefiner, SyntheticRenderer, default_config
+    from rnnpose_amd.transformation import SE3Sequence
+    from oracle import rnnpose_oracle as orc
+    d = syn.make_inputs(1, 128, 160, seed=15)
+    D = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    img1 = D(syn.uniform("img_render", (1, 3, 128, 160), 5, 0.0, 255.0))
+    img2 = D(syn.uniform("img_target", (1, 3, 128, 160), 6, 0.0, 255.0))
+    kw = dict(syn_img=img1, image_crop=img2, cfea=D(d["ctx"]), geofea1=D(d["g1"]), geofea2_crop=D(d["g2"]), syn_depth=D(d["depth"]),
+              intrinsics_crop=D(d["K"]))
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("RNNPOSE_KSPLIT", flag)
+        ref = PoseRefiner(default_config(RENDER_ITER_COUNT=2, ITER_COUNT=3, OPTIM_ITER_COUNT=1), renderer=SyntheticRenderer(**kw)).cuda().eval()
+        ref.cf_net.update_block.load_state_dict({k: torch.from_numpy(v) for k, v in syn.make_module_weights(orc.UPDATE_BLOCK_SHAPES, seed=0).items()})
+        ref.image_fea_enc.fnet.load_state_dict({k: torch.from_numpy(v) for k, v in syn.make_module_weights(orc.encoder_shapes(), seed=2).items()})
+        assert ref.cf_net.engine().ksplit == (flag == "1")
+        runs = []
+        for _ in range(3):                      # later calls replay the captured graphs
+            out = ref(None, SE3Sequence(matrix=D(d["G0"])), D(d["K"]))
+            runs.append((out["Ti_pred"].G.clone(), out["flow_last"].clone()))
+        assert torch.equal(runs[1][0], runs[2][0]) and torch.equal(runs[1][1], runs[2][1])
+        outs.append(runs[-1])
+    assert float((outs[0][0] - outs[1][0]).abs().max()) < 2e-6
+    assert float((outs[0][1] - outs[1][1]).abs().max()) < 1e-4

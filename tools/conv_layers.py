@@ -3,7 +3,7 @@
 60x80), each alone: time, executed fp16 TFLOP/s, fraction of the 2.5 PF peak -- for fp32 sources (on-the-fly split) and for
 split-tensor sources in every tile shape (1 = 128x64, 2 = 128x128 as 4 column waves, 3 = 128x128 as 2x2 waves).
 Also the target of the SQ counter passes (tools/pmc_sq.sh): `python tools/conv_layers.py 3 [mode]` launches every layer 3
-times in one mode (f32 | hl0 | hl1 | hl2 | hl3) and prints nothing else."""
+times in one mode (f32 | hl0 | hl1 | hl2 | hl3 | f32ks) and prints nothing else."""
 import os
 import sys
 import time
@@ -24,7 +24,9 @@ shapes = [("convc2 3x3 256->192", [256], 192, 3, 3),
           ("gru zr 5x1 256->256", [128, 128], 256, 5, 1), ("gru q 5x1 256->128", [128, 128], 128, 5, 1),
           ("heads 3x3 128->512", [128], 512, 3, 3), ("inp 1x5 128->384", [128], 384, 1, 5),
           ("enc l1 3x3 64->64 @240x320", [64], 64, 3, 3)]
-modes = [("f32", False, 0), ("f32t1", False, 1), ("f32t2", False, 2), ("hl0", True, 0), ("hl1", True, 1), ("hl2", True, 2), ("hl3", True, 3), ("hl4", True, 4)]
+modes = [("f32", False, 0), ("f32t1", False, 1), ("f32t2", False, 2), ("hl0", True, 0), ("hl1", True, 1), ("hl2", True, 2), ("hl3", True, 3), ("hl4", True, 4),
+         ("f32ks", False, 0)]          # f32ks: fp32 sources with a K-split workspace (small launches split their K loop)
+ksws = ops.conv_ksplit_workspace("cuda")
 for B in batches:
     for name, segs, co, kh, kw in shapes:
         if flt and not any(f in name for f in flt):
@@ -40,7 +42,8 @@ for B in batches:
         for mname, hl, tile in modes:
             if only and mname not in only.split(","):
                 continue
-            run = lambda: ops.conv2d_nhwc(pc, xs if hl else xf, (out, 0), ops.EPI_RELU, src_hl=hl, dst_hl=hl, tile=tile)
+            run = lambda: ops.conv2d_nhwc(pc, xs if hl else xf, (out, 0), ops.EPI_RELU, src_hl=hl, dst_hl=hl, tile=tile,
+                                          ksplit_ws=ksws if mname.endswith("ks") else None)
             if reps:
                 for _ in range(reps):
                     run()
