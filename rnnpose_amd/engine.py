@@ -492,6 +492,8 @@ class EncoderEngine:
         # Two halves of the image batch (rendered | observed) as two independent streams = two hipGraph branches with a
         # single join at the end: the chains drift apart, so one half's HBM-bound instance-norm passes and latency-bound
         # finalize launches run under the other half's convolutions.  Bit-identical (instance norm is per image).
+        # (r03: small image sets -- 2 x 1 x 240 x 240 -- as ONE concatenated batch instead of two streams measured 1.5 % slower:
+        #  5.16 vs 5.08 ms per refinement; the two launch chains do overlap in graph replay)
         if len(imgs) > 1:                      # one stream per input tensor (rendered | observed)
             jobs, o = [], 0
             for t in imgs:
