@@ -160,7 +160,11 @@ template <int NI, bool STRIDED, bool COLS4 = false, int TT = 0, bool NORM = fals
 #ifndef RP_COLS4_WAVES
 #define RP_COLS4_WAVES 2      // waves per SIMD the 4-column layout is compiled for (3: 168 VGPRs with 60-90 spilled once the statistics are fp64; 2: none; measured equal)
 #endif
-__global__ __launch_bounds__(NT, ((NI == 2 || DEEP || SPATIAL) ? 2 : (COLS4 ? (TT == 3 ? 3 : RP_COLS4_WAVES) : (TT > 0 ? 3 : 2)))) void conv_igemm_f16x3_kernel(const KParams p) {
+#ifndef RP_SP_SINGLE
+#define RP_SP_SINGLE 0        // 1: patch-tiled 3x3 layers (2x2 waves) keep ONE halo tile in LDS (29 KB, three workgroups per CU, two barriers
+#endif                        // per channel block) instead of a double-buffered one (58 KB, two per CU).  r03 same-box: 669.8 vs 672.4
+                              // iters/s, single image 5.20 vs 5.08 ms -- the kernel does not respond to occupancy either; off
+__global__ __launch_bounds__(NT, ((NI == 2 || DEEP || (SPATIAL && (COLS4 || !RP_SP_SINGLE))) ? 2 : (SPATIAL ? 3 : (COLS4 ? (TT == 3 ? 3 : RP_COLS4_WAVES) : (TT > 0 ? 3 : 2))))) void conv_igemm_f16x3_kernel(const KParams p) {
   static_assert(!DEEP || (HLIN && !COLS4 && TT >= 3), "the deep pipeline is for split sources, the 2x2 wave layout, 3 or 5 taps");
   static_assert(!SPATIAL || (TT == 9 && !STRIDED && !DEEP), "patch tiling is the 3x3 stride-1 form: nine taps on one staged tile");
   constexpr int ARW = SPATIAL ? SPR : AROWS;            // staged rows
@@ -174,8 +178,14 @@ __global__ __launch_bounds__(NT, ((NI == 2 || DEEP || SPATIAL) ? 2 : (COLS4 ? (T
   // wave loads its own MFMA B fragments straight from the fragment-ordered packed array (two waves of a workgroup read
   // the same lines; the second hits L1).  r01 ablation: staging weights through LDS cost 16 % in ds_write alone, made
   // the LDS pipe a co-bottleneck with the matrix pipe, and needed a barrier per tap (now: one per 32-channel block).
-  __shared__ __attribute__((aligned(16))) _Float16 sA[2][2][PRW * RS];
-  _Float16* const sAf = &sA[0][0][0];
+  // SPATIAL + RP_SP_SINGLE (2x2 waves): one buffer; the next block's tile is stored between two barriers once every wave is done
+  // with the current one (108 MFMAs per wave between barrier pairs)
+  constexpr int NBUF = (SPATIAL && RP_SP_SINGLE && !COLS4) ? 1 : 2;
+  constexpr int EPI_H = (4 * 32 * (32 * NI + 4) * 4 + 4 * (8 * NI) * 8 * 8) / 2;      // epilogue staging + statistics, in halfs
+  constexpr int LDS_H = NBUF * 2 * PRW * RS > EPI_H ? NBUF * 2 * PRW * RS : EPI_H;
+  __shared__ __attribute__((aligned(16))) _Float16 sA[LDS_H];
+  _Float16* const sAf = &sA[0];
+#define RP_BUF(X_) (NBUF == 1 ? 0 : (X_))
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = COLS4 ? 0 : wave >> 1, wn = COLS4 ? wave : wave & 1;
   const int l31 = lane & 31, lh = lane >> 5;
@@ -305,7 +315,7 @@ __global__ __launch_bounds__(NT, ((NI == 2 || DEEP || SPATIAL) ? 2 : (COLS4 ? (T
         const unsigned mk_ = 0u - ((amask##S_ >> R_) & 1u);                                                 \
         uint4 u_ = __builtin_bit_cast(uint4, av##S_##_##R_);                                                \
         u_.x &= mk_; u_.y &= mk_; u_.z &= mk_; u_.w &= mk_;                                                 \
-        *reinterpret_cast<uint4*>(sAf + (AB_) * (2 * PRW * RS) + (c4 & 1) * (PRW * RS) + j_ * RS + (c4 >> 1) * 8) = u_; \
+        *reinterpret_cast<uint4*>(sAf + RP_BUF(AB_) * (2 * PRW * RS) + (c4 & 1) * (PRW * RS) + j_ * RS + (c4 >> 1) * 8) = u_; \
       }                                                                                                     \
     } else if (j_ < ARW) {                                                                                  \
       h4 hi_, lo_;                                                                                          \
@@ -314,8 +324,8 @@ __global__ __launch_bounds__(NT, ((NI == 2 || DEEP || SPATIAL) ? 2 : (COLS4 ? (T
       if (NORM) xv_ = make_float4(fmaxf((xv_.x - nrm01.x) * nrm01.y, 0.f), fmaxf((xv_.y - nrm01.z) * nrm01.w, 0.f), \
                                   fmaxf((xv_.z - nrm23.x) * nrm23.y, 0.f), fmaxf((xv_.w - nrm23.z) * nrm23.w, 0.f)); \
       split4((amask##S_ >> R_) & 1u ? xv_ : z4_, p.a_scale, hi_, lo_);   /* padding / out-of-range rows: zeros (AFTER the norm) */ \
-      *reinterpret_cast<h4*>(sAf + (AB_) * (2 * PRW * RS) + j_ * RS + c4 * 4) = hi_;                        \
-      *reinterpret_cast<h4*>(sAf + (AB_) * (2 * PRW * RS) + PRW * RS + j_ * RS + c4 * 4) = lo_;             \
+      *reinterpret_cast<h4*>(sAf + RP_BUF(AB_) * (2 * PRW * RS) + j_ * RS + c4 * 4) = hi_;                        \
+      *reinterpret_cast<h4*>(sAf + RP_BUF(AB_) * (2 * PRW * RS) + PRW * RS + j_ * RS + c4 * 4) = lo_;             \
     }                                                                                                       \
   }
 #define RP_SAT_ROW(R_, S_) sat_n += (((amask##S_ >> R_) & 1u) && rp::quad_saturates(av##S_##_##R_, p.a_scale)) ? 1 : 0;
@@ -364,8 +374,8 @@ __global__ __launch_bounds__(NT, ((NI == 2 || DEEP || SPATIAL) ? 2 : (COLS4 ? (T
          of 8 v_cndmask per fragment; -4 % on the 64-wide kernels); the 4-column layout sits at its 168-VGPR cap, where \
          the extra address registers spilled (measured slower), so it masks the loaded fragments instead */ \
       const int row = (COLS4 || okm_[mi]) ? wm * 64 + mi * 32 + l31 + HALO + dv_ : AROWS;                   \
-      ah[mi] = *reinterpret_cast<const h8*>(sAf + (AB_) * (2 * PRW * RS) + row * RS + ko);                 \
-      al[mi] = *reinterpret_cast<const h8*>(sAf + (AB_) * (2 * PRW * RS) + PRW * RS + row * RS + ko);      \
+      ah[mi] = *reinterpret_cast<const h8*>(sAf + RP_BUF(AB_) * (2 * PRW * RS) + row * RS + ko);                 \
+      al[mi] = *reinterpret_cast<const h8*>(sAf + RP_BUF(AB_) * (2 * PRW * RS) + PRW * RS + row * RS + ko);      \
       if (COLS4 && !okm_[mi]) { ah[mi] = zero_; al[mi] = zero_; }                                           \
     }                                                                                                       \
     bh[0] = __builtin_bit_cast(h8, b##S_##h0##KK_);                                                         \
@@ -414,7 +424,7 @@ __global__ __launch_bounds__(NT, ((NI == 2 || DEEP || SPATIAL) ? 2 : (COLS4 ? (T
     }                                                                                                       \
   } while (0)
 
-  if (tid < 4 * (RS / 8)) {       // the zero row of each (buffer, hi/lo) plane: 80 bytes = 5 x 16, never overwritten
+  if (tid < NBUF * 2 * (RS / 8)) {       // the zero row of each (buffer, hi/lo) plane: 80 bytes = 5 x 16, never overwritten
     const uint4 z = make_uint4(0u, 0u, 0u, 0u);
     *reinterpret_cast<uint4*>(sAf + (tid / (RS / 8)) * (PRW * RS) + ARW * RS + (tid % (RS / 8)) * 8) = z;
   }
@@ -452,8 +462,8 @@ __global__ __launch_bounds__(NT, ((NI == 2 || DEEP || SPATIAL) ? 2 : (COLS4 ? (T
         /* SPATIAL: the lane's halo-tile row of the centre tap + the tap's constant offset; nothing to mask */ \
         const int row = SPATIAL ? fv[mi] + dv_                                                              \
                                 : ((TT == 1 || COLS4 || okm_[mi]) ? wm * 64 + mi * 32 + l31 + HALO + dv_ : AROWS); \
-        ah[mi] = *reinterpret_cast<const h8*>(sAf + (AB_) * (2 * PRW * RS) + row * RS + ko);               \
-        al[mi] = *reinterpret_cast<const h8*>(sAf + (AB_) * (2 * PRW * RS) + PRW * RS + row * RS + ko);    \
+        ah[mi] = *reinterpret_cast<const h8*>(sAf + RP_BUF(AB_) * (2 * PRW * RS) + row * RS + ko);               \
+        al[mi] = *reinterpret_cast<const h8*>(sAf + RP_BUF(AB_) * (2 * PRW * RS) + PRW * RS + row * RS + ko);    \
         if (!SPATIAL && TT != 1 && COLS4 && !okm_[mi]) { ah[mi] = zero_; al[mi] = zero_; }                  \
       }                                                                                                     \
       _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) {                                                   \
@@ -488,8 +498,8 @@ __global__ __launch_bounds__(NT, ((NI == 2 || DEEP || SPATIAL) ? 2 : (COLS4 ? (T
       _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) {                                                   \
         const bool ok_ = SPATIAL || TT == 1 || static_cast<unsigned>(fv[mi] + dvr_) < static_cast<unsigned>(p.V); \
         const int row = SPATIAL ? fv[mi] + dvr_ : (ok_ ? wm * 64 + mi * 32 + l31 + HALO + dvr_ : AROWS);    /* masked tap: the all-zero row */ \
-        fa_h[SET_][mi] = *reinterpret_cast<const h8*>(sAf + (AB_) * (2 * PRW * RS) + row * RS + ko);       \
-        fa_l[SET_][mi] = *reinterpret_cast<const h8*>(sAf + (AB_) * (2 * PRW * RS) + PRW * RS + row * RS + ko); \
+        fa_h[SET_][mi] = *reinterpret_cast<const h8*>(sAf + RP_BUF(AB_) * (2 * PRW * RS) + row * RS + ko);       \
+        fa_l[SET_][mi] = *reinterpret_cast<const h8*>(sAf + RP_BUF(AB_) * (2 * PRW * RS) + PRW * RS + row * RS + ko); \
       }                                                                                                     \
     }
 #define RP_MFMA6(SET_, S_, KK_)                                                                             \
@@ -565,6 +575,7 @@ __global__ __launch_bounds__(NT, ((NI == 2 || DEEP || SPATIAL) ? 2 : (COLS4 ? (T
       s0 += TT;                                                                                             \
       ccb = ncb_; cg = ng_;                                                                                 \
       if (!OVL) {                                                                                           \
+        if (NBUF == 1 && !(RP_ABL & 8)) __syncthreads();   /* single buffer: every wave is done reading the current tile */ \
         if (DEEP) { RP_STORE_A(OTH_, OTH_); }            /* the NEXT block's tile, requested one block ago */  \
         else if (!(RP_ABL & 4)) { RP_STORE_A(OTH_, 0); }                                                    \
         if (!(RP_ABL & 8)) __syncthreads();                                                                 \
@@ -675,7 +686,7 @@ __global__ __launch_bounds__(NT, ((NI == 2 || DEEP || SPATIAL) ? 2 : (COLS4 ? (T
   // first layers see an almost constant image (2 (x / 255) - 1 of a [0,1] image: model/CFNet.py:42-43), mean^2 / var up to 2e3 --
   // fp32 sums lost 4-5 digits of the variance there and were the largest single source of the GPU's distance to the oracle
   double ts0 = 0., ts1 = 0., ts2 = 0., ts3 = 0., tq0 = 0., tq1 = 0., tq2 = 0., tq3 = 0.;
-  float* S = reinterpret_cast<float*>(&sA[0][0][0]) + wave * (32 * ES);    // 4 x 32 x 68 floats = 34.8 KB <= 43.5 KB
+  float* S = reinterpret_cast<float*>(sAf) + wave * (32 * ES);    // 4 x 32 x 68 floats = 34.8 KB <= 43.5 KB
   const int colw = n0 + wn * (32 * NI);
   // Every lane works on ONE column quad (64 % F4 == 0): its bias is loaded once.  Per 32-row block (mi) the epilogue operands of
   // all 4*NI row groups -- the additive map, h and z of the GRU forms -- are requested up front, unconditionally (rows /
@@ -812,7 +823,7 @@ __global__ __launch_bounds__(NT, ((NI == 2 || DEEP || SPATIAL) ? 2 : (COLS4 ? (T
           }
       }
     } else {
-      double* TS = reinterpret_cast<double*>(reinterpret_cast<float*>(&sA[0][0][0]) + 4 * (32 * ES));      // behind the four staging tiles (8-byte aligned: 32 * ES is even)
+      double* TS = reinterpret_cast<double*>(reinterpret_cast<float*>(sAf) + 4 * (32 * ES));      // behind the four staging tiles (8-byte aligned: 32 * ES is even)
       __syncthreads();
       if (lane < F4) {
         double* t = TS + (wave * F4 + lane) * 8;
