@@ -32,9 +32,23 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+TRAFFIC_KERNEL_FILES = ("conv_igemm.hip", "corr_pyramid.hip")      # the kernels whose HBM counters profiles/traffic.json holds
+
+
 def source_digest() -> str:
-    """Digest of the kernel sources + flags (what profiles/traffic.json records, so that bench.py can tell stale counters)."""
-    return _digest()
+    """Digest of the sources the two kernels measured in profiles/traffic.json are compiled from (their .hip files, every shared
+    csrc header, the compiler flags): bench.py refuses counters measured on other kernel sources.  (The stamp of the library
+    itself, _digest(), covers every source and the public header.)"""
+    h = hashlib.sha256()
+    files = [os.path.join(CSRC, f) for f in TRAFFIC_KERNEL_FILES] + sorted(glob.glob(os.path.join(CSRC, "*.hpp"))) + \
+        sorted(glob.glob(os.path.join(CSRC, "*.cuh")))
+    for f in files:
+        h.update(os.path.relpath(f, ROOT).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(FLAGS).encode())
+    h.update(repr(sorted((k, v) for k, v in PER_FILE_FLAGS.items() if k in TRAFFIC_KERNEL_FILES)).encode())
+    return h.hexdigest()
 
 
 def _digest() -> str:

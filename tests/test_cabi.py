@@ -73,6 +73,18 @@ def test_workspace_and_argument_validation(lib):
     assert lib.rnnpose_corr_weight_f32(one, one, one, 2, one, one, 1, 32, 8, 8, one, null) == 1
     assert lib.rnnpose_corr_pyramid_f32(one, one, 1, 250, 16, 16, 4, one, null) == 1
     assert b"multiple of 16" in lib.rnnpose_last_error()
+    # r03 entry points: operands handed over as split tensors; K-split workspace / limits of the convolution
+    assert lib.rnnpose_corr_pyramid_split(null, null, 1, 256, 16, 16, 4, 8.0, null, null) == 1
+    assert b"null pointer" in lib.rnnpose_last_error()
+    assert lib.rnnpose_corr_pyramid_split(C.c_void_p(8), C.c_void_p(16), 1, 256, 16, 16, 4, 8.0, one, null) == 1
+    assert b"16-byte aligned" in lib.rnnpose_last_error()
+    assert lib.rnnpose_corr_pyramid_split(one, one, 1, 48, 16, 16, 4, 8.0, one, null) == 1
+    assert b"multiple of 32" in lib.rnnpose_last_error()
+    assert lib.rnnpose_conv_ksplit_workspace_bytes() == 1024 + 192 * 256 * 32 * 4
+    assert lib.rnnpose_conv_ksplit_limits(0, 4) == 1 and b"max_tiles" in lib.rnnpose_last_error()
+    assert lib.rnnpose_conv_ksplit_limits(24, 9) == 1
+    assert lib.rnnpose_conv_ksplit_limits(24, 4) == 0
+    assert lib.rnnpose_conv_ksplit(1) == 0
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

@@ -30,6 +30,9 @@ if [ "$2" != "noprof" ]; then
       CONV_LAYERS_FILTER="zr 1x5,q 1x5,heads,convc2,enc l1" CONV_LAYERS_B=4,8,1 RNNPOSE_LIB=$R/rnnpose_amd/lib/$lib.so timeout 200 python tools/conv_layers.py 0 f32,hl1 2>&1 | grep -v amdgpu.ids
     done > $OUT/${TAG}_conv_ablation.txt
   fi
+  if ls rnnpose_amd/lib/cv_*.so > /dev/null 2>&1; then      # diagnostics builds of the volume kernel (bash tools/corr_ablate.sh ...) + the store-pattern probe
+    bash tools/corr_ablate_run.sh $TAG > /dev/null 2>&1
+  fi
   python tools/conv_layers.py > $OUT/${TAG}_conv_layers_alone.txt 2>&1
   python tools/drift_probe.py > $OUT/${TAG}_drift.log 2>&1; cp $OUT/drift_probe.json $OUT/${TAG}_drift.json; tail -1 $OUT/${TAG}_drift.log
   ( cd /tmp && export TMPDIR=/tmp

@@ -16,6 +16,7 @@ tools/gpu_round.sh runs it ON the GPU box with outdir = gpurun_out/<tag>_summary
   <tag>_pmc_traffic_bench.json FETCH/WRITE bytes per kernel over one eager bench step
   <tag>_drift.json             free-running 3x8 drift against the fp64 oracle (tools/drift_probe.py)
   <tag>_conv_ablation.txt      ablation builds of the convolution kernel (tools/conv_ablate.sh): time without weight loads / LDS reads / staging / ...
+  <tag>_corr_ablation.txt, <tag>_corr_store_patterns.txt   diagnostics builds of the volume kernel + the store-pattern probe (tools/corr_ablate_run.sh)
   <tag>_error_budget.json      fp64 evaluation vs the fp32 CPU oracle vs the GPU as the feature magnitude grows (tools/error_budget.py)
   <tag>_parity_probe.json      first-iteration flow of the timed configuration: GPU vs both oracle forms, encoder in / out (tools/parity_probe.py)
   <tag>_pytest_gpu.txt, <tag>_smoke.txt, <tag>_device.txt
@@ -74,7 +75,7 @@ for suffix in ("bench", "bench_nograph", "bench_S1", "bench_S5", "bench_B16", "b
     if src and os.path.getsize(src):
         shutil.copy(src, os.path.join(P, f"{TAG}_{suffix}.json"))
 for suffix, n in (("pytest_gpu.log", 12), ("smoke.log", 4), ("device.txt", 5), ("conv_layers_alone.txt", 40), ("drift.log", 60),
-                  ("conv_ablation.txt", 200)):
+                  ("conv_ablation.txt", 200), ("corr_ablation.txt", 60), ("corr_store_patterns.txt", 40)):
     src = have(f"{TAG}_{suffix}")
     if src:
         tail(src, os.path.join(P, f"{TAG}_{suffix.replace('.log', '.txt')}"), n)
