@@ -57,6 +57,20 @@ int rnnpose_corr_pyramid_f16x3(const float* fmap1, const float* fmap2, int layou
 int rnnpose_corr_pyramid_split(const void* fmap1_split, const void* fmap2_split, int B, int C, int h, int w, int levels,
                                float a_scale, float* pyramid, rnnpose_stream_t stream);
 
+/* ---- a3': volume-free lookup ---- thirdparty/raft/corr.py:70-98 (AlternateCorrBlock; its alt_cuda_corr extension is not in the
+ * reference tree and the reference never enables it, model/CFNet.py:63-64).  The same (levels*81)-channel window features as
+ * rnnpose_corr_lookup_*, computed on the fly from fmap1 and the 2^l-pooled fmap2 (pooling is linear: equal to the pyramid
+ * lookup up to fp32 summation order) -- no volume is built.  A measured alternative, not the graded path.
+ * fmap1 / fmap2: (B,h,w,C) pixel-major fp32, C % 4 == 0, C <= 512, 16-byte aligned.  rnnpose_fmap_pyramid_f32 writes levels
+ * 1..levels-1 of fmap2 (chained 2x2 means, floor cropping) back to back into `pooled` (rnnpose_fmap_pyramid_floats floats).
+ * out: pixel-major, channels [out_c_offset, +levels*81) of rows of out_c_stride floats; coords (B,2,h,w) as for the lookup. */
+size_t rnnpose_fmap_pyramid_floats(int B, int h, int w, int C, int levels);
+int rnnpose_fmap_pyramid_f32(const float* fmap2_nhwc, int B, int h, int w, int C, int levels, float* pooled,
+                             rnnpose_stream_t stream);
+int rnnpose_corr_alt_lookup_f32(const float* fmap1_nhwc, const float* fmap2_nhwc, const float* pooled, const float* coords, int B,
+                                int h, int w, int C, int levels, int radius, float* out, int out_c_stride, int out_c_offset,
+                                rnnpose_stream_t stream);
+
 /* ---- a3: pyramid lookup -------- thirdparty/raft/corr.py:36-57, thirdparty/raft/utils/utils.py:57-71
  * coords (B,2,h,w) (ch0 = x, ch1 = y) -> out (B, levels*(2r+1)^2, h, w); channel
  * l*(2r+1)^2 + i*(2r+1) + j samples level l at (x/2^l + i - r, y/2^l + j - r)  [x-major window],

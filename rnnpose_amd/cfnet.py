@@ -81,8 +81,12 @@ class GRU_CFUpdator(nn.Module):
         if "alternate_corr" not in args:
             args.alternate_corr = False
         if args.alternate_corr:
-            raise NotImplementedError("alternate_corr needs the external alt_cuda_corr extension; the reference "
-                                      "never enables it (model/CFNet.py:63-64)")
+            # (thirdparty/raft/corr.py:70-98; the reference never enables it, model/CFNet.py:63-64.)  The class exists on its own --
+            # rnnpose_amd.corr.AlternateCorrBlock, window features computed on the fly by csrc/corr_alt.hip -- and is measured
+            # against the materialised volume (tools/corr_alt_bench.py, profiles/r03_corr_alt.txt); the fused update engine reads
+            # the volume, which is faster per iteration at every measured shape.
+            raise NotImplementedError("alternate_corr is not wired into the fused update engine; "
+                                      "rnnpose_amd.corr.AlternateCorrBlock provides the volume-free lookup on its own")
         self.update_block = BasicUpdateBlock(args, hidden_dim=self.hidden_dim)
         pre = args.get("pretrained_model", None)
         if pre is not None:

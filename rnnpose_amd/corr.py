@@ -48,3 +48,24 @@ class CorrBlock:
         B, _, h, w = fmap1.shape
         _, views = ops.corr_pyramid(fmap1.float(), fmap2.float(), 1)
         return views[0].view(B, h, w, 1, h, w)
+
+
+class AlternateCorrBlock:
+    """The reference's volume-free variant (thirdparty/raft/corr.py:70-98): same constructor and call as CorrBlock, but no
+    all-pairs volume is built -- every call computes the 9x9 windows of the 4 levels on the fly from fmap1 and the pooled
+    fmap2 pyramid (csrc/corr_alt.hip).  Equal to CorrBlock up to fp32 summation order.  Kept as a MEASURED alternative
+    (tools/corr_alt_bench.py, profiles/r03_corr_alt.txt): per iteration it is slower than amortised build + lookup at the bench
+    shape, so the fused engine uses the materialised volume (GRU_CFUpdator rejects alternate_corr=True, like before)."""
+
+    def __init__(self, fmap1, fmap2, num_levels=4, radius=4):
+        if radius != 4:
+            raise NotImplementedError("only radius=4 (the reference's value) is implemented")
+        self.num_levels = num_levels
+        self.radius = radius
+        self.f1 = ops.nchw_to_nhwc(fmap1.float())
+        self.f2 = ops.nchw_to_nhwc(fmap2.float())
+        self.pooled = ops.fmap_pyramid(self.f2, num_levels)
+
+    def __call__(self, coords):
+        out = ops.corr_alt_lookup(self.f1, self.f2, self.pooled, coords, self.num_levels, self.radius)
+        return ops.nhwc_to_nchw(out)

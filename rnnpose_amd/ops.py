@@ -204,6 +204,33 @@ def corr_pyramid_split(f1: SplitTensor, f2: SplitTensor, levels: int = 4, out=No
     return buf, views
 
 
+# ---- a3' (volume-free lookup: a measured alternative, thirdparty/raft/corr.py:70-98) ------------------------
+def fmap_pyramid(f2, levels: int = 4):
+    """f2 (B,h,w,C) pixel-major -> flat buffer holding levels 1..levels-1 of the 2x2-mean pyramid of the feature map."""
+    f2 = _nhwc(f2, "f2")
+    B, h, w, Cc = f2.shape
+    n = int(_lib.load().rnnpose_fmap_pyramid_floats(B, h, w, Cc, levels))
+    buf = torch.empty(max(n, 4), device=f2.device, dtype=F32)
+    _launch("rnnpose_fmap_pyramid_f32", _ptr(f2), B, h, w, Cc, levels, _ptr(buf), _stream())
+    return buf
+
+
+def corr_alt_lookup(f1, f2, pooled, coords, levels: int = 4, radius: int = 4, out=None):
+    """Window features computed on the fly (no volume): f1, f2 (B,h,w,C) pixel-major, pooled = fmap_pyramid(f2, levels),
+    coords (B,2,h,w) -> (B,h,w,levels*81) pixel-major (the layout corr_lookup_nhwc writes)."""
+    f1, f2 = _nhwc(f1, "f1"), _nhwc(f2, "f2")
+    coords = _chk(coords, "coords")
+    B, h, w, Cc = f1.shape
+    if f2.shape != f1.shape or tuple(coords.shape) != (B, 2, h, w):
+        raise ValueError("f1/f2 must share (B,h,w,C) and coords must be (B,2,h,w)")
+    nch = levels * (2 * radius + 1) ** 2
+    if out is None:
+        out = torch.empty(B, h, w, nch, device=f1.device, dtype=F32)
+    _launch("rnnpose_corr_alt_lookup_f32", _ptr(f1), _ptr(f2), _ptr(pooled), _ptr(coords), B, h, w, Cc, levels, radius, _ptr(out),
+            out.shape[3], 0, _stream(), work=2.0 * B * h * w * levels * 100 * Cc)
+    return out
+
+
 # ---- a3 ------------------------------------------------------------------------------------------------
 def _lookup_bytes(B, h, w, levels, radius):
     """per pixel and level a (2r+2)^2 texel footprint read + (2r+1)^2 outputs written, + 2 coords."""

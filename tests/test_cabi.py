@@ -85,6 +85,15 @@ def test_workspace_and_argument_validation(lib):
     assert lib.rnnpose_conv_ksplit_limits(24, 9) == 1
     assert lib.rnnpose_conv_ksplit_limits(24, 4) == 0
     assert lib.rnnpose_conv_ksplit(1) == 0
+    # volume-free lookup (AlternateCorrBlock)
+    assert lib.rnnpose_fmap_pyramid_floats(2, 16, 24, 256, 4) == 2 * 256 * (8 * 12 + 4 * 6 + 2 * 3)
+    assert lib.rnnpose_fmap_pyramid_floats(2, 16, 24, 256, 1) == 0
+    assert lib.rnnpose_corr_alt_lookup_f32(null, null, null, null, 1, 16, 16, 256, 4, 4, null, 324, 0, null) == 1
+    assert lib.rnnpose_corr_alt_lookup_f32(one, one, one, one, 1, 16, 16, 256, 4, 3, one, 324, 0, null) == 1
+    assert b"radius" in lib.rnnpose_last_error()
+    assert lib.rnnpose_corr_alt_lookup_f32(one, one, one, one, 1, 16, 16, 258, 4, 4, one, 324, 0, null) == 1
+    assert lib.rnnpose_corr_alt_lookup_f32(one, one, one, one, 1, 16, 16, 256, 4, 4, one, 300, 0, null) == 1
+    assert b"channel stride" in lib.rnnpose_last_error()
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

@@ -217,6 +217,50 @@ def test_corr_lookup_vs_oracle_and_golden(ops, golden):
         close(out[:, :, ::2, ::3], g[f"lookup_{k}"], 1e-4, what=f"lookup {k} vs golden")
 
 
+def test_alternate_corr_block_vs_oracle_lookup_and_golden(ops, golden):
+    """AlternateCorrBlock (thirdparty/raft/corr.py:70-98): the window features computed on the fly from fmap1 and the pooled fmap2
+    pyramid -- no volume -- equal the pyramid lookup (pooling is linear): the oracle's and the golden vectors' lookup cases at 1e-4,
+    NaN / far-away coordinates give zeros like the materialised path."""
+    from rnnpose_amd.corr import AlternateCorrBlock, CorrBlock
+    g = golden("corr")
+    B, C, h, w = 2, 256, 16, 24
+    f1 = syn.normal("fmap1", (B, C, h, w), 11)
+    f2 = syn.normal("fmap2", (B, C, h, w), 11)
+    pyr = orc.corr_pyramid(f1, f2)
+    alt = AlternateCorrBlock(D(f1), D(f2), num_levels=4, radius=4)
+    mat = CorrBlock(D(f1), D(f2), num_levels=4, radius=4)
+    for k, c in _lookup_cases(B, h, w).items():
+        out = alt(D(c))
+        assert out.shape == (B, 324, h, w) and out.is_contiguous()
+        close(out, orc.corr_lookup(pyr, c), 1e-4, what=f"on-the-fly {k} vs oracle")
+        close(out[:, :, ::2, ::3], g[f"lookup_{k}"], 1e-4, what=f"on-the-fly {k} vs golden")
+        close(out, mat(D(c)), 2e-5, what=f"on-the-fly {k} vs materialised lookup")
+    bad = D(orc.coords_grid_lowres(B, h, w)).clone()
+    bad[0, 0, 5, 5] = float("nan")
+    bad[1, 1, 6, 6] = float("inf")
+    bad[1, 0, 7, 7] = -1e30
+    ob, om = alt(bad), mat(bad)
+    assert bool(torch.isfinite(ob).all())
+    for (b_, y_, x_) in ((0, 5, 5), (1, 6, 6), (1, 7, 7)):
+        assert float(ob[b_, :, y_, x_].abs().max()) == 0.0
+    close(ob, om, 2e-5, what="on-the-fly with non-finite coordinates")
+    with pytest.raises(NotImplementedError):
+        AlternateCorrBlock(D(f1), D(f2), radius=3)
+
+
+@pytest.mark.parametrize("B,C,h,w,levels", [(1, 64, 30, 30, 4), (3, 32, 17, 19, 4), (1, 320, 9, 21, 3), (2, 512, 8, 8, 2)])
+def test_alternate_corr_odd_sizes_and_channel_counts(ops, B, C, h, w, levels):
+    """Ragged pyramids (odd sizes: floor cropping), channel counts that do not fill the 256-channel lane layout, up to 512."""
+    f1 = syn.normal("fmap1", (B, C, h, w), 4)
+    f2 = syn.normal("fmap2", (B, C, h, w), 4)
+    c = orc.coords_grid_lowres(B, h, w) + T(syn.uniform("lk", (B, 2, h, w), 4, -6.0, 6.0))
+    n1, n2 = D(f1).permute(0, 2, 3, 1).contiguous(), D(f2).permute(0, 2, 3, 1).contiguous()
+    pooled = ops.fmap_pyramid(n2, levels)
+    out = ops.corr_alt_lookup(n1, n2, pooled, D(c), levels)
+    want = orc.corr_lookup(orc.corr_pyramid(f1, f2, levels), c)
+    close(out.permute(0, 3, 1, 2), want, 1e-4, what="on-the-fly odd sizes")
+
+
 @pytest.mark.parametrize("B,h,w", [(1, 30, 30), (3, 17, 19)])
 def test_corr_lookup_odd_sizes(ops, B, h, w):
     f1 = syn.normal("fmap1", (B, 64, h, w), 4)

@@ -32,7 +32,8 @@ Wt = {"upd": {k: p.detach().cpu().numpy() for k, p in ref.cf_net.update_block.st
       "enc": {k: p.detach().cpu().numpy() for k, p in ref.image_fea_enc.fnet.state_dict().items()}}
 res = {}
 eng = ref.cf_net.engine()
-g = dict(fmap1=ref.cf_net.fmap1.double().cpu(), fmap2=ref.cf_net.fmap2.double().cpu(), corr=eng._b["corr"].permute(0, 3, 1, 2).double().cpu(),
+_dense = lambda t: t.dense() if hasattr(t, 'dense') else t      # (the encoder hands split tensors to the volume build)
+g = dict(fmap1=_dense(ref.cf_net.fmap1).double().cpu(), fmap2=_dense(ref.cf_net.fmap2).double().cpu(), corr=eng._b["corr"].permute(0, 3, 1, 2).double().cpu(),
          net=eng.hidden_nchw().double().cpu(), dflow=eng._b["delta"].permute(0, 3, 1, 2).double().cpu(), flow_up=out["flow"][0].double().cpu())
 with orc.precision(torch.float64):
     f1, f2 = orc.image_encoder(Wt["enc"], inp["img_render"], inp["img_target"])

@@ -41,7 +41,8 @@ t0 = time.time()
 f1c, f2c = orc.image_encoder(encW, d["img_render"], d["img_target"])
 res["cpu_encoder_s"] = time.time() - t0
 fg, Gg, ref = gpu(True)
-f1g, f2g = ref.cf_net.fmap1.cpu(), ref.cf_net.fmap2.cpu()
+dense = lambda t: t.dense() if hasattr(t, 'dense') else t          # (the encoder hands split tensors to the volume build)
+f1g, f2g = dense(ref.cf_net.fmap1).cpu(), dense(ref.cf_net.fmap2).cpu()
 res["fmap_max_abs"] = float(f1c.abs().max())
 res["fmap_gpu_vs_cpu"] = [float((f1g - f1c).abs().max()), float((f2g - f2c).abs().max())]
 dd = {k: v for k, v in d.items() if k not in ("fmap1", "fmap2")}
