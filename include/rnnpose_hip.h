@@ -56,6 +56,7 @@ int rnnpose_corr_pyramid_f16x3(const float* fmap1, const float* fmap2, int layou
                                rnnpose_stream_t stream);
 int rnnpose_corr_pyramid_split(const void* fmap1_split, const void* fmap2_split, int B, int C, int h, int w, int levels,
                                float a_scale, float* pyramid, rnnpose_stream_t stream);
+int rnnpose_corr_supertile(int max_side);   /* measurement switch: tile-order supertiles of at most max_side x max_side (default 20) */
 
 /* ---- a3': volume-free lookup ---- thirdparty/raft/corr.py:70-98 (AlternateCorrBlock; its alt_cuda_corr extension is not in the
  * reference tree and the reference never enables it, model/CFNet.py:63-64).  The same (levels*81)-channel window features as

@@ -389,7 +389,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 template <bool ALIGNED>
 __global__ __launch_bounds__(NT, 2) void corr_pyramid_h3_kernel(const _Float16* __restrict__ f1, const _Float16* __restrict__ f2,
                                                                 float* __restrict__ pyr, int B, int C, int h, int w, int n_it,
-                                                                int n_py, int n_px, float scale, PyrInfo info) {
+                                                                int n_py, int n_px, float scale, PyrInfo info, int sti, int stp) {
   // [A | B][hi | lo][128 rows x HRS] halfs = 40 KiB (single buffer, the next slab waits in registers);
   // the epilogue's 36 KiB of float staging aliases it
   __shared__ __attribute__((aligned(16))) _Float16 sT[2 * 2 * 128 * HRS];
@@ -405,14 +405,18 @@ __global__ __launch_bounds__(NT, 2) void corr_pyramid_h3_kernel(const _Float16* 
     const int xcd = bid & 7, idx = bid >> 3;
     bid = xcd * per + (xcd < rem ? xcd : rem) + idx;
   }
+  // Within an image, tiles are ordered in SUPERTILES of sti i tiles x stp patches (host: the smallest even split of the image with
+  // at most 20 of each, 19 x 20 at 60 x 80): the tiles an XCD has in flight share sti + stp operand panels of 64 KB (2.5 MB of
+  // its 4 MB L2).  8 x 8 supertiles (r01-r02) re-fetched every panel 4 times: 326 MB per launch for 79 MB of operands.
   const int n_patch = n_py * n_px;
-  const int n_ps = (n_patch + ST - 1) / ST, n_is = (n_it + ST - 1) / ST;
-  const int per_img = n_ps * n_is * ST * ST;
+  const int n_ps = (n_patch + stp - 1) / stp, n_is = (n_it + sti - 1) / sti;
+  const int sts = sti * stp;
+  const int per_img = n_ps * n_is * sts;
   const int b = bid / per_img;
   const int tloc = bid - b * per_img;
-  const int sidx = tloc / (ST * ST), within = tloc - sidx * (ST * ST);
-  const int it = (sidx / n_ps) * ST + within / ST;
-  const int patch = (sidx % n_ps) * ST + within % ST;
+  const int sidx = tloc / sts, within = tloc - sidx * sts;
+  const int it = (sidx / n_ps) * sti + within / stp;
+  const int patch = (sidx % n_ps) * stp + within % stp;
   if (it >= n_it || patch >= n_patch) return;
   const int i0 = it * BM;
   const int y0 = (patch / n_px) * PY;
@@ -566,6 +570,7 @@ size_t rnnpose_corr_pyramid_f16x3_workspace_bytes(int B, int C, int h, int w) {
 }
 
 namespace {
+int g_corr_supertile = 20;      // (rnnpose_corr_supertile: measurement)
 int launch_h3(const char* fn, const _Float16* f1, const _Float16* f2, int B, int C, int h, int w, int levels, float a_scale,
               float* pyramid, hipStream_t st) {
   RP_REQUIRE(C > 0 && C % HBK == 0, fn, "C must be a positive multiple of 32");
@@ -578,19 +583,31 @@ int launch_h3(const char* fn, const _Float16* f1, const _Float16* f2, int B, int
   const int N = h * w;
   RP_REQUIRE(B < 65536 && 2LL * B * N * C < (1LL << 31), fn, "feature maps too large for 32-bit element offsets");
   const int n_it = rp::cdiv(N, BM), n_py = rp::cdiv(h, PY), n_px = rp::cdiv(w, PX);
-  const long long ntiles = static_cast<long long>(B) * rp::cdiv(n_it, ST) * rp::cdiv(n_py * n_px, ST) * ST * ST;
+  // supertile = the smallest even split of the image's (i tiles) x (patches) with at most g_corr_supertile of each
+  const int n_patch = n_py * n_px;
+  const int sti = rp::cdiv(n_it, rp::cdiv(n_it, g_corr_supertile)), stp = rp::cdiv(n_patch, rp::cdiv(n_patch, g_corr_supertile));
+  const long long ntiles = static_cast<long long>(B) * rp::cdiv(n_it, sti) * rp::cdiv(n_patch, stp) * sti * stp;
   RP_REQUIRE(ntiles < (1LL << 31), fn, "grid too large");
   const float scale = 1.0f / (sqrtf(static_cast<float>(C)) * a_scale * a_scale);
   const bool aligned = (N % 4 == 0) && (w % 4 == 0) && (reinterpret_cast<uintptr_t>(pyramid) % 16 == 0);
   dim3 grid(static_cast<unsigned>(ntiles)), block(NT);
   if (aligned) {
-    hipLaunchKernelGGL(corr_pyramid_h3_kernel<true>, grid, block, 0, st, f1, f2, pyramid, B, C, h, w, n_it, n_py, n_px, scale, info);
+    hipLaunchKernelGGL(corr_pyramid_h3_kernel<true>, grid, block, 0, st, f1, f2, pyramid, B, C, h, w, n_it, n_py, n_px, scale, info, sti, stp);
   } else {
-    hipLaunchKernelGGL(corr_pyramid_h3_kernel<false>, grid, block, 0, st, f1, f2, pyramid, B, C, h, w, n_it, n_py, n_px, scale, info);
+    hipLaunchKernelGGL(corr_pyramid_h3_kernel<false>, grid, block, 0, st, f1, f2, pyramid, B, C, h, w, n_it, n_py, n_px, scale, info, sti, stp);
   }
   return rp::check_launch(fn);
 }
 }  // namespace
+
+int rnnpose_corr_supertile(int max_side) {       // measurement: side limit of the fp16x3 kernel's tile-order supertiles (default 20; 8 = r02)
+  if (max_side < 1 || max_side > 64) {
+    rp::set_error("rnnpose_corr_supertile: max_side 1..64");
+    return 1;
+  }
+  g_corr_supertile = max_side;
+  return 0;
+}
 
 int rnnpose_corr_pyramid_f16x3(const float* fmap1, const float* fmap2, int layout, int B, int C, int h, int w, int levels,
                                float a_scale, void* workspace, size_t workspace_bytes, float* pyramid,

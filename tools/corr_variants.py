@@ -7,6 +7,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from rnnpose_amd import ops
 B, h, w = (int(v) for v in sys.argv[1:4]) if len(sys.argv) >= 4 else (8, 60, 80)
+if os.environ.get("CORR_SUPERTILE"):
+    from rnnpose_amd import _lib
+    _lib.call("rnnpose_corr_supertile", int(os.environ["CORR_SUPERTILE"]))
 C = 256
 dev = torch.device("cuda:0")
 g = torch.Generator(device="cpu").manual_seed(5)
@@ -45,7 +48,7 @@ for rep in range(3):
     tss.append(e0.elapsed_time(e1) / n * 1e3)
 t2 = min(tss)
 nbytes = 4.0 * buf.numel() + 2 * 4.0 * B * N * C
-print(f"{os.path.basename(os.environ.get('RNNPOSE_LIB', 'in-tree')):28s} {t:8.1f} us  {nbytes / t / 1e3:7.1f} GB/s  err L0 {err0:.2e} L1 {err1:.2e} L3 {err3:.2e} | split operands {t2:7.1f} us {nbytes / t2 / 1e3:7.1f} GB/s same={same}")
+print(f"{os.path.basename(os.environ.get('RNNPOSE_LIB', 'in-tree')) + (' st=' + os.environ['CORR_SUPERTILE'] if os.environ.get('CORR_SUPERTILE') else ''):28s} {t:8.1f} us  {nbytes / t / 1e3:7.1f} GB/s  err L0 {err0:.2e} L1 {err1:.2e} L3 {err3:.2e} | split operands {t2:7.1f} us {nbytes / t2 / 1e3:7.1f} GB/s same={same}")
 if os.environ.get("CORR_FILL"):
     for rep in range(2):
         e0.record()
