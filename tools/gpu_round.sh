@@ -44,6 +44,11 @@ if [ "$2" != "noprof" ]; then
   PMC_TRAFFIC_ONLY=1 bash tools/pmc_sq.sh ${TAG}_b python bench.py --steps 1 --warmup 1 --no-graph --no-cpu-baseline > /dev/null 2>&1
   # summaries on the box (gpurun merges <= 64 MiB back), then drop the databases except the main kernel trace
   python tools/summarize_profiles.py $TAG $OUT/${TAG}_summary > $OUT/${TAG}_summary.log 2>&1; tail -3 $OUT/${TAG}_summary.log
+  # the headline line once more, now with THIS pass's counter digest (bench.py refuses a traffic.json measured on other sources)
+  cp $OUT/${TAG}_summary/traffic.json profiles/traffic.json
+  mv $OUT/${TAG}_bench.json $OUT/${TAG}_bench_first.json
+  python bench.py --steps 20 --warmup 3 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+  cp $OUT/${TAG}_bench.json $OUT/${TAG}_summary/${TAG}_bench.json; head -c 200 $OUT/${TAG}_bench.json; echo
   rm -rf $OUT/${TAG}_*_pmc[0-9] $OUT/${TAG}_prof_unsplit $OUT/${TAG}_prof_convs
   du -sh $OUT | cut -f1
 fi
