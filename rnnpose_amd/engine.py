@@ -31,6 +31,7 @@ class UpdateEngine:
         import os
         self.split_batch = os.environ.get("RNNPOSE_SPLIT_BATCH", "1") != "0"   # concurrent part-batch chains
         self.parts = int(os.environ.get("RNNPOSE_PARTS", "2"))
+        self.parts_forced = "RNNPOSE_PARTS" in os.environ                         # explicit part count: no small-batch merging
         self.fused_mask = os.environ.get("RNNPOSE_FUSED_MASK", "1") != "0"       # mask.2 inside the up-sampling kernel
         self.resident_1x1 = os.environ.get("RNNPOSE_RESIDENT_1X1", "1") != "0"    # convc1 through csrc/conv1x1_resident.hip
         self.ksplit = os.environ.get("RNNPOSE_KSPLIT", "1") != "0"                # small launches (B = 1 crops) split their K loop
@@ -204,9 +205,18 @@ class UpdateEngine:
         self._chain(W, b, flow, torch.cuda.current_stream(), None, flow_is_delta=True, want_mask=True)
         return (ops.nhwc_to_nchw(b["hA"]), ops.nhwc_to_nchw(b["mask"]), ops.nhwc_to_nchw(b["delta"]))
 
+    MIN_CHAIN_PIXELS = 8192     # 1/8-resolution pixels per chain below which the batch stays ONE chain
+
     def halves(self, B):
-        """Image ranges of the concurrent chains: `parts` parts of the batch (one stream each), or the whole batch."""
+        """Image ranges of the concurrent chains: `parts` parts of the batch (one stream each), or the whole batch.
+        A chain needs enough pixels to fill the chip on its own launches: B=16 at 240x240 (14400 pixels at 1/8 resolution) runs
+        3 % faster as one chain than as two of 7200 (1009 vs 978 iters/s), B=32 (two of 14400) 3 % faster as two, the headline
+        shape (two of 19200) 5 % faster as two (r02); RNNPOSE_PARTS / RNNPOSE_SPLIT_BATCH override."""
         n = 1 if (B < 2 or not self.split_batch) else min(self.parts, B)
+        if n > 1 and not self.parts_forced and self._buf_key is not None:
+            _, h, w, _ = self._buf_key
+            while n > 1 and B * h * w < n * self.MIN_CHAIN_PIXELS:
+                n -= 1
         cuts = [B * i // n for i in range(n + 1)]
         return list(zip(cuts[:-1], cuts[1:]))
 

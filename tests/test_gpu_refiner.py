@@ -296,3 +296,30 @@ def test_k_split_schedule_matches_single_pass(ops, monkeypatch):
         outs.append(runs[-1])
     assert float((outs[0][0] - outs[1][0]).abs().max()) < 2e-6
     assert float((outs[0][1] - outs[1][1]).abs().max()) < 1e-4
+
+
+def test_two_chains_equal_one_chain(ops, monkeypatch):
+    """Small batches run as ONE chain (engine.halves: a chain needs >= 8192 pixels at 1/8 resolution to fill the chip); RNNPOSE_PARTS=2
+    forces the two-stream schedule the large shapes use.  Images are independent: identical results, also through graph replay."""
+    from rnnpose_amd import synthetic as syn
+    from rnnpose_amd.pose_refiner import PoseRefiner, SyntheticRenderer, default_config
+    from rnnpose_amd.transformation import SE3Sequence
+    from oracle import rnnpose_oracle as orc
+    d = syn.make_inputs(2, 128, 160, seed=12)
+    D = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    z3 = torch.zeros(2, 3, 128, 160, device="cuda")
+    kw = dict(syn_img=z3, image_crop=z3, cfea=D(d["ctx"]), geofea1=D(d["g1"]), geofea2_crop=D(d["g2"]), syn_depth=D(d["depth"]),
+              intrinsics_crop=D(d["K"]), fmap1=D(d["fmap1"]), fmap2=D(d["fmap2"]))
+    outs = []
+    for parts in (None, "2"):
+        if parts is None:
+            monkeypatch.delenv("RNNPOSE_PARTS", raising=False)
+        else:
+            monkeypatch.setenv("RNNPOSE_PARTS", parts)
+        ref = PoseRefiner(default_config(RENDER_ITER_COUNT=2, ITER_COUNT=3, OPTIM_ITER_COUNT=1), renderer=SyntheticRenderer(**kw)).cuda().eval()
+        ref.cf_net.update_block.load_state_dict({k: torch.from_numpy(v) for k, v in syn.make_module_weights(orc.UPDATE_BLOCK_SHAPES, seed=0).items()})
+        for _ in range(2):
+            out = ref(None, SE3Sequence(matrix=D(d["G0"])), D(d["K"]))
+        assert len(ref.cf_net.engine().halves(2)) == (1 if parts is None else 2)
+        outs.append((out["Ti_pred"].G.clone(), out["flow_last"].clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
