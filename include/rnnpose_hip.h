@@ -288,7 +288,8 @@ int rnnpose_f16x3_saturation_peek(unsigned long long* d_count, rnnpose_stream_t 
  * img (N,3,H,W) fp32 NCHW -> out (N, ceil(H/2), ceil(W/2), 64) fp32 NHWC = conv7x7_s2_p3(normalize ? 2*(img/255)-1 : img) + bias.
  * Weights (64,3,7,7) packed once by rnnpose_stem_pack_weights_f16x3 (2 arrays of rnnpose_stem_packed_halfs() fp16).
  * tile_stats (optional): (N * tiles_per_image, 64, 2) per-tile column sums / sums of squares for
- * rnnpose_instnorm_tiles_nhwc_f32 (rows_per_tile = 128); only when rnnpose_stem_tiles reports exact tiling. */
+ * rnnpose_instnorm_tiles_nhwc_f32 (8 x 16 output tiles; pixels of a ragged tile outside the image never enter the sums, so the
+ * statistics hold for every size -- rnnpose_stem_tiles reports h_exact = 1 always since r03; the field is kept for callers). */
 long long rnnpose_stem_packed_halfs(void);
 int rnnpose_stem_pack_weights_f16x3(const float* w_oihw, float w_scale, void* w_hi, void* w_lo, rnnpose_stream_t stream);
 int rnnpose_stem_tiles(int H, int W, int* h_tiles_per_image, int* h_exact);

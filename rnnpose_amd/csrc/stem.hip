@@ -207,7 +207,11 @@ int rnnpose_stem_tiles(int H, int W, int* tiles_per_image, int* exact) {
   if (H <= 0 || W <= 0 || !tiles_per_image || !exact) return rp::fail_arg("rnnpose_stem_tiles", "bad argument");
   const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
   *tiles_per_image = rp::cdiv(Ho, TH) * rp::cdiv(Wo, TW);
-  *exact = (Ho % TH == 0 && Wo % TW == 0) ? 1 : 0;
+  // r03: always 1.  The epilogue drops the pixels of a ragged tile that lie outside the image BEFORE they enter the sums, and
+  // instnorm_finalize_tiles divides by the true H*W -- the statistics of ragged tilings (every 240 x 240 crop: 120 x 120
+  // outputs are 15 x 7.5 tiles) were always right; r01-r02 sent those shapes through a full instance-norm pass instead.
+  (void)Ho; (void)Wo;
+  *exact = 1;
   return 0;
 }
 
@@ -222,7 +226,7 @@ int rnnpose_stem_conv7x7_s2_f16x3(const float* img_nchw, int N, int H, int W, in
              fn, "out / bias / packed weights must be 16-byte aligned");
   const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
   const int tiles_x = rp::cdiv(Wo, TW), tiles_y = rp::cdiv(Ho, TH);
-  if (tile_stats) RP_REQUIRE(Ho % TH == 0 && Wo % TW == 0, fn, "tile_stats needs ceil(H/2) % 8 == 0 and ceil(W/2) % 16 == 0");
+  // (tile_stats: ragged tilings included -- pixels outside the image are dropped before they enter the sums)
   const long long blocks = static_cast<long long>(N) * tiles_x * tiles_y;
   RP_REQUIRE(blocks < (1LL << 31), fn, "too many tiles");
   hipLaunchKernelGGL(stem_conv7x7_s2_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, rp::as_stream(stream), img_nchw,

@@ -646,12 +646,17 @@ def test_encoder_stem_kernel(ops, N, H, W):
         ref32 = F.conv2d(xin.float(), wt, bias, stride=2, padding=3).permute(0, 2, 3, 1)
         err, err32 = float((out.double() - want).abs().max()), float((ref32.double() - want).abs().max())
         assert err <= max(3 * err32, 2e-6), (err, err32)
-        if ts is not None:
-            t = ts.view(N, -1, 64, 2).double().sum(1)
-            close(t[..., 0], want.sum((1, 2)), 1e-3, 1e-5, what="tile sums")
-            close(t[..., 1], (want * want).sum((1, 2)), 1e-3, 1e-5, what="tile sums of squares")
-        else:
-            assert ((H + 1) // 2) % 8 or ((W + 1) // 2) % 16
+        assert ts is not None          # (r03: ragged tilings too -- pixels outside the image never enter the sums)
+        t = ts.view(N, -1, 64, 2).double().sum(1)
+        close(t[..., 0], want.sum((1, 2)), 1e-3, 1e-5, what="tile sums")
+        close(t[..., 1], (want * want).sum((1, 2)), 1e-3, 1e-5, what="tile sums of squares")
+        # and the lazily normalised stem output built on them == instance norm + ReLU of the fp64 convolution
+        mr = ops.instnorm_tiles_nhwc(out, ts, stats_only=True)
+        got = ops.instnorm_tiles_nhwc(out, ts, relu=True)
+        w64 = want.permute(0, 3, 1, 2)
+        n64 = F.relu(F.instance_norm(w64, eps=1e-5)).permute(0, 2, 3, 1)
+        assert tuple(mr.shape) == (N, 64, 2)
+        close(got, n64, 2e-5, what="instance norm from (ragged) tile statistics")
 
 
 def test_stem_statistics_on_a_nearly_constant_image(ops):
