@@ -7,7 +7,7 @@ echo "# tools/corr_variants.py: B=8, 60x80, C=256, 4 levels; whole C-ABI call fr
 echo "# RPC_ABL bits: 1 K loop requests no operands after the first slab, 2 no epilogue stores, 4 no K loop, 8 no epilogue, 16 K loop does not refill LDS,"
 echo "#               32 no level-0 stores, 64 no pooled-level stores;  nt0 / nt2: level-0 stores temporal / all levels non-temporal"
 CORR_FILL=1 python tools/corr_variants.py 2>&1 | tail -2
-for f in $(ls rnnpose_amd/lib/cv_*.so 2>/dev/null | sort -V); do RNNPOSE_LIB=$R/$f python tools/corr_variants.py 2>&1 | tail -1; done
+for f in $(ls gpurun_extra/cv_*.so 2>/dev/null | sort -V); do RNNPOSE_LIB=$R/$f python tools/corr_variants.py 2>&1 | tail -1; done
 python tools/corr_variants.py 2>&1 | tail -1
 echo "# other shapes (in-tree build): B=16 30x30 (LINEMOD crops), B=8 120x160 (960x1280 images)"
 python tools/corr_variants.py 16 30 30 2>&1 | tail -1

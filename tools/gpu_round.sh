@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 mkdir -p $OUT
 cd $R
-rocminfo 2>/dev/null | grep -m3 -E "Marketing Name|Compute Unit|gfx" > $OUT/${TAG}_device.txt
+rocminfo 2>/dev/null | grep -E "^Agent|Marketing Name|Compute Unit|Max Clock Freq|Name: +gfx|Device Type|Wavefront Size" > $OUT/${TAG}_device.txt   # every agent: the EPYC host and the gfx950 GPU
 ( time python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider ) > $OUT/${TAG}_pytest_gpu.log 2>&1
 tail -5 $OUT/${TAG}_pytest_gpu.log
 python __graft_entry__.py smoke > $OUT/${TAG}_smoke.log 2>&1; tail -2 $OUT/${TAG}_smoke.log
@@ -24,13 +24,13 @@ if [ "$2" != "noprof" ]; then
   RNNPOSE_SPLIT_TENSORS=1 python bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/${TAG}_bench_split_tensors.json 2>/dev/null
   timeout 600 python tools/error_budget.py > $OUT/${TAG}_error_budget.log 2>&1; cp $OUT/error_budget.json $OUT/${TAG}_error_budget.json
   timeout 900 python tools/parity_probe.py > $OUT/${TAG}_parity_probe.log 2>&1; cp $OUT/parity_probe.json $OUT/${TAG}_parity_probe.json
-  if ls rnnpose_amd/lib/abl_*.so > /dev/null 2>&1; then     # ablation builds (bash tools/conv_ablate.sh 1 2 4 8 16 32 7 31 in the build container)
-    for lib in librnnpose_hip $(ls rnnpose_amd/lib | grep -E '^abl_[0-9]+\.so$' | sed 's/\.so//' | sort -t_ -k2 -n); do
+  if ls gpurun_extra/abl_*.so > /dev/null 2>&1; then     # ablation builds (bash tools/conv_ablate.sh 1 2 4 8 16 32 7 31 in the build container)
+    for lib in rnnpose_amd/lib/librnnpose_hip $(ls gpurun_extra | grep -E '^abl_[0-9]+\.so$' | sed 's/\.so//' | sort -t_ -k2 -n | sed 's#^#gpurun_extra/#'); do
       echo "== $lib  (RP_ABL bits: 1 no weight loads, 2 no LDS fragment reads, 4 no activation staging, 8 no barrier, 16 no epilogue stores, 32 half the waves request weights)"
-      CONV_LAYERS_FILTER="zr 1x5,q 1x5,heads,convc2,enc l1" CONV_LAYERS_B=4,8,1 RNNPOSE_LIB=$R/rnnpose_amd/lib/$lib.so timeout 200 python tools/conv_layers.py 0 f32,hl1 2>&1 | grep -v amdgpu.ids
+      CONV_LAYERS_FILTER="zr 1x5,q 1x5,heads,convc2,enc l1" CONV_LAYERS_B=4,8,1 RNNPOSE_LIB=$R/$lib.so timeout 200 python tools/conv_layers.py 0 f32,hl1 2>&1 | grep -v amdgpu.ids
     done > $OUT/${TAG}_conv_ablation.txt
   fi
-  if ls rnnpose_amd/lib/cv_*.so > /dev/null 2>&1; then      # diagnostics builds of the volume kernel (bash tools/corr_ablate.sh ...) + the store-pattern probe
+  if ls gpurun_extra/cv_*.so > /dev/null 2>&1; then      # diagnostics builds of the volume kernel (bash tools/corr_ablate.sh ...) + the store-pattern probe
     bash tools/corr_ablate_run.sh $TAG > /dev/null 2>&1
   fi
   python tools/conv_layers.py > $OUT/${TAG}_conv_layers_alone.txt 2>&1
