@@ -26,7 +26,10 @@ extern "C" {
 
 typedef void* rnnpose_stream_t;
 
-#define RNNPOSE_ABI_VERSION 1
+/* 2 (round 4): rnnpose_conv_desc_t grew the split-tensor / K-split members, the packed weight array holds two orders
+ * (rnnpose_conv_packed_halfs doubled), tile statistics are fp64, rnnpose_lm_step_* needs a zero-filled workspace: a consumer
+ * built against version 1 must not pass the check. */
+#define RNNPOSE_ABI_VERSION 2
 #define RNNPOSE_MAX_LEVELS 4
 
 int rnnpose_abi_version(void);
@@ -244,7 +247,12 @@ typedef struct {
                                   encoder sets it: every convolution input there is an instance-normalised map or a ReLU sum of a few
                                   (|(x - mean) * rstd| <= sqrt(H*W); extractor.py:48-58), two orders below the fp16x3 range */
   int tile;                    /* 0 = automatic; 1 = 128x64, 2 = 128x128 as 4 column waves, 3 = 128x128 as 2x2 waves, 4 = 128x64 with
-                                  a block-deep register pipeline (3, 4: split sources only) */
+                                  a block-deep register pipeline (3, 4: split sources only); 5 = the STRIP kernels (160 output
+                                  pixels x 96 / 128 columns per workgroup, weights and split-tensor activations by LDS-DMA:
+                                  stride 1, 3x3 / 1x5 / 5x1, c_out > 64; split-tensor sources need channel counts in multiples
+                                  of 16; a launch with tile_stats / src0_mean_rstd tiles every image into
+                                  rnnpose_conv_tiles_per_image_ex(..., 5) tiles).  The automatic choice takes the strip kernels
+                                  for these layer shapes when the map fills the chip with strips (rnnpose_conv_strip(0): never). */
   void* ksplit_ws;             /* optional (NULL = off): workspace of rnnpose_conv_ksplit_workspace_bytes() bytes, 16-byte aligned,
                                   its first 1024 bytes ZERO before the first launch (the kernel leaves them zero).  With it, a
                                   stride-1 launch of few tiles (B = 1 crops: 8-64 workgroups on 256 CUs) splits its K loop over up
@@ -264,8 +272,13 @@ int rnnpose_conv_ksplit_limits(int max_tiles, int max_splits);   /* measurement:
  * output pixels (ceil(H_out*W_out/128) when tiled per image).  rnnpose_conv_spatial_tiles(0) switches the patch tiling off
  * (measurement: the r02 row-major tiling for 3x3 layers too). */
 int rnnpose_conv_tiles_per_image(int H, int W, int kh, int kw, int stride);
+/* The same for the kernel a launch with this c_out and `tile` request (0 automatic .. 5 strips) will take: the strip kernels
+ * tile an image into ceil(W/16) * ceil(H/10) patches of 10 x 16 pixels (3x3) or ceil(H*W/160) runs of 160 pixels. */
+int rnnpose_conv_tiles_per_image_ex(int H, int W, int kh, int kw, int stride, int c_out, int tile);
 int rnnpose_conv_spatial_tiles(int enable);
-/* number of fp16 elements of the packed weight array (hi and lo parts interleaved); -1 on bad arguments */
+int rnnpose_conv_strip(int mode);          /* measurement switch: 0 = the automatic choice never takes the strip kernels, 1 = default */
+/* number of fp16 elements of the packed weight array (hi and lo parts interleaved, in the fragment order of the 128-row kernels
+ * followed by the record order of the strip kernels); -1 on bad arguments */
 long long rnnpose_conv_packed_halfs(int c_out, int kh, int kw, const int* h_seg_counts, int n_seg);
 int rnnpose_conv_pack_weights_f16x3(const float* w_oihw, int c_out, int c_in, int kh, int kw, const int* h_seg_counts,
                                     int n_seg, float w_scale, void* w_packed, rnnpose_stream_t stream);

@@ -68,7 +68,9 @@ PROTOTYPES = {
     "rnnpose_gru_gate_f32": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p]),
     "rnnpose_gru_update_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _i, _p]),
     "rnnpose_conv_tiles_per_image": (_i, [_i, _i, _i, _i, _i]),
+    "rnnpose_conv_tiles_per_image_ex": (_i, [_i, _i, _i, _i, _i, _i, _i]),
     "rnnpose_conv_spatial_tiles": (_i, [_i]),
+    "rnnpose_conv_strip": (_i, [_i]),
     "rnnpose_conv_ksplit": (_i, [_i]),
     "rnnpose_conv_ksplit_limits": (_i, [_i, _i]),
     "rnnpose_conv_ksplit_workspace_bytes": (_z, []),
@@ -143,7 +145,7 @@ def load() -> C.CDLL:
             raise RuntimeError(f"{LIB_PATH} does not export {name}; rebuild it") from e
         fn.restype = res
         fn.argtypes = args
-    if lib.rnnpose_abi_version() != 1:
+    if lib.rnnpose_abi_version() != 2:
         raise RuntimeError("librnnpose_hip.so ABI version mismatch; rebuild it")
     _lib = lib
     return lib

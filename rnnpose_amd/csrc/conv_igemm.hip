@@ -28,86 +28,19 @@
 //     for the encoder's instance norm, writing straight into a channel slice of the destination NHWC tensor.
 #include "common.hpp"
 #include "f16x3.cuh"
+#include "conv_common.cuh"
 
 #include <cstdlib>
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 32, NT = 256;
+constexpr int BM = 128, BN = 128, NT = 256;
 constexpr int HALO = 4;                 // rows of halo on each side (taps up to +-3 along the fast axis)
 constexpr int AROWS = BM + 2 * HALO;    // 136
 constexpr int PROWS = AROWS + 1;        // rows per LDS plane: + one all-zero row that masked-out fragment lanes read
 constexpr int RS = 40;                  // LDS row stride in halfs: 32 + 8 pad = 80 bytes
-constexpr int MAX_CB = 24;
 
-using rp::h8; using rp::h4; using rp::h2; using rp::f32x2; using rp::f32x16; using rp::u32x2; using rp::split4;
-
-struct Seg {
-  const float* ptr;
-  int cstride, coff, ccount;
-};
-
-struct KParams {
-  Seg seg0, seg1, seg2, seg3;       // separate members: a dynamically indexed by-value array would be copied to LDS
-  int cb1, cb2, cb3;                // first channel block of segments 1..3 (ncb if absent)
-  int ncb;
-  int B, U, V, su, sv;              // slow / fast axis extents and pixel strides
-  int G, T, du0, dv0;               // groups (slow-axis taps) x taps per group (fast axis)
-  int stride, Uin, Vin, gkw, dvg0;  // strided mode (stride 2): no tap sharing, G = kh*kw groups decoded as (g / gkw, g % gkw)
-  const uint4* wpk;                 // packed weights: [g][cb][t][32-col tile][hi kk0, hi kk1, lo kk0, lo kk1][lane] x 16 bytes
-  int Npad;
-  const float* bias;
-  int Cout;
-  float a_scale, out_scale;
-  int epi;
-  float* dst;
-  int dst_cs, dst_co;
-  const float* aux0;
-  int aux0_cs, aux0_co;
-  const float* aux1;
-  int aux1_cs, aux1_co;
-  float* dst2;
-  int dst2_cs, dst2_co;
-  int gru_c;
-  double* tstats;  // optional per-tile column statistics (linear epilogue), fp64: sum, sum of squares
-  const float* addm;   // optional per-pixel bias map (NHWC), added before the epilogue
-  int addm_cs, addm_co;
-  int tpi;             // > 0: M is tiled PER IMAGE (tpi tiles of 128 rows each, the last one ragged): no tile straddles two images
-  const float* in_mr;  // NORM variant: (B, seg0.cstride, 2) mean / rstd of source 0, applied with ReLU while staging
-  int n_mt, n_nt;
-  unsigned long long* sat;   // fp16x3 range guard: counter of clamped / non-finite activation quads (NULL = check off)
-  int sp_tx, sp_ty;          // SPATIAL kernels: 16-pixel-wide / 8-pixel-high patches per image row / column
-  int dst_hl, dst2_hl;       // dst / dst2 receive the PRE-SPLIT fp16 hi|lo form (rnnpose_hip.h, "split tensors") instead of fp32
-  float* dsth;               // optional second destination of the primary result, always in split form (GRU: h' as fp32 AND split)
-  int dsth_cs, dsth_co;
-  int ksplit;                // > 1: gridDim.x = tiles * ksplit, workgroup (tile, s) multiplies channel blocks [nit s / ksplit, nit (s + 1) / ksplit)
-  float* ks_ws;              // ksplit partial accumulators: [tile][split][acc register][thread] floats
-  unsigned* ks_cnt;          // per-tile arrival counters (zero between launches)
-};
-
-// One output quad (4 consecutive channels starting at channel ch of the pixel row `row`) in split form: the 8-channel group
-// g = ch / 8 occupies 32 bytes = [hi x 8 | lo x 8] fp16; a quad is the 8-byte half (ch / 4) & 1 of each plane.  nv < 4 (the
-// ragged tail of a 126-channel layer): only the first nv fp16 of each plane are written -- their neighbours belong to
-// another producer (the flow channels of the motion features).
-__device__ __forceinline__ void store_quad_hl(float* row, int ch, float y0, float y1, float y2, float y3, int nv, float a_scale,
-                                              int& sat_n) {
-  h4 hi, lo;
-  const float4 v = make_float4(y0, nv > 1 ? y1 : 0.f, nv > 2 ? y2 : 0.f, nv > 3 ? y3 : 0.f);
-  split4(v, a_scale, hi, lo);
-  sat_n += rp::quad_saturates(v, a_scale) ? 1 : 0;
-  float* ph = row + (ch & ~7) + ((ch >> 2) & 1) * 2;
-  if (nv == 4) {
-    *reinterpret_cast<h4*>(ph) = hi;
-    *reinterpret_cast<h4*>(ph + 4) = lo;
-  } else {
-    _Float16* hh = reinterpret_cast<_Float16*>(ph);
-    _Float16* ll = reinterpret_cast<_Float16*>(ph + 4);
-    if (nv > 0) { hh[0] = hi.x; ll[0] = lo.x; }
-    if (nv > 1) { hh[1] = hi.y; ll[1] = lo.y; }
-    if (nv > 2) { hh[2] = hi.z; ll[2] = lo.z; }
-  }
-}
-
+using namespace rpconv;
 
 // Every global load of the main loop is UNCONDITIONAL (out-of-range activation rows read element 0 of their tensor and
 // are zeroed when they are split into LDS, weight requests past the end re-read the last tile): with loads under
@@ -120,7 +53,6 @@ __device__ __forceinline__ void store_quad_hl(float* row, int ch, float y0, floa
 //        convert is exact), lo = fp16(x - hi) (x - hi is exact in fp32; 11 more bits) -> 21-22 significant bits.
 // Packed fp32 math (v_pk_mul_f32 / v_pk_add_f32) and v_cvt_pk_f16_f32 halve the rest.  |x*s| > 65504: hi converts to
 // inf and is clamped to +-65504 (lo stays tiny): saturation, never NaN from finite inputs.
-__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
 
 // NI = MFMA column tiles per wave: output tile = 128 x (64*NI).  NI=2 (128x128) for wide layers, NI=1 (128x64) when
 // the 128-wide tiling would leave the 256 CUs short of workgroups (Cout <= 128 at 300 row tiles) or pad Cout.
@@ -847,15 +779,6 @@ __global__ __launch_bounds__(NT, ((NI == 2 || DEEP || (SPATIAL && (COLS4 || !RP_
 }
 
 // ---- weight packing: (Cout, Cin, kh, kw) fp32 -> [g][t][cb][Npad][32] fp16 hi / lo -------------------------
-struct PackParams {
-  int Cout, Cin, kh, kw, G, T, ncb, Npad, vertical;
-  unsigned char cb_seg[MAX_CB];
-  short cb_c0[MAX_CB];
-  short seg_start[4];     // first input channel (in the concatenated Cin order) of each segment
-  short seg_count[4];
-  float w_scale;
-};
-
 __global__ void pack_weights_kernel(const float* __restrict__ w, _Float16* __restrict__ pk, const PackParams q) {
   const long long total = static_cast<long long>(q.G) * q.T * q.ncb * q.Npad * BK * 2;
   const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -903,6 +826,9 @@ int fill_cb_tables(const int* counts, int n, unsigned char* cb_seg, short* cb_c0
 
 }  // namespace
 
+using namespace rpconv;
+
+static int g_conv_strip = 1;            // 0: never the strip kernels (conv_strip.hip); 1: automatic (rnnpose_conv_strip)
 static bool g_conv_spatial = true;      // 3x3 stride-1 convolutions on 8 x 16 image patches (rnnpose_conv_spatial_tiles)
 static bool g_conv_ksplit = true;       // K split of launches with few tiles when the caller provides a workspace (rnnpose_conv_ksplit)
 static int g_ks_max_tiles = 24, g_ks_max_splits = 4;      // (rnnpose_conv_ksplit_limits: measurement)
@@ -913,6 +839,15 @@ extern "C" {
 
 int rnnpose_conv_spatial_tiles(int enable) {     // measurement switch: 0 = the r02 row-major tiling for 3x3 layers too
   g_conv_spatial = enable != 0;
+  return 0;
+}
+
+int rnnpose_conv_strip(int mode) {               // 0 = never the strip kernels, 1 = automatic (default)
+  if (mode < 0 || mode > 1) {
+    rp::set_error("rnnpose_conv_strip: mode 0 or 1");
+    return 1;
+  }
+  g_conv_strip = mode;
   return 0;
 }
 
@@ -941,6 +876,13 @@ int rnnpose_conv_tiles_per_image(int H, int W, int kh, int kw, int stride) {
   return rp::cdiv(static_cast<long long>(Ho) * Wo, BM);
 }
 
+int rnnpose_conv_tiles_per_image_ex(int H, int W, int kh, int kw, int stride, int c_out, int tile) {
+  if (H <= 0 || W <= 0 || (stride != 1 && stride != 2) || c_out <= 0 || tile < 0 || tile > 5) return -1;
+  const bool strip = tile == 5 || (tile == 0 && g_conv_strip && strip_auto(H, W, kh, kw, stride, c_out));
+  if (strip) return stride == 1 ? strip_tiles_per_image(H, W, kh, kw) : -1;
+  return rnnpose_conv_tiles_per_image(H, W, kh, kw, stride);
+}
+
 long long rnnpose_conv_packed_halfs(int c_out, int kh, int kw, const int* h_seg_counts, int n_seg) {
   if (c_out <= 0 || kh <= 0 || kw <= 0 || !h_seg_counts || n_seg < 1 || n_seg > 4) return -1;
   unsigned char cs[MAX_CB];
@@ -948,7 +890,8 @@ long long rnnpose_conv_packed_halfs(int c_out, int kh, int kw, const int* h_seg_
   const int ncb = fill_cb_tables(h_seg_counts, n_seg, cs, c0);
   if (ncb < 0) return -1;
   const long long Npad = static_cast<long long>(rp::cdiv(c_out, BN)) * BN;
-  return static_cast<long long>(kh) * kw * ncb * Npad * BK * 2;       // hi and lo parts interleaved in one array
+  // hi and lo parts interleaved; TWO copies: the 128-row kernels' fragment order, then the strip kernels' record order
+  return 2 * static_cast<long long>(kh) * kw * ncb * Npad * BK * 2;
 }
 
 int rnnpose_conv_pack_weights_f16x3(const float* w_oihw, int c_out, int c_in, int kh, int kw, const int* h_seg_counts,
@@ -977,6 +920,7 @@ int rnnpose_conv_pack_weights_f16x3(const float* w_oihw, int c_out, int c_in, in
   const long long total = static_cast<long long>(q.G) * q.T * q.ncb * q.Npad * BK * 2;
   hipLaunchKernelGGL(pack_weights_kernel, dim3(rp::cdiv(total, 256)), dim3(256), 0, rp::as_stream(stream), w_oihw,
                      static_cast<_Float16*>(w_packed), q);
+  strip_pack(w_oihw, static_cast<_Float16*>(w_packed) + total, q, rp::as_stream(stream));      // (3x3, 1x5, 5x1 only)
   return rp::check_launch(fn);
 }
 
@@ -1081,10 +1025,30 @@ int rnnpose_conv2d_nhwc_f16x3(const rnnpose_conv_desc_t* d, rnnpose_stream_t str
   if (d->dst_split) RP_REQUIRE(d->epilogue != 2 && d->dst_split_c_stride % 8 == 0 && d->dst_split_c_offset % 4 == 0 &&
                                    reinterpret_cast<uintptr_t>(d->dst_split) % 32 == 0, fn,
                                "dst_split: not with the GRU z|r epilogue; channel stride multiple of 8, offset of 4, 32-byte aligned");
-  RP_REQUIRE(d->tile >= 0 && d->tile <= 4, fn, "tile must be 0 (auto), 1 (128x64), 2 (128x128, 4 column waves), 3 (128x128, 2x2 waves) or 4 (128x64, deep pipeline)");
+  RP_REQUIRE(d->tile >= 0 && d->tile <= 5, fn, "tile must be 0 (auto), 1 (128x64), 2 (128x128, 4 column waves), 3 (128x128, 2x2 waves), 4 (128x64, deep pipeline) or 5 (160-row strips)");
   if (d->tile_stats) RP_REQUIRE(d->epilogue == 0, fn, "tile_stats needs the linear epilogue");
   const long long Mtot = static_cast<long long>(d->B) * Ho * Wo;
   RP_REQUIRE(Mtot < (1LL << 31) - 256 && static_cast<long long>(d->B) * d->H * d->W < (1LL << 31) - 256, fn, "too many pixels");
+  {
+    // the packed array holds both orders (rnnpose_conv_packed_halfs): the strip kernels' copy sits behind the first one
+    const long long first = static_cast<long long>(d->kh) * d->kw * p.ncb * p.Npad * BK * 2;
+    p.wpk_strip = reinterpret_cast<const uint4*>(static_cast<const _Float16*>(d->w_packed) + first);
+  }
+  // ---- strip kernels (conv_strip.hip): 160-row strips, operands by LDS-DMA.  tile 5 asks for them; the automatic choice takes
+  // them for the stride-1 3x3 / 1x5 / 5x1 layers of maps that fill the chip with strips (shape only: a launch with tile
+  // statistics must tile like rnnpose_conv_tiles_per_image_ex said it would)
+  if (d->tile == 5 || (d->tile == 0 && g_conv_strip && strip_auto(d->H, d->W, d->kh, d->kw, d->stride, d->c_out))) {
+    bool ok = true;
+    if (hlin)
+      for (int s = 0; s < d->n_src; ++s) ok = ok && d->src[s].c_count % 16 == 0;
+    if (d->src0_mean_rstd && !(d->kh == 3 && d->kw == 3)) ok = false;
+    const bool per_image = d->tile_stats || d->src0_mean_rstd;
+    if (ok || d->tile == 5 || per_image) {           // (forced, or the caller sized its statistics for strips: errors surface)
+      if (vertical) { p.G = 1; p.T = d->kh; p.du0 = 0; p.dv0 = -(d->kh / 2); }
+      else { p.G = d->kh; p.T = d->kw; p.du0 = -(d->kh / 2); p.dv0 = -(d->kw / 2); }
+      return strip_launch(p, d->H, d->W, d->kh, d->kw, hlin, per_image, rp::as_stream(stream));
+    }
+  }
   p.n_mt = rp::cdiv(Mtot, BM);
   p.tpi = 0;
   if (d->tile_stats || d->src0_mean_rstd) {      // statistics / fused normalisation are per image: tile M per image

@@ -516,7 +516,8 @@ def conv2d_nhwc(pc: PackedConv, srcs, dst, epilogue: int = EPI_LINEAR, aux0=None
     Writes in place into dst (and dst2); returns nothing.
     src_hl / dst_hl / dst2_hl: the sources / dst / dst2 are SPLIT tensors (fp16 hi|lo per 8-channel group in a buffer of the
     fp32 tensor's shape: include/rnnpose_hip.h; split_hl / unsplit_hl convert); dst_split = (tensor, c_offset): an additional
-    split-form copy of the primary result; tile: 0 auto, 1..3 tile-shape override (measurement)."""
+    split-form copy of the primary result; tile: 0 auto, 1..4 tile shapes of the 128-row kernels, 5 the strip kernels
+    (160-row strips, operands by LDS-DMA: include/rnnpose_hip.h)."""
     _apply_conv_env()
     d = _lib.ConvDesc()
     if len(srcs) != len(pc.seg_counts):
@@ -552,7 +553,7 @@ def conv2d_nhwc(pc: PackedConv, srcs, dst, epilogue: int = EPI_LINEAR, aux0=None
     d.gru_c = gru_c
     if tile_stats is not None:
         # (B * ceil(HWout/128), c_out, 2) fp32: per-tile column sums / sums of squares for instnorm_tiles_nhwc
-        tpi = conv_tiles_per_image(H, W, pc.kh, pc.kw, stride)
+        tpi = conv_tiles_per_image(H, W, pc.kh, pc.kw, stride, pc.c_out, tile)
         if not (tile_stats.is_cuda and tile_stats.dtype == F64 and tile_stats.is_contiguous()
                 and tile_stats.numel() >= B * tpi * pc.c_out * 2):
             raise ValueError("tile_stats must be a contiguous FP64 CUDA tensor of (B * conv_tiles_per_image(...), c_out, 2)")
@@ -573,10 +574,14 @@ def conv2d_nhwc(pc: PackedConv, srcs, dst, epilogue: int = EPI_LINEAR, aux0=None
             work=2.0 * B * (-(-H // stride)) * (-(-W // stride)) * pc.c_out * pc.c_in_real * pc.kh * pc.kw)
 
 
-def conv_tiles_per_image(H, W, kh, kw, stride=1) -> int:
-    """Records per image of a convolution's tile_stats (3x3 stride 1: 8 x 16 patches; else runs of 128 output pixels)."""
+def conv_tiles_per_image(H, W, kh, kw, stride=1, c_out=None, tile: int = 0) -> int:
+    """Records per image of a convolution's tile_stats.  128-row kernels: 3x3 stride 1 on 8 x 16 patches, else runs of 128
+    output pixels; with c_out given: for the kernel a launch of that width and `tile` request takes -- the strip kernels
+    (csrc/conv_strip.hip, tile=5 or the automatic choice) tile an image into 10 x 16 patches / runs of 160 pixels."""
     _apply_conv_env()
-    return int(_lib.load().rnnpose_conv_tiles_per_image(int(H), int(W), int(kh), int(kw), int(stride)))
+    if c_out is None:
+        return int(_lib.load().rnnpose_conv_tiles_per_image(int(H), int(W), int(kh), int(kw), int(stride)))
+    return int(_lib.load().rnnpose_conv_tiles_per_image_ex(int(H), int(W), int(kh), int(kw), int(stride), int(c_out), int(tile)))
 
 
 _conv_env_applied = False
@@ -593,6 +598,9 @@ def _apply_conv_env():
         v = _os.environ.get("RNNPOSE_KSPLIT")
         if v is not None:
             _lib.call("rnnpose_conv_ksplit", int(v != "0"))
+        v = _os.environ.get("RNNPOSE_STRIP")               # 0: the automatic tile choice never takes the strip kernels (same-box A/B)
+        if v is not None:
+            _lib.call("rnnpose_conv_strip", int(v != "0"))
         v = _os.environ.get("RNNPOSE_KSPLIT_LIMITS")          # "max_tiles,max_splits" (measurement)
         if v:
             a, b = (int(t) for t in v.split(","))
@@ -601,6 +609,12 @@ def _apply_conv_env():
 
 def conv_spatial_tiles(enable: bool = True):
     _lib.call("rnnpose_conv_spatial_tiles", int(bool(enable)))
+
+
+def conv_strip(enable: bool = True):
+    """Measurement switch: False = the automatic tile choice never takes the strip kernels (RNNPOSE_STRIP=0)."""
+    _apply_conv_env()
+    _lib.call("rnnpose_conv_strip", int(bool(enable)))
 
 
 def conv_ksplit(enable: bool = True):

@@ -30,7 +30,7 @@ def test_header_symbols_exported_and_typed(lib):
         assert hasattr(lib, n), f"{n} declared in the header but not exported"
         assert n in _lib.PROTOTYPES, f"{n} has no ctypes prototype"
     assert sorted(_lib.PROTOTYPES) == names
-    assert lib.rnnpose_abi_version() == 1
+    assert lib.rnnpose_abi_version() == 2
 
 
 def test_gfx950_code_object_present():
@@ -133,4 +133,4 @@ def test_header_is_plain_c99_and_links_against_the_library(tmp_path):
     assert out.returncode == 0, out.stderr
     ver, total = out.stdout.split()
     n = 2 * 16 * 24
-    assert int(ver) == 1 and int(total) == n * (16 * 24 + 8 * 12 + 4 * 6 + 2 * 3)
+    assert int(ver) == 2 and int(total) == n * (16 * 24 + 8 * 12 + 4 * 6 + 2 * 3)

@@ -621,3 +621,146 @@ def test_conv_k_split_with_statistics_norm_and_gru_epilogues(ops):
     assert float((nchw(hnew).double() - h64).abs().max()) < 3e-6
     torch.cuda.synchronize()
     assert int(ws[:256].abs().max()) == 0
+
+
+# ---- the strip kernels (csrc/conv_strip.hip: tile=5, or the automatic choice on maps that fill the chip with strips) ----
+STRIP_SHAPES = [
+    (2, 12, 20, [192, 64], 126, 3, 3),     # two sources, ragged output tail, ragged 10 x 16 patches
+    (1, 16, 16, [128, 128], 256, 1, 5),    # two column tiles of 128
+    (3, 7, 11, [128, 128], 128, 5, 1),     # vertical taps, strips straddle image lines and images (231 rows)
+    (1, 20, 32, [128], 512, 3, 3),         # exact patches, four column tiles
+    (2, 9, 13, [256], 192, 3, 3),          # three-wave workgroups (96 columns)
+    (1, 23, 37, [96], 96, 3, 3),           # three channel blocks, three waves, ragged patches
+    (2, 13, 29, [64, 32], 320, 1, 5),      # a 64-channel and a 32-channel source, Cout = 2.5 column tiles
+]
+
+
+@pytest.mark.parametrize("hl", [False, True])
+@pytest.mark.parametrize("B,H,W,segs,cout,kh,kw", STRIP_SHAPES)
+def test_conv_strip_vs_fp64(ops, hl, B, H, W, segs, cout, kh, kw):
+    """160-row strips with both operand paths (split-tensor sources by LDS-DMA, fp32 sources through registers) against fp64 and
+    against the 128-row kernel on the same operands; fp32 and split-form destinations; bytes around the slice untouched."""
+    cin = sum(segs)
+    x = syn.normal("sx", (B, cin, H, W), 21, std=1.5)
+    w = syn.normal("sw", (cout, cin, kh, kw), 21, std=float(np.sqrt(2.0 / (cin * kh * kw))))
+    b = syn.uniform("sb", (cout,), 21, -0.5, 0.5)
+    xd, wd, bd = D(x), D(w), D(b)
+    y64 = F.conv2d(xd.double(), wd.double(), bd.double(), padding=(kh // 2, kw // 2))
+    y32 = F.conv2d(xd, wd, bd, padding=(kh // 2, kw // 2))
+    pc = ops.PackedConv(wd, bd, segs)
+    xs, off = [], 0
+    for c in segs:                       # sources inside wider tensors at a channel offset of 8
+        t = torch.zeros(B, H, W, c + 16, device="cuda")
+        t[..., 8:8 + c] = nhwc(xd[:, off:off + c])
+        xs.append((ops.split_hl(t) if hl else t, 8))
+        off += c
+    cs = (cout + 23) // 8 * 8
+    out = torch.full((B, H, W, cs), 7.0, device="cuda")
+    ops.conv2d_nhwc(pc, xs, (out, 8), ops.EPI_RELU, src_hl=hl, tile=5)
+    check(nchw(out[..., 8:8 + cout]), y64.clamp(min=0), y32.clamp(min=0), f"strip {kh}x{kw} hl={hl}")
+    assert float((out[..., :8] - 7).abs().max()) == 0 and float((out[..., 8 + cout:] - 7).abs().max()) == 0
+    ref = torch.full((B, H, W, cs), 7.0, device="cuda")
+    ops.conv2d_nhwc(pc, xs, (ref, 8), ops.EPI_RELU, src_hl=hl, tile=1)           # same fp16 operands, other summation order
+    assert float((out - ref).abs().max()) <= 2e-6 * float(y64.abs().max())
+    again = torch.full((B, H, W, cs), 7.0, device="cuda")
+    ops.conv2d_nhwc(pc, xs, (again, 8), ops.EPI_RELU, src_hl=hl, tile=5)
+    assert torch.equal(out, again)                                               # deterministic
+    outs = torch.zeros(B, H, W, cs, device="cuda")
+    extra = torch.zeros(B, H, W, cs, device="cuda")
+    ops.conv2d_nhwc(pc, xs, (outs, 8), ops.EPI_RELU, src_hl=hl, dst_hl=True, tile=5)
+    ops.conv2d_nhwc(pc, xs, (again, 8), ops.EPI_LINEAR, src_hl=hl, dst_split=(extra, 8), tile=5)
+    check(nchw(again[..., 8:8 + cout]), y64, y32, f"strip {kh}x{kw} linear")
+    full = out[..., 8:8 + cout]
+    assert float(((ops.unsplit_hl(outs)[..., 8:8 + cout] - full).abs() / full.abs().clamp(min=1e-2)).max()) < 2.0 ** -20
+    lin = again[..., 8:8 + cout]
+    assert float(((ops.unsplit_hl(extra)[..., 8:8 + cout] - lin).abs() / lin.abs().clamp(min=1e-2)).max()) < 2.0 ** -20
+
+
+@pytest.mark.parametrize("hl", [False, True])
+@pytest.mark.parametrize("kh,kw", [(1, 5), (5, 1)])
+def test_conv_strip_gru_epilogues(ops, kh, kw, hl):
+    """GRU gate / state-update epilogues + additive map in the strip kernels (update.py:47-58, hoisted context share)."""
+    B, H, W, C = 2, 11, 19, 128
+    h = np.tanh(syn.normal("h", (B, C, H, W), 2))
+    x = syn.normal("x", (B, C, H, W), 2)
+    am = syn.normal("am", (B, 3 * C, H, W), 2, std=0.3)
+    wz, wr, wq = (syn.normal(n, (C, 2 * C, kh, kw), 2, std=0.03) for n in ("wz", "wr", "wq"))
+    bz, br, bq = (syn.uniform(n, (C,), 2, -0.2, 0.2) for n in ("bz", "br", "bq"))
+    hd, xd, amd = D(h), D(x), D(am)
+    pad = (kh // 2, kw // 2)
+    hx = torch.cat([hd, xd], 1).double()
+    z64 = torch.sigmoid(F.conv2d(hx, D(wz).double(), D(bz).double(), padding=pad) + amd[:, :C].double())
+    r64 = torch.sigmoid(F.conv2d(hx, D(wr).double(), D(br).double(), padding=pad) + amd[:, C:2 * C].double())
+    q64 = torch.tanh(F.conv2d(torch.cat([r64 * hd.double(), xd.double()], 1), D(wq).double(), D(bq).double(), padding=pad) + amd[:, 2 * C:].double())
+    h64 = (1 - z64) * hd.double() + z64 * q64
+    pzr = ops.PackedConv(torch.cat([D(wz), D(wr)], 0), torch.cat([D(bz), D(br)], 0), [C, C])
+    pq = ops.PackedConv(D(wq), D(bq), [C, C])
+    hN, xN, aN = nhwc(hd), nhwc(xd), nhwc(amd)
+    hS, xS = (ops.split_hl(hN), ops.split_hl(xN)) if hl else (hN, xN)
+    z = torch.empty(B, H, W, C, device="cuda")
+    rh = torch.empty(B, H, W, C, device="cuda")
+    hnew = torch.empty(B, H, W, C, device="cuda")
+    hnew_s = torch.empty(B, H, W, C, device="cuda")
+    ops.conv2d_nhwc(pzr, [(hS, 0), (xS, 0)], (z, 0), ops.EPI_GRU_ZR, aux0=(hN, 0), dst2=(rh, 0), dst2_hl=hl, gru_c=C, src_hl=hl,
+                    add_map=(aN, 0), tile=5)
+    assert float((nchw(z).double() - z64).abs().max()) < 2e-6
+    rhd = ops.unsplit_hl(rh) if hl else rh
+    assert float((nchw(rhd).double() - r64 * hd.double()).abs().max()) < 2e-6
+    ops.conv2d_nhwc(pq, [(rh, 0), (xS, 0)], (hnew, 0), ops.EPI_GRU_Q, aux0=(hN, 0), aux1=(z, 0), src_hl=hl, dst_split=(hnew_s, 0),
+                    add_map=(aN, 2 * C), tile=5)
+    assert float((nchw(hnew).double() - h64).abs().max()) < 3e-6
+    assert float((ops.unsplit_hl(hnew_s) - hnew).abs().max()) < 2.0 ** -20
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout", [(3, 15, 20, 96, 96), (2, 60, 80, 96, 128), (2, 20, 32, 128, 128)])
+def test_conv_strip_tile_stats_and_fused_input_norm(ops, B, H, W, cin, cout):
+    """The encoder's pair (extractor.py:48-58) on strips: conv1 with fp64 tile statistics per 10 x 16 patch, conv2 reading
+    relu(norm1(conv1 x)) in its load == the materialised sequence, bit for bit."""
+    x = syn.normal("pn.x", (B, cin, H, W), 4, std=2.0) + 0.7
+    w1 = syn.normal("pn.w1", (cin, cin, 3, 3), 4, std=float(np.sqrt(2.0 / (cin * 9))))
+    w2 = syn.normal("pn.w2", (cout, cin, 3, 3), 5, std=float(np.sqrt(2.0 / (cin * 9))))
+    b1, b2 = syn.uniform("pn.b1", (cin,), 4, -0.5, 0.5), syn.uniform("pn.b2", (cout,), 5, -0.5, 0.5)
+    p1, p2 = ops.PackedConv(D(w1), D(b1), [cin]), ops.PackedConv(D(w2), D(b2), [cin])
+    tpi = ops.conv_tiles_per_image(H, W, 3, 3, 1, cin, 5)
+    assert tpi == -(-H // 10) * -(-W // 16)
+    c1 = torch.empty(B, H, W, cin, device="cuda")
+    ts = torch.full((B * tpi, cin, 2), -1.0, device="cuda", dtype=torch.float64)
+    ops.conv2d_nhwc(p1, [(nhwc(D(x)), 0)], (c1, 0), ops.EPI_LINEAR, tile_stats=ts, tile=5)
+    y64 = F.conv2d(D(x).double(), D(w1).double(), D(b1).double(), padding=1)
+    n64 = F.relu(F.instance_norm(y64, eps=1e-5))
+    t = ts.view(B, tpi, cin, 2).double().sum(1)
+    assert float((t[..., 0] - y64.sum((2, 3))).abs().max()) <= 2e-5 * float(y64.abs().sum((2, 3)).max())
+    assert float((t[..., 1] - (y64 * y64).sum((2, 3))).abs().max()) <= 2e-5 * float((y64 * y64).sum((2, 3)).max())
+    got = ops.instnorm_tiles_nhwc(c1, ts, relu=True)
+    assert float((nchw(got).double() - n64).abs().max()) < 2e-5
+    mr = ops.instnorm_tiles_nhwc(c1, ts, stats_only=True)
+    fused = torch.empty(B, H, W, cout, device="cuda")
+    ops.conv2d_nhwc(p2, [(c1, 0)], (fused, 0), ops.EPI_LINEAR, in_norm=mr, tile=5)
+    plain = torch.empty(B, H, W, cout, device="cuda")
+    ops.conv2d_nhwc(p2, [(got, 0)], (plain, 0), ops.EPI_LINEAR, tile=5)
+    assert torch.equal(fused, plain)
+    z64 = F.conv2d(n64, D(w2).double(), D(b2).double(), padding=1)
+    z32 = F.conv2d(n64.float(), D(w2), D(b2), padding=1)
+    check(nchw(fused), z64, z32, "strip: fused norm + conv")
+
+
+def test_conv_strip_is_the_automatic_choice_at_the_update_block_shape(ops):
+    """60 x 80 maps (the headline's 1/8 resolution): the automatic tile choice takes strips (30 patches per image instead of 40),
+    RNNPOSE_STRIP=0 / ops.conv_strip(False) restores the 128-row kernels; same result to summation order."""
+    assert ops.conv_tiles_per_image(60, 80, 3, 3, 1, 192) == 30 and ops.conv_tiles_per_image(60, 80, 3, 3, 1, 192, 1) == 40
+    assert ops.conv_tiles_per_image(30, 30, 3, 3, 1, 192) == 8            # LINEMOD crops: too ragged / too few strips
+    B, H, W = 2, 60, 80
+    x = D(syn.normal("ax", (B, H, W, 256), 31, std=1.2))
+    w = D(syn.normal("aw", (192, 256, 3, 3), 31, std=0.02))
+    pc = ops.PackedConv(w, D(syn.uniform("ab", (192,), 31, -0.5, 0.5)), [256])
+    a, b = torch.empty(B, H, W, 192, device="cuda"), torch.empty(B, H, W, 192, device="cuda")
+    ops.conv2d_nhwc(pc, [(x, 0)], (a, 0), ops.EPI_RELU)
+    ops.conv2d_nhwc(pc, [(x, 0)], (b, 0), ops.EPI_RELU, tile=5)
+    assert torch.equal(a, b)
+    try:
+        ops.conv_strip(False)
+        assert ops.conv_tiles_per_image(60, 80, 3, 3, 1, 192) == 40
+        ops.conv2d_nhwc(pc, [(x, 0)], (a, 0), ops.EPI_RELU)
+    finally:
+        ops.conv_strip(True)
+    assert not torch.equal(a, b) and float((a - b).abs().max()) < 2e-6 * float(b.abs().max())
