@@ -249,8 +249,7 @@ typedef struct {
   int tile;                    /* 0 = automatic; 1 = 128x64, 2 = 128x128 as 4 column waves, 3 = 128x128 as 2x2 waves, 4 = 128x64 with
                                   a block-deep register pipeline (3, 4: split sources only); 5 = the STRIP kernels (160 output
                                   pixels x 96 / 128 columns per workgroup, weights and split-tensor activations by LDS-DMA:
-                                  stride 1, 3x3 / 1x5 / 5x1, c_out > 64; split-tensor sources need channel counts in multiples
-                                  of 16; a launch with tile_stats / src0_mean_rstd tiles every image into
+                                  stride 1, 3x3 / 1x5 / 5x1, c_out > 64, source channel counts in multiples of 32; a launch with tile_stats / src0_mean_rstd tiles every image into
                                   rnnpose_conv_tiles_per_image_ex(..., 5) tiles).  The automatic choice takes the strip kernels
                                   for these layer shapes when the map fills the chip with strips (rnnpose_conv_strip(0): never). */
   void* ksplit_ws;             /* optional (NULL = off): workspace of rnnpose_conv_ksplit_workspace_bytes() bytes, 16-byte aligned,
@@ -276,7 +275,8 @@ int rnnpose_conv_tiles_per_image(int H, int W, int kh, int kw, int stride);
  * tile an image into ceil(W/16) * ceil(H/10) patches of 10 x 16 pixels (3x3) or ceil(H*W/160) runs of 160 pixels. */
 int rnnpose_conv_tiles_per_image_ex(int H, int W, int kh, int kw, int stride, int c_out, int tile);
 int rnnpose_conv_spatial_tiles(int enable);
-int rnnpose_conv_strip(int mode);          /* measurement switch: 0 = the automatic choice never takes the strip kernels, 1 = default */
+int rnnpose_conv_strip(int mode);          /* measurement switch: 0 = the automatic choice never takes the strip kernels, 1 = default,
+                                              2 / 3 = strips with one / two 32-column tiles per wave only */
 /* number of fp16 elements of the packed weight array (hi and lo parts interleaved, in the fragment order of the 128-row kernels
  * followed by the record order of the strip kernels); -1 on bad arguments */
 long long rnnpose_conv_packed_halfs(int c_out, int kh, int kw, const int* h_seg_counts, int n_seg);

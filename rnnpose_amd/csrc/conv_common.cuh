@@ -92,7 +92,8 @@ struct PackParams {
 };
 
 // conv_strip.hip: the strip kernels (160-row strips, operands by LDS-DMA)
-int strip_waves(int c_out);                                    // waves per workgroup (3 or 4: 32 columns each), 0 = unsupported width
+int strip_waves(int c_out);                                    // workgroup shape: 16 * (32-column tiles per wave) + waves; 0 = unsupported width
+void strip_force_ni(int ni);                                   // measurement: 0 automatic, 1 / 2 column tiles per wave
 bool strip_auto(int H, int W, int kh, int kw, int stride, int c_out);      // does the automatic choice take the strip kernel? (shape only)
 int strip_tiles_per_image(int H, int W, int kh, int kw);      // output tiles per image when tiled per image (tile_stats records)
 // launches the strip kernel for the already filled parameter block (U, V, su, sv, T, dv0, segments, epilogue ...); sets the tiling

@@ -842,12 +842,13 @@ int rnnpose_conv_spatial_tiles(int enable) {     // measurement switch: 0 = the 
   return 0;
 }
 
-int rnnpose_conv_strip(int mode) {               // 0 = never the strip kernels, 1 = automatic (default)
-  if (mode < 0 || mode > 1) {
-    rp::set_error("rnnpose_conv_strip: mode 0 or 1");
+int rnnpose_conv_strip(int mode) {               // 0 = never the strip kernels, 1 = automatic (default); 2 / 3 = automatic with one / two
+  if (mode < 0 || mode > 3) {                    // 32-column tiles per wave forced (measurement)
+    rp::set_error("rnnpose_conv_strip: mode 0..3");
     return 1;
   }
-  g_conv_strip = mode;
+  g_conv_strip = mode != 0;
+  strip_force_ni(mode == 3 ? 2 : 1);
   return 0;
 }
 
@@ -1039,8 +1040,7 @@ int rnnpose_conv2d_nhwc_f16x3(const rnnpose_conv_desc_t* d, rnnpose_stream_t str
   // statistics must tile like rnnpose_conv_tiles_per_image_ex said it would)
   if (d->tile == 5 || (d->tile == 0 && g_conv_strip && strip_auto(d->H, d->W, d->kh, d->kw, d->stride, d->c_out))) {
     bool ok = true;
-    if (hlin)
-      for (int s = 0; s < d->n_src; ++s) ok = ok && d->src[s].c_count % 16 == 0;
+    for (int s = 0; s < d->n_src; ++s) ok = ok && d->src[s].c_count % 32 == 0;
     if (d->src0_mean_rstd && !(d->kh == 3 && d->kw == 3)) ok = false;
     const bool per_image = d->tile_stats || d->src0_mean_rstd;
     if (ok || d->tile == 5 || per_image) {           // (forced, or the caller sized its statistics for strips: errors surface)

@@ -8,21 +8,29 @@
 //   * One workgroup = a STRIP of 160 output pixels x 32*NW output channels, NW = 3 or 4 waves; a wave owns ALL 160 rows of its
 //     32 columns (five 32x32 accumulator tiles).  160 rows because the launches of this workload then come out even: 60x80
 //     feature maps are 30 strips per image (3x3 layers: 10 x 16 pixel patches), 240 strips x column tiles per batch of 8 on
-//     256 CUs, two workgroups per CU (<= 62 KB of LDS, <= 256 registers).
+//     256 CUs, two workgroups per CU (64 / 76 KB of LDS, <= 256 registers).
 //   * Every operand arrives by LDS-DMA (global_load_lds_dwordx4, 1 KB per wave instruction, no registers, no vector ALU):
 //       - weights: WAVE-PRIVATE.  A wave only ever multiplies its own 32 columns, so its weight fragments go through its own
-//         4-slot ring of 2-KB records (one record = 16 channels x 32 columns x (hi, lo) of one tap), three steps ahead, waited for
-//         with a counted s_waitcnt vmcnt -- no workgroup barrier is involved in the weight stream at all;
+//         ring of 2-KB records (one record = 16 channels x 32 columns x (hi, lo) of one tap; 5 / 6 slots), requested four / five
+//         steps ahead from a scalar base address and waited for with a counted s_waitcnt vmcnt -- no workgroup barrier is
+//         involved in the weight stream at all;
 //       - activations: from SPLIT TENSORS (rnnpose_hip.h: fp16 hi|lo per 8-channel group, written by the producer's epilogue),
 //         one HALF block (16 channels = one MFMA K) of the strip with its halo at a time, two slots; the next half block is
 //         requested a whole half block (5 or 9 taps) ahead.  ONE barrier per half block, placed in front of its last tap.
-//       LDS rows are 64 bytes ([group 0 hi | group 0 lo | group 1 hi | group 1 lo] x 8 fp16); the 16-byte chunk position is
-//       XOR-swizzled with (row >> 2) & 3 -- on the SOURCE address of the DMA (the LDS image of a DMA is lane-linear), in the
-//       packed weight order, and on every fragment read: ds_read_b128 of 16 different rows hits 16 different bank groups.
 //     fp32 sources (and the encoder's fused instance norm + ReLU, which needs the vector ALU anyway) take the same kernel with the
 //     activation half block staged through registers instead (MODE 1 / 2).
-//   * A step = one tap of one half block: 15 MFMAs per wave (5 row tiles x 3 products), 12 ds_read_b128, 2 DMA requests.  The
-//     fragments of step s+1 are read while the MFMAs of step s run (two register sets).
+//   * LDS image of a half block / a weight record: a hi plane and a lo plane of 32-byte rows (2 groups x 8 fp16 of one pixel /
+//     column), so that the lo fragment sits at a CONSTANT offset from the hi one; the 16-byte group position is XOR-swizzled --
+//     with bit 3 of the row (linear strips, weight records) or the parity of the halo-tile line (3x3 patches) -- on the SOURCE
+//     address of the DMA (the LDS image of a DMA is lane-linear), in the packed weight order, and in the fragment addresses:
+//     a ds_read_b128 lane group (16 lanes) touches 16 different bank slots.  With the line-parity swizzle a 3x3 tap is the
+//     centre address plus a compile-time offset, so that EVERY fragment read of the main loop is `one address register +
+//     immediate`: 25 (1x5 / 5x1: tap masks folded in) or 10 (3x3) address registers per lane, no vector ALU work per step.
+//   * A step = one tap of one half block: 15 MFMAs per wave (5 row tiles x 3 products) interleaved one to one with the 12
+//     ds_read_b128 of the NEXT step's fragments (two register sets), one counted wait, one DMA statement.  Taps and pairs of half
+//     blocks are unrolled: ring slots, fragment sets and every wait count are compile-time constants (round 4, first version: a
+//     rolled step with ~200 scalar / vector bookkeeping instructions in front of each 15-MFMA group ran 1.1-1.9x SLOWER than the
+//     128-row kernels -- a lone wave issues one instruction per ~4 cycles, the bookkeeping was 2x the MFMA time).
 //   * Epilogue: the parameter block's fused forms (bias, ReLU, GRU gates, additive map, split outputs, fp64 tile statistics),
 //     through a wave-private LDS tile (the wave's own weight ring) with 16-byte row-contiguous stores.
 #include "common.hpp"
@@ -34,18 +42,17 @@ namespace {
 using namespace rpconv;
 
 constexpr int SM = 160, SMI = 5;        // strip rows, 32-row MFMA tiles per wave
-constexpr int SHALO = 4;                // linear strips: halo rows on each side (taps up to +-2 along the fast axis; 4 keeps 16-row pieces)
+constexpr int SHALO = 4;                // linear strips: halo rows on each side (taps up to +-2 along the fast axis)
 constexpr int SPH = 10, SPW = 16;       // 3x3: patch of 10 x 16 pixels ...
 constexpr int SHW = SPW + 2, SHR = (SPH + 2) * SHW;       // ... staged with a one-pixel halo: 12 x 18 = 216 rows
-constexpr int NBST = 4;                 // weight ring slots per wave (2 KB each)
 
 __device__ __attribute__((aligned(64))) const unsigned char g_zero_page[64] = {0};
 
-// One LDS-DMA request: 64 lanes x 16 bytes from per-lane global addresses to LDS bytes [dst, dst + 1024) (wave-uniform dst).
-// Inline asm on purpose: hipcc (ROCm 7.2) models the builtin as a FLAT access to both global memory and LDS, and while one is
-// outstanding every wait it inserts becomes lgkmcnt(0) / vmcnt(0) -- the fragment prefetch of the next step would be waited for
-// in front of every MFMA group.  The compiler neither counts nor waits for these requests: every wait is an explicit counted
-// s_waitcnt vmcnt below.  M0 (the DMA's LDS base) is saved and restored inside the statement.
+// LDS-DMA requests.  Inline asm on purpose: hipcc (ROCm 7.2) models the builtin as a FLAT access to both global memory and LDS,
+// and while one is outstanding every wait it inserts becomes lgkmcnt(0) / vmcnt(0) -- the fragment prefetch of the next step
+// would be waited for in front of every MFMA.  The compiler neither counts nor waits for these requests: every wait is an
+// explicit counted s_waitcnt vmcnt below.  M0 (the DMA's LDS base) is saved and restored inside the statement.
+// One piece: 64 lanes x 16 bytes from per-lane global addresses to LDS bytes [dst, dst + 1024) (wave-uniform dst).
 __device__ __forceinline__ void glds16(const void* g, unsigned dst) {
   unsigned keep;
   asm volatile(
@@ -58,6 +65,38 @@ __device__ __forceinline__ void glds16(const void* g, unsigned dst) {
       : "v"(g), "s"(dst)
       : "memory");
 }
+// One weight record of NI x 2 KB: lanes read base + voff (+ 1024 k) into [dst, dst + 2048 NI).  The instruction offset applies to
+// the global address AND to the LDS address; scalar base: no per-lane address arithmetic (s_nop 4: the base may come from a
+// v_readfirstlane)
+template <int NI>
+__device__ __forceinline__ void glds_rec(const void* base, unsigned voff, unsigned dst) {
+  unsigned keep;
+  if constexpr (NI == 1) {
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 4\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(base), "s"(dst)
+        : "memory");
+  } else {
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 4\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+        "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+        "global_load_lds_dwordx4 %1, %2 offset:3072\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(base), "s"(dst)
+        : "memory");
+  }
+}
 template <int N>
 __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -69,27 +108,45 @@ __device__ __forceinline__ void wg_barrier() {
   asm volatile("" ::: "memory");
 }
 
+#ifndef RS_VAR
+#define RS_VAR 0          // schedule variants (measurement): 1 s_setprio(1) around a step's MFMAs, 2 fragment reads in front of the
+#endif                    // MFMAs instead of between them, 4 the first read behind the third MFMA
+#ifndef RS_ABL
+#define RS_ABL 0          // diagnostics builds (tools/strip_ablate.sh; results WRONG): 1 no weight requests in the loop, 2 no activation
+#endif                    // requests, 4 no fragment reads, 8 no MFMAs, 32 no barrier, 64 no vmcnt waits, 128 no activation fragment
+                          // reads, 256 no weight fragment reads
+// TT = taps per half block: 5 (1x5, 5x1: linear strips) or 9 (3x3: 10 x 16 patches with a halo).
 // MODE 0: split-tensor sources by LDS-DMA; 1: fp32 sources through registers; 2: fp32 source + fused instance norm / ReLU (p.in_mr)
-template <int NW, bool SPATIAL, int MODE>
-__global__ __launch_bounds__(NW * 64, 2) void conv_strip_f16x3_kernel(const KParams p) {
+// NI = 32-column tiles per wave: 1 (wave tile 160 x 32, two workgroups per CU = two waves per SIMD, <= 256 registers) or
+// 2 (160 x 64, ONE wave per SIMD with up to 512 registers).  Round 4 ablation of the NI = 1 form (profiles/r04_strip_ablation.txt):
+// without MFMAs its LDS / DMA stream alone takes 36 of 78 us -- every wave reads the WHOLE activation tile from LDS for its 32
+// columns, 12 ds_read_b128 per 15 MFMAs, and the LDS pipe is a co-bottleneck of the matrix pipe.  With two column tiles per wave
+// an activation fragment feeds twice the MFMAs: 14 reads per 30.
+template <int NW, int TT, int MODE, int NI>
+__global__ __launch_bounds__(NW * 64, NI == 2 ? 1 : 2) void conv_strip_f16x3_kernel(const KParams p) {
+  constexpr bool SPATIAL = TT == 9;
+  constexpr int BREC = 2048 * NI;                          // weight record of one wave and step
+  constexpr int NBST = SPATIAL ? 6 : 5;                    // weight ring slots per wave: 2 TT is a multiple (slots are compile-time)
+  static_assert((2 * TT) % NBST == 0 && NBST - 2 < TT - 1, "ring period");
   constexpr int NT_ = NW * 64;
   constexpr int ARV = SPATIAL ? SHR : SM + 2 * SHALO;      // staged rows that carry data (216 / 168)
-  constexpr int AR = (ARV + 15) / 16 * 16;                 // rows per slot: whole 16-row DMA pieces (224 / 176)
-  constexpr int ASLOT = AR * 64;
-  constexpr int NPIECE = AR / 16;
+  constexpr int AR = (ARV + 31) / 32 * 32;                 // rows per plane: whole 32-row DMA pieces (224 / 192); rows >= ARV stay zero
+  constexpr int PLANE = AR * 32;                           // hi plane, then lo plane: 32 bytes per row
+  constexpr int ASLOT = 2 * PLANE;
+  constexpr int NPP = AR / 32, NPIECE = 2 * NPP;           // DMA pieces per plane / per half block
   constexpr int PA = (NPIECE + NW - 1) / NW;               // DMA pieces per wave and half block
   constexpr int NQ = (ARV * 4 + NT_ - 1) / NT_;            // register path: float4 per thread and half block
   constexpr int PAW = MODE == 0 ? PA : (MODE == 1 ? NQ : NQ + 2);      // vector-memory requests of one activation half block per wave
-  constexpr int ZOFF = 2 * ASLOT;                          // one all-zero row (taps outside the image line read it)
-  constexpr int BOFF = ZOFF + 64;
-  constexpr int LDSB = BOFF + NW * NBST * 2048;
-  static_assert(PAW + 2 <= 63, "vmcnt is a 6-bit counter");
+  constexpr int ZROW = ARV * 32;                           // an all-zero row of either plane (taps outside the image line read it)
+  constexpr int BOFF = 2 * ASLOT;
+  constexpr int LDSB = BOFF + NW * NBST * BREC;
+  static_assert(PAW + 2 * NI * (NBST - 3) <= 63, "vmcnt is a 6-bit counter");
+  static_assert(ZROW + 32 <= PLANE, "a zero row behind the data rows");
   __shared__ __attribute__((aligned(1024))) unsigned char lds[LDSB];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lh = lane >> 5;
-  const int TT = p.T;
 
   // ---- tile id: XCD-contiguous chunks, column tiles of one strip next to each other (they stage the same activations) ----
   int bid = static_cast<int>(blockIdx.x);
@@ -107,11 +164,11 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_strip_f16x3_kernel(const KPar
   const int py0_ = SPATIAL ? (pt_ / p.sp_tx) * SPH : 0, px0_ = SPATIAL ? (pt_ % p.sp_tx) * SPW : 0;
   const int m0 = p.tpi > 0 ? img_ * UV + pt_ * SM : mt_i * SM;
   const int mend = p.tpi > 0 ? (img_ + 1) * UV : Mtot;
-  const int ct32 = nt_i * NW + wave;               // this wave's 32-column tile
+  const int ct32 = (nt_i * NW + wave) * NI;        // this wave's first 32-column tile
   const int ntiles32 = p.Npad >> 5;
-  unsigned char* const sB = lds + BOFF + wave * (NBST * 2048);      // this wave's weight ring
+  unsigned char* const sB = lds + BOFF + wave * (NBST * BREC);      // this wave's weight ring
   const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) unsigned char*)lds));   // LDS byte address
-  const unsigned sB0 = lds0 + BOFF + wave * (NBST * 2048);
+  const unsigned sB0 = lds0 + BOFF + wave * (NBST * BREC);
 
   // staged row j of the strip -> pixel index (or -1: outside the image / the problem -> zeros)
 #define RS_ROW_PIXEL(OUT_, J_)                                                                               \
@@ -131,15 +188,20 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_strip_f16x3_kernel(const KPar
       OUT_ = ok_ ? b_ * UV + u_ * p.su + v_ * p.sv : -1;                                                     \
     }                                                                                                        \
   }
-  // MODE 0: this lane's row of each of the wave's PA pieces (piece = 16 rows x 64 bytes; lane -> row lane >> 2, chunk position
-  // lane & 3, which holds the logical chunk (lane & 3) ^ ((row >> 2) & 3) = (lane & 3) ^ ((lane >> 4) & 3))
+  // swizzle bit of staged row j: bit 3 of the row (linear strips), parity of the halo-tile line (3x3)
+#define RS_SWZ(J_) (SPATIAL ? (((J_) / SHW) & 1) : (((J_) >> 3) & 1))
+  // MODE 0: DMA piece q = wave + NW i of a half block = 32 rows of one plane; lane -> row lane >> 1, group position lane & 1,
+  // which holds group (lane & 1) ^ swizzle(row): apix = the row's pixel, asrc = byte offset of the lane's 16 bytes inside the
+  // pixel's 64-byte half block ([g0 hi | g0 lo | g1 hi | g1 lo])
   int apix[PA > NQ ? PA : NQ];
-  const int acho = MODE == 0 ? (((lane & 3) ^ ((lane >> 4) & 3)) << 4) : 0;
+  int asrc[MODE == 0 ? PA : 1];
   if constexpr (MODE == 0) {
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
-      const int pc = wave + NW * i < NPIECE ? wave + NW * i : NPIECE - 1;      // (surplus requests repeat the last piece: identical bytes)
-      RS_ROW_PIXEL(apix[i], pc * 16 + (lane >> 2))
+      const int q = wave + NW * i < NPIECE ? wave + NW * i : NPIECE - 1;      // (surplus requests repeat the last piece: identical bytes)
+      const int plane = q / NPP, j = (q - plane * NPP) * 32 + (lane >> 1);
+      RS_ROW_PIXEL(apix[i], j)
+      asrc[i] = (((lane & 1) ^ RS_SWZ(j)) << 5) + (plane << 4);
     }
   } else {        // register path: quad idx = tid + NT_ * i -> row idx >> 2, channels 4 (idx & 3) .. +3 of the half block
 #pragma unroll
@@ -148,80 +210,106 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_strip_f16x3_kernel(const KPar
       RS_ROW_PIXEL(apix[i], idx >> 2)
     }
   }
-  // fragment rows of this lane: tile row r = 32 mi + l31
-  int rowc[SMI], fv[SMI];
+  // fragment addresses of this lane inside an activation slot (hi plane; lo: + PLANE), tile row r = 32 mi + l31:
+  //   linear: one per (row tile, tap), the tap mask folded in (taps beyond the image line read the zero row)
+  //   3x3:    per row tile the top-left tap of an even-offset line (dy = 0, 2) and of the centre line (dy = 1); tap (dy, dx) adds
+  //           the compile-time offset (dy = 2 ? 2 * 18 * 32 : 0) + 32 dx
+  int aad[SMI][SPATIAL ? 2 : TT];
 #pragma unroll
   for (int mi = 0; mi < SMI; ++mi) {
     const int r = mi * 32 + l31;
-    if (SPATIAL) {
-      rowc[mi] = ((r >> 4) + 1) * SHW + (r & 15) + 1;     // halo-tile row of the centre tap
-      fv[mi] = 0;
+    if constexpr (SPATIAL) {
+      const int hyc = (r >> 4) + 1, xc = (r & 15) + 1;
+      aad[mi][0] = ((hyc - 1) * SHW + xc - 1) * 32 + ((lh ^ ((hyc - 1) & 1)) << 4);
+      aad[mi][1] = (hyc * SHW + xc - 1) * 32 + ((lh ^ (hyc & 1)) << 4);
     } else {
       const int m = m0 + r;
-      rowc[mi] = r + SHALO;
-      fv[mi] = m < mend ? m % p.V : -1000;                // fast-axis coordinate: taps beyond the image line are masked
+      const int fv = m < mend ? m % p.V : -1000;          // fast-axis coordinate
+#pragma unroll
+      for (int t = 0; t < TT; ++t) {
+        const int dv = p.dv0 + t, row = r + SHALO + dv;
+        const bool ok = static_cast<unsigned>(fv + dv) < static_cast<unsigned>(p.V);
+        aad[mi][t] = ok ? row * 32 + ((lh ^ ((row >> 3) & 1)) << 4) : ZROW + (lh << 4);
+      }
     }
   }
-  const int boff = l31 * 64 + (((lh * 2) ^ ((l31 >> 2) & 3)) << 4);      // this lane's hi chunk inside a weight record (lo: ^ 16)
+  const int boff = l31 * 32 + ((lh ^ ((l31 >> 3) & 1)) << 4);      // this lane's hi fragment inside a weight record (lo: + 1024)
+  const unsigned lane16 = lane * 16;
 
-  f32x16 acc[SMI];
+  f32x16 acc[SMI][NI];
 #pragma unroll
   for (int i = 0; i < SMI; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int NHB = 2 * p.ncb;                 // half blocks
-  const int S = NHB * TT;                    // steps (even)
+  const int NHB = 2 * p.ncb;                 // half blocks (even)
+  const int S = NHB * TT;                    // steps
   float4 areg[MODE == 0 ? 1 : NQ];           // register path: the half block in flight
   float4 nrm01 = make_float4(0.f, 1.f, 0.f, 1.f), nrm23 = nrm01;
-  unsigned amask = 0u;
   int sat_n = 0;
   const bool sat_here = MODE != 0 && p.sat != nullptr && nt_i == 0;
 
-  // half block HB_ -> segment, first channel inside it, in range?
-#define RS_SEG(HB_)                                                                                          \
-  Seg sg_ = p.seg0;                                                                                          \
-  int cb0_ = 0;                                                                                              \
+  // ---- activation half blocks are requested in order 0, 1, 2, ...: the per-lane source pointers of the NEXT one to request are
+  // kept and advanced by 64 bytes (16 channels) per half block inside a source segment; only at a segment change (virtual concat:
+  // at most three times per launch) are they rebuilt from the parameter block.  Rows outside the image / the problem point at the
+  // zero page and do not advance.  Past the last half block the pointers stay: the surplus requests of the last steps re-read it.
+  int a_next = 0;                            // half block the pointers stand at
+  int a_seg_end = 0;                         // first half block of the next segment
+  const unsigned char* asp[MODE == 0 ? PA : NQ];       // MODE 0: this lane's 16 bytes of piece i; else: its float4 of quad i
+  unsigned ainc[MODE == 0 ? PA : NQ];
+  const float* nsp = p.in_mr;                // MODE 2: mean / rstd of the lane's four channels
+#define RS_A_REBUILD()                                                                                       \
   {                                                                                                          \
-    const int blk_ = (HB_) >> 1;                                                                             \
-    if (blk_ >= p.cb1) { sg_ = p.seg1; cb0_ = p.cb1; }                                                       \
-    if (blk_ >= p.cb2) { sg_ = p.seg2; cb0_ = p.cb2; }                                                       \
-    if (blk_ >= p.cb3) { sg_ = p.seg3; cb0_ = p.cb3; }                                                       \
-  }                                                                                                          \
-  const int cl_ = (((HB_) >> 1) - cb0_) * BK + ((HB_) & 1) * 16;
-  // MODE 0: request half block HB_ into activation slot SLOT_ (PA DMA pieces per wave)
-#define RS_ISSUE_A(HB_, SLOT_)                                                                               \
-  {                                                                                                          \
-    RS_SEG(HB_)                                                                                              \
-    const bool cok_ = cl_ < sg_.ccount;                                                                      \
-    const unsigned char* sb_ = reinterpret_cast<const unsigned char*>(sg_.ptr + sg_.coff + cl_) + acho;     \
-    _Pragma("unroll") for (int i = 0; i < PA; ++i) {                                                         \
-      const int pc_ = wave + NW * i < NPIECE ? wave + NW * i : NPIECE - 1;                                   \
-      const bool ok_ = cok_ && apix[i] >= 0;                                                                 \
+    Seg sg_ = p.seg0;                                                                                        \
+    int cb0_ = 0, cbe_ = p.cb1;                                                                              \
+    const int blk_ = a_next >> 1;                                                                            \
+    if (blk_ >= p.cb1) { sg_ = p.seg1; cb0_ = p.cb1; cbe_ = p.cb2; }                                         \
+    if (blk_ >= p.cb2) { sg_ = p.seg2; cb0_ = p.cb2; cbe_ = p.cb3; }                                         \
+    if (blk_ >= p.cb3) { sg_ = p.seg3; cb0_ = p.cb3; cbe_ = p.ncb; }                                         \
+    a_seg_end = 2 * (cbe_ < p.ncb ? cbe_ : p.ncb);                                                           \
+    const int cl_ = (blk_ - cb0_) * BK + (a_next & 1) * 16 + (MODE == 0 ? 0 : (tid & 3) * 4);                \
+    const unsigned char* sb_ = reinterpret_cast<const unsigned char*>(sg_.ptr + sg_.coff + cl_);            \
+    _Pragma("unroll") for (int i = 0; i < (MODE == 0 ? PA : NQ); ++i) {                                      \
+      const bool ok_ = apix[i] >= 0;                                                                         \
       const unsigned eo_ = static_cast<unsigned>(apix[i]) * static_cast<unsigned>(sg_.cstride);              \
-      const unsigned char* src_ = ok_ ? sb_ + static_cast<size_t>(eo_) * 4 : g_zero_page + ((lane & 3) << 4); \
-      glds16(src_, __builtin_amdgcn_readfirstlane(lds0 + (SLOT_) * ASLOT + pc_ * 1024));                     \
+      if (MODE == 0) asp[i] = ok_ ? sb_ + (static_cast<size_t>(eo_) * 4 + asrc[i]) : g_zero_page + ((lane & 3) << 4); \
+      else asp[i] = ok_ ? sb_ + static_cast<size_t>(eo_) * 4 : g_zero_page;                                  \
+      ainc[i] = ok_ ? 64u : 0u;                                                                              \
+    }                                                                                                        \
+    if (MODE == 2) nsp = p.in_mr + (static_cast<long long>(img_) * sg_.cstride + sg_.coff + cl_) * 2;        \
+  }
+#define RS_A_ADVANCE()                                                                                       \
+  {                                                                                                          \
+    if (a_next + 1 < NHB) {                                                                                  \
+      ++a_next;                                                                                              \
+      if (a_next == a_seg_end) {                                                                             \
+        RS_A_REBUILD()                                                                                       \
+      } else {                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < (MODE == 0 ? PA : NQ); ++i) asp[i] += ainc[i];                 \
+        if (MODE == 2) nsp += 32;                                                                            \
+      }                                                                                                      \
     }                                                                                                        \
   }
-  // MODE 1 / 2: request half block HB_ into registers ...
-#define RS_LOAD_A(HB_)                                                                                       \
+  // MODE 0: request the next half block into activation slot SLOT_ (PA DMA pieces per wave)
+#define RS_ISSUE_A(SLOT_)                                                                                    \
   {                                                                                                          \
-    RS_SEG(HB_)                                                                                              \
-    const int cq_ = cl_ + (tid & 3) * 4;                                                                     \
-    const bool cok_ = cq_ < sg_.ccount;                                                                      \
-    const float* sb_ = sg_.ptr + sg_.coff + cq_;                                                             \
+    _Pragma("unroll") for (int i = 0; i < PA; ++i) {                                                         \
+      const int q_ = wave + NW * i < NPIECE ? wave + NW * i : NPIECE - 1;                                    \
+      glds16(asp[i], __builtin_amdgcn_readfirstlane(lds0 + (SLOT_) * ASLOT + q_ * 1024));                    \
+    }                                                                                                        \
+    RS_A_ADVANCE()                                                                                           \
+  }
+  // MODE 1 / 2: request the next half block into registers ...
+#define RS_LOAD_A()                                                                                          \
+  {                                                                                                          \
     if (MODE == 2) {                                                                                         \
-      const float* mr_ = p.in_mr + (static_cast<long long>(img_) * sg_.cstride + sg_.coff + (cok_ ? cq_ : 0)) * 2; \
-      nrm01 = *reinterpret_cast<const float4*>(mr_);                                                         \
-      nrm23 = *reinterpret_cast<const float4*>(mr_ + 4);                                                     \
+      nrm01 = *reinterpret_cast<const float4*>(nsp);                                                         \
+      nrm23 = *reinterpret_cast<const float4*>(nsp + 4);                                                     \
     }                                                                                                        \
-    amask = 0u;                                                                                              \
-    _Pragma("unroll") for (int i = 0; i < NQ; ++i) {                                                         \
-      const bool ok_ = cok_ && apix[i] >= 0;                                                                 \
-      const unsigned eo_ = ok_ ? static_cast<unsigned>(apix[i]) * static_cast<unsigned>(sg_.cstride) : 0u;   \
-      areg[i] = *reinterpret_cast<const float4*>((ok_ ? sb_ : sg_.ptr) + eo_);                               \
-      amask |= ok_ ? (1u << i) : 0u;                                                                         \
-    }                                                                                                        \
+    _Pragma("unroll") for (int i = 0; i < NQ; ++i) areg[i] = *reinterpret_cast<const float4*>(asp[i]);       \
+    RS_A_ADVANCE()                                                                                           \
   }
   // ... and split + store it into slot SLOT_ (rows outside the image: zeros, AFTER the normalisation)
 #define RS_STORE_A(SLOT_)                                                                                    \
@@ -232,132 +320,135 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_strip_f16x3_kernel(const KPar
         float4 xv_ = areg[i];                                                                                \
         if (MODE == 2) xv_ = make_float4(fmaxf((xv_.x - nrm01.x) * nrm01.y, 0.f), fmaxf((xv_.y - nrm01.z) * nrm01.w, 0.f), \
                                          fmaxf((xv_.z - nrm23.x) * nrm23.y, 0.f), fmaxf((xv_.w - nrm23.z) * nrm23.w, 0.f)); \
-        const bool in_ = (amask >> i) & 1u;                                                                  \
+        const bool in_ = apix[i] >= 0;                                                                       \
         if (sat_here) sat_n += (in_ && rp::quad_saturates(xv_, p.a_scale)) ? 1 : 0;                          \
         h4 hi_, lo_;                                                                                         \
         split4(in_ ? xv_ : make_float4(0.f, 0.f, 0.f, 0.f), p.a_scale, hi_, lo_);                            \
-        const int ad_ = (SLOT_) * ASLOT + row_ * 64 + ((((quad_ >> 1) * 2) ^ ((row_ >> 2) & 3)) << 4) + (quad_ & 1) * 8; \
+        const int ad_ = (SLOT_) * ASLOT + row_ * 32 + (((quad_ >> 1) ^ RS_SWZ(row_)) << 4) + (quad_ & 1) * 8; \
         *reinterpret_cast<h4*>(lds + ad_) = hi_;                                                             \
-        *reinterpret_cast<h4*>(lds + (ad_ ^ 16)) = lo_;                                                      \
+        *reinterpret_cast<h4*>(lds + ad_ + PLANE) = lo_;                                                     \
       }                                                                                                      \
     }                                                                                                        \
   }
-  // weight record of step S_ -> this wave's ring slot S_ & 3 (2 DMA pieces)
-#define RS_ISSUE_B(S_)                                                                                       \
+  // weight records are requested in step order from a scalar pointer that advances by one record row per step; past the last
+  // step it stays (the surplus requests re-read the last record into slots nobody reads any more: the request counts are the
+  // same in every step)
+  const unsigned char* wptr = reinterpret_cast<const unsigned char*>(p.wpk_strip) + static_cast<size_t>(ct32) * 2048;
+  const size_t wstep = static_cast<size_t>(ntiles32) * 2048;
+  int b_left = S - 1;                        // records behind the one wptr stands at
+#define RS_ISSUE_B(SL_)                                                                                      \
   {                                                                                                          \
-    const unsigned char* src_ = reinterpret_cast<const unsigned char*>(p.wpk_strip) +                        \
-                                (static_cast<size_t>(S_) * ntiles32 + ct32) * 2048 + lane * 16;             \
-    const unsigned dst_ = __builtin_amdgcn_readfirstlane(sB0 + ((S_) & (NBST - 1)) * 2048);                  \
-    glds16(src_, dst_);                                                                                      \
-    glds16(src_ + 1024, dst_ + 1024);                                                                        \
+    glds_rec<NI>(wptr, lane16, __builtin_amdgcn_readfirstlane(sB0 + (SL_) * BREC));                          \
+    if (b_left > 0) { wptr += wstep; --b_left; }                                                             \
   }
-  h8 fa_h[2][SMI], fa_l[2][SMI], fb_h[2], fb_l[2];
-  // fragments of the step (tap TAP_, activation slot ASL_, weight slot BSL_) -> register set SET_
-#define RS_READ(SET_, TAP_, ASL_, BSL_)                                                                      \
+  h8 fa_h[2][SMI], fa_l[2][SMI], fb_h[2][NI], fb_l[2][NI];
+  constexpr int NRD = 2 * NI + 2 * SMI;      // fragment reads per step
+  constexpr int NMM = 3 * SMI * NI;          // MFMAs per step
+  // fragment K_ (weights hi x NI, activations lo x 5, weights lo x NI, activations hi x 5 -- the order the MFMAs want them) of
+  // tap TN_ of activation slot AS_ / weight slot BS_ -> register set SET_
+#define RS_READ1(K_, SET_, TN_, AS_, BS_)                                                                    \
   {                                                                                                          \
-    const int tq_ = ((TAP_) * 11) >> 5;                          /* TAP_ / 3 for TAP_ < 9 */                 \
-    const int sh_ = SPATIAL ? (tq_ - 1) * SHW + ((TAP_) - 3 * tq_) - 1 : p.dv0 + (TAP_);                      \
-    _Pragma("unroll") for (int mi = 0; mi < SMI; ++mi) {                                                     \
-      const int row_ = rowc[mi] + sh_;                                                                       \
-      int ad_ = (ASL_) * ASLOT + row_ * 64 + (((lh * 2) ^ ((row_ >> 2) & 3)) << 4);                          \
-      if (!SPATIAL) {        /* tap beyond the image line: the all-zero row (mask arithmetic: a select here is compiled into a   \
-                                branch per row tile, and a branch between the reads costs the counted lgkmcnt waits) */    \
-        const int ok_ = -static_cast<int>(static_cast<unsigned>(fv[mi] + sh_) < static_cast<unsigned>(p.V));  \
-        ad_ = (ZOFF + lh * 32) + ((ad_ - (ZOFF + lh * 32)) & ok_);                                             \
-      }                                                                                                      \
-      fa_h[SET_][mi] = *reinterpret_cast<const h8*>(lds + ad_);                                              \
-      fa_l[SET_][mi] = *reinterpret_cast<const h8*>(lds + (ad_ ^ 16));                                       \
+    if ((K_) < NI) fb_h[SET_][(K_)] = *reinterpret_cast<const h8*>(sB + (BS_) * BREC + (K_) * 2048 + boff);  \
+    else if ((K_) >= NI + SMI && (K_) < 2 * NI + SMI)                                                        \
+      fb_l[SET_][(K_) - NI - SMI] = *reinterpret_cast<const h8*>(sB + (BS_) * BREC + ((K_) - NI - SMI) * 2048 + 1024 + boff); \
+    else {                                                                                                   \
+      const bool lo_ = (K_) < NI + SMI;                                                                      \
+      const int mi_ = lo_ ? (K_) - NI : (K_) - 2 * NI - SMI;                                                 \
+      const int dyq_ = (TN_) / 3;                                                                            \
+      const int ad_ = SPATIAL ? aad[mi_][dyq_ == 1 ? 1 : 0] + (dyq_ == 2 ? 2 * SHW * 32 : 0) + ((TN_) - 3 * dyq_) * 32 \
+                              : aad[mi_][SPATIAL ? 0 : (TN_)];                                               \
+      if (lo_) fa_l[SET_][mi_] = *reinterpret_cast<const h8*>(lds + (AS_) * ASLOT + PLANE + ad_);            \
+      else fa_h[SET_][mi_] = *reinterpret_cast<const h8*>(lds + (AS_) * ASLOT + ad_);                        \
     }                                                                                                        \
-    fb_h[SET_] = *reinterpret_cast<const h8*>(sB + (BSL_) * 2048 + boff);                                    \
-    fb_l[SET_] = *reinterpret_cast<const h8*>(sB + (BSL_) * 2048 + (boff ^ 16));                             \
   }
-  // term-major: consecutive MFMAs go to different accumulator tiles
-#define RS_MMA(SET_)                                                                                         \
+  // MFMA K_ of a step in term-major order (consecutive MFMAs go to different accumulator tiles): lo x hi, hi x lo, hi x hi
+#define RS_MMA1(K_, SET_)                                                                                    \
   {                                                                                                          \
-    _Pragma("unroll") for (int mi = 0; mi < SMI; ++mi)                                                       \
-        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_l[SET_][mi], fb_h[SET_], acc[mi], 0, 0, 0);     \
-    _Pragma("unroll") for (int mi = 0; mi < SMI; ++mi)                                                       \
-        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_h[SET_][mi], fb_l[SET_], acc[mi], 0, 0, 0);     \
-    _Pragma("unroll") for (int mi = 0; mi < SMI; ++mi)                                                       \
-        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_h[SET_][mi], fb_h[SET_], acc[mi], 0, 0, 0);     \
+    const int term_ = (K_) / (SMI * NI), idx_ = (K_) % (SMI * NI), mi_ = idx_ % SMI, ni_ = idx_ / SMI;       \
+    if (term_ == 0) acc[mi_][ni_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_l[SET_][mi_], fb_h[SET_][ni_], acc[mi_][ni_], 0, 0, 0);       \
+    else if (term_ == 1) acc[mi_][ni_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_h[SET_][mi_], fb_l[SET_][ni_], acc[mi_][ni_], 0, 0, 0);  \
+    else acc[mi_][ni_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_h[SET_][mi_], fb_h[SET_][ni_], acc[mi_][ni_], 0, 0, 0);  \
   }
 
-  // ---- prologue: zero row, half blocks 0 and 1, weight records 0..2 ----
-  if (tid < 4) *reinterpret_cast<uint4*>(lds + ZOFF + tid * 16) = make_uint4(0u, 0u, 0u, 0u);
-  if constexpr (MODE == 0) {
-    RS_ISSUE_A(0, 0)
-    if (NHB > 1) RS_ISSUE_A(1, 1)
+  // ---- prologue: half blocks 0 and 1, weight records 0 .. NBST-2 ----
+  if constexpr (MODE != 0) {       // the zero row of both planes of both slots (the DMA path refills it with every half block)
+    if (tid < 8) *reinterpret_cast<uint4*>(lds + (tid >> 2) * ASLOT + ((tid >> 1) & 1) * PLANE + ZROW + (tid & 1) * 16) = make_uint4(0u, 0u, 0u, 0u);
   }
-  RS_ISSUE_B(0)
-  if (1 < S) RS_ISSUE_B(1)
-  if (2 < S) RS_ISSUE_B(2)
+  RS_A_REBUILD()
+  if constexpr (MODE == 0) {
+    RS_ISSUE_A(0)
+    RS_ISSUE_A(1)
+  }
+#pragma unroll
+  for (int i = 0; i < NBST - 1; ++i) RS_ISSUE_B(i)
   if constexpr (MODE != 0) {
-    RS_LOAD_A(0)
+    RS_LOAD_A()
     RS_STORE_A(0)
-    if (NHB > 1) {
-      RS_LOAD_A(1)
-      RS_STORE_A(1)
-    }
+    RS_LOAD_A()
+    RS_STORE_A(1)
   }
   wait_vm<0>();
   wg_barrier();
-  RS_READ(0, 0, 0, 0)
+#pragma unroll
+  for (int k = 0; k < NRD; ++k) RS_READ1(k, 0, 0, 0, 0)
 
-  // ---- main loop.  Step s = tap `tap` of half block `hb`:
-  //   (a) wait for weight record s+1 (requested two steps ago; the newest requests stay in flight)
-  //   (b) last tap of a half block: barrier -- every wave's share of half block hb+1 has landed (requested a half block ago) and
-  //       nobody reads slot hb & 1 any more (the fragments of this step are in registers) -> request half block hb+2 into it
-  //   (c) request weight record s+3   (d) read the fragments of step s+1   (e) 15 MFMAs of step s
-  int tap = 0, hb = 0;
-  bool a_pending = false;          // the previous step requested an activation half block (it sits between two weight records in the queue)
-  bool a_in_regs = false;          // register path: a half block is waiting in registers for its LDS store
-#define RS_STEP(CUR_, NXT_)                                                                                  \
+  // ---- main loop: pairs of half blocks (activation slots 0, 1), taps unrolled.  Step s = tap T_ of half block hb = hbp + H_:
+  //   (a) wait for weight record s+1: the NBST-3 newest records stay in flight -- and the activation half block requested at
+  //       the last boundary while it sits between them in the queue (the first NBST-3 taps of a half block)
+  //   (b) last tap: barrier -- every wave's share of half block hb+1 has landed (requested a half block ago) and nobody reads
+  //       slot H_ any more (the fragments of this step are in registers) -> request half block hb+2 into it
+  //   (c) request weight record s+NBST-1
+  //   (d) 15 MFMAs of step s, the 12 fragment reads of step s+1 between them
+#define RS_STEP(H_, T_)                                                                                      \
   {                                                                                                          \
-    if (s + 2 < S) {                                                                                         \
-      if (a_pending) wait_vm<PAW + 2>(); else wait_vm<2>();                                                  \
-    } else {                                                                                                 \
-      wait_vm<0>();                                                                                          \
-    }                                                                                                        \
-    a_pending = false;                                                                                       \
-    if constexpr (MODE != 0) {                                                                               \
-      if (a_in_regs && tap == 1) {                       /* (half block hb+1, requested at the last boundary) */ \
-        RS_STORE_A((hb + 1) & 1)                                                                             \
-        a_in_regs = false;                                                                                   \
-      }                                                                                                      \
-    }                                                                                                        \
-    if (tap == TT - 1 && hb + 1 < NHB) {                                                                     \
+    constexpr int q_ = (H_) * TT + (T_);                       /* step inside the pair: set q_ & 1, weight slot q_ % NBST */ \
+    constexpr int set_ = q_ & 1, sl_ = q_ % NBST;                                                            \
+    constexpr bool last_ = (T_) == TT - 1;                                                                   \
+    constexpr int tn_ = last_ ? 0 : (T_) + 1, asn_ = last_ ? 1 - (H_) : (H_);                                \
+    if (!(RS_ABL & 64)) wait_vm<2 * NI * (NBST - 3) + ((T_) <= NBST - 4 ? PAW : 0)>();                       \
+    if constexpr (MODE != 0 && (T_) == NBST - 2) { RS_STORE_A(1 - (H_)) }    /* (requested at the last boundary; landed: (a)) */ \
+    if constexpr (last_) {                                                                                   \
       wait_lds();                                                                                            \
-      wg_barrier();                                                                                          \
-      if (hb + 2 < NHB) {                                                                                    \
-        if constexpr (MODE == 0) { RS_ISSUE_A(hb + 2, hb & 1) } else { RS_LOAD_A(hb + 2) a_in_regs = true; } \
-        a_pending = true;                                                                                    \
+      if (!(RS_ABL & 32)) wg_barrier();                                                                      \
+      if (!(RS_ABL & 2)) { if constexpr (MODE == 0) { RS_ISSUE_A(H_) } else { RS_LOAD_A() } }   /* (half block hb+2; past the end: the last one again) */ \
+    }                                                                                                        \
+    if (!(RS_ABL & 1)) RS_ISSUE_B((sl_ + NBST - 1) % NBST)                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    if (RS_VAR & 2) {              /* variant: all fragment reads of the next step in front of the MFMAs */    \
+      _Pragma("unroll") for (int k = 0; k < NRD; ++k) RS_READ1(k, 1 - set_, tn_, asn_, (sl_ + 1) % NBST)     \
+      __builtin_amdgcn_sched_barrier(0);                                                                     \
+    }                                                                                                        \
+    if (RS_VAR & 1) __builtin_amdgcn_s_setprio(1);                                                           \
+    _Pragma("unroll") for (int k = 0; k < NMM; ++k) {                                                        \
+      if (!(RS_ABL & 8)) RS_MMA1(k, set_)                                                                    \
+      if (!(RS_VAR & 2)) {                                                                                   \
+        constexpr int kr0_ = (RS_VAR & 4) ? 2 : 0;        /* variant: the first reads behind the third MFMA */ \
+        const bool isb_ = (k - kr0_ < NI) || (k - kr0_ >= NI + SMI && k - kr0_ < 2 * NI + SMI);              \
+        if (k >= kr0_ && k - kr0_ < NRD && !(RS_ABL & 4) && !((RS_ABL & 128) && !isb_) && !((RS_ABL & 256) && isb_)) \
+          RS_READ1(k - kr0_, 1 - set_, tn_, asn_, (sl_ + 1) % NBST)                                          \
       }                                                                                                      \
+      __builtin_amdgcn_sched_barrier(0);                                                                     \
     }                                                                                                        \
-    if (s + 3 < S) RS_ISSUE_B(s + 3)                                                                         \
-    {   /* (unconditional: a read under a branch makes the compiler wait lgkmcnt(0) in front of every MFMA group; behind the \
-           last step it fetches a stale slot, harmlessly) */                                                 \
-      const bool wrap_ = tap == TT - 1;                                                                      \
-      const int nt_ = wrap_ ? 0 : tap + 1, nh_ = wrap_ ? hb + 1 : hb;                                        \
-      RS_READ(NXT_, nt_, nh_ & 1, (s + 1) & (NBST - 1))                                                      \
-    }                                                                                                        \
-    __builtin_amdgcn_sched_barrier(0);                                                                       \
-    RS_MMA(CUR_)                                                                                             \
-    __builtin_amdgcn_sched_barrier(0);                                                                       \
-    ++s;                                                                                                     \
-    if (++tap == TT) { tap = 0; ++hb; }                                                                      \
+    if (RS_VAR & 1) __builtin_amdgcn_s_setprio(0);                                                           \
   }
-  for (int s = 0; s < S;) {
-    RS_STEP(0, 1)
-    RS_STEP(1, 0)
+  for (int hbp = 0; hbp < NHB; hbp += 2) {
+    if constexpr (TT == 5) {
+      RS_STEP(0, 0) RS_STEP(0, 1) RS_STEP(0, 2) RS_STEP(0, 3) RS_STEP(0, 4)
+      RS_STEP(1, 0) RS_STEP(1, 1) RS_STEP(1, 2) RS_STEP(1, 3) RS_STEP(1, 4)
+    } else {
+      RS_STEP(0, 0) RS_STEP(0, 1) RS_STEP(0, 2) RS_STEP(0, 3) RS_STEP(0, 4) RS_STEP(0, 5) RS_STEP(0, 6) RS_STEP(0, 7) RS_STEP(0, 8)
+      RS_STEP(1, 0) RS_STEP(1, 1) RS_STEP(1, 2) RS_STEP(1, 3) RS_STEP(1, 4) RS_STEP(1, 5) RS_STEP(1, 6) RS_STEP(1, 7) RS_STEP(1, 8)
+    }
   }
+  wait_vm<0>();        // (the surplus requests of the last steps land in slots the epilogue is about to reuse)
   wait_lds();
 
   // ------------------------------------------- epilogue -------------------------------------------
   // accumulators -> wave-private LDS tile (the wave's own weight ring: every request into it has been waited for, all its
   // fragment reads are done) -> 16-byte row-contiguous stores; the operands of all four row groups of a 32-row block (additive
   // map, h, z) are requested before the block goes through LDS (conv_igemm.hip has the history of this order).
-  constexpr int ES = 36, F4 = 8, KG = 4;
-  float* S_ = reinterpret_cast<float*>(sB);              // 32 x 36 floats = 4.5 KB <= 8 KB
+  constexpr int ES = 32 * NI + 4, F4 = 8 * NI, KG = 4 * NI;       // row stride of the staging tile (floats), float4 per row, row groups per block
+  float* S_ = reinterpret_cast<float*>(sB);              // 32 x ES floats = 4.5 / 8.5 KB <= the ring's 10 / 24 KB
   const int colw = ct32 * 32;
   const int colq = colw + (lane % F4) * 4;
   const bool colok = colq < p.Cout;
@@ -368,8 +459,22 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_strip_f16x3_kernel(const KPar
   for (int e = 0; e < 4; ++e) bq[e] = p.bias[colc + (e < nv ? e : 0)];
   const int c2 = colc >= p.gru_c ? colc - p.gru_c : 0;
   double ts0 = 0., ts1 = 0., ts2 = 0., ts3 = 0., tq0 = 0., tq1 = 0., tq2 = 0., tq3 = 0.;
-#pragma unroll
+  // (the row-tile loop stays ROLLED: five copies of this body pass the compiler's unroll budget at NI = 2, a partly unrolled
+  //  loop indexes the accumulators dynamically, and they then live in scratch memory for the whole main loop.  The tile of
+  //  the iteration is selected by a uniform switch over constant indices instead.)
+#pragma unroll 1
   for (int mi = 0; mi < SMI; ++mi) {
+    f32x16 at[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      switch (mi) {
+        case 0: at[ni] = acc[0][ni]; break;
+        case 1: at[ni] = acc[1][ni]; break;
+        case 2: at[ni] = acc[2][ni]; break;
+        case 3: at[ni] = acc[3][ni]; break;
+        default: at[ni] = acc[4][ni]; break;
+      }
+    }
     long long pixk[KG];
     float4 am[KG], hv[KG], zv[KG];
     unsigned rowok = 0u;
@@ -410,7 +515,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_strip_f16x3_kernel(const KPar
       }
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) S_[((r & 3) + 8 * (r >> 2) + 4 * lh) * ES + l31] = acc[mi][r] * p.out_scale;
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) S_[((r & 3) + 8 * (r >> 2) + 4 * lh) * ES + ni * 32 + l31] = at[ni][r] * p.out_scale;
 #pragma unroll
     for (int k = 0; k < KG; ++k) {
       const int idx = lane + 64 * k;
@@ -486,24 +593,24 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_strip_f16x3_kernel(const KPar
   }
 }
 
-// packed order of the strip kernels: [half block hb = 2 cb + kk][tap][32-column tile][column n][chunk position][8] fp16 -- one
-// step's record of one column tile is 2 KB contiguous = the LDS image itself (the DMA copies it linearly): column n is a 64-byte
-// row [group 0 hi | group 0 lo | group 1 hi | group 1 lo] of channels 16 kk + 8 g + j, chunk position = logical chunk ^ ((n >> 2) & 3)
+// packed order of the strip kernels: [half block hb = 2 cb + kk][tap][32-column tile] records of 2 KB = the LDS image itself (the
+// DMA copies it linearly): [hi plane | lo plane] x [column n: 32 bytes] x [group position: 16 bytes] x 8 fp16, position pos of
+// column n holding group g = pos ^ ((n >> 3) & 1) = channels 16 kk + 8 g + j of the block
 __global__ void pack_strip_kernel(const float* __restrict__ w, _Float16* __restrict__ pk, const PackParams q, int TT, int spatial) {
   const int nt32 = q.Npad / 32;
   const long long total = static_cast<long long>(q.ncb) * 2 * TT * q.Npad * 32;
   const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int j8 = static_cast<int>(i & 7);
-  const int cp = static_cast<int>((i >> 3) & 3);
-  const int n32 = static_cast<int>((i >> 5) & 31);
+  const int pos = static_cast<int>((i >> 3) & 1);
+  const int n32 = static_cast<int>((i >> 4) & 31);
+  const int part = static_cast<int>((i >> 9) & 1);
   const int ctile = static_cast<int>((i >> 10) % nt32);
   const long long st = (i >> 10) / nt32;
   const int tap = static_cast<int>(st % TT);
   const int hbk = static_cast<int>(st / TT);
   const int blk = hbk >> 1, kk = hbk & 1;
-  const int c = cp ^ ((n32 >> 2) & 3);
-  const int g = c >> 1, part = c & 1;
+  const int g = pos ^ ((n32 >> 3) & 1);
   const int k = kk * 16 + g * 8 + j8;
   const int n = ctile * 32 + n32;
   const int s = q.cb_seg[blk];
@@ -524,10 +631,27 @@ bool strip_kernel_shape(int kh, int kw) { return (kh == 3 && kw == 3) || (kh == 
 
 namespace rpconv {
 
+// Column tiles per wave: 1 unless forced.  The two-tile form (one wave per SIMD, 160 x 64 per wave, 14 fragment reads per 30
+// MFMAs instead of 12 per 15) is built, tested and SLOWER (r04, profiles/r04_strip_ni2.txt: GRU z|r at B = 8 84.6 vs 76.4 us, even
+// with every memory operation compiled out 70 vs 56 us): a lone wave does not keep its SIMD's matrix pipe busy.
+static int g_strip_ni = 1;           // 1 / 2: column tiles per wave (strip_force_ni; 0: the least-waste shape over both)
+
+void strip_force_ni(int ni) { g_strip_ni = ni; }      // (rnnpose_conv_strip: mode 1 -> 1, mode 2 -> 1, mode 3 -> 2)
+
+// workgroup shape for c_out output channels: NI column tiles of 32 per wave x NW waves; returns NI * 16 + NW (0 = unsupported).
+// NI = 2 (one wave per SIMD, 160 x 64 per wave) wherever whole 64-column wave tiles fit; the column-tile width that wastes
+// the fewest columns, the wider one on a tie.
 int strip_waves(int c_out) {
-  if (c_out <= 64) return 0;                          // (two-wave workgroups are not built: such layers stay on the 128-row kernel)
-  if (c_out % 96 == 0 && c_out % 128 != 0) return 3;  // 96, 192, 288: whole 96-column tiles
-  return 4;
+  if (c_out <= 64) return 0;                          // (one- and two-wave 32-column workgroups are not built: such layers stay on the 128-row kernel)
+  int best = 0, best_waste = 1 << 30;
+  const int cand[5][2] = {{2, 4}, {2, 3}, {2, 2}, {1, 4}, {1, 3}};       // 256, 192, 128, 128, 96 columns
+  for (const auto& c : cand) {
+    if (g_strip_ni != 0 && c[0] != g_strip_ni) continue;
+    const int wdt = 32 * c[0] * c[1];
+    const int waste = rp::cdiv(c_out, wdt) * wdt - c_out;
+    if (waste < best_waste) { best_waste = waste; best = c[0] * 16 + c[1]; }
+  }
+  return best;
 }
 
 int strip_tiles_per_image(int H, int W, int kh, int kw) {
@@ -537,7 +661,7 @@ int strip_tiles_per_image(int H, int W, int kh, int kw) {
 
 bool strip_auto(int H, int W, int kh, int kw, int stride, int c_out) {
   if (stride != 1 || !strip_kernel_shape(kh, kw) || strip_waves(c_out) == 0) return false;
-  const int nw = strip_waves(c_out);
+  const int cfg = strip_waves(c_out), nw = (cfg & 15) * (cfg >> 4);         // 32-column wave tiles per workgroup
   const long long tiles = static_cast<long long>(strip_tiles_per_image(H, W, kh, kw)) * rp::cdiv(c_out, 32 * nw);
   if (tiles < 24) return false;                       // (a few images of this size do not fill the chip with strips)
   if (kh == 3) {                                      // ragged patches: at most 15 % of the rows wasted
@@ -557,21 +681,23 @@ void strip_pack(const float* w, _Float16* pk, const PackParams& q, hipStream_t s
 int strip_launch(KParams& p, int H, int W, int kh, int kw, bool hlin, bool per_image, hipStream_t st) {
   const char* fn = "rnnpose_conv2d_nhwc_f16x3";
   RP_REQUIRE(strip_kernel_shape(kh, kw) && p.stride == 1, fn, "strip kernel: 3x3, 1x5 or 5x1, stride 1");
-  const int nw = strip_waves(p.Cout);
-  RP_REQUIRE(nw != 0, fn, "strip kernel: c_out must exceed 64");
+  const int cfg = strip_waves(p.Cout);
+  RP_REQUIRE(cfg != 0, fn, "strip kernel: c_out must exceed 64");
+  const int ni = cfg >> 4, nw = cfg & 15;
   const bool spatial = kh == 3;
   const bool norm = p.in_mr != nullptr;
   RP_REQUIRE(!norm || (spatial && !hlin), fn, "strip kernel: the fused normalisation is the 3x3 fp32-source form");
-  if (hlin) {        // LDS-DMA: whole 64-byte half blocks
+  {
     const Seg* sg[4] = {&p.seg0, &p.seg1, &p.seg2, &p.seg3};
     const int nseg = p.cb3 < p.ncb ? 4 : (p.cb2 < p.ncb ? 3 : (p.cb1 < p.ncb ? 2 : 1));
-    for (int s = 0; s < nseg; ++s)
-      RP_REQUIRE(sg[s]->ccount % 16 == 0 && sg[s]->coff % 8 == 0 && sg[s]->cstride % 8 == 0, fn,
-                 "strip kernel, split-tensor sources: channel counts in multiples of 16 (whole half blocks), offsets / strides of 8");
+    for (int s = 0; s < nseg; ++s) {     // whole 32-channel blocks: the source pointers advance by half blocks without a range test
+      RP_REQUIRE(sg[s]->ccount % 32 == 0, fn, "strip kernel: source channel counts in multiples of 32");
+      if (hlin) RP_REQUIRE(sg[s]->coff % 8 == 0 && sg[s]->cstride % 8 == 0, fn, "strip kernel, split-tensor sources: channel offsets / strides of 8");
+    }
   }
   p.ksplit = 1;
-  p.n_nt = rp::cdiv(p.Cout, 32 * nw);
-  RP_REQUIRE(p.n_nt * nw * 32 <= p.Npad, fn, "strip kernel: column tiles exceed the packed width");
+  p.n_nt = rp::cdiv(p.Cout, 32 * ni * nw);
+  RP_REQUIRE(p.n_nt * ni * nw * 32 <= p.Npad, fn, "strip kernel: column tiles exceed the packed width");
   if (spatial) {
     p.T = 9; p.dv0 = 0;
     p.sp_tx = rp::cdiv(W, SPW); p.sp_ty = rp::cdiv(H, SPH);
@@ -585,16 +711,20 @@ int strip_launch(KParams& p, int H, int W, int kh, int kw, bool hlin, bool per_i
     p.n_mt = rp::cdiv(static_cast<long long>(p.B) * H * W, SM);
   }
   const dim3 grid(static_cast<unsigned>(p.n_mt) * p.n_nt), block(nw * 64);
-#define RS_LAUNCH(NW_)                                                                                                    \
+#define RS_LAUNCH(NW_, NI_)                                                                                               \
   if (spatial) {                                                                                                          \
-    if (norm) hipLaunchKernelGGL((conv_strip_f16x3_kernel<NW_, true, 2>), grid, block, 0, st, p);                         \
-    else if (hlin) hipLaunchKernelGGL((conv_strip_f16x3_kernel<NW_, true, 0>), grid, block, 0, st, p);                    \
-    else hipLaunchKernelGGL((conv_strip_f16x3_kernel<NW_, true, 1>), grid, block, 0, st, p);                              \
+    if (norm) hipLaunchKernelGGL((conv_strip_f16x3_kernel<NW_, 9, 2, NI_>), grid, block, 0, st, p);                       \
+    else if (hlin) hipLaunchKernelGGL((conv_strip_f16x3_kernel<NW_, 9, 0, NI_>), grid, block, 0, st, p);                  \
+    else hipLaunchKernelGGL((conv_strip_f16x3_kernel<NW_, 9, 1, NI_>), grid, block, 0, st, p);                            \
   } else {                                                                                                                \
-    if (hlin) hipLaunchKernelGGL((conv_strip_f16x3_kernel<NW_, false, 0>), grid, block, 0, st, p);                        \
-    else hipLaunchKernelGGL((conv_strip_f16x3_kernel<NW_, false, 1>), grid, block, 0, st, p);                             \
+    if (hlin) hipLaunchKernelGGL((conv_strip_f16x3_kernel<NW_, 5, 0, NI_>), grid, block, 0, st, p);                       \
+    else hipLaunchKernelGGL((conv_strip_f16x3_kernel<NW_, 5, 1, NI_>), grid, block, 0, st, p);                            \
   }
-  if (nw == 3) { RS_LAUNCH(3) } else { RS_LAUNCH(4) }
+  if (ni == 2) {
+    if (nw == 4) { RS_LAUNCH(4, 2) } else if (nw == 3) { RS_LAUNCH(3, 2) } else { RS_LAUNCH(2, 2) }
+  } else {
+    if (nw == 3) { RS_LAUNCH(3, 1) } else { RS_LAUNCH(4, 1) }
+  }
 #undef RS_LAUNCH
   return rp::check_launch(fn);
 }

@@ -555,8 +555,9 @@ def conv2d_nhwc(pc: PackedConv, srcs, dst, epilogue: int = EPI_LINEAR, aux0=None
         # (B * ceil(HWout/128), c_out, 2) fp32: per-tile column sums / sums of squares for instnorm_tiles_nhwc
         tpi = conv_tiles_per_image(H, W, pc.kh, pc.kw, stride, pc.c_out, tile)
         if not (tile_stats.is_cuda and tile_stats.dtype == F64 and tile_stats.is_contiguous()
-                and tile_stats.numel() >= B * tpi * pc.c_out * 2):
-            raise ValueError("tile_stats must be a contiguous FP64 CUDA tensor of (B * conv_tiles_per_image(...), c_out, 2)")
+                and tile_stats.numel() == B * tpi * pc.c_out * 2):      # exact: the consumer takes the tiling from this shape
+            raise ValueError("tile_stats must be a contiguous FP64 CUDA tensor of (B * conv_tiles_per_image(H, W, kh, kw, stride, "
+                             f"c_out, tile) = {B * tpi}, c_out, 2): the tile count depends on the kernel the launch takes")
         d.tile_stats = tile_stats.data_ptr()
     if in_norm is not None:          # (B, C_src, 2) mean / rstd of source 0: read relu((x - mean) * rstd) instead of x
         if not (in_norm.is_cuda and in_norm.dtype == F32 and in_norm.is_contiguous() and tuple(in_norm.shape) == (B, srcs[0][0].shape[3], 2)):
@@ -598,9 +599,9 @@ def _apply_conv_env():
         v = _os.environ.get("RNNPOSE_KSPLIT")
         if v is not None:
             _lib.call("rnnpose_conv_ksplit", int(v != "0"))
-        v = _os.environ.get("RNNPOSE_STRIP")               # 0: the automatic tile choice never takes the strip kernels (same-box A/B)
-        if v is not None:
-            _lib.call("rnnpose_conv_strip", int(v != "0"))
+        v = _os.environ.get("RNNPOSE_STRIP")               # 0: the automatic tile choice never takes the strip kernels (same-box A/B);
+        if v is not None:                                  # 2 / 3: strips with one / two column tiles per wave only
+            _lib.call("rnnpose_conv_strip", int(v))
         v = _os.environ.get("RNNPOSE_KSPLIT_LIMITS")          # "max_tiles,max_splits" (measurement)
         if v:
             a, b = (int(t) for t in v.split(","))
@@ -611,10 +612,11 @@ def conv_spatial_tiles(enable: bool = True):
     _lib.call("rnnpose_conv_spatial_tiles", int(bool(enable)))
 
 
-def conv_strip(enable: bool = True):
-    """Measurement switch: False = the automatic tile choice never takes the strip kernels (RNNPOSE_STRIP=0)."""
+def conv_strip(mode=True):
+    """Measurement switch: False / 0 = the automatic tile choice never takes the strip kernels (RNNPOSE_STRIP=0); 2 / 3 = strips
+    with one / two 32-column tiles per wave only."""
     _apply_conv_env()
-    _lib.call("rnnpose_conv_strip", int(bool(enable)))
+    _lib.call("rnnpose_conv_strip", int(mode))
 
 
 def conv_ksplit(enable: bool = True):

@@ -227,7 +227,7 @@ def test_conv_tile_stats_feed_instnorm(ops, B, H, W, cin, cout, k, stride):
     Ho, Wo = -(-H // stride), -(-W // stride)
     assert (Ho * Wo) % 128 == 0
     out = torch.empty(B, Ho, Wo, cout, device="cuda")
-    tpi = ops.conv_tiles_per_image(H, W, k, k, stride)         # 3x3 stride 1: 8 x 16 patches; else runs of 128 output pixels
+    tpi = ops.conv_tiles_per_image(H, W, k, k, stride, cout)   # 3x3 stride 1: 8 x 16 patches (strips: 10 x 16); else runs of 128 output pixels
     ts = torch.full((B * tpi, cout, 2), -1.0, device="cuda", dtype=torch.float64)      # fp64 tile statistics
     ops.conv2d_nhwc(pc, [(nhwc(D(x)), 0)], (out, 0), ops.EPI_LINEAR, stride=stride, tile_stats=ts)
     y64 = F.conv2d(D(x).double(), D(w).double(), D(b).double(), stride=stride, padding=k // 2)
@@ -256,7 +256,7 @@ def test_conv_per_image_tiles_and_fused_input_norm(ops, B, H, W, cin, cout):
     w2 = syn.normal("pn.w2", (cout, cin, 3, 3), 5, std=float(np.sqrt(2.0 / (cin * 9))))
     b1, b2 = syn.uniform("pn.b1", (cin,), 4, -0.5, 0.5), syn.uniform("pn.b2", (cout,), 5, -0.5, 0.5)
     p1, p2 = ops.PackedConv(D(w1), D(b1), [cin]), ops.PackedConv(D(w2), D(b2), [cout if False else cin])
-    tpi = ops.conv_tiles_per_image(H, W, 3, 3, 1)
+    tpi = ops.conv_tiles_per_image(H, W, 3, 3, 1, cin)          # (60 x 80 x 96: the automatic choice takes the strip kernels)
     c1 = torch.empty(B, H, W, cin, device="cuda")
     ts = torch.full((B * tpi, cin, 2), -1.0, device="cuda", dtype=torch.float64)
     ops.conv2d_nhwc(p1, [(nhwc(D(x)), 0)], (c1, 0), ops.EPI_LINEAR, tile_stats=ts)
@@ -488,6 +488,7 @@ def test_conv3x3_patch_tiling_equals_row_major(ops, B, H, W, cin, cout, hl):
     cs = (cout + 7) // 8 * 8
     outs, stats = [], []
     try:
+        ops.conv_strip(0)                      # (this is about the two tilings of the 128-row kernels)
         for sp in (True, False):
             ops.conv_spatial_tiles(sp)
             tpi = ops.conv_tiles_per_image(H, W, 3, 3, 1)
@@ -499,6 +500,7 @@ def test_conv3x3_patch_tiling_equals_row_major(ops, B, H, W, cin, cout, hl):
             stats.append(None if ts is None else ts.view(B, tpi, cout, 2).sum(1))
     finally:
         ops.conv_spatial_tiles(True)
+        ops.conv_strip(1)
     y64 = F.conv2d(D(x).double(), D(w).double(), D(b).double(), padding=1)
     y32 = F.conv2d(D(x), D(w), D(b), padding=1)
     check(nchw(outs[0][..., :cout]), y64, y32, "3x3 on patches")
@@ -635,9 +637,18 @@ STRIP_SHAPES = [
 ]
 
 
+@pytest.fixture(params=[1, 2], ids=["auto", "one-tile-waves"])
+def strip_mode(ops, request):
+    """The strip kernels in their automatic shape (two 32-column tiles per wave where whole 64-column wave tiles fit) and with
+    one tile per wave forced (ops.conv_strip(2): the two-workgroups-per-CU form)."""
+    ops.conv_strip(request.param)
+    yield request.param
+    ops.conv_strip(1)
+
+
 @pytest.mark.parametrize("hl", [False, True])
 @pytest.mark.parametrize("B,H,W,segs,cout,kh,kw", STRIP_SHAPES)
-def test_conv_strip_vs_fp64(ops, hl, B, H, W, segs, cout, kh, kw):
+def test_conv_strip_vs_fp64(ops, strip_mode, hl, B, H, W, segs, cout, kh, kw):
     """160-row strips with both operand paths (split-tensor sources by LDS-DMA, fp32 sources through registers) against fp64 and
     against the 128-row kernel on the same operands; fp32 and split-form destinations; bytes around the slice untouched."""
     cin = sum(segs)
@@ -678,7 +689,7 @@ def test_conv_strip_vs_fp64(ops, hl, B, H, W, segs, cout, kh, kw):
 
 @pytest.mark.parametrize("hl", [False, True])
 @pytest.mark.parametrize("kh,kw", [(1, 5), (5, 1)])
-def test_conv_strip_gru_epilogues(ops, kh, kw, hl):
+def test_conv_strip_gru_epilogues(ops, strip_mode, kh, kw, hl):
     """GRU gate / state-update epilogues + additive map in the strip kernels (update.py:47-58, hoisted context share)."""
     B, H, W, C = 2, 11, 19, 128
     h = np.tanh(syn.normal("h", (B, C, H, W), 2))
@@ -713,7 +724,7 @@ def test_conv_strip_gru_epilogues(ops, kh, kw, hl):
 
 
 @pytest.mark.parametrize("B,H,W,cin,cout", [(3, 15, 20, 96, 96), (2, 60, 80, 96, 128), (2, 20, 32, 128, 128)])
-def test_conv_strip_tile_stats_and_fused_input_norm(ops, B, H, W, cin, cout):
+def test_conv_strip_tile_stats_and_fused_input_norm(ops, strip_mode, B, H, W, cin, cout):
     """The encoder's pair (extractor.py:48-58) on strips: conv1 with fp64 tile statistics per 10 x 16 patch, conv2 reading
     relu(norm1(conv1 x)) in its load == the materialised sequence, bit for bit."""
     x = syn.normal("pn.x", (B, cin, H, W), 4, std=2.0) + 0.7

@@ -3,7 +3,7 @@ mapping of the LDS-DMA pieces, the XOR swizzle and the fragment read addresses a
 expressions and checked against what the MFMA operands must contain:
 
   A fragment of lane (l31, lh), row tile mi, tap t, half block hb:  pixel(row 32 mi + l31 shifted by tap t), channels
-      32 (hb >> 1) + 16 (hb & 1) + 8 lh + j,  hi at the address, lo at address ^ 16
+      32 (hb >> 1) + 16 (hb & 1) + 8 lh + j,  hi at the address, lo one plane further
   B fragment: column 32 ct + l31, the same channels, tap t
 and that every ds_read_b128 lane group (MI355X: 4 groups of 16 lanes) touches 16 different 16-byte bank slots.
 It is the review-time proof of the layout; the numerical proof is tests/test_gpu_conv.py on the GPU."""
@@ -18,28 +18,30 @@ GROUPS = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6
 GROUPS = GROUPS + [[l + 32 for l in g] for g in GROUPS]
 
 
+def swz(spatial, j):
+    return ((j // SHW) & 1) if spatial else ((j >> 3) & 1)
+
+
 def a_slot_image(spatial, NW, row_pixel):
-    """LDS bytes of one activation slot after the DMA pieces of all waves: address -> (pixel, chunk, byte in chunk)."""
+    """LDS bytes of one activation slot after the DMA pieces of all waves: address -> (pixel, group, part, byte in group)."""
     ARV = SHR if spatial else SM + 2 * SHALO
-    AR = (ARV + 15) // 16 * 16
-    NPIECE = AR // 16
+    AR = (ARV + 31) // 32 * 32
+    NPP = AR // 32
+    NPIECE = 2 * NPP
     PA = (NPIECE + NW - 1) // NW
     img = {}
     for wave in range(NW):
         for i in range(PA):
-            pc = min(wave + NW * i, NPIECE - 1)
+            q = min(wave + NW * i, NPIECE - 1)
+            plane = q // NPP
             for lane in range(64):
-                row = pc * 16 + (lane >> 2)
-                chunk = (lane & 3) ^ ((lane >> 4) & 3)          # acho >> 4
-                pix = row_pixel(row) if row < ARV else -1
+                j = (q - plane * NPP) * 32 + (lane >> 1)
+                g = (lane & 1) ^ swz(spatial, j)                  # asrc = (g << 5) + (plane << 4)
+                pix = row_pixel(j) if j < ARV else -1
                 for t in range(16):
-                    img[pc * 1024 + lane * 16 + t] = (pix, chunk, t)
+                    img[q * 1024 + lane * 16 + t] = (pix, g, plane, t)
     assert len(img) == AR * 64
-    return img
-
-
-def frag_addr(row, lh):
-    return row * 64 + (((lh * 2) ^ ((row >> 2) & 3)) << 4)
+    return img, AR * 32
 
 
 @pytest.mark.parametrize("NW", [3, 4])
@@ -52,31 +54,31 @@ def test_spatial_activation_fragments(NW):
         y, x = py0 - 1 + hy, px0 - 1 + (j - hy * SHW)
         return y * W + x if (j < SHR and 0 <= y < H and 0 <= x < W) else -1
 
-    img = a_slot_image(True, NW, row_pixel)
+    img, PLANE = a_slot_image(True, NW, row_pixel)
+
+    def addr(mi, lane, tap):            # the kernel's aad[mi][dy == 1] + compile-time tap offset
+        l31, lh = lane & 31, lane >> 5
+        r = mi * 32 + l31
+        hyc, xc = (r >> 4) + 1, (r & 15) + 1
+        a0 = ((hyc - 1) * SHW + xc - 1) * 32 + ((lh ^ ((hyc - 1) & 1)) << 4)
+        a1 = (hyc * SHW + xc - 1) * 32 + ((lh ^ (hyc & 1)) << 4)
+        dy, dx = tap // 3, tap % 3
+        return (a1 if dy == 1 else a0) + (2 * SHW * 32 if dy == 2 else 0) + dx * 32
+
     for tap, mi, lane in itertools.product(range(9), range(5), range(64)):
         l31, lh = lane & 31, lane >> 5
         r = mi * 32 + l31
-        rowc = ((r >> 4) + 1) * SHW + (r & 15) + 1
-        tq = (tap * 11) >> 5
-        assert tq == tap // 3
-        row = rowc + (tq - 1) * SHW + (tap - 3 * tq) - 1
-        ad = frag_addr(row, lh)
+        ad = addr(mi, lane, tap)
         y, x = py0 + (r >> 4) + tap // 3 - 1, px0 + (r & 15) + tap % 3 - 1
         want = y * W + x if (0 <= y < H and 0 <= x < W) else -1
-        for part, a in ((0, ad), (1, ad ^ 16)):
+        for part, a in ((0, ad), (1, ad + PLANE)):
             for j in range(8):
-                pix, chunk, t = img[a + 2 * j]
-                assert pix == want and chunk == 2 * lh + part and t == 2 * j
-    # bank conflicts: a 16-lane group must touch 16 different 16-byte slots of the 256-byte bank row
+                pix, g, plane, t = img[a + 2 * j]
+                assert pix == want and g == lh and plane == part and t == 2 * j
     for tap, mi in itertools.product(range(9), range(5)):
         for g in GROUPS:
-            slots = set()
-            for lane in g:
-                l31, lh = lane & 31, lane >> 5
-                r = mi * 32 + l31
-                row = ((r >> 4) + 1) * SHW + (r & 15) + 1 + (tap // 3 - 1) * SHW + tap % 3 - 1
-                slots.add((frag_addr(row, lh) % 256) // 16)
-            assert len(slots) >= 8, (tap, mi, g, sorted(slots))      # (halo rows jump by 18 between patch rows: <= 2-way)
+            slots = {(addr(mi, lane, tap) % 256) // 16 for lane in g}
+            assert len(slots) == 16, (tap, mi, g, sorted(slots))      # conflict-free with the line-parity swizzle
 
 
 @pytest.mark.parametrize("vertical", [False, True])
@@ -84,37 +86,41 @@ def test_linear_activation_fragments(vertical):
     H, W, B = 7, 12, 3
     U, V, su, sv = (W, H, 1, W) if vertical else (H, W, W, 1)
     UV, Mtot = U * V, B * U * V
+    ARV = SM + 2 * SHALO
     for m0 in (0, SM, 2 * SM if 2 * SM < Mtot else 0):
         def row_pixel(j):
             m = m0 - SHALO + j
-            if not (j < SM + 2 * SHALO and 0 <= m < Mtot):
+            if not (j < ARV and 0 <= m < Mtot):
                 return -1
             q, v = divmod(m, V)
             b, u = divmod(q, U)
             return b * UV + u * su + v * sv
 
-        img = a_slot_image(False, 4, row_pixel)
+        img, PLANE = a_slot_image(False, 4, row_pixel)
         for tap, mi, lane in itertools.product(range(5), range(5), range(64)):
             l31, lh = lane & 31, lane >> 5
             r = mi * 32 + l31
             m = m0 + r
-            if m >= Mtot:
-                continue
             dv = tap - 2
-            fv = m % V
+            fv = m % V if m < Mtot else -1000
             ok = 0 <= fv + dv < V
-            if not ok:
-                continue          # the kernel reads the all-zero row
-            ad = frag_addr(r + SHALO + dv, lh)
-            q, v = divmod(m, V)
-            b, u = divmod(q, U)
-            want = b * UV + u * su + (v + dv) * sv          # the neighbour along the fast axis, same line, same image
-            for part, a in ((0, ad), (1, ad ^ 16)):
-                pix, chunk, t = img[a]
-                assert pix == want and chunk == 2 * lh + part and t == 0
+            row = r + SHALO + dv
+            ad = row * 32 + ((lh ^ ((row >> 3) & 1)) << 4) if ok else ARV * 32 + (lh << 4)
+            if ok:
+                q, v = divmod(m, V)
+                b, u = divmod(q, U)
+                want = b * UV + u * su + (v + dv) * sv      # the neighbour along the fast axis, same line, same image
+            else:
+                want = -1                                     # the zero row (a padding row of the slot: refilled from the zero page)
+            for part, a in ((0, ad), (1, ad + PLANE)):
+                pix, g, plane, t = img[a]
+                assert pix == want and plane == part and t == 0 and (g == lh or not ok)
     for tap, mi in itertools.product(range(5), range(5)):
         for g in GROUPS:
-            slots = {(frag_addr(mi * 32 + (lane & 31) + SHALO + tap - 2, lane >> 5) % 256) // 16 for lane in g}
+            slots = set()
+            for lane in g:
+                row = mi * 32 + (lane & 31) + SHALO + tap - 2
+                slots.add(((row * 32 + (((lane >> 5) ^ ((row >> 3) & 1)) << 4)) % 256) // 16)
             assert len(slots) == 16
 
 
@@ -125,18 +131,18 @@ def test_packed_weight_record():
     total = ncb * 2 * TT * Npad * 32
 
     def decode(i):
-        j8, cp, n32 = i & 7, (i >> 3) & 3, (i >> 5) & 31
+        j8, pos, n32, part = i & 7, (i >> 3) & 1, (i >> 4) & 31, (i >> 9) & 1
         ctile, st = (i >> 10) % nt32, (i >> 10) // nt32
         tap, hbk = st % TT, st // TT
-        c = cp ^ ((n32 >> 2) & 3)
-        return (ctile * 32 + n32, (hbk >> 1) * 32 + (hbk & 1) * 16 + (c >> 1) * 8 + j8, tap, c & 1)
+        g = pos ^ ((n32 >> 3) & 1)
+        return (ctile * 32 + n32, (hbk >> 1) * 32 + (hbk & 1) * 16 + g * 8 + j8, tap, part)
 
     seen = set()
     for step in (0, 5, TT * 2 * ncb - 1):
         for ct, lane in itertools.product(range(nt32), range(64)):
             l31, lh = lane & 31, lane >> 5
-            boff = l31 * 64 + (((lh * 2) ^ ((l31 >> 2) & 3)) << 4)
-            for part, a in ((0, boff), (1, boff ^ 16)):
+            boff = l31 * 32 + ((lh ^ ((l31 >> 3) & 1)) << 4)
+            for part, a in ((0, boff), (1, boff + 1024)):
                 for j in range(8):
                     i = ((step * nt32 + ct) * 2048 + a) // 2 + j
                     assert i < total
@@ -145,5 +151,5 @@ def test_packed_weight_record():
                     seen.add(i)
     assert len(seen) == 3 * nt32 * 1024           # every half of the three records is read exactly once
     for g in GROUPS:
-        slots = {((l & 31) * 64 + ((((l >> 5) * 2) ^ (((l & 31) >> 2) & 3)) << 4)) % 256 // 16 for l in g}
+        slots = {((l & 31) * 32 + (((l >> 5) ^ (((l & 31) >> 3) & 1)) << 4)) % 256 // 16 for l in g}
         assert len(slots) == 16

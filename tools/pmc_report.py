@@ -9,7 +9,7 @@ import sys
 
 
 def short(n):
-    m = re.search(r"(conv_igemm_f16x3_kernel<[^>]*>|corr_pyramid_h3_kernel|[A-Za-z0-9_]+_kernel)", n)
+    m = re.search(r"(conv_igemm_f16x3_kernel<[^>]*>|conv_strip_f16x3_kernel<[^>]*>|corr_pyramid_h3_kernel|[A-Za-z0-9_]+_kernel)", n)
     return m.group(1) if m else n[:48]
 
 

@@ -13,6 +13,7 @@ for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
            "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
   if [ -n "$PMC_TRAFFIC_ONLY" ] && [ $i -lt 3 ]; then continue; fi     # FETCH_SIZE / WRITE_SIZE passes only (pmc3, pmc4)
+  if [ -n "$PMC_SQ_ONLY" ] && [ $i -gt 2 ]; then continue; fi          # the two SQ passes only
   ( cd $R && rocprofv3 --pmc $SET --kernel-trace -d $OUT/${TAG}_pmc$i -o run -- "$@" ) > $OUT/${TAG}_pmc$i.log 2>&1
   tail -1 $OUT/${TAG}_pmc$i.log | cut -c1-200
 done
