@@ -194,14 +194,19 @@ def parity_block(refiner, rend, K, G0, args, want):
     flow_mag = float(wf.abs().max())
     d_last = float((out["flow_last"] - T(want["flow_last"])).abs().max())
     d_w = float((out["weight"][:, 0, 0] - T(want["weight_last"])).abs().max())
-    flow_ok = bool(d_first <= FLOW_TOL or d_gpu64 <= max(FLOW_TOL, 2.0 * d_cpu64))
-    ok = bool(max(dG, dT) <= POSE_TOL and flow_ok)
+    # `ok` = the LITERAL north-star criterion only: pose 1e-5 and |GPU - CPU oracle| <= 1e-4 on the first
+    # iteration's field.  The fp64 yardstick stays in the record as a diagnostic (`ok_fp64_leg`); `leg` says which one held.
+    ok_literal = bool(d_first <= FLOW_TOL)
+    ok_fp64 = bool(d_gpu64 <= max(FLOW_TOL, 2.0 * d_cpu64))
+    leg = "literal" if ok_literal else ("fp64" if ok_fp64 else "none")
+    ok = bool(max(dG, dT) <= POSE_TOL and ok_literal)
     return {"max_abs_dpose": max(dG, dT), "max_abs_dpose_final": dG, "max_abs_dflow_first": d_first,
             "first_iteration_vs_fp64": {"gpu": d_gpu64, "cpu_oracle_fp32": d_cpu64, "fp64_oracle_seconds": round(want["fp64_seconds"], 1)},
             "max_abs_dflow_last": d_last, "max_abs_dweight_last": d_w, "max_abs_flow_first": flow_mag,
-            "tol": {"pose": POSE_TOL, "flow_first_iteration": f"|gpu - cpu| <= {FLOW_TOL}, or |gpu - fp64| <= max({FLOW_TOL}, 2 |cpu - fp64|)",
+            "tol": {"pose": POSE_TOL, "flow_first_iteration": f"|gpu - cpu| <= {FLOW_TOL} (literal: the gate); diagnostic leg: |gpu - fp64| <= max({FLOW_TOL}, 2 |cpu - fp64|)",
                     "flow_last_drift_bound": 5e-4},
-            "ok": ok, "drift_ok": bool(d_last <= 5e-4),
+            "ok": ok, "leg": leg, "ok_literal": bool(max(dG, dT) <= POSE_TOL and ok_literal), "ok_fp64_leg": bool(max(dG, dT) <= POSE_TOL and ok_fp64),
+            "drift_ok": bool(d_last <= 5e-4),
             "what": (f"GPU refiner vs the CPU oracle on the identical device-generated inputs and weights of the timed run: batch "
                      f"{args.batch} x {args.height}x{args.width}, encoder in the loop, 1 outer x {args.inner} inner iterations "
                      f"(the unit the timed schedule repeats {args.outer} times); poses of all {args.inner} iterations and the final pose")}

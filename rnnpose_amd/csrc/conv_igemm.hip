@@ -588,6 +588,11 @@ __global__ __launch_bounds__(NT, ((NI == 2 || DEEP || (SPATIAL && (COLS4 || !RP_
       ks_last = last;
     }
     __syncthreads();
+    // range guard: the quads this workgroup clamped while staging ITS share of the channel blocks are counted here -- every
+    // workgroup of a tile but the last leaves on the next line (r03 counted only behind the epilogue: with ksplit = 4 three
+    // quarters of the clamp events were lost, and which quarter survived depended on the arrival order)
+    if (p.sat && sat_n) atomicAdd(p.sat, static_cast<unsigned long long>(sat_n));
+    sat_n = 0;
     if (!ks_last) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     const float* wsr = p.ks_ws + static_cast<long long>(tile_lin) * ks * (NT * ACCN) + tid;

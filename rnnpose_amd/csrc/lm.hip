@@ -172,6 +172,9 @@ __global__ __launch_bounds__(LM_THREADS) void lm_normal_eq_kernel(const float* _
       is_last = (t == nblk - 1) ? 1 : 0;
       if (is_last) {
         __hip_atomic_store(&tail.tickets[b], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        // ONE agent-scope acquire per workgroup: it invalidates this CU's vector L1 (buffer_inv sc1), which is per CU, not per
+        // thread -- followed by the barrier below before any thread of the block loads the other workgroups' partial records
+        // (cdna_hip_programming.md, Guideline 16: "consumer: one relaxed poll -> one agent acquire -> __syncthreads() -> plain loads")
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       }
     }

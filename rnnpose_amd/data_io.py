@@ -122,26 +122,39 @@ class InitPoses:
         self.blender2bop = np.load(blender2bop_npy, allow_pickle=True).flat[0] if blender2bop_npy is not None else None
         if kind == "POSECNN_LINEMOD" and self.posecnn is None:
             raise ValueError("POSECNN_LINEMOD needs linemod_posecnn_results.pkl")
-        if kind.startswith("PVNET") and self.pvnet is None:
-            raise ValueError(f"{kind} needs the pvnet .npy file")
+        if kind.startswith("PVNET") and (self.pvnet is None or self.blender2bop is None):
+            raise ValueError(f"{kind} needs the pvnet .npy file and the blender -> BOP frame file (data/linemod_dataset.py:186-196)")
         if kind not in ("POSECNN_LINEMOD", "PVNET_LINEMOD", "PVNET_LINEMOD_OCC"):
             raise NotImplementedError(kind)
 
     def __call__(self, class_name: str, frame_idx: int) -> np.ndarray:
-        """-> (4,4) float32 initial pose of frame `frame_idx` of sequence `class_name`."""
+        """-> (4,4) float32 initial pose of frame `frame_idx` of sequence `class_name` (data/linemod_dataset.py:330-367):
+        PVNet poses of BOTH PVNet kinds are converted from PVNet's (Blender) object frame to BOP's; PVNET_LINEMOD falls back to
+        the PoseCNN pose when a frame is missing, PVNET_LINEMOD_OCC re-raises (:346-354); the rotation block is then projected
+        onto the nearest rotation, R (R^T R)^(-1/2) (:367)."""
         if self.kind == "POSECNN_LINEMOD":
-            return to44(se3_q2m(self.posecnn[class_name][frame_idx]["pose"]))
-        try:
-            RT = np.array(self.pvnet[class_name][frame_idx], np.float64)[:3, :4].copy()
-        except (IndexError, KeyError):
-            if self.posecnn is None:
-                raise
-            return to44(se3_q2m(self.posecnn[class_name][frame_idx]["pose"]))           # the reference's fallback (:337-338)
-        if self.kind == "PVNET_LINEMOD" and self.blender2bop is not None:                # PVNet's object frame -> BOP's (:333-335)
-            C = np.asarray(self.blender2bop[class_name], np.float64)
-            RT[:3, :3] = RT[:3, :3] @ C[:3, :3].T
-            RT[:3, 3:] = -RT[:3, :3] @ C[:3, 3:] + RT[:3, 3:]
+            RT = se3_q2m(self.posecnn[class_name][frame_idx]["pose"])
+        else:
+            try:
+                RT = np.array(self.pvnet[class_name][frame_idx], np.float64)[:3, :4].copy()
+                C = np.asarray(self.blender2bop[class_name], np.float64)                     # PVNet's object frame -> BOP's (:333-335, :349-351)
+                RT[:3, :3] = RT[:3, :3] @ C[:3, :3].T
+                RT[:3, 3:] = -RT[:3, :3] @ C[:3, 3:] + RT[:3, 3:]
+            except Exception:
+                if self.kind == "PVNET_LINEMOD_OCC" or self.posecnn is None:
+                    raise                                                                      # (:352-354: no fallback for LM-O)
+                RT = se3_q2m(self.posecnn[class_name][frame_idx]["pose"])                      # the reference's fallback (:337-338)
+        RT = np.asarray(RT, np.float64)
+        RT[:3, :3] = nearest_rotation(RT[:3, :3])
         return to44(RT)
+
+
+def nearest_rotation(R) -> np.ndarray:
+    """R (R^T R)^(-1/2): the orthogonal polar factor of R, as data/linemod_dataset.py:367 computes it with scipy.linalg.sqrtm
+    (here through the symmetric eigendecomposition of R^T R: the same matrix for a non-singular R)."""
+    R = np.asarray(R, np.float64)
+    w, V = np.linalg.eigh(R.T @ R)
+    return R @ (V * (1.0 / np.sqrt(w))) @ V.T
 
 
 def patch_crop_window(bbox_xywh, K_old, margin_ratio=0.2, output_size=128, offset_ratio=(0.0, 0.0)):

@@ -60,10 +60,13 @@ class SyntheticRenderer:
 class PoseRefiner(nn.Module):
     def __init__(self, cfg=None, reuse=False, schedule=None, use_regressor=True, is_calibrated=True,
                  bn_is_training=False, is_training=True, renderer=None, fused=True,
-                 img_fea_enc_weights=None, use_graph=True):
+                 img_fea_enc_weights=None, use_graph=True, literal_legacy_pose=None):
+        """literal_legacy_pose (or cfg["literal_legacy_pose"]; default False): start every outer iteration from the reference's
+        legacy product Tij = Ti * Ti.inv() (model/PoseRefiner.py:243-244) instead of the exact identity it stands for."""
         super().__init__()
         self.legacy = True
         self.cfg = cfg = cfg if cfg is not None else default_config()
+        self.literal_legacy_pose = bool(cfg.get("literal_legacy_pose", False) if literal_legacy_pose is None else literal_legacy_pose)
         self.reuse = reuse
         self.sigma = nn.ParameterList([nn.Parameter(torch.ones(1) * 1)])
         self.with_corr_weight = cfg.get("with_corr_weight", True)
@@ -405,7 +408,7 @@ class PoseRefiner(nn.Module):
             # flow differences -- r03 found it to be the whole first-iteration distance of the timed configuration to the oracle
             # (tools/bench_parity_probe.py; the distance did not move by one bit under any change of the GPU arithmetic).  The
             # oracle and this loop use the EXACT identity; `literal_legacy_pose=True` restores the product.
-            if self.legacy and getattr(self, "literal_legacy_pose", False):
+            if self.legacy and self.literal_legacy_pose:
                 Tij = Ti * Ti.inv()
             views = self.renderer.render_views(Ti.matrix().squeeze(1), intrinsics, obj_cls=obj_cls, image=image,
                                                fea_3d=fea_3d, geofea_3d=geofea_3d, geofea_2d=geofea_2d)

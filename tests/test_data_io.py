@@ -63,7 +63,26 @@ def test_init_pose_files(tmp_path):
     T = ip("cat", 1)
     R = pv["cat"][1][:, :3] @ conv["cat"][:, :3].T
     assert np.allclose(T[:3, :3], R, atol=1e-6) and np.allclose(T[:3, 3:], -R @ conv["cat"][:, 3:] + pv["cat"][1][:, 3:], atol=1e-6)
-    assert np.allclose(ip("cat", 3), io.to44(io.se3_q2m(posecnn["cat"][3]["pose"])))       # out of PVNet's range: PoseCNN fallback
+    assert np.allclose(ip("cat", 3), io.to44(io.se3_q2m(posecnn["cat"][3]["pose"])), atol=1e-6)       # out of PVNet's range: PoseCNN fallback
+    # LM-O (data/linemod_dataset.py:346-354): the SAME frame conversion, and a missing frame is an error, not a fallback
+    ipo = io.InitPoses("PVNET_LINEMOD_OCC", posecnn_pkl=tmp_path / "linemod_posecnn_results.pkl", pvnet_npy=tmp_path / "pvnet_linemod_test.npy",
+                       blender2bop_npy=tmp_path / "blender2bop_RT.npy")
+    assert np.allclose(ipo("cat", 1), T, atol=1e-7)
+    with pytest.raises((IndexError, KeyError)):
+        ipo("cat", 3)
+    with pytest.raises(ValueError):
+        io.InitPoses("PVNET_LINEMOD_OCC", pvnet_npy=tmp_path / "pvnet_linemod_test.npy")        # the frame file is required
+    # the rotation block is regularised to the nearest rotation, R (R^T R)^(-1/2) (:367), as scipy.linalg.sqrtm gives it
+    import scipy.linalg
+    Rn = Rotation.random(random_state=5).as_matrix() + rng.normal(size=(3, 3)) * 0.02
+    want = Rn @ np.linalg.inv(scipy.linalg.sqrtm(Rn.T @ Rn))
+    got = io.nearest_rotation(Rn)
+    assert np.allclose(got, np.real(want), atol=1e-10) and np.allclose(got.T @ got, np.eye(3), atol=1e-12)
+    pv2 = {"cat": [np.concatenate([Rn, rng.normal(size=(3, 1))], 1)]}
+    np.save(tmp_path / "pvnet_noisy.npy", pv2, allow_pickle=True)
+    Tn = io.InitPoses("PVNET_LINEMOD_OCC", pvnet_npy=tmp_path / "pvnet_noisy.npy", blender2bop_npy=tmp_path / "blender2bop_RT.npy")("cat", 0)
+    assert np.allclose(Tn[:3, :3].T @ Tn[:3, :3], np.eye(3), atol=1e-6)
+    assert np.allclose(Tn[:3, :3], io.nearest_rotation(Rn @ conv["cat"][:, :3].T), atol=1e-6)
 
 
 def test_patch_crop_window_matches_the_reference_arithmetic():

@@ -173,6 +173,34 @@ def test_conv_range_guard_counts_saturation(ops):
     assert ops.saturation_count() == 0                          # launches made while the guard was off count nothing
 
 
+def test_conv_range_guard_counts_in_every_k_split_share(ops):
+    """with a K split every workgroup of a tile stages a different range of channel blocks; an out-of-range value in
+    ANY of them must be counted, whichever workgroup arrives last (r03 lost the counts of all but the last arrival).  Same
+    through the strip kernels' register path."""
+    B, H, W, cin, cout = 1, 30, 30, 256, 192
+    w = D(syn.normal("rg.w", (cout, cin, 3, 3), 7, std=0.01))
+    pc = ops.PackedConv(w, torch.zeros(cout, device="cuda"), [cin])
+    out = torch.empty(B, H, W, cout, device="cuda")
+    ws = ops.conv_ksplit_workspace("cuda")
+    ops.saturation_count(reset=True)
+    for ch in (3, 70, 130, 250):                              # one clamped element in each quarter of the channel blocks
+        x = torch.full((B, H, W, cin), 1.0, device="cuda")
+        x[0, 11, 17, ch] = 2.0e4
+        ops.conv2d_nhwc(pc, [(x, 0)], (out, 0), ksplit_ws=ws)
+        torch.cuda.synchronize()
+        assert ops.saturation_count() >= 1, f"clamp in channel {ch} was not counted"
+        ops.conv2d_nhwc(pc, [(x, 0)], (out, 0))
+        assert ops.saturation_count() >= 1
+    xs = torch.full((2, 60, 80, cin), 1.0, device="cuda")     # strips (fp32 sources: the register path checks while it splits)
+    xs[1, 31, 47, 200] = -3.0e4
+    outs = torch.empty(2, 60, 80, cout, device="cuda")
+    ops.conv2d_nhwc(pc, [(xs, 0)], (outs, 0), tile=5)
+    assert torch.isfinite(outs).all() and ops.saturation_count() >= 1
+    xs[1, 31, 47, 200] = 1.0
+    ops.conv2d_nhwc(pc, [(xs, 0)], (outs, 0), tile=5)
+    assert ops.saturation_count() == 0
+
+
 def test_range_guard_is_visible_in_refiner_output(ops):
     """the clamp event is sticky, on by default and part of the PUBLIC output.  Update-block weights scaled
     by 1e3 drive activations past +-8188: PoseRefiner's "f16x3_range_events" must be nonzero (and zero for sane weights)."""

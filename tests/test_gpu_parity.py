@@ -864,20 +864,23 @@ def _enc_weights(seed=3):
     return syn.make_module_weights(orc.encoder_shapes(), seed=seed)
 
 
-def test_timed_configuration_vs_oracle(ops):
+@pytest.mark.parametrize("enc_gain", [0.25, 1.0])
+def test_timed_configuration_vs_oracle(ops, enc_gain):
     """the BENCHMARKED configuration itself -- batch 8, 480x640, the RAFT encoder inside the loop
     (model/PoseRefiner.py:311), 1 outer x 8 inner iterations (the unit bench.py's 3x8 schedule repeats) -- against the CPU oracle
-    on identical images and hash-generated encoder / update-block weights (feature maps of magnitude ~30: 10x the synthetic maps of
-    the other tests).  Pose: 1e-5 at every iteration.  First-iteration field: within 1e-4 of the CPU oracle, OR -- the oracle being
-    an fp32 evaluation itself, ~1e-4 away from the fp64 evaluation of the same arithmetic at this size -- within
-    max(1e-4, 2 x the oracle's own distance) of the fp64 evaluation (bench.py's parity rule; profiles/r03_error_budget.json)."""
+    on identical images and hash-generated encoder / update-block weights.  Pose: 1e-5 at every iteration.
+    First-iteration field (r04): with encoder weights at kaiming gain 0.25 (feature maps |f| ~ 8) the gate is the
+    LITERAL north-star tolerance, |GPU - CPU oracle| <= 1e-4.  At gain 1 (|f| ~ 31, |corr| ~ 900) the oracle -- an fp32 evaluation
+    itself -- sits ~2e-4 from the fp64 evaluation of the same arithmetic (tests/golden/loop_480.npz shows the reference's own CPU
+    result at the same distance), so there the GPU must be within max(1e-4, 2 x the oracle's own distance) of the fp64 field, and the
+    leg that held is printed (bench.py's `parity.leg`)."""
     from rnnpose_amd.pose_refiner import PoseRefiner, SyntheticRenderer, default_config
     from rnnpose_amd.transformation import SE3Sequence
     B, H, W, inner = 8, 480, 640, 8
     dt = syn.make_inputs_t(B, H, W, seed=7, device="cuda", with_images=True)
     d = {k: v.cpu().numpy() for k, v in dt.items()}
     d.pop("fmap1"), d.pop("fmap2")
-    encW, updW = _enc_weights(), upd_weights()
+    encW, updW = syn.make_module_weights(orc.encoder_shapes(), seed=3, gain=enc_gain), upd_weights()
     torch.set_num_threads(min(os.cpu_count() or 1, 64))
     want = orc.refine(d, {"upd": updW, "enc": encW}, outer=1, inner=inner, optim_iters=1, capture=True, fast=True)
     with orc.precision(torch.float64):
@@ -895,12 +898,118 @@ def test_timed_configuration_vs_oracle(ops):
     gf, wf = out["flow"][0].double().cpu(), want["trace"][0]["flow_up"].double()
     d_gc, d_g64, d_c64 = float((gf - wf).abs().max()), float((gf - w64).abs().max()), float((wf - w64).abs().max())
     d_last = float((out["flow_last"].cpu() - want["flow_up"]).abs().max())
-    print(f"first flow: |gpu-cpu| {d_gc:.3e}  |gpu-fp64| {d_g64:.3e}  |cpu-fp64| {d_c64:.3e}   last flow |gpu-cpu| {d_last:.3e}   max|flow| {float(wf.abs().max()):.1f}")
-    assert d_gc <= 1e-4 or d_g64 <= max(1e-4, 2.0 * d_c64), (d_gc, d_g64, d_c64)
-    # free-running over 8 iterations at 10x the feature magnitude of the other loops (those hold 5e-4): the CPU oracle itself starts
-    # 2e-4 away from the fp64 evaluation at iteration 1 here, so the bound scales with that distance
-    assert d_last <= max(1e-3, 8.0 * d_c64), (d_last, d_c64)
+    leg = "literal" if d_gc <= 1e-4 else ("fp64" if d_g64 <= max(1e-4, 2.0 * d_c64) else "none")
+    print(f"encoder gain {enc_gain}: first flow |gpu-cpu| {d_gc:.3e}  |gpu-fp64| {d_g64:.3e}  |cpu-fp64| {d_c64:.3e}   last flow |gpu-cpu| {d_last:.3e}   "
+          f"max|flow| {float(wf.abs().max()):.1f}   -> leg: {leg}")
+    if enc_gain < 1.0:
+        assert leg == "literal", (d_gc, d_g64, d_c64)
+        assert d_last <= 5e-4, d_last                       # free-running over 8 iterations: the drift bound of the other loops
+    else:
+        assert leg != "none", (d_gc, d_g64, d_c64)
+        # free-running over 8 iterations at 10x the feature magnitude of the other loops (those hold 5e-4): the CPU oracle itself starts
+        # 2e-4 away from the fp64 evaluation at iteration 1 here, so the bound scales with that distance
+        assert d_last <= max(1e-3, 8.0 * d_c64), (d_last, d_c64)
     assert int(out["f16x3_range_events"].item()) == 0
+
+
+@pytest.mark.parametrize("fixture", ["loop_480_g25", "loop_480"])
+def test_loop_480_vs_reference_fixture(ops, golden, fixture):
+    """the GPU path against the REFERENCE ITSELF at the headline resolution.  tests/golden/loop_480.npz was
+    produced by the reference's own BasicEncoder + GRU_CFUpdator + reprojction_optim (B = 2, 480 x 640, encoder in the loop, 1 outer
+    x 2 inner iterations, hash weights, its legacy start pose Ti * Ti.inv()).
+
+    Two fixtures: encoder weights at kaiming gain 0.25 (feature maps |f| ~ 8) and at gain 1 (|f| ~ 31, |corr| ~ 900: the harshest
+    fp32 conditioning this path sees).
+
+    (1) The gate -- north_star's tolerances on IDENTICAL INPUTS, through the reference's module boundaries: ImageFeaEncoder ->
+        GRU_CFUpdator.forward(fmap1, fmap2, flow_init, context_fea) -> descriptor weight -> reprojction_optim, every iteration started
+        from the REFERENCE's pose (iteration 1: its Ti * Ti.inv(), formed here with the torch CPU operations the reference forms
+        it with; iteration 2: the pose the fixture holds).  Pose 1e-5 and weight 1e-4 on both fixtures; the field LITERALLY at 1e-4
+        on the gain-0.25 fixture.  At gain 1 the reference's own fp32 result sits ~2e-4 px from the fp64 evaluation of the same
+        arithmetic (computed here with the oracle in fp64), so no implementation with another summation order can be within 1e-4
+        of it: there the GPU must be no further from the fp64 field than max(1e-4, the reference's own distance), and which leg
+        held is printed.
+    (2) The free-running PoseRefiner, with the literal legacy product (formed by the device kernels) and with the exact identity
+        (default): reported with a 5e-4 bound.  Both start from a pose that differs from the reference's by ~1e-7; at this resolution
+        the induced start flow is a difference of ~600-pixel coordinates in fp32 (ulp 6e-5 px), i.e. rounding noise whose pattern
+        depends on the operation order of the implementation, and un-normalised correlation features (|f| ~ 31, |corr| ~ 900)
+        turn 1e-5 px of start coordinate into 1e-4-level field differences -- the CPU oracle shows the same sensitivity to the same
+        substitution (tests/test_oracle_golden.py: 1.6e-4 with the identity, 3.7e-5 with the literal product)."""
+    from rnnpose_amd.pose_refiner import PoseRefiner, SyntheticRenderer, default_config
+    from rnnpose_amd.transformation import SE3Sequence
+    from test_oracle_golden import LOOP480, loop480_inputs
+    g = golden(fixture)
+    dt = loop480_inputs("cuda")
+    encW, updW = syn.make_module_weights(orc.encoder_shapes(), seed=3, gain=float(g["enc_gain"])), upd_weights()
+    harsh = float(g["enc_gain"]) == 1.0
+    rend = SyntheticRenderer(syn_img=dt["img_render"], image_crop=dt["img_target"], cfea=dt["ctx"], geofea1=dt["g1"], geofea2_crop=dt["g2"],
+                             syn_depth=dt["depth"], intrinsics_crop=dt["K"])
+    cfg = default_config(RENDER_ITER_COUNT=1, ITER_COUNT=LOOP480["inner"], OPTIM_ITER_COUNT=1)
+    md = lambda a, b: float((a.double().cpu() - torch.from_numpy(np.asarray(b)).double()).abs().max())
+
+    def refiner(lit):
+        ref = PoseRefiner(cfg, renderer=rend, fused=True, literal_legacy_pose=lit).cuda().eval()
+        ref.cf_net.update_block.load_state_dict({k: T(v) for k, v in updW.items()}, strict=True)
+        ref.image_fea_enc.fnet.load_state_dict({k: T(v) for k, v in encW.items()}, strict=True)
+        return ref
+
+    # ---- (1) identical inputs, module by module
+    ref = refiner(False)
+    with torch.no_grad():
+        f1, f2 = ref.image_fea_enc(dt["img_render"], dt["img_target"])
+    fmax = float(g["max_abs_fmap"].max())
+    d_f = max(md(f1[:, ::16, ::5, ::5], g["fmap1_sub"]), md(f2[:, ::16, ::5, ::5], g["fmap2_sub"]))
+    assert d_f < 1e-5 * fmax, (d_f, fmax)                                  # encoder output after 20 layers + instance norms of an almost constant image: the bound the CPU oracle is held to (|f| up to 31)
+    Gc = dt["G0"].cpu().reshape(-1, 4, 4)                                    # Ti * Ti.inv() as geometry/se3.py:194-208 + transformation.py:95-98 do
+    Rt = Gc[:, :3, :3].permute(0, 2, 1)
+    Ginv = torch.cat([torch.cat([Rt, -torch.matmul(Rt, Gc[:, :3, 3:])], -1), torch.tensor([0.0, 0.0, 0.0, 1.0]).reshape(1, 1, 4).repeat(Gc.shape[0], 1, 1)], -2)
+    Tij = torch.matmul(Gc, Ginv).reshape(-1, 1, 4, 4)
+    depth_c, K_c = dt["depth"].cpu().numpy(), dt["K"].cpu().numpy()
+    gate = {}
+    for it, (key_f, upd) in enumerate((("flow_first", True), ("flow_last", False))):
+        flow_init, _ = orc.induced_flow(depth_c, K_c, Tij)                   # (the oracle's restatement of PoseRefiner.py:324-328, pinned above)
+        with torch.no_grad():
+            flow_up = ref.cf_net(f1, f2, flow_init=flow_init.cuda(), context_fea=dt["ctx"], update_corr_fn=upd)[-1]
+        wmap = ops.corr_weight(dt["g1"], dt["g2"], flow_up, dt["depth"], dt["sigma"])
+        Gn, _, _, xi, _ = ops.lm_step(flow_up, wmap, dt["depth"], dt["K"], Tij.cuda(), num_iters=1)
+        gate[it] = dict(flow=md(flow_up[:, :, ::8, ::8], g[key_f]), pose=md(Gn[:, None], g["G_iters"][it]),
+                        weight=md(wmap[:, ::8, ::8], g["w_first" if it == 0 else "w_last"]))
+        Tij = torch.from_numpy(np.asarray(g["G_iters"][it]))                 # teacher forcing: the REFERENCE's pose starts the next iteration
+    print(fixture, "identical inputs, GPU vs the reference:", gate)
+    for it in gate:
+        assert gate[it]["pose"] < 1e-5 and gate[it]["weight"] < 1e-4, (it, gate[it])
+    if not harsh:
+        assert gate[0]["flow"] < 1e-4 and gate[1]["flow"] < 1e-4, gate                       # the literal gate
+    else:
+        # fp64 yardstick of the first iteration: the same arithmetic, same literal start pose, evaluated in double precision
+        d = {k: v.cpu().numpy() for k, v in dt.items() if k not in ("fmap1", "fmap2")}
+        torch.set_num_threads(min(os.cpu_count() or 1, 64))
+        with orc.precision(torch.float64):
+            w64 = orc.refine(d, {"upd": updW, "enc": encW}, outer=1, inner=1, optim_iters=1, capture=True, fast=True,
+                             literal_legacy_pose=True)["trace"][0]["flow_up"][:, :, ::8, ::8].double()
+        with torch.no_grad():
+            f_gpu = ref.cf_net(f1, f2, flow_init=orc.induced_flow(depth_c, K_c, torch.matmul(Gc, Ginv).reshape(-1, 1, 4, 4))[0].cuda(),
+                               context_fea=dt["ctx"], update_corr_fn=True)[-1][:, :, ::8, ::8].double().cpu()
+        d_ref64 = float((torch.from_numpy(np.asarray(g["flow_first"])).double() - w64).abs().max())
+        d_gpu64 = float((f_gpu - w64).abs().max())
+        leg = "literal" if gate[0]["flow"] < 1e-4 else "fp64"
+        print(f"{fixture}: first field |gpu - reference| {gate[0]['flow']:.3e}, |reference - fp64| {d_ref64:.3e}, |gpu - fp64| {d_gpu64:.3e} -> leg: {leg}")
+        assert gate[0]["flow"] < 1e-4 or d_gpu64 <= max(1e-4, d_ref64), (gate, d_ref64, d_gpu64)
+        assert gate[0]["flow"] < 5e-4 and gate[1]["flow"] < 5e-4, gate
+    # ---- (2) free-running refiner, both start-pose forms
+    dist = {}
+    for lit in (True, False):
+        ref = refiner(lit)
+        out = ref(dt["img_target"], SE3Sequence(matrix=dt["G0"].clone()), dt["K"])
+        Gi = torch.stack([t.G for t in ref.residual_pose_history]).cpu()
+        dist[lit] = dict(pose=max(md(Gi, g["G_iters"]), md(out["Ti_pred"].G, g["G_final"])),
+                         flow_first=md(out["flow"][0][:, :, ::8, ::8], g["flow_first"]),
+                         flow_last=md(out["flow_last"][:, :, ::8, ::8], g["flow_last"]),
+                         w_last=md(out["weight"][:, 0, 0, ::8, ::8], g["w_last"]))
+        assert int(out["f16x3_range_events"].item()) == 0
+    print(fixture, "free-running GPU refiner vs the reference: literal Ti*Ti^-1:", dist[True], " exact identity (default):", dist[False])
+    for lit in (True, False):
+        assert dist[lit]["pose"] < 1e-5 and dist[lit]["flow_first"] < 5e-4 and dist[lit]["flow_last"] < 1e-3, (lit, dist[lit])
 
 
 @pytest.mark.parametrize("B", [16, 32])
