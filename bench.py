@@ -60,7 +60,15 @@ def parse():
     ap.add_argument("--no-encoder", action="store_true", help="feed synthetic feature maps (kernel-only runs)")
     ap.add_argument("--unfused", action="store_true", help="literal reference call sequence through the facade")
     ap.add_argument("--no-graph", action="store_true", help="eager launches only (no hipGraph replay; for counter passes)")
-    return ap.parse_args()
+    ap.add_argument("--workload", choices=["cfg1", "cfg4"], default=None,
+                    help="a BASELINE.json configuration verbatim: cfg1 = configs[1] (640x480, batch 8/GPU, 3x8: the default), cfg4 = "
+                         "configs[4] (1280x960 high-res, batch 8/GPU = batch 64 over 8 GPUs, 3x8)")
+    args = ap.parse_args()
+    if args.workload == "cfg4":
+        args.batch, args.height, args.width, args.outer, args.inner = 8, 960, 1280, 3, 8
+    elif args.workload == "cfg1":
+        args.batch, args.height, args.width, args.outer, args.inner = 8, 480, 640, 3, 8
+    return args
 
 
 def spawn_ranks(n):
@@ -226,7 +234,8 @@ def main():
     device = torch.device("cuda", local % torch.cuda.device_count())
     torch.cuda.set_device(device)
     from rnnpose_amd import build, ops
-    build.build()
+    D.build_once(build.build)                       # rank 0 compiles, the others wait at a barrier and then only check the stamp
+    host_threads = D.pin_host_threads(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)), max_threads=64 if world == 1 else 16)
     from rnnpose_amd.pose_refiner import PoseRefiner, default_config
     from rnnpose_amd.transformation import SE3Sequence
 
@@ -261,7 +270,10 @@ def main():
         step()
     torch.cuda.synchronize()
     D.barrier()
-    dt = D.max_over_ranks(time.perf_counter() - t0)
+    dt_rank = time.perf_counter() - t0
+    dt = D.max_over_ranks(dt_rank)
+    seen = D.ranks_seen()                            # the collective's own count of ranks (must equal n_gpus)
+    per_rank = D.gather_values(args.steps * args.outer * args.inner / dt_rank)
     prof = ops.summarize(rec)
     prof_steps = (1.0 / args.outer) if (args.outer > 1 and not args.unfused) else 1.0     # fraction of one step that was instrumented
 
@@ -309,21 +321,28 @@ def main():
     dom = max(prof.items(), key=lambda kv: kv[1][2])[0] if prof else None
     roofline = None
     if dom == "rnnpose_conv2d_nhwc_f16x3":
-        n, mean_ms, tot_ms, work, _ = prof[dom]
-        ach = 3 * work / (tot_ms * 1e-3) / 1e12
-        roofline = {"kernel": "conv_igemm_f16x3_kernel (NHWC implicit-GEMM convolution, fp16x3-split MFMA = fp32-class accuracy; "
-                              "all update-block and encoder convolutions but the stem)",
-                    "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_F16_MFMA_TFLOPS, 4), "traffic": tr("conv_igemm"), "traffic_note": traffic_note,
-                    "note": "achieved = EXECUTED fp16 MFMA flops (3 products per algorithmic multiply-add: SURVEY 8d's 2*MAC count "
-                            "of every launch x 3) / summed HIP-event duration of those launches.  In the event-instrumented outer "
-                            "iteration every launch goes to ONE stream, so each is timed alone on the chip (the same durations "
-                            "rocprofv3's kernel trace reports: profiles/).  The production schedule runs two half-batch chains "
-                            "concurrently on two streams: chip_level is the aggregate over the whole step",
-                    "frac_label": "mfma_pipe_util: EXECUTED fp16 flops / fp16 dense peak (3 MFMAs per algorithmic multiply-add)",
-                    "frac_algorithmic": round(work / (tot_ms * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4),
-                    "fp32_equivalent_TFLOPps": round(work / (tot_ms * 1e-3) / 1e12, 1),
-                    "fp32_equivalent_over_f32_mfma_peak": round(work / (tot_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 3),
+        n, mean_ms, tot_ms, work, nbytes = prof[dom]
+        ach_alg = work / (tot_ms * 1e-3) / 1e12                   # 2 * MAC of every launch / its duration
+        ach_exec = 3 * ach_alg                                    # one algorithmic multiply-add = three fp16 MFMA products (fp16x3 split)
+        roofline = {"kernel": "conv_strip_f16x3_kernel + conv_igemm_f16x3_kernel (NHWC implicit-GEMM convolutions, fp16x3-split MFMA = fp32-class "
+                              "accuracy: csrc/conv_strip.hip takes the stride-1 3x3 / 1x5 / 5x1 layers of maps that fill the chip with 160-row "
+                              "strips, csrc/conv_igemm.hip the rest; all update-block and encoder convolutions but the stem)",
+                    "bound": "mfma", "achieved": round(ach_alg, 1), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach_alg / PEAK_F16_MFMA_TFLOPS, 4),
+                    "frac_label": "ALGORITHMIC flops (SURVEY 8d: 2 * multiply-adds of the convolution) / duration / fp16 dense MFMA peak",
+                    "pipe_util": round(ach_exec / PEAK_F16_MFMA_TFLOPS, 4),
+                    "pipe_util_label": "EXECUTED fp16 MFMA flops (3 products per algorithmic multiply-add) / duration / fp16 dense peak",
+                    "executed_fp16_TFLOPps": round(ach_exec, 1),
+                    "traffic": tr("conv"), "traffic_note": traffic_note,
+                    "algorithmic_bytes_per_launch": int(nbytes / n) if nbytes else None,
+                    "traffic_over_algorithmic": (round(tr("conv") / (nbytes / n), 3) if (tr("conv") and nbytes) else None),
+                    "note": "achieved = ALGORITHMIC flops of the timed launches / their summed HIP-event duration.  In the event-instrumented "
+                            "outer iteration every launch goes to ONE stream, so each is timed alone on the chip (the same durations "
+                            "rocprofv3's kernel trace reports: profiles/).  traffic = mean HBM bytes per launch of both kernel families from the "
+                            "FETCH_SIZE / WRITE_SIZE counter passes over the same command, algorithmic_bytes_per_launch = the mean over the "
+                            "same launches of inputs + weights + outputs + epilogue operands.  The production schedule runs two half-batch "
+                            "chains concurrently on two streams: chip_level is the aggregate over the whole step",
+                    "fp32_equivalent_over_f32_mfma_peak": round(ach_alg / PEAK_F32_MFMA_TFLOPS, 3),
                     "launches_timed": n,
                     "mean_ms": round(mean_ms, 4), "share_of_step": round(tot_ms / prof_steps / ms_step, 4),
                     "algorithmic_flops_timed": work}
@@ -357,10 +376,15 @@ def main():
                 corr_vol["executed_fp16_TFLOPps"] = round(3 * work / (tot_ms * 1e-3) / 1e12, 1)
             break
     is_cfg1 = (B, H, W, args.outer, args.inner) == (8, 480, 640, 3, 8)
-    cfg_label = "BASELINE.json configs[1]" if is_cfg1 else "NOT the headline configuration: a different shape of the same workload"
+    is_cfg4 = (B, H, W, args.outer, args.inner) == (8, 960, 1280, 3, 8)
+    cfg_label = ("BASELINE.json configs[1]" if is_cfg1 else
+                 f"BASELINE.json configs[4]: 1280x960 high-res, global batch {8 * world} data-parallel over {world} GPU(s) -- NOT the headline configuration" if is_cfg4
+                 else "NOT the headline configuration: a different shape of the same workload")
     res = {
         "metric": "pose-refine iters/sec (640x480, B=8, 3x8 recurrent)", "value": round(value, 3), "unit": "iters/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
+        "n_gpus": world, "ranks_seen": seen, "dist_backend": D.backend_name() + (" (RCCL)" if D.backend_name() == "nccl" else ""),
+        "per_rank_iters_per_sec": [round(v, 2) for v in per_rank], "host_threads_per_rank": host_threads,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32 (convolutions and volume build: fp16x3-split MFMA, fp32-class accuracy; LM: f64)",
         "data": "synthetic", "image_iters_per_sec": round(value * B, 2),
@@ -386,6 +410,8 @@ def main():
         res["cpu_baseline"] = None
         res["parity"] = None
     res["f16x3_range_events"] = int(ops.saturation_count(reset=False))     # clamped activation quads over the whole run (sticky counter)
+    if seen != world:
+        raise SystemExit(f"bench.py: the collective reached {seen} ranks, the line would claim {world}")
     print(json.dumps(res))
     if res["parity"] is not None and not res["parity"]["ok"]:
         raise SystemExit("bench.py: the timed configuration is OUTSIDE the parity tolerances against the CPU oracle "

@@ -98,9 +98,7 @@ def max_over_ranks(seconds: float, device=None) -> float:
     """all_reduce(MAX) of one double -- the throughput clock of bench.py."""
     if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
         return seconds
-    if device is None:
-        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else "cpu"
-    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    t = torch.tensor([seconds], dtype=torch.float64, device=_coll_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -108,3 +106,70 @@ def max_over_ranks(seconds: float, device=None) -> float:
 def barrier():
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()
+
+
+def backend_name() -> str:
+    """"nccl" (= RCCL on ROCm) / "gloo" / "none" (single process)."""
+    return dist.get_backend() if (dist.is_available() and dist.is_initialized()) else "none"
+
+
+def _coll_device(device=None):
+    if device is not None:
+        return device
+    return torch.device("cuda", torch.cuda.current_device()) if backend_name() == "nccl" else "cpu"
+
+
+def ranks_seen(device=None) -> int:
+    """all_reduce(SUM) of a one per rank: how many ranks the collective actually reached (bench.py prints it next to n_gpus,
+    so that a line produced by fewer ranks than it claims cannot pass)."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return 1
+    t = torch.ones(1, dtype=torch.float64, device=_coll_device(device))
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(round(float(t.item())))
+
+
+def gather_values(value: float, device=None) -> list:
+    """Every rank's `value` on every rank, in rank order (one all_reduce(SUM) of a one-hot vector: the path has no other
+    collective to piggy-back on)."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return [float(value)]
+    t = torch.zeros(dist.get_world_size(), dtype=torch.float64, device=_coll_device(device))
+    t[dist.get_rank()] = float(value)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(x) for x in t.cpu()]
+
+
+def build_once(build_fn):
+    """Rank 0 compiles (or finds the stamp) while the others wait at a barrier, then every rank calls build_fn -- a stamp
+    check for all but rank 0.  N ranks racing for the build lock is correct (rnnpose_amd/build.py holds a file lock) but makes
+    N-1 processes sit in flock behind a minute of hipcc; this makes the order explicit."""
+    world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+    rank = dist.get_rank() if world > 1 else 0
+    out = build_fn() if rank == 0 else None
+    barrier()
+    return out if rank == 0 else build_fn()
+
+
+def pin_host_threads(local_rank: int, local_world: int, max_threads: int = 16) -> int:
+    """Give this rank its own slice of the host cores (sched_setaffinity) and cap torch's intra-op threads: N ranks x
+    torch.get_num_threads() = all cores each would oversubscribe the host as soon as any rank does CPU work (the oracle legs of
+    bench.py run at world size 1 only, but tensor construction / hashing of synthetic inputs does not).  -> threads in use."""
+    n = os.cpu_count() or 1
+    per = max(1, n // max(1, local_world))
+    lo = (local_rank % max(1, local_world)) * per
+    try:
+        avail = sorted(os.sched_getaffinity(0))
+        if len(avail) >= local_world:                    # slice what this process is actually allowed to use
+            per = max(1, len(avail) // local_world)
+            mine = avail[(local_rank % local_world) * per:(local_rank % local_world + 1) * per]
+        else:
+            mine = list(range(lo, min(n, lo + per)))
+        if mine:
+            os.sched_setaffinity(0, mine)
+            per = len(mine)
+    except (AttributeError, OSError):
+        pass
+    t = max(1, min(per, max_threads))
+    torch.set_num_threads(t)
+    return t

@@ -571,8 +571,14 @@ def conv2d_nhwc(pc: PackedConv, srcs, dst, epilogue: int = EPI_LINEAR, aux0=None
         d.dst_split, d.dst_split_c_stride, d.dst_split_c_offset = t.data_ptr(), t.shape[3], off
     if ksplit_ws is not None:
         d.ksplit_ws, d.ksplit_ws_bytes = ksplit_ws.data_ptr(), ksplit_ws.numel() * ksplit_ws.element_size()
+    Ho, Wo = -(-H // stride), -(-W // stride)
+    # algorithmic bytes of the launch: every input element and weight read once, every output written once, the
+    # epilogue's operands (additive map; h of the gate, h and z of the state update) read once -- 4 bytes each
+    nb = B * H * W * pc.c_in_real + pc.c_out * pc.c_in_real * pc.kh * pc.kw + B * Ho * Wo * pc.c_out
+    nb += B * Ho * Wo * pc.c_out * (add_map is not None) + B * Ho * Wo * (gru_c if epilogue == EPI_GRU_ZR else 0)
+    nb += 2 * B * Ho * Wo * pc.c_out * (epilogue == EPI_GRU_Q) + B * Ho * Wo * pc.c_out * (dst_split is not None)
     _launch("rnnpose_conv2d_nhwc_f16x3", C.byref(d), _stream(),
-            work=2.0 * B * (-(-H // stride)) * (-(-W // stride)) * pc.c_out * pc.c_in_real * pc.kh * pc.kw)
+            work=2.0 * B * Ho * Wo * pc.c_out * pc.c_in_real * pc.kh * pc.kw, nbytes=4.0 * nb)
 
 
 def conv_tiles_per_image(H, W, kh, kw, stride=1, c_out=None, tile: int = 0) -> int:

@@ -28,6 +28,13 @@ def _worker(rank, world, port, n_items, q):
     D.barrier()
     res = acc.reduce()
     t = D.max_over_ranks(1.0 + rank)
+    # first-contact helpers of bench.py
+    assert D.ranks_seen() == world and D.backend_name() == "gloo"
+    assert D.gather_values(rank + 0.5) == [r + 0.5 for r in range(world)]
+    calls = []
+    assert D.build_once(lambda: calls.append(rank) or "lib") == "lib" and calls == [rank]      # every rank ends with the build result
+    nthr = D.pin_host_threads(rank, world, max_threads=4)
+    assert 1 <= nthr <= 4 and torch.get_num_threads() == nthr
     q.put((rank, res, t, idx))
     torch.distributed.destroy_process_group()
 
@@ -55,3 +62,40 @@ def test_two_rank_metric_reduction():
         assert abs(res["glue"]["proj2d"] - sum(glue) / len(glue)) < 1e-12
         assert res["cat"]["add2"] == 1.0
     assert sorted(outs[0][3] + outs[1][3]) == sorted(items + [0])    # one wrap-around duplicate
+
+
+def _nccl_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    from rnnpose_amd import distributed as D
+    r, w, local = D.init_from_env()                       # backend "nccl" = RCCL, communicator bound to this rank's device
+    assert D.backend_name() == "nccl" and torch.cuda.current_device() == local
+    acc = D.MetricAccumulator(("cat",))
+    acc.update("cat", dict(add=float(rank)), unique=True)
+    res = acc.reduce()
+    q.put((rank, D.ranks_seen(), D.gather_values(10.0 + rank), D.max_over_ranks(1.0 + rank), res["cat"]["add"], res["cat"]["n"]))
+    D.barrier()
+    torch.distributed.destroy_process_group()
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="the RCCL path needs two devices (one rank per GPU): first executed by the driver's multi-GPU run")
+def test_two_rank_rccl_on_two_devices():
+    """The `nccl` (= RCCL) branch of distributed.init_from_env on real devices: one rank per GPU, device-bound communicator, the
+    packed metric all_reduce(SUM), the MAX clock, ranks_seen.  Skipped on single-GPU boxes (every gpurun lease of this build)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_nccl_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for rank, seen, vals, t, add, n in outs:
+        assert seen == 2 and vals == [10.0, 11.0] and t == 2.0 and n == 2 and abs(add - 0.5) < 1e-12

@@ -107,7 +107,7 @@ kern = pmc("k", f"{TAG}_pmc_kernels.json")
 pmc("c", f"{TAG}_pmc_convs.json", by_grid=True)
 bench = pmc("b", f"{TAG}_pmc_traffic_bench.json")
 src_of = {}
-for key, pat in (("conv_igemm", r"^conv_igemm_f16x3_kernel"), ("corr_pyramid_h3", r"corr_pyramid_h3_kernel"), ("corr_pyramid", r"corr_pyramid_kernel")):
+for key, pat in (("conv", r"^conv_(igemm|strip)_f16x3_kernel"), ("corr_pyramid_h3", r"corr_pyramid_h3_kernel"), ("corr_pyramid", r"corr_pyramid_kernel")):
     for table, label in ((bench, f"{TAG}_pmc_traffic_bench.json"), (kern, f"{TAG}_pmc_kernels.json")):
         rows = [v for k, v in table.items() if re.search(pat, k) and "HBM_MB" in v]
         if rows:
