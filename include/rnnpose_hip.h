@@ -39,8 +39,13 @@ int rnnpose_device_info(int dev, char* h_name, int name_len, int* h_cus);
 
 /* ---- a1+a2: all-pairs correlation volume + pyramid ------------- thirdparty/raft/corr.py:13-34,59-67
  * level 0: corr[b,i,j] = sum_c fmap1[b,c,i]*fmap2[b,c,j] / sqrt(C); level l = 2x2 mean of level l-1
- * (floor cropping).  `pyramid` is ONE buffer holding all levels back to back, level l laid out as
- * (B*h*w, h_l, w_l); sizes/offsets (in floats) come from rnnpose_corr_pyramid_layout.
+ * (floor cropping).  `pyramid` is ONE buffer holding all levels back to back; sizes/offsets (in floats) come from
+ * rnnpose_corr_pyramid_layout.  Levels 1.. are laid out as (B*h*w, h_l, w_l).  LEVEL 0 (r04) is stored J-PATCH-MAJOR:
+ * [b][patch py * ceil(w/16) + px][i][8][16], i.e. corr[b,i,(y,x)] sits at
+ *     ((b * n_patch + (y >> 3) * ceil(w/16) + (x >> 4)) * h*w + i) * 128 + (y & 7) * 16 + (x & 15),   n_patch = ceil(h/8) ceil(w/16)
+ * (whole 8 x 16 patches: cells outside the image hold zeros).  The volume kernel's 128 (i) x one-patch tile then leaves the
+ * chip as one contiguous 64-KB run and the lookup's 10 x 10 window reads a few contiguous patch rows instead of ten rows
+ * 4*w bytes apart.  Only the lookup entry points read it; rnnpose_amd.ops.pyramid_level0_dense un-blocks it for inspection.
  * fmap1,fmap2: (B,C,h,w) fp32, C % 4 == 0.                                                       */
 int rnnpose_corr_pyramid_layout(int B, int h, int w, int levels, int64_t* h_offsets /*[levels+1]*/,
                                 int* h_hl /*[levels]*/, int* h_wl /*[levels]*/);

@@ -17,8 +17,9 @@ def coords_grid(batch, ht, wd, device=None):
 class CorrBlock:
     """corr_fn = CorrBlock(fmap1, fmap2, num_levels=4, radius=4); corr = corr_fn(coords)
 
-    `corr_pyramid` is the list of (B*h*w, 1, h_l, w_l) levels like the reference's attribute; they are
-    views into one device buffer (all levels are produced by a single kernel launch)."""
+    `corr_pyramid` is the list of (B*h*w, 1, h_l, w_l) levels like the reference's attribute (ops.PyramidLevels: levels 1.. are
+    views into the one device buffer a single kernel launch fills; level 0, which the buffer holds j-patch-major for the store and
+    lookup kernels, is un-blocked into a copy when it is asked for)."""
 
     def __init__(self, fmap1, fmap2, num_levels=4, radius=4, downsample_rate=1, reuse=None, precision="f32"):
         if downsample_rate != 1:

@@ -29,6 +29,7 @@ struct LookupInfo {
   long long off[RNNPOSE_MAX_LEVELS];
   int hl[RNNPOSE_MAX_LEVELS];
   int wl[RNNPOSE_MAX_LEVELS];
+  int n_px, n_patch;          // level 0 is stored j-patch-major: [image][8 x 16 patch][i][8][16] (csrc/corr_pyramid.hip)
 };
 
 __global__ __launch_bounds__(64) void corr_lookup_kernel(const float* __restrict__ pyr, const float* __restrict__ coords,
@@ -46,6 +47,9 @@ __global__ __launch_bounds__(64) void corr_lookup_kernel(const float* __restrict
 
   float cx = 0.f, cy = 0.f;
   int b = 0, pix = 0;
+  // row of this lane's pixel in the pyramid (image of the WHOLE batch the pyramid was built for, pixel inside it)
+  const long long prow = p_off + (p < total ? p : total - 1);
+  const int bg = static_cast<int>(prow / N), pixg = static_cast<int>(prow - static_cast<long long>(bg) * N);
   if (live) {
     b = static_cast<int>(p / N);
     pix = static_cast<int>(p - static_cast<long long>(b) * N);
@@ -83,12 +87,20 @@ __global__ __launch_bounds__(64) void corr_lookup_kernel(const float* __restrict
       const int q = qb + j;
       const int qq = q < npix ? q : npix - 1;
       const int qbx = __shfl(bx, qq), qby = __shfl(by, qq);
-      const float* src = lvl_base + (p_off + first + qq) * img;       // p_off: first pyramid row of this launch's images
       const int xa = qbx + tx0, ya = qby + ty0, xb = qbx + tx1, yb = qby + ty1;
       const bool oka = xa >= 0 && xa < wl && ya >= 0 && ya < hl;
       const bool okb = has1 && xb >= 0 && xb < wl && yb >= 0 && yb < hl;
-      v0[j] = src[oka ? ya * wl + xa : 0];
-      v1[j] = src[okb ? yb * wl + xb : 0];
+      if (lvl == 0) {        // j-patch-major: texel (y, x) of pixel i = patch ((y >> 3) n_px + (x >> 4)), row i, cell (y & 7, x & 15)
+        const int qbg = __shfl(bg, qq), qpix = __shfl(pixg, qq);
+        const float* src = lvl_base + (static_cast<long long>(qbg) * info.n_patch * N + qpix) * 128;
+        const long long pstride = static_cast<long long>(N) * 128;
+        v0[j] = src[oka ? ((ya >> 3) * info.n_px + (xa >> 4)) * pstride + (ya & 7) * 16 + (xa & 15) : 0];
+        v1[j] = src[okb ? ((yb >> 3) * info.n_px + (xb >> 4)) * pstride + (yb & 7) * 16 + (xb & 15) : 0];
+      } else {
+        const float* src = lvl_base + (p_off + first + qq) * img;     // p_off: first pyramid row of this launch's images
+        v0[j] = src[oka ? ya * wl + xa : 0];
+        v1[j] = src[okb ? yb * wl + xb : 0];
+      }
       ok |= (oka ? 1u : 0u) << (2 * j) | (okb ? 2u : 0u) << (2 * j);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -154,6 +166,8 @@ static int launch_lookup(const char* fn, const float* pyramid, const float* coor
   int64_t offs[RNNPOSE_MAX_LEVELS + 1];
   LookupInfo info{};
   if (int e = rnnpose_corr_pyramid_layout(B_total, h, w, levels, offs, info.hl, info.wl)) return e;
+  info.n_px = rp::cdiv(w, 16);
+  info.n_patch = rp::cdiv(h, 8) * info.n_px;
   for (int l = 0; l < levels; ++l) {
     info.off[l] = offs[l];
     // the reference divides by (W_l - 1): a 1-wide level yields inf/NaN there

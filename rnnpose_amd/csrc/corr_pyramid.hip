@@ -120,7 +120,7 @@ template <bool ALIGNED>
 __device__ __forceinline__ void pyramid_epilogue(const f32x16& acc0, const f32x16& acc1, const f32x16& acc2,
                                                  const f32x16& acc3, float* smem, float* __restrict__ pyr,
                                                  const PyrInfo& info, int b, int N, int h, int w, int i0, int y0, int x0,
-                                                 float scale, int wave, int lane) {
+                                                 float scale, int wave, int lane, int patch, int n_patch) {
   const int kh = lane >> 5, l31 = lane & 31;
   const f32x16 acc[4] = {acc0, acc1, acc2, acc3};
   const int Nm = ((RPC_ABL & 2) && scale != 1234.5f) ? 0 : N;      // diagnostics: every store below is masked by i < Nm
@@ -130,7 +130,11 @@ __device__ __forceinline__ void pyramid_epilogue(const f32x16& acc0, const f32x1
   float* L1 = S + 1024;             // [32 i][4 Y1][8 X1]
   float* L2 = S + 2048;             // [32 i][2 Y2][4 X2]
   const int iw = i0 + wave * 32;    // first i row of this wave
-  float* p0 = pyr + info.off[0] + static_cast<long long>(b) * N * N;
+  // level 0 is stored J-PATCH-MAJOR (r04): [image][8 x 16 patch of j][i][8][16] -- the 128 i rows x one patch of a workgroup are
+  // ONE contiguous 64-KB run (a wave: 16 KB), rows of other i tiles of the same patch follow it.  r03's row-major level 0 left the
+  // chip as 64-byte pieces 19 KB apart (3.6-4.3 TB/s in the store-pattern probe against 5.9-6.5 for linear runs).  Patches at the
+  // image border are stored whole: their columns outside the image were multiplied with zero rows.
+  float* p0 = pyr + info.off[0] + (static_cast<long long>(b) * n_patch + patch) * N * BN;
   const int h1 = info.hl[1], w1 = info.wl[1];
   float* p1 = info.levels > 1 ? pyr + info.off[1] + static_cast<long long>(b) * N * h1 * w1 : nullptr;
 
@@ -150,22 +154,15 @@ __device__ __forceinline__ void pyramid_epilogue(const f32x16& acc0, const f32x1
       const int row = f >> 3;
       const int c = (f & 7) << 2;
       const int yy = c >> 4, xx = c & 15;
-      const int i = iw + row, y = y0 + 2 * s + yy, x = x0 + xx;
-      if (i < Nm0 && y < h) {
+      const int i = iw + row;
+      if (i < Nm0) {
         const float4 v = *reinterpret_cast<const float4*>(S + row * 32 + c);
-        float* dst = p0 + static_cast<long long>(i) * N + static_cast<long long>(y) * w + x;
-        if (ALIGNED && x + 3 < w) {
-          if (RPC_NT) {
-            const f4v vv = {v.x, v.y, v.z, v.w};
-            __builtin_nontemporal_store(vv, reinterpret_cast<f4v*>(dst));
-          } else {
-            *reinterpret_cast<float4*>(dst) = v;
-          }
+        float* dst = p0 + static_cast<long long>(i) * BN + (2 * s + yy) * PX + xx;      // 16-byte aligned (layout offsets are multiples of 4)
+        if (RPC_NT) {
+          const f4v vv = {v.x, v.y, v.z, v.w};
+          __builtin_nontemporal_store(vv, reinterpret_cast<f4v*>(dst));
         } else {
-          if (x + 0 < w) dst[0] = v.x;
-          if (x + 1 < w) dst[1] = v.y;
-          if (x + 2 < w) dst[2] = v.z;
-          if (x + 3 < w) dst[3] = v.w;
+          *reinterpret_cast<float4*>(dst) = v;
         }
       }
     }
@@ -296,7 +293,7 @@ __global__ __launch_bounds__(NT) void corr_pyramid_kernel(const float* __restric
   }
 
   // ---------------------------------- epilogue ----------------------------------
-  pyramid_epilogue<ALIGNED>(acc[0], acc[1], acc[2], acc[3], smem, pyr, info, b, N, h, w, i0, y0, x0, scale, wave, lane);
+  pyramid_epilogue<ALIGNED>(acc[0], acc[1], acc[2], acc[3], smem, pyr, info, b, N, h, w, i0, y0, x0, scale, wave, lane, patch, n_patch);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -511,7 +508,7 @@ __global__ __launch_bounds__(NT, 2) void corr_pyramid_h3_kernel(const _Float16* 
 #undef RPH_LOAD
 #undef RPH_STORE
 #undef RPH_ST
-  pyramid_epilogue<ALIGNED>(acc0, acc1, acc2, acc3, smem, pyr, info, b, N, h, w, i0, y0, x0, scale, wave, lane);
+  pyramid_epilogue<ALIGNED>(acc0, acc1, acc2, acc3, smem, pyr, info, b, N, h, w, i0, y0, x0, scale, wave, lane, patch, n_patch);
 }
 
 }  // namespace
@@ -530,7 +527,8 @@ int rnnpose_corr_pyramid_layout(int B, int h, int w, int levels, int64_t* h_offs
     if (h_offsets) h_offsets[l] = off;
     if (h_hl) h_hl[l] = hl;
     if (h_wl) h_wl[l] = wl;
-    off += rows * hl * wl;
+    // level 0: j-patch-major, whole 8 x 16 patches (see pyramid_epilogue); levels 1..: (B*h*w, hl, wl) row-major
+    off += l == 0 ? rows * rp::cdiv(h, PY) * rp::cdiv(w, PX) * BN : rows * hl * wl;
   }
   if (h_offsets) h_offsets[levels] = off;
   return 0;

@@ -111,6 +111,57 @@ def pyramid_layout(B, h, w, levels=4):
     return list(offs), list(hl), list(wl)
 
 
+def pyramid_level0_dense(buf, B, h, w):
+    """Level 0 of a pyramid buffer in the reference's shape (B*h*w, 1, h, w): the buffer holds it j-patch-major
+    ([b][8 x 16 patch][i][8][16], include/rnnpose_hip.h); a COPY made with torch indexing -- for the CorrBlock facade's
+    `corr_pyramid` attribute and for tests, never on the refinement path (1 GB at the headline shape)."""
+    N, npy, npx = h * w, -(-h // 8), -(-w // 16)
+    v = buf[:B * npy * npx * N * 128].view(B, npy, npx, N, 8, 16)
+    return v.permute(0, 3, 1, 4, 2, 5).reshape(B * N, 1, npy * 8, npx * 16)[:, :, :h, :w].contiguous()
+
+
+def pyramid_from_levels(levels):
+    """Inverse of PyramidLevels: the reference-shaped list [(B*h*w, 1, h_l, w_l)] -> the flat buffer the lookup kernels read
+    (level 0 re-blocked j-patch-major with zero padding).  For the dispatcher-level operator set (torch_ops), which carries the
+    pyramid as Tensor[]; the refinement path never leaves the buffer form."""
+    l0 = levels[0]
+    BN, _, h, w = l0.shape
+    N = h * w
+    B = BN // N
+    npy, npx = -(-h // 8), -(-w // 16)
+    p = torch.nn.functional.pad(l0[:, 0], (0, npx * 16 - w, 0, npy * 8 - h))
+    blocked = p.view(B, N, npy, 8, npx, 16).permute(0, 2, 4, 1, 3, 5).reshape(-1)
+    return torch.cat([blocked] + [lv.reshape(-1) for lv in levels[1:]])
+
+
+class PyramidLevels:
+    """The levels of a pyramid buffer as the reference's list of (B*h*w, 1, h_l, w_l) tensors (thirdparty/raft/corr.py:23-34),
+    materialised on access: levels 1.. are views of the buffer, level 0 is un-blocked into a copy (pyramid_level0_dense)."""
+
+    def __init__(self, buf, offs, hl, wl, B, h, w):
+        self.buf, self.offs, self.hl, self.wl, self.B, self.h, self.w = buf, offs, hl, wl, B, h, w
+
+    def __len__(self):
+        return len(self.hl)
+
+    def __getitem__(self, l):
+        if isinstance(l, slice):
+            return [self[i] for i in range(*l.indices(len(self)))]
+        l = range(len(self))[l]
+        if l == 0:
+            return pyramid_level0_dense(self.buf, self.B, self.h, self.w)
+        return self.buf[self.offs[l]:self.offs[l + 1]].view(self.B * self.h * self.w, 1, self.hl[l], self.wl[l])
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+
+def _pyramid_bytes(B, Cc, h, w, levels, hl, wl):
+    """algorithmic bytes of a volume build: both operands read once, every pyramid cell written once (fp32) --
+    without the padding cells of level 0's border patches"""
+    return 4.0 * (2 * B * h * w * Cc + B * h * w * sum(hl[l] * wl[l] for l in range(levels)))
+
+
 def corr_pyramid(fmap1, fmap2, levels: int = 4, out=None, precision: str = "f32"):
     """fmap1,fmap2 (B,C,h,w) -> (flat buffer, [views (B*h*w,1,h_l,w_l)])   thirdparty/raft/corr.py:13-34.
     `out`: an existing flat buffer of the right size to overwrite (keeps the address stable for captured graphs).
@@ -127,9 +178,8 @@ def corr_pyramid(fmap1, fmap2, levels: int = 4, out=None, precision: str = "f32"
     buf = out if (out is not None and out.numel() == offs[-1] and out.device == fmap1.device) else \
         torch.empty(offs[-1], device=fmap1.device, dtype=F32)
     _launch("rnnpose_corr_pyramid_f32", _ptr(fmap1), _ptr(fmap2), B, Cc, h, w, levels, _ptr(buf), _stream(),
-            work=2.0 * B * (h * w) ** 2 * Cc, nbytes=4.0 * (2 * B * h * w * Cc + offs[-1]))
-    views = [buf[offs[l]:offs[l + 1]].view(B * h * w, 1, hl[l], wl[l]) for l in range(levels)]
-    return buf, views
+            work=2.0 * B * (h * w) ** 2 * Cc, nbytes=_pyramid_bytes(B, Cc, h, w, levels, hl, wl))
+    return buf, PyramidLevels(buf, offs, hl, wl, B, h, w)
 
 
 _pyr_ws = {}
@@ -146,9 +196,8 @@ def _corr_pyramid_f16x3(f1, f2, layout, B, Cc, h, w, levels, out, a_scale):
     buf = out if (out is not None and out.numel() == offs[-1] and out.device == f1.device) else \
         torch.empty(offs[-1], device=f1.device, dtype=F32)
     _launch("rnnpose_corr_pyramid_f16x3", _ptr(f1), _ptr(f2), layout, B, Cc, h, w, levels, float(a_scale), _ptr(ws), n,
-            _ptr(buf), _stream(), work=2.0 * B * (h * w) ** 2 * Cc, nbytes=4.0 * (2 * B * h * w * Cc + offs[-1]))
-    views = [buf[offs[l]:offs[l + 1]].view(B * h * w, 1, hl[l], wl[l]) for l in range(levels)]
-    return buf, views
+            _ptr(buf), _stream(), work=2.0 * B * (h * w) ** 2 * Cc, nbytes=_pyramid_bytes(B, Cc, h, w, levels, hl, wl))
+    return buf, PyramidLevels(buf, offs, hl, wl, B, h, w)
 
 
 def corr_pyramid_nhwc(f1, f2, levels: int = 4, out=None, a_scale: float = 8.0):
@@ -199,9 +248,8 @@ def corr_pyramid_split(f1: SplitTensor, f2: SplitTensor, levels: int = 4, out=No
     dev = f1.device
     buf = out if (out is not None and out.numel() == offs[-1] and out.device == dev) else torch.empty(offs[-1], device=dev, dtype=F32)
     _launch("rnnpose_corr_pyramid_split", _ptr(f1.data), _ptr(f2.data), B, Cc, h, w, levels, f1.a_scale, _ptr(buf), _stream(),
-            work=2.0 * B * (h * w) ** 2 * Cc, nbytes=4.0 * (2 * B * h * w * Cc + offs[-1]))
-    views = [buf[offs[l]:offs[l + 1]].view(B * h * w, 1, hl[l], wl[l]) for l in range(levels)]
-    return buf, views
+            work=2.0 * B * (h * w) ** 2 * Cc, nbytes=_pyramid_bytes(B, Cc, h, w, levels, hl, wl))
+    return buf, PyramidLevels(buf, offs, hl, wl, B, h, w)
 
 
 # ---- a3' (volume-free lookup: a measured alternative, thirdparty/raft/corr.py:70-98) ------------------------

@@ -37,23 +37,16 @@ def _level_sizes(h, w, levels):
 
 
 def _flat_pyramid(pyramid):
-    """Tensor[] levels -> the flat buffer the lookup kernel reads.  Levels produced by rnnpose::corr_pyramid are views of
-    one buffer (zero-copy); anything else is packed once."""
-    base = pyramid[0]
-    n = sum(p.numel() for p in pyramid)
-    off, ok = base.storage_offset(), True
-    for p in pyramid:
-        ok = ok and p.is_contiguous() and p.untyped_storage().data_ptr() == base.untyped_storage().data_ptr() and p.storage_offset() == off
-        off += p.numel()
-    if ok:
-        return base.as_strided((n,), (1,), base.storage_offset())
-    return torch.cat([p.reshape(-1) for p in pyramid])
+    """Tensor[] levels in the reference's shapes -> the flat buffer the lookup kernel reads (level 0 j-patch-major:
+    include/rnnpose_hip.h).  The dispatcher-level operators carry the pyramid as the reference does, a list of dense levels, so
+    this packs once per call; the refinement path (CorrBlock / the engine) keeps the buffer form and never comes through here."""
+    return ops.pyramid_from_levels(list(pyramid))
 
 
 # ---- CUDA (HIP) implementations ----------------------------------------------------------------------------------------
 def _corr_pyramid(fmap1, fmap2, levels=4):
     _, views = ops.corr_pyramid(fmap1, fmap2, levels)
-    return views
+    return list(views)
 
 
 def _corr_lookup(pyramid, coords, radius=4):

@@ -49,7 +49,8 @@ def test_pyramid_layout(lib):
     assert lib.rnnpose_corr_pyramid_layout(8, 60, 80, 4, offs, hl, wl) == 0
     assert list(hl) == [60, 30, 15, 7] and list(wl) == [80, 40, 20, 10]
     n = 8 * 4800
-    assert list(offs) == [0, n * 4800, n * 6000, n * 6300, n * 6370]
+    l0 = n * (8 * 5) * 128                                                    # level 0 j-patch-major: 8 x 5 whole patches of 8 x 16 cells
+    assert list(offs) == [0, l0, l0 + n * 1200, l0 + n * 1500, l0 + n * 1570]
     assert lib.rnnpose_corr_pyramid_layout(1, 30, 30, 4, offs, hl, wl) == 0
     assert list(hl) == [30, 15, 7, 3]
     assert lib.rnnpose_corr_pyramid_layout(1, 4, 4, 4, offs, hl, wl) == 1        # level 3 would be empty
@@ -133,4 +134,4 @@ def test_header_is_plain_c99_and_links_against_the_library(tmp_path):
     assert out.returncode == 0, out.stderr
     ver, total = out.stdout.split()
     n = 2 * 16 * 24
-    assert int(ver) == 2 and int(total) == n * (16 * 24 + 8 * 12 + 4 * 6 + 2 * 3)
+    assert int(ver) == 2 and int(total) == n * (2 * 2 * 128 + 8 * 12 + 4 * 6 + 2 * 3)     # level 0: 2 x 2 whole patches (16 x 24 -> 16 x 32 cells)
