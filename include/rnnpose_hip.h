@@ -254,7 +254,7 @@ typedef struct {
   int tile;                    /* 0 = automatic; 1 = 128x64, 2 = 128x128 as 4 column waves, 3 = 128x128 as 2x2 waves, 4 = 128x64 with
                                   a block-deep register pipeline (3, 4: split sources only); 5 = the STRIP kernels (160 output
                                   pixels x 96 / 128 columns per workgroup, weights and split-tensor activations by LDS-DMA:
-                                  stride 1, 3x3 / 1x5 / 5x1, c_out > 64, source channel counts in multiples of 32; a launch with tile_stats / src0_mean_rstd tiles every image into
+                                  stride 1, 3x3 / 1x5 / 5x1, c_out > 32, source channel counts in multiples of 32; a launch with tile_stats / src0_mean_rstd tiles every image into
                                   rnnpose_conv_tiles_per_image_ex(..., 5) tiles).  The automatic choice takes the strip kernels
                                   for these layer shapes when the map fills the chip with strips (rnnpose_conv_strip(0): never). */
   void* ksplit_ws;             /* optional (NULL = off): workspace of rnnpose_conv_ksplit_workspace_bytes() bytes, 16-byte aligned,

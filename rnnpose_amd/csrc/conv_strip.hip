@@ -639,10 +639,12 @@ static int g_strip_ni = 1;           // 1 / 2: column tiles per wave (strip_forc
 void strip_force_ni(int ni) { g_strip_ni = ni; }      // (rnnpose_conv_strip: mode 1 -> 1, mode 2 -> 1, mode 3 -> 2)
 
 // workgroup shape for c_out output channels: NI column tiles of 32 per wave x NW waves; returns NI * 16 + NW (0 = unsupported).
+// c_out <= 64: two waves of one tile each (three workgroups per CU).
 // NI = 2 (one wave per SIMD, 160 x 64 per wave) wherever whole 64-column wave tiles fit; the column-tile width that wastes
 // the fewest columns, the wider one on a tie.
 int strip_waves(int c_out) {
-  if (c_out <= 64) return 0;                          // (one- and two-wave 32-column workgroups are not built: such layers stay on the 128-row kernel)
+  if (c_out <= 32) return 0;                          // (one-wave workgroups are not built)
+  if (c_out <= 64) return g_strip_ni == 2 ? 0 : 1 * 16 + 2;      // two waves of 32 columns: the encoder's 64-channel layers (strip_auto: large maps only)
   int best = 0, best_waste = 1 << 30;
   const int cand[5][2] = {{2, 4}, {2, 3}, {2, 2}, {1, 4}, {1, 3}};       // 256, 192, 128, 128, 96 columns
   for (const auto& c : cand) {
@@ -664,6 +666,8 @@ bool strip_auto(int H, int W, int kh, int kw, int stride, int c_out) {
   const int cfg = strip_waves(c_out), nw = (cfg & 15) * (cfg >> 4);         // 32-column wave tiles per workgroup
   const long long tiles = static_cast<long long>(strip_tiles_per_image(H, W, kh, kw)) * rp::cdiv(c_out, 32 * nw);
   if (tiles < 24) return false;                       // (a few images of this size do not fill the chip with strips)
+  if (nw == 2) return false;            // two-wave workgroups (c_out <= 64: the encoder's 64-channel layers at 240 x 320) are built and tested (tile = 5)
+                                        // but measured EQUAL to the 128-row kernel there (r04: 183 vs 185 us at B = 8): not the automatic choice
   if (kh == 3) {                                      // ragged patches: at most 15 % of the rows wasted
     const long long covered = static_cast<long long>(rp::cdiv(W, SPW)) * SPW * rp::cdiv(H, SPH) * SPH;
     if (covered * 100 > static_cast<long long>(H) * W * 115) return false;
@@ -682,7 +686,7 @@ int strip_launch(KParams& p, int H, int W, int kh, int kw, bool hlin, bool per_i
   const char* fn = "rnnpose_conv2d_nhwc_f16x3";
   RP_REQUIRE(strip_kernel_shape(kh, kw) && p.stride == 1, fn, "strip kernel: 3x3, 1x5 or 5x1, stride 1");
   const int cfg = strip_waves(p.Cout);
-  RP_REQUIRE(cfg != 0, fn, "strip kernel: c_out must exceed 64");
+  RP_REQUIRE(cfg != 0, fn, "strip kernel: c_out must exceed 32");
   const int ni = cfg >> 4, nw = cfg & 15;
   const bool spatial = kh == 3;
   const bool norm = p.in_mr != nullptr;
@@ -723,7 +727,7 @@ int strip_launch(KParams& p, int H, int W, int kh, int kw, bool hlin, bool per_i
   if (ni == 2) {
     if (nw == 4) { RS_LAUNCH(4, 2) } else if (nw == 3) { RS_LAUNCH(3, 2) } else { RS_LAUNCH(2, 2) }
   } else {
-    if (nw == 3) { RS_LAUNCH(3, 1) } else { RS_LAUNCH(4, 1) }
+    if (nw == 2) { RS_LAUNCH(2, 1) } else if (nw == 3) { RS_LAUNCH(3, 1) } else { RS_LAUNCH(4, 1) }
   }
 #undef RS_LAUNCH
   return rp::check_launch(fn);

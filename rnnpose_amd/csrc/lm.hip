@@ -17,8 +17,17 @@ using rp::Pose;
 constexpr int NACC = 27;        // 21 (upper triangle of H, row-major) + 6 (b)
 constexpr int PSTRIDE = 32;     // doubles per partial record
 constexpr int LM_THREADS = 256;
-constexpr int LM_BATCH = 4;      // pixels per thread whose loads are in flight together
-constexpr int LM_PIX_PER_BLOCK = 2048;   // 150 workgroups per 480x640 image: >4 per CU at B=8 (latency hiding for the fp64 chain)
+// r04 sweep (B = 4 / B = 8 x 480 x 640, us per fused LM step): 1024 px per workgroup, 4 in flight 40.6 / 70.7; 2048, 4 (r03) 35.9 / 52.4;
+// 4096, 8 33.9 / 40.5; 8192, 8 37.1 / 46.9; 16384, 16 58.7 / 59.6 -- fewer partial records shorten the last-arrival tail until the
+// main loop of a workgroup becomes the chain
+#ifndef RP_LM_BATCH
+#define RP_LM_BATCH 8
+#endif
+#ifndef RP_LM_PPB
+#define RP_LM_PPB 4096
+#endif
+constexpr int LM_BATCH = RP_LM_BATCH;      // pixels per thread whose loads are in flight together
+constexpr int LM_PIX_PER_BLOCK = RP_LM_PPB;   // 75 workgroups per 480x640 image
 constexpr int LM_MAX_BLOCKS = 256;
 
 __host__ __device__ inline int lm_blocks_per_image(long long P) {
@@ -146,14 +155,30 @@ __global__ __launch_bounds__(LM_THREADS) void lm_normal_eq_kernel(const float* _
       }
     }
   }
-  // wave reduction (64 lanes), then across the 4 waves through LDS
+  // wave reduction as a butterfly REDUCE-SCATTER (r04): at offset o = 32, 16, 8, 4, 2 a lane keeps the half of its (32, 16, 8, 4,
+  // 2) slots that bit o of its lane number selects, sends the other half to lane ^ o and adds what it receives -- 16 + 8 + 4 + 2 +
+  // 1 exchanged doubles per lane, after which lanes 2k and 2k + 1 hold the two halves of slot k = lane >> 1 (bit order below) and one
+  // last exchange completes it: 32 double exchanges per lane instead of the 27 x 6 = 162 of a full butterfly per accumulator
+  // (the reduction was as long as the fp64 accumulation itself).  Fixed tree: deterministic.  Then across the 4 waves through LDS.
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  {
+    double v[32];
 #pragma unroll
-  for (int i = 0; i < NACC; ++i) {
-    double v = acc[i];
+    for (int i = 0; i < 32; ++i) v[i] = i < NACC ? acc[i] : 0.0;
 #pragma unroll
-    for (int dlt = 32; dlt >= 1; dlt >>= 1) v += shfl_down_f64(v, dlt);
-    if (lane == 0) red[wave][i] = v;
+    for (int o = 32, n = 32; o >= 2; o >>= 1, n >>= 1) {         // n slots live before the step, n / 2 after
+      const bool hi = (lane & o) != 0;
+#pragma unroll
+      for (int i = 0; i < n / 2; ++i) {
+        const double send = hi ? v[i] : v[i + n / 2];
+        const double keep = hi ? v[i + n / 2] : v[i];
+        v[i] = keep + rp::shfl_xor_f64(send, o);
+      }
+    }
+    const double tot = v[0] + rp::shfl_xor_f64(v[0], 1);
+    // slot held by this lane pair: bit 5 of the lane chose the upper half of 32, bit 4 of 16, ... bit 1 of 2
+    const int slot = ((lane >> 5) & 1) * 16 + ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+    if (!(lane & 1) && slot < NACC) red[wave][slot] = tot;
   }
   __syncthreads();
   if (threadIdx.x < NACC) {

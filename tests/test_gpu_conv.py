@@ -662,6 +662,8 @@ STRIP_SHAPES = [
     (2, 9, 13, [256], 192, 3, 3),          # three-wave workgroups (96 columns)
     (1, 23, 37, [96], 96, 3, 3),           # three channel blocks, three waves, ragged patches
     (2, 13, 29, [64, 32], 320, 1, 5),      # a 64-channel and a 32-channel source, Cout = 2.5 column tiles
+    (2, 40, 48, [64], 64, 3, 3),           # two-wave workgroups (the encoder's 64-channel layers)
+    (1, 21, 33, [64], 48, 3, 3),           # ... with a ragged column tile
 ]
 
 
@@ -751,7 +753,7 @@ def test_conv_strip_gru_epilogues(ops, strip_mode, kh, kw, hl):
     assert float((ops.unsplit_hl(hnew_s) - hnew).abs().max()) < 2.0 ** -20
 
 
-@pytest.mark.parametrize("B,H,W,cin,cout", [(3, 15, 20, 96, 96), (2, 60, 80, 96, 128), (2, 20, 32, 128, 128)])
+@pytest.mark.parametrize("B,H,W,cin,cout", [(3, 15, 20, 96, 96), (2, 60, 80, 96, 128), (2, 20, 32, 128, 128), (2, 40, 48, 64, 64)])
 def test_conv_strip_tile_stats_and_fused_input_norm(ops, strip_mode, B, H, W, cin, cout):
     """The encoder's pair (extractor.py:48-58) on strips: conv1 with fp64 tile statistics per 10 x 16 patch, conv2 reading
     relu(norm1(conv1 x)) in its load == the materialised sequence, bit for bit."""

@@ -42,7 +42,7 @@ for B in batches:
         for mname, hl, tile in modes:
             if only and mname not in only.split(","):
                 continue
-            if tile == 5 and (co <= 64 or (B == 1 and "@240" not in name)):
+            if tile == 5 and (co <= 32 or (B == 1 and "@240" not in name)):
                 continue                      # (strips: c_out > 64; the 30 x 30 crops do not fill the chip with them)
             run = lambda: ops.conv2d_nhwc(pc, xs if hl else xf, (out, 0), ops.EPI_RELU, src_hl=hl, dst_hl=hl, tile=tile,
                                           ksplit_ws=ksws if mname.endswith("ks") else None)
