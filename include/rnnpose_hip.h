@@ -281,7 +281,8 @@ int rnnpose_conv_tiles_per_image(int H, int W, int kh, int kw, int stride);
 int rnnpose_conv_tiles_per_image_ex(int H, int W, int kh, int kw, int stride, int c_out, int tile);
 int rnnpose_conv_spatial_tiles(int enable);
 int rnnpose_conv_strip(int mode);          /* measurement switch: 0 = the automatic choice never takes the strip kernels, 1 = default,
-                                              2 / 3 = strips with one / two 32-column tiles per wave only */
+                                              2 = automatic without the two-wave workgroups of 64-channel layers, 3 = two 32-column
+                                              tiles per wave (one workgroup per CU) */
 /* number of fp16 elements of the packed weight array (hi and lo parts interleaved, in the fragment order of the 128-row kernels
  * followed by the record order of the strip kernels); -1 on bad arguments */
 long long rnnpose_conv_packed_halfs(int c_out, int kh, int kw, const int* h_seg_counts, int n_seg);

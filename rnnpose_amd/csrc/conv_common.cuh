@@ -54,6 +54,7 @@ struct KParams {
   float* ks_ws;              // ksplit partial accumulators: [tile][split][acc register][thread] floats
   unsigned* ks_cnt;          // per-tile arrival counters (zero between launches)
   const uint4* wpk_strip;    // the same weights in the strip kernel's order (conv_strip.hip), behind the first copy in w_packed
+  int off32;                 // strip kernels: every destination / epilogue operand spans < 2^32 elements (32-bit offsets in the fast epilogue)
 };
 
 // One output quad (4 consecutive channels starting at channel ch of the pixel row `row`) in split form: the 8-channel group
@@ -93,6 +94,7 @@ struct PackParams {
 
 // conv_strip.hip: the strip kernels (160-row strips, operands by LDS-DMA)
 int strip_waves(int c_out);                                    // workgroup shape: 16 * (32-column tiles per wave) + waves; 0 = unsupported width
+void strip_allow_two_wave(int on);                             // measurement: two-wave workgroups (c_out <= 64) in the automatic choice (default on)
 void strip_force_ni(int ni);                                   // measurement: 0 automatic, 1 / 2 column tiles per wave
 bool strip_auto(int H, int W, int kh, int kw, int stride, int c_out);      // does the automatic choice take the strip kernel? (shape only)
 int strip_tiles_per_image(int H, int W, int kh, int kw);      // output tiles per image when tiled per image (tile_stats records)

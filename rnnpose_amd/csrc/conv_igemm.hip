@@ -847,12 +847,13 @@ int rnnpose_conv_spatial_tiles(int enable) {     // measurement switch: 0 = the 
   return 0;
 }
 
-int rnnpose_conv_strip(int mode) {               // 0 = never the strip kernels, 1 = automatic (default); 2 / 3 = automatic with one / two
-  if (mode < 0 || mode > 3) {                    // 32-column tiles per wave forced (measurement)
+int rnnpose_conv_strip(int mode) {               // 0 = never the strip kernels, 1 = automatic (default); measurement: 2 = automatic without
+  if (mode < 0 || mode > 3) {                    // the two-wave workgroups of the 64-channel layers, 3 = two 32-column tiles per wave
     rp::set_error("rnnpose_conv_strip: mode 0..3");
     return 1;
   }
   g_conv_strip = mode != 0;
+  strip_allow_two_wave(mode != 2);
   strip_force_ni(mode == 3 ? 2 : 1);
   return 0;
 }

@@ -97,6 +97,11 @@ __device__ __forceinline__ void glds_rec(const void* base, unsigned voff, unsign
         : "memory");
   }
 }
+// gates of the fast epilogue: v_exp_f32 / v_rcp_f32 (1 ulp each) instead of the library's expf / tanhf / IEEE division --
+// |error| <= ~2e-7 absolute on values in [0, 1] / [-1, 1]; saturates correctly (exp2 -> inf -> rcp -> 0)
+__device__ __forceinline__ float fast_sigmoid(float v) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f)); }
+__device__ __forceinline__ float fast_tanh(float v) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(v * 2.8853900817779268f)); }
+
 template <int N>
 __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -108,6 +113,15 @@ __device__ __forceinline__ void wg_barrier() {
   asm volatile("" ::: "memory");
 }
 
+#ifndef RS_ABL
+#define RS_ABL 0
+#endif
+#if RS_ABL & 512          // diagnostics build: wave 0 of every workgroup stamps the 100-MHz clock at four points (tools/strip_timeline.py)
+__device__ unsigned long long g_strip_clk[8 * 65536];
+#define RS_CLK(I_) { if (tid == 0 && blockIdx.x < 65536) g_strip_clk[blockIdx.x * 8 + (I_)] = wall_clock64(); }
+#else
+#define RS_CLK(I_)
+#endif
 #ifndef RS_VAR
 #define RS_VAR 0          // schedule variants (measurement): 1 s_setprio(1) around a step's MFMAs, 2 fragment reads in front of the
 #endif                    // MFMAs instead of between them, 4 the first read behind the third MFMA
@@ -115,6 +129,165 @@ __device__ __forceinline__ void wg_barrier() {
 #define RS_ABL 0          // diagnostics builds (tools/strip_ablate.sh; results WRONG): 1 no weight requests in the loop, 2 no activation
 #endif                    // requests, 4 no fragment reads, 8 no MFMAs, 32 no barrier, 64 no vmcnt waits, 128 no activation fragment
                           // reads, 256 no weight fragment reads
+// ---- fast epilogue (r04; tools/strip_timeline.py: the general form in the kernel costs 6-13 us of a workgroup's 30-60 us -- ~7
+// cycles per instruction of a code path that tests every option and every row's validity per row group, multiplies 64-bit
+// addresses and waits for each staging write on the spot).  For a wave whose 160 x 32 tile lies INSIDE the problem and one of the
+// five option sets the engines use (EV: 0 linear / ReLU -> fp32; 1 the same + tile statistics; 2 linear / ReLU -> split;
+// 3 GRU z | r*h with an additive map; 4 GRU h' with an additive map and a split copy): no validity masks, no option tests, the five
+// 32-row blocks unrolled over two staging tiles (block mi+1 is written while block mi is read back), the operands of block
+// mi+1 requested BEFORE the stores of block mi (vmcnt is in order: a load behind stores waits for them), pixel indices by a walk,
+// 32-bit element offsets (strip_launch checks the extents), gates by v_exp / v_rcp.
+struct StripEpi {        // the members of the parameter block the fast epilogue reads, by value (a reference to the whole block
+  float* dst;            // made the compiler keep its segment table in scratch memory)
+  int dst_cs, dst_co;
+  float* dst2;
+  int dst2_cs, dst2_co;
+  float* dsth;
+  int dsth_cs, dsth_co;
+  const float* addm;
+  int addm_cs, addm_co;
+  const float* aux0;
+  int aux0_cs, aux0_co;
+  const float* aux1;
+  int aux1_cs, aux1_co;
+  float out_scale, a_scale;
+  int epi, gru_c, U, V, su, sv;
+};
+template <int EV, bool SPATIAL, int NBLK, int NI>
+__device__ __forceinline__ void strip_epilogue_fast(const StripEpi p, f32x16 (&acc)[NBLK][NI], float* S_, int lane, int colq, int c2,
+                                                    const float (&bq)[4], int pixb, int lv, int lu, int UV, double& ts0, double& ts1,
+                                                    double& ts2, double& ts3, double& tq0, double& tq1, double& tq2, double& tq3,
+                                                    int& sat_n) {
+  constexpr int ES = 36, STILE = 32 * ES;
+  const int l31 = lane & 31, lh = lane >> 5;
+  float* const Sw = S_ + (4 * lh) * ES + l31;                   // staging write base: row (r & 3) + 8 (r >> 2) + 4 lh, column l31
+  const float* const Sr = S_ + (lane >> 3) * ES + (lane & 7) * 4;      // read base: row 8 k + (lane >> 3), the lane's quad
+  const bool zside = colq < p.gru_c;                            // (EV 3: uniform in the wave, gru_c is a multiple of 32)
+  const float lo_ = p.epi == 1 ? 0.f : -__builtin_inff();       // ReLU as a clamp
+  const int wrap_v = p.su - p.V * p.sv, wrap_u = UV - p.U * p.su;
+  // pixel of row group k of block mi: 3x3 patches: line 2 mi + (k >> 1), column 8 (k & 1) + (lane >> 3) of the patch; linear
+  // strips: row 32 mi + 8 k + (lane >> 3) of the strip, walked 8 rows at a time through (fast coordinate, slow coordinate, image)
+  int lpix = pixb;
+  auto pixel = [&](int mi, int k) {
+    if constexpr (SPATIAL) {
+      return pixb + (k & 1) * 8 + (2 * mi + (k >> 1)) * p.V;
+    } else {
+      const int r = lpix;
+      lv += 8;
+      lpix += 8 * p.sv;
+      if (lv >= p.V) {
+        lv -= p.V;
+        lpix += wrap_v;
+        if (++lu >= p.U) { lu = 0; lpix += wrap_u; }
+      }
+      return r;
+    }
+  };
+  auto eoff = [](int pix, int cs, int co) { return static_cast<size_t>(static_cast<unsigned>(pix) * static_cast<unsigned>(cs) + static_cast<unsigned>(co)); };
+  auto stage = [&](int mi, const f32x16& a) {
+    float* w = Sw + (mi & 1) * STILE;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) w[((r & 3) + 8 * (r >> 2)) * ES] = a[r] * p.out_scale;
+  };
+  int pix[4], pixn[4];
+  float4 am[4], hv[4], zv[4];
+  auto request = [&](const int (&px)[4]) {       // operands of a block: additive map, h, z
+    if constexpr (EV >= 3) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) am[k] = *reinterpret_cast<const float4*>(p.addm + eoff(px[k], p.addm_cs, p.addm_co + colq));
+    }
+    if constexpr (EV == 3) {
+      if (!zside) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) hv[k] = *reinterpret_cast<const float4*>(p.aux0 + eoff(px[k], p.aux0_cs, p.aux0_co + c2));
+      }
+    }
+    if constexpr (EV == 4) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        zv[k] = *reinterpret_cast<const float4*>(p.aux1 + eoff(px[k], p.aux1_cs, p.aux1_co + colq));
+        hv[k] = *reinterpret_cast<const float4*>(p.aux0 + eoff(px[k], p.aux0_cs, p.aux0_co + colq));
+      }
+    }
+  };
+#pragma unroll
+  for (int k = 0; k < 4; ++k) pix[k] = pixel(0, k);
+  request(pix);
+  stage(0, acc[0][0]);
+#pragma unroll
+  for (int mi = 0; mi < NBLK; ++mi) {
+    if (mi + 1 < NBLK) stage(mi + 1, acc[mi + 1 < NBLK ? mi + 1 : mi][0]);
+    float4 y[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float4 a = *reinterpret_cast<const float4*>(Sr + (mi & 1) * STILE + k * 8 * ES);
+      y[k] = make_float4(a.x + bq[0], a.y + bq[1], a.z + bq[2], a.w + bq[3]);
+    }
+    if constexpr (EV >= 3) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { y[k].x += am[k].x; y[k].y += am[k].y; y[k].z += am[k].z; y[k].w += am[k].w; }
+    }
+    if constexpr (EV == 1) {        // tile statistics: four rows per column and block in fp32, the block sums in fp64
+      ts0 += static_cast<double>((y[0].x + y[1].x) + (y[2].x + y[3].x));
+      ts1 += static_cast<double>((y[0].y + y[1].y) + (y[2].y + y[3].y));
+      ts2 += static_cast<double>((y[0].z + y[1].z) + (y[2].z + y[3].z));
+      ts3 += static_cast<double>((y[0].w + y[1].w) + (y[2].w + y[3].w));
+      tq0 += static_cast<double>(fmaf(y[0].x, y[0].x, y[1].x * y[1].x) + fmaf(y[2].x, y[2].x, y[3].x * y[3].x));
+      tq1 += static_cast<double>(fmaf(y[0].y, y[0].y, y[1].y * y[1].y) + fmaf(y[2].y, y[2].y, y[3].y * y[3].y));
+      tq2 += static_cast<double>(fmaf(y[0].z, y[0].z, y[1].z * y[1].z) + fmaf(y[2].z, y[2].z, y[3].z * y[3].z));
+      tq3 += static_cast<double>(fmaf(y[0].w, y[0].w, y[1].w * y[1].w) + fmaf(y[2].w, y[2].w, y[3].w * y[3].w));
+    }
+    if constexpr (EV <= 2) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) y[k] = make_float4(fmaxf(y[k].x, lo_), fmaxf(y[k].y, lo_), fmaxf(y[k].z, lo_), fmaxf(y[k].w, lo_));
+    } else if constexpr (EV == 3) {
+      if (zside) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) y[k] = make_float4(fast_sigmoid(y[k].x), fast_sigmoid(y[k].y), fast_sigmoid(y[k].z), fast_sigmoid(y[k].w));    // z
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)                                                                                                               // r * h
+          y[k] = make_float4(fast_sigmoid(y[k].x) * hv[k].x, fast_sigmoid(y[k].y) * hv[k].y, fast_sigmoid(y[k].z) * hv[k].z, fast_sigmoid(y[k].w) * hv[k].w);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {                                                                                                               // h' = (1-z) h + z q
+        const float4 z = zv[k], h = hv[k];
+        y[k] = make_float4((1.f - z.x) * h.x + z.x * fast_tanh(y[k].x), (1.f - z.y) * h.y + z.y * fast_tanh(y[k].y),
+                           (1.f - z.z) * h.z + z.z * fast_tanh(y[k].z), (1.f - z.w) * h.w + z.w * fast_tanh(y[k].w));
+      }
+    }
+    if (mi + 1 < NBLK) {            // (the next block's operands go out in front of this block's stores)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) pixn[k] = pixel(mi + 1, k);
+      request(pixn);
+    }
+    if constexpr (EV == 0 || EV == 1 || EV == 4) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(p.dst + eoff(pix[k], p.dst_cs, p.dst_co + colq)) = y[k];
+    }
+    if constexpr (EV == 2) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) store_quad_hl(p.dst + eoff(pix[k], p.dst_cs, 0), p.dst_co + colq, y[k].x, y[k].y, y[k].z, y[k].w, 4, p.a_scale, sat_n);
+    }
+    if constexpr (EV == 3) {
+      if (zside) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(p.dst + eoff(pix[k], p.dst_cs, p.dst_co + colq)) = y[k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) store_quad_hl(p.dst2 + eoff(pix[k], p.dst2_cs, 0), p.dst2_co + c2, y[k].x, y[k].y, y[k].z, y[k].w, 4, p.a_scale, sat_n);
+      }
+    }
+    if constexpr (EV == 4) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) store_quad_hl(p.dsth + eoff(pix[k], p.dsth_cs, 0), p.dsth_co + colq, y[k].x, y[k].y, y[k].z, y[k].w, 4, p.a_scale, sat_n);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pix[k] = pixn[k];
+  }
+}
+
 // TT = taps per half block: 5 (1x5, 5x1: linear strips) or 9 (3x3: 10 x 16 patches with a halo).
 // MODE 0: split-tensor sources by LDS-DMA; 1: fp32 sources through registers; 2: fp32 source + fused instance norm / ReLU (p.in_mr)
 // NI = 32-column tiles per wave: 1 (wave tile 160 x 32, two workgroups per CU = two waves per SIMD, <= 256 registers) or
@@ -147,6 +320,7 @@ __global__ __launch_bounds__(NW * 64, NI == 2 ? 1 : 2) void conv_strip_f16x3_ker
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lh = lane >> 5;
+  RS_CLK(0)
 
   // ---- tile id: XCD-contiguous chunks, column tiles of one strip next to each other (they stage the same activations) ----
   int bid = static_cast<int>(blockIdx.x);
@@ -389,6 +563,7 @@ __global__ __launch_bounds__(NW * 64, NI == 2 ? 1 : 2) void conv_strip_f16x3_ker
   }
   wait_vm<0>();
   wg_barrier();
+  RS_CLK(1)
 #pragma unroll
   for (int k = 0; k < NRD; ++k) RS_READ1(k, 0, 0, 0, 0)
 
@@ -442,6 +617,7 @@ __global__ __launch_bounds__(NW * 64, NI == 2 ? 1 : 2) void conv_strip_f16x3_ker
   }
   wait_vm<0>();        // (the surplus requests of the last steps land in slots the epilogue is about to reuse)
   wait_lds();
+  RS_CLK(2)
 
   // ------------------------------------------- epilogue -------------------------------------------
   // accumulators -> wave-private LDS tile (the wave's own weight ring: every request into it has been waited for, all its
@@ -459,9 +635,43 @@ __global__ __launch_bounds__(NW * 64, NI == 2 ? 1 : 2) void conv_strip_f16x3_ker
   for (int e = 0; e < 4; ++e) bq[e] = p.bias[colc + (e < nv ? e : 0)];
   const int c2 = colc >= p.gru_c ? colc - p.gru_c : 0;
   double ts0 = 0., ts1 = 0., ts2 = 0., ts3 = 0., tq0 = 0., tq1 = 0., tq2 = 0., tq3 = 0.;
-  // (the row-tile loop stays ROLLED: five copies of this body pass the compiler's unroll budget at NI = 2, a partly unrolled
-  //  loop indexes the accumulators dynamically, and they then live in scratch memory for the whole main loop.  The tile of
-  //  the iteration is selected by a uniform switch over constant indices instead.)
+  // ---- fast path (strip_epilogue_fast above): a wave whose 160 x 32 tile lies inside the problem, with one of the option sets the
+  // engines use -- every strip of the update block and the encoder at the headline shapes
+  int ev_ = -1;
+  if (NI == 1 && p.off32 && colw + 32 <= p.Cout && (SPATIAL ? (py0_ + SPH <= p.U && px0_ + SPW <= p.V) : (m0 + SM <= mend && p.V >= 8))) {
+    if (p.epi <= 1 && !p.addm && !p.dsth) ev_ = p.dst_hl ? (p.tstats ? -1 : 2) : (p.tstats ? 1 : 0);
+    else if (p.epi == 2 && p.addm && !p.dst_hl && p.dst2_hl && !p.dsth && (p.gru_c & 31) == 0 && !p.tstats) ev_ = 3;
+    else if (p.epi == 3 && p.addm && !p.dst_hl && p.dsth && !p.tstats) ev_ = 4;
+  }
+  if (NI == 1 && ev_ >= 0) {
+    int pixb, lv_ = 0, lu_ = 0;
+    if constexpr (SPATIAL) {
+      pixb = img_ * UV + py0_ * p.V + px0_ + (lane >> 3);
+    } else {
+      const int m = m0 + (lane >> 3);
+      const int q = m / p.V;
+      lv_ = m - q * p.V;
+      const int b = q / p.U;
+      lu_ = q - b * p.U;
+      pixb = b * UV + lu_ * p.su + lv_ * p.sv;
+    }
+    const StripEpi pe_{p.dst, p.dst_cs, p.dst_co, p.dst2, p.dst2_cs, p.dst2_co, p.dsth, p.dsth_cs, p.dsth_co, p.addm, p.addm_cs, p.addm_co,
+                       p.aux0, p.aux0_cs, p.aux0_co, p.aux1, p.aux1_cs, p.aux1_co, p.out_scale, p.a_scale, p.epi, p.gru_c, p.U, p.V, p.su, p.sv};
+    RS_CLK(4)
+#define RS_FAST(EV_) strip_epilogue_fast<EV_, SPATIAL, SMI, NI>(pe_, acc, S_, lane, colq, c2, bq, pixb, lv_, lu_, UV, ts0, ts1, ts2, ts3, tq0, tq1, tq2, tq3, sat_n);
+    switch (ev_) {
+      case 0: RS_FAST(0) break;
+      case 1: RS_FAST(1) break;
+      case 2: RS_FAST(2) break;
+      case 3: RS_FAST(3) break;
+      default: RS_FAST(4) break;
+    }
+#undef RS_FAST
+    RS_CLK(7)
+  } else {
+  // ---- general form: any tile (ragged rows / columns), any option.  (The row-tile loop stays ROLLED: five copies of this body pass
+  //  the compiler's unroll budget at NI = 2, a partly unrolled loop indexes the accumulators dynamically, and they then live in
+  //  scratch memory for the whole main loop.  The tile of the iteration is selected by a uniform switch over constant indices.)
 #pragma unroll 1
   for (int mi = 0; mi < SMI; ++mi) {
     f32x16 at[NI];
@@ -570,6 +780,7 @@ __global__ __launch_bounds__(NW * 64, NI == 2 ? 1 : 2) void conv_strip_f16x3_ker
       if (p.dsth) store_quad_hl(p.dsth + pix * p.dsth_cs, p.dsth_co + colq, y[0], y[1], y[2], y[3], nv, p.a_scale, sat_n);
     }
   }
+  }
   if (p.sat && sat_n) atomicAdd(p.sat, static_cast<unsigned long long>(sat_n));
   if (p.tstats) {
     // a wave owns all 160 rows of its 32 columns: lanes sharing a column quad (same lane % 8) -> lanes 0..7, fixed order; one
@@ -591,6 +802,7 @@ __global__ __launch_bounds__(NW * 64, NI == 2 ? 1 : 2) void conv_strip_f16x3_ker
         }
     }
   }
+  RS_CLK(3)
 }
 
 // packed order of the strip kernels: [half block hb = 2 cb + kk][tap][32-column tile] records of 2 KB = the LDS image itself (the
@@ -634,8 +846,10 @@ namespace rpconv {
 // Column tiles per wave: 1 unless forced.  The two-tile form (one wave per SIMD, 160 x 64 per wave, 14 fragment reads per 30
 // MFMAs instead of 12 per 15) is built, tested and SLOWER (r04, profiles/r04_strip_ni2.txt: GRU z|r at B = 8 84.6 vs 76.4 us, even
 // with every memory operation compiled out 70 vs 56 us): a lone wave does not keep its SIMD's matrix pipe busy.
+static int g_strip_two_wave = 1;     // two-wave workgroups (c_out <= 64: the encoder's 64-channel layers at 240 x 320) in the automatic choice
 static int g_strip_ni = 1;           // 1 / 2: column tiles per wave (strip_force_ni; 0: the least-waste shape over both)
 
+void strip_allow_two_wave(int on) { g_strip_two_wave = on; }
 void strip_force_ni(int ni) { g_strip_ni = ni; }      // (rnnpose_conv_strip: mode 1 -> 1, mode 2 -> 1, mode 3 -> 2)
 
 // workgroup shape for c_out output channels: NI column tiles of 32 per wave x NW waves; returns NI * 16 + NW (0 = unsupported).
@@ -666,8 +880,7 @@ bool strip_auto(int H, int W, int kh, int kw, int stride, int c_out) {
   const int cfg = strip_waves(c_out), nw = (cfg & 15) * (cfg >> 4);         // 32-column wave tiles per workgroup
   const long long tiles = static_cast<long long>(strip_tiles_per_image(H, W, kh, kw)) * rp::cdiv(c_out, 32 * nw);
   if (tiles < 24) return false;                       // (a few images of this size do not fill the chip with strips)
-  if (nw == 2) return false;            // two-wave workgroups (c_out <= 64: the encoder's 64-channel layers at 240 x 320) are built and tested (tile = 5)
-                                        // but measured EQUAL to the 128-row kernel there (r04: 183 vs 185 us at B = 8): not the automatic choice
+  if (nw == 2 && g_strip_two_wave == 0) return false;      // (two-wave workgroups, c_out <= 64: see strip_allow_two_wave)
   if (kh == 3) {                                      // ragged patches: at most 15 % of the rows wasted
     const long long covered = static_cast<long long>(rp::cdiv(W, SPW)) * SPW * rp::cdiv(H, SPH) * SPH;
     if (covered * 100 > static_cast<long long>(H) * W * 115) return false;
@@ -698,6 +911,16 @@ int strip_launch(KParams& p, int H, int W, int kh, int kw, bool hlin, bool per_i
       RP_REQUIRE(sg[s]->ccount % 32 == 0, fn, "strip kernel: source channel counts in multiples of 32");
       if (hlin) RP_REQUIRE(sg[s]->coff % 8 == 0 && sg[s]->cstride % 8 == 0, fn, "strip kernel, split-tensor sources: channel offsets / strides of 8");
     }
+  }
+  {      // 32-bit element offsets in the fast epilogue: pixel index x channel stride of every destination / operand below 2^32
+    const long long npix = static_cast<long long>(p.B) * H * W;
+    long long cs = p.dst_cs;
+    if (p.dst2 && p.dst2_cs > cs) cs = p.dst2_cs;
+    if (p.dsth && p.dsth_cs > cs) cs = p.dsth_cs;
+    if (p.addm && p.addm_cs > cs) cs = p.addm_cs;
+    if (p.aux0 && p.aux0_cs > cs) cs = p.aux0_cs;
+    if (p.aux1 && p.aux1_cs > cs) cs = p.aux1_cs;
+    p.off32 = (npix + 1) * (cs + 1) < (1LL << 32) ? 1 : 0;
   }
   p.ksplit = 1;
   p.n_nt = rp::cdiv(p.Cout, 32 * ni * nw);
@@ -734,3 +957,9 @@ int strip_launch(KParams& p, int H, int W, int kh, int kw, bool hlin, bool per_i
 }
 
 }  // namespace rpconv
+
+#if RS_ABL & 512
+extern "C" int rnnpose_debug_strip_clk(unsigned long long* host, int n_wg) {
+  return static_cast<int>(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_strip_clk), static_cast<size_t>(n_wg) * 8 * sizeof(unsigned long long)));
+}
+#endif

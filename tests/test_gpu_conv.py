@@ -667,10 +667,10 @@ STRIP_SHAPES = [
 ]
 
 
-@pytest.fixture(params=[1, 2], ids=["auto", "one-tile-waves"])
+@pytest.fixture(params=[1, 3], ids=["auto", "two-tile-waves"])
 def strip_mode(ops, request):
-    """The strip kernels in their automatic shape (two 32-column tiles per wave where whole 64-column wave tiles fit) and with
-    one tile per wave forced (ops.conv_strip(2): the two-workgroups-per-CU form)."""
+    """The strip kernels in their automatic shape (one 32-column tile per wave, two workgroups per CU) and with two tiles per
+    wave forced (ops.conv_strip(3): the one-workgroup-per-CU measurement form; its epilogue is the general one)."""
     ops.conv_strip(request.param)
     yield request.param
     ops.conv_strip(1)
@@ -681,6 +681,8 @@ def strip_mode(ops, request):
 def test_conv_strip_vs_fp64(ops, strip_mode, hl, B, H, W, segs, cout, kh, kw):
     """160-row strips with both operand paths (split-tensor sources by LDS-DMA, fp32 sources through registers) against fp64 and
     against the 128-row kernel on the same operands; fp32 and split-form destinations; bytes around the slice untouched."""
+    if strip_mode == 3 and cout <= 64:
+        pytest.skip("two tiles per wave need more than 64 output channels")
     cin = sum(segs)
     x = syn.normal("sx", (B, cin, H, W), 21, std=1.5)
     w = syn.normal("sw", (cout, cin, kh, kw), 21, std=float(np.sqrt(2.0 / (cin * kh * kw))))
@@ -757,6 +759,8 @@ def test_conv_strip_gru_epilogues(ops, strip_mode, kh, kw, hl):
 def test_conv_strip_tile_stats_and_fused_input_norm(ops, strip_mode, B, H, W, cin, cout):
     """The encoder's pair (extractor.py:48-58) on strips: conv1 with fp64 tile statistics per 10 x 16 patch, conv2 reading
     relu(norm1(conv1 x)) in its load == the materialised sequence, bit for bit."""
+    if strip_mode == 3 and min(cin, cout) <= 64:
+        pytest.skip("two tiles per wave need more than 64 output channels")
     x = syn.normal("pn.x", (B, cin, H, W), 4, std=2.0) + 0.7
     w1 = syn.normal("pn.w1", (cin, cin, 3, 3), 4, std=float(np.sqrt(2.0 / (cin * 9))))
     w2 = syn.normal("pn.w2", (cout, cin, 3, 3), 5, std=float(np.sqrt(2.0 / (cin * 9))))

@@ -23,7 +23,8 @@ shapes = [("convc2 3x3 256->192", [256], 192, 3, 3),
           ("gru zr 1x5 256->256", [128, 128], 256, 1, 5), ("gru q 1x5 256->128", [128, 128], 128, 1, 5),
           ("gru zr 5x1 256->256", [128, 128], 256, 5, 1), ("gru q 5x1 256->128", [128, 128], 128, 5, 1),
           ("heads 3x3 128->512", [128], 512, 3, 3), ("inp 1x5 128->384", [128], 384, 1, 5),
-          ("enc l1 3x3 64->64 @240x320", [64], 64, 3, 3)]
+          ("enc l1 3x3 64->64 @240x320", [64], 64, 3, 3), ("enc l2 3x3 96->96 @120x160", [96], 96, 3, 3),
+          ("enc l3 3x3 128->128 @60x80", [128], 128, 3, 3)]
 modes = [("f32", False, 0), ("f32t5", False, 5), ("hl5", True, 5), ("f32t1", False, 1), ("f32t2", False, 2), ("hl0", True, 0), ("hl1", True, 1), ("hl2", True, 2), ("hl3", True, 3), ("hl4", True, 4),
          ("f32ks", False, 0)]          # f32ks: fp32 sources with a K-split workspace (small launches split their K loop)
 ksws = ops.conv_ksplit_workspace("cuda")
@@ -31,7 +32,7 @@ for B in batches:
     for name, segs, co, kh, kw in shapes:
         if flt and not any(f in name for f in flt):
             continue
-        hh, ww = (240, 320) if "@240" in name else ((30, 30) if B == 1 else (h, w))
+        hh, ww = [int(v) for v in name.split("@")[1].split("x")] if "@" in name else ((30, 30) if B == 1 else (h, w))
         ci = sum(segs)
         wt = torch.randn(co, ci, kh, kw, device="cuda") * (2.0 / (ci * kh * kw)) ** 0.5
         pc = ops.PackedConv(wt, torch.randn(co, device="cuda"), segs)
@@ -42,7 +43,7 @@ for B in batches:
         for mname, hl, tile in modes:
             if only and mname not in only.split(","):
                 continue
-            if tile == 5 and (co <= 32 or (B == 1 and "@240" not in name)):
+            if tile == 5 and (co <= 32 or (B == 1 and "@" not in name)):
                 continue                      # (strips: c_out > 64; the 30 x 30 crops do not fill the chip with them)
             run = lambda: ops.conv2d_nhwc(pc, xs if hl else xf, (out, 0), ops.EPI_RELU, src_hl=hl, dst_hl=hl, tile=tile,
                                           ksplit_ws=ksws if mname.endswith("ks") else None)
