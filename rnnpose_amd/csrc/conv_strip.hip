@@ -555,11 +555,25 @@ __global__ __launch_bounds__(NW * 64, NI == 2 ? 1 : 2) void conv_strip_f16x3_ker
   }
 #pragma unroll
   for (int i = 0; i < NBST - 1; ++i) RS_ISSUE_B(i)
-  if constexpr (MODE != 0) {
+  if constexpr (MODE != 0) {       // both half blocks requested before the first is split (one memory latency instead of two: r04 timeline)
     RS_LOAD_A()
-    RS_STORE_A(0)
+    float4 areg0[NQ];
+    const float4 n01 = nrm01, n23 = nrm23;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) areg0[i] = areg[i];
     RS_LOAD_A()
-    RS_STORE_A(1)
+    {
+      float4 areg1[NQ];
+      const float4 m01 = nrm01, m23 = nrm23;
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) { areg1[i] = areg[i]; areg[i] = areg0[i]; }
+      nrm01 = n01; nrm23 = n23;
+      RS_STORE_A(0)
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) areg[i] = areg1[i];
+      nrm01 = m01; nrm23 = m23;
+      RS_STORE_A(1)
+    }
   }
   wait_vm<0>();
   wg_barrier();
