@@ -548,6 +548,7 @@ __global__ __launch_bounds__(NW * 64, NI == 2 ? 1 : 2) void conv_strip_f16x3_ker
   if constexpr (MODE != 0) {       // the zero row of both planes of both slots (the DMA path refills it with every half block)
     if (tid < 8) *reinterpret_cast<uint4*>(lds + (tid >> 2) * ASLOT + ((tid >> 1) & 1) * PLANE + ZROW + (tid & 1) * 16) = make_uint4(0u, 0u, 0u, 0u);
   }
+  RS_CLK(5)
   RS_A_REBUILD()
   if constexpr (MODE == 0) {
     RS_ISSUE_A(0)
@@ -575,6 +576,7 @@ __global__ __launch_bounds__(NW * 64, NI == 2 ? 1 : 2) void conv_strip_f16x3_ker
       RS_STORE_A(1)
     }
   }
+  RS_CLK(6)
   wait_vm<0>();
   wg_barrier();
   RS_CLK(1)

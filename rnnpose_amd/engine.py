@@ -37,10 +37,11 @@ class UpdateEngine:
         self.ksplit = os.environ.get("RNNPOSE_KSPLIT", "1") != "0"                # small launches (B = 1 crops) split their K loop
         # SPLIT TENSORS (include/rnnpose_hip.h): every activation that only feeds further convolutions is written once, by its
         # producer's epilogue, as fp16 hi|lo pairs and staged by the consumers with a plain 16-byte copy (no per-tile re-split).
-        # MEASURED (r03, profiles/r03_conv_ablation.txt): per layer -1..+3 %, on the step -1.3 % (the two extra split launches per
-        # outer iteration and the second copy of h cost more than the staging saves) -- the vector instructions of the split were
-        # not what bounds the kernel.  Therefore OFF by default; RNNPOSE_SPLIT_TENSORS=1 enables it (tests cover both).
-        self.hl = os.environ.get("RNNPOSE_SPLIT_TENSORS", "0") != "0"
+        # r03 (128-row kernels, which re-stage through registers anyway): -1.3 % on the step, off.  r04: the strip kernels take split
+        # tensors by LDS-DMA (no registers, no split instructions in the loop) and their specialised epilogue writes the split form
+        # at 4-6 us per workgroup: +2-3 % on the step (profiles/r04_ab_split_tensors.txt, same box: 724 vs 690-713 iters/s).  ON by
+        # default; RNNPOSE_SPLIT_TENSORS=0 restores fp32 activations everywhere (tests cover both).
+        self.hl = os.environ.get("RNNPOSE_SPLIT_TENSORS", "1") != "0"
         # tile-shape override per layer for measurements: RNNPOSE_CONV_TILE="zr=3,q=1,heads=2" (0 auto, see conv2d_nhwc)
         self.tile = {}
         for kv in filter(None, os.environ.get("RNNPOSE_CONV_TILE", "").split(",")):

@@ -212,8 +212,8 @@ def test_torch_ops_namespace_runs_the_hip_kernels(ops):
 
 
 def test_split_tensor_schedule_matches_default(ops, monkeypatch):
-    """RNNPOSE_SPLIT_TENSORS=1 (activations pre-split into fp16 hi|lo by their producers, csrc/conv_igemm.hip HLIN) is the same
-    computation as the default schedule: a 2x3 refinement through hipGraph replay agrees to fp32 round-off (the fp16 operands
+    """Split tensors (activations pre-split into fp16 hi|lo by their producers: the default since r04) and RNNPOSE_SPLIT_TENSORS=0
+    (fp32 activations, split again by every consumer) are the same computation: a 2x3 refinement through hipGraph replay agrees to fp32 round-off (the fp16 operands
     are bit-identical, only the order of the K sum inside the resident 1x1 kernel's consumer differs)."""
     from rnnpose_amd import synthetic as syn
     from rnnpose_amd.pose_refiner import PoseRefiner, SyntheticRenderer, default_config

@@ -21,7 +21,7 @@ if [ "$2" != "noprof" ]; then
   python bench.py --steps 10 --warmup 2 --no-cpu-baseline --batch 16 > $OUT/${TAG}_bench_B16.json 2>/dev/null
   python bench.py --steps 10 --warmup 2 --no-cpu-baseline --batch 16 --height 240 --width 240 --inner 4 > $OUT/${TAG}_bench_B16_240.json 2>/dev/null   # configs[2] shape
   python bench.py --steps 10 --warmup 2 --no-cpu-baseline --batch 32 --height 240 --width 240 --inner 4 > $OUT/${TAG}_bench_B32_240.json 2>/dev/null   # configs[3] shape
-  RNNPOSE_SPLIT_TENSORS=1 python bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/${TAG}_bench_split_tensors.json 2>/dev/null
+  RNNPOSE_SPLIT_TENSORS=0 python bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/${TAG}_bench_fp32_activations.json 2>/dev/null
   timeout 600 python tools/error_budget.py > $OUT/${TAG}_error_budget.log 2>&1; cp $OUT/error_budget.json $OUT/${TAG}_error_budget.json
   timeout 900 python tools/parity_probe.py > $OUT/${TAG}_parity_probe.log 2>&1; cp $OUT/parity_probe.json $OUT/${TAG}_parity_probe.json
   if ls gpurun_extra/abl_*.so > /dev/null 2>&1; then     # ablation builds (bash tools/conv_ablate.sh 1 2 4 8 16 32 7 31 in the build container)

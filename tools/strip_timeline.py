@@ -53,7 +53,7 @@ for name, segs, co, kh, kw, hh, ww, hl in cases:
     life = (sel[:, 3] - sel[:, 0]).sum() / 100.0
     print(f"{name:30s} wgs {len(sel):5d} span {span:7.1f} us | prologue {pro.mean():5.2f} (med {np.median(pro):5.2f}) loop {loop.mean():6.2f} (med {np.median(loop):6.2f}) "
           f"epilogue {epi.mean():5.2f} (med {np.median(epi):5.2f}) us | resident wgs {life / span:6.1f} = {life / span / 256:4.2f} per CU", flush=True)
-    if sel[:, 4].max() > 0:      # finer stamps inside the epilogue: first staging write, block 0 out, block 2 out, block 4 out
+    if sel[:, 5].max() > 0:      # finer stamps: address set-up done, all prologue requests issued, epilogue set-up done, last store issued
         d = lambda a, b: (sel[:, b] - sel[:, a]).mean() / 100.0
-        print(f"{'':30s} epilogue parts: setup+stage0 {d(2, 4):5.2f} | block 0 {d(4, 5):5.2f} | blocks 1-2 {d(5, 6):5.2f} | blocks 3-4 {d(6, 7):5.2f} | tail {d(7, 3):5.2f} us", flush=True)
-    # reset the stamps for the next layer (the buffer is only ever overwritten by workgroups that exist)
+        print(f"{'':30s} prologue: set-up {d(0, 5):5.2f} | requests (+ split of the fp32 forms) {d(5, 6):5.2f} | wait + barrier {d(6, 1):5.2f} us;  "
+              f"epilogue: set-up {d(2, 4):5.2f} | five blocks {d(4, 7):5.2f} | tail {d(7, 3):5.2f} us", flush=True)
