@@ -130,7 +130,7 @@ int rnnpose_corr_weight_f32(const float* g1, const float* g2, const float* targe
  *      geometry/projective_ops.py:116-124, geometry/transformation.py:27-46
  * Hm (B,6,6) = sum v*w*J^T J, bv (B,6) = sum v*w*J^T (target - x'), UNDAMPED, fp64.
  * weight (B,H,W) fp32; target/target_mode as above; depth raw (+depth_eps inside).
- * workspace: at least rnnpose_lm_workspace_bytes(B,H,W) bytes of device memory (block partials).   */
+ * workspace: at least rnnpose_lm_workspace_bytes(B,H,W) bytes of device memory ([B arrival counters][block partials]). */
 size_t rnnpose_lm_workspace_bytes(int B, int H, int W);
 int rnnpose_lm_normal_eq_f64(const float* target, int target_mode, const float* weight, const float* depth,
                              float depth_eps, const float* K, const float* G, int B, int H, int W,

@@ -598,12 +598,12 @@ __global__ __launch_bounds__(NW * 64, NI == 2 ? 1 : 2) void conv_strip_f16x3_ker
     constexpr int tn_ = last_ ? 0 : (T_) + 1, asn_ = last_ ? 1 - (H_) : (H_);                                \
     if (!(RS_ABL & 64)) wait_vm<2 * NI * (NBST - 3) + ((T_) <= NBST - 4 ? PAW : 0)>();                       \
     if constexpr (MODE != 0 && (T_) == NBST - 2) { RS_STORE_A(1 - (H_)) }    /* (requested at the last boundary; landed: (a)) */ \
-    if constexpr (last_) {                                                                                   \
+    if constexpr (last_ && !(RS_VAR & 8)) {                                                                  \
       wait_lds();                                                                                            \
       if (!(RS_ABL & 32)) wg_barrier();                                                                      \
       if (!(RS_ABL & 2)) { if constexpr (MODE == 0) { RS_ISSUE_A(H_) } else { RS_LOAD_A() } }   /* (half block hb+2; past the end: the last one again) */ \
     }                                                                                                        \
-    if (!(RS_ABL & 1)) RS_ISSUE_B((sl_ + NBST - 1) % NBST)                                                   \
+    if (!(RS_ABL & 1) && !(RS_VAR & 8)) RS_ISSUE_B((sl_ + NBST - 1) % NBST)                                  \
     __builtin_amdgcn_sched_barrier(0);                                                                       \
     if (RS_VAR & 2) {              /* variant: all fragment reads of the next step in front of the MFMAs */    \
       _Pragma("unroll") for (int k = 0; k < NRD; ++k) RS_READ1(k, 1 - set_, tn_, asn_, (sl_ + 1) % NBST)     \
@@ -612,6 +612,11 @@ __global__ __launch_bounds__(NW * 64, NI == 2 ? 1 : 2) void conv_strip_f16x3_ker
     if (RS_VAR & 1) __builtin_amdgcn_s_setprio(1);                                                           \
     _Pragma("unroll") for (int k = 0; k < NMM; ++k) {                                                        \
       if (!(RS_ABL & 8)) RS_MMA1(k, set_)                                                                    \
+      if (RS_VAR & 8) {            /* variant: the step's bookkeeping between its last MFMAs instead of in front of the first */ \
+        if (last_ && k == 2 * SMI * NI) { if (!(RS_ABL & 32)) wg_barrier(); }       /* (every fragment of this step has fed an MFMA: the reads of slot H_ are complete) */ \
+        if (last_ && k == 2 * SMI * NI + 1) { if (!(RS_ABL & 2)) { if constexpr (MODE == 0) { RS_ISSUE_A(H_) } else { RS_LOAD_A() } } } \
+        if (k == 2 * SMI * NI + 2) { if (!(RS_ABL & 1)) RS_ISSUE_B((sl_ + NBST - 1) % NBST) }                \
+      }                                                                                                      \
       if (!(RS_VAR & 2)) {                                                                                   \
         constexpr int kr0_ = (RS_VAR & 4) ? 2 : 0;        /* variant: the first reads behind the third MFMA */ \
         const bool isb_ = (k - kr0_ < NI) || (k - kr0_ >= NI + SMI && k - kr0_ < 2 * NI + SMI);              \

@@ -1,0 +1,74 @@
+// a8: the descriptor reliability weight of ONE pixel (model/PoseRefiner.py:342-345), shared by the stand-alone weight kernel
+// (pointwise.hip) and the fused weight + normal-equation kernel (lm.hip):
+//   taps  normalize_coords_grid (align_corners=True formula) then grid_sample's align_corners=False unnormalise, zero padding
+//   dot   s = sum_c g1[c, pixel] * bilinear(g2[c], taps), channels in batches whose 5 loads each are in flight together
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace rp {
+
+struct DescTaps {
+  float w00, w10, w01, w11;
+  long long o00, o10, o01, o11;
+};
+
+__device__ __forceinline__ DescTaps descriptor_taps(float tx, float ty, int H, int W) {
+  const float gx = 2.f * tx / static_cast<float>(W - 1) - 1.f;
+  const float gy = 2.f * ty / static_cast<float>(H - 1) - 1.f;
+  const float px = ((gx + 1.f) * static_cast<float>(W) - 1.f) / 2.f;
+  const float py = ((gy + 1.f) * static_cast<float>(H) - 1.f) / 2.f;
+  const bool sane = (px > -1.0e6f) && (px < 1.0e6f) && (py > -1.0e6f) && (py < 1.0e6f);
+  const float fx0 = floorf(px), fy0 = floorf(py);
+  const int x0 = sane ? static_cast<int>(fx0) : -10, y0 = sane ? static_cast<int>(fy0) : -10;
+  const float ax = px - fx0, ay = py - fy0;
+  const bool vx0 = x0 >= 0 && x0 < W, vx1 = x0 + 1 >= 0 && x0 + 1 < W;
+  const bool vy0 = y0 >= 0 && y0 < H, vy1 = y0 + 1 >= 0 && y0 + 1 < H;
+  DescTaps t;
+  t.w00 = (vx0 && vy0) ? (1.f - ax) * (1.f - ay) : 0.f;
+  t.w10 = (vx1 && vy0) ? ax * (1.f - ay) : 0.f;
+  t.w01 = (vx0 && vy1) ? (1.f - ax) * ay : 0.f;
+  t.w11 = (vx1 && vy1) ? ax * ay : 0.f;
+  const int cx0 = min(max(x0, 0), W - 1), cx1 = min(max(x0 + 1, 0), W - 1);
+  const int cy0 = min(max(y0, 0), H - 1), cy1 = min(max(y0 + 1, 0), H - 1);
+  t.o00 = static_cast<long long>(cy0) * W + cx0;
+  t.o10 = static_cast<long long>(cy0) * W + cx1;
+  t.o01 = static_cast<long long>(cy1) * W + cx0;
+  t.o11 = static_cast<long long>(cy1) * W + cx1;
+  return t;
+}
+
+// a = g1 + (b * D) * P + pixel, q = g2 + (b * D) * P.  NB channels per batch: all their loads are issued before the first use (the
+// fence keeps the compiler from serialising them behind vmcnt(0) waits, which it does as soon as the surrounding control flow
+// changes: 104 vs 259 us per launch, r02)
+template <int NB>
+__device__ __forceinline__ float descriptor_dot(const float* __restrict__ a, const float* __restrict__ q, long long P, int D,
+                                                const DescTaps& t) {
+  float s = 0.f;
+  int c = 0;
+  for (; c + NB <= D; c += NB) {
+    float av[NB], v00[NB], v10[NB], v01[NB], v11[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const float* qc = q + (c + j) * P;
+      av[j] = a[(c + j) * P];
+      v00[j] = qc[t.o00];
+      v10[j] = qc[t.o10];
+      v01[j] = qc[t.o01];
+      v11[j] = qc[t.o11];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const float wv = ((v00[j] * t.w00 + v10[j] * t.w10) + v01[j] * t.w01) + v11[j] * t.w11;
+      s += av[j] * wv;
+    }
+  }
+  for (; c < D; ++c) {
+    const float* qc = q + c * P;
+    const float wv = ((qc[t.o00] * t.w00 + qc[t.o10] * t.w10) + qc[t.o01] * t.w01) + qc[t.o11] * t.w11;
+    s += a[c * P] * wv;
+  }
+  return s;
+}
+
+}  // namespace rp

@@ -62,8 +62,108 @@ struct LmTail {
   double ep, lm, max_update;
 };
 __device__ void lm_finalize_block_one(const double* __restrict__ partials, int nblk, int b, double* __restrict__ Hm, double* __restrict__ bv);
-__device__ void lm_solve_one(const double* Hm, const double* bv, const float* G, int b, double ep, double lm, double max_update,
+__device__ __forceinline__ void lm_solve_one(const double* Hm, const double* bv, const float* G, int b, double ep, double lm, double max_update,
                              float* G_new, float* xi_out, int* info);
+
+// one pixel's contribution to the 21 + 6 sums (fp64), J and the residual from the TRANSFORMED point
+__device__ __forceinline__ void lm_accumulate(double (&acc)[NACC], float wgt, float dep, float tx, float ty, int x, int y, int target_mode,
+                                          float eps, const Intr& k, const Pose& g) {
+  const float Z = dep + eps;
+  if (target_mode != 0) {
+    tx += static_cast<float>(x);
+    ty += static_cast<float>(y);
+  }
+  const rp::Reproj r = rp::reproject(Z, static_cast<float>(x), static_cast<float>(y), k, g);
+  const bool valid = (r.Z0 > rp::kMinDepthValid) && (r.Z1 > rp::kMinDepthValid);   // transformation.py:289
+  const double vw = valid ? static_cast<double>(wgt) : 0.0;
+  // J_pi in fp32 (projective_ops.py:118-124): zeros where clamped Z <= 0.02
+  const bool tiny = r.Zc <= rp::kMinDepthProj + 0.01f;
+  const float zi1 = tiny ? 0.f : 1.0f / r.Zc;
+  const float zi2 = tiny ? 0.f : 1.0f / (r.Zc * r.Zc);
+  const double a = static_cast<double>(k.fx * zi1);
+  const double c = static_cast<double>(-k.fx * r.X1 * zi2);
+  const double d = static_cast<double>(k.fy * zi1);
+  const double e = static_cast<double>(-k.fy * r.Y1 * zi2);
+  const double X1 = r.X1, Y1 = r.Y1, Z1 = r.Z1;
+  // J = J_pi * J_T with J_T = [I | -[X']x] built from the TRANSFORMED point (transformation.py:27-46,85-90)
+  double J0[6], J1[6];
+  J0[0] = a;   J0[1] = 0.0; J0[2] = c; J0[3] = c * Y1;            J0[4] = a * Z1 + c * (-X1); J0[5] = a * (-Y1);
+  J1[0] = 0.0; J1[1] = d;   J1[2] = e; J1[3] = d * (-Z1) + e * Y1; J1[4] = e * (-X1);          J1[5] = d * X1;
+  const double r0 = static_cast<double>(tx) - static_cast<double>(r.u);
+  const double r1 = static_cast<double>(ty) - static_cast<double>(r.v);
+  int idx = 0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const double wi0 = vw * J0[i], wi1 = vw * J1[i];
+#pragma unroll
+    for (int jj = i; jj < 6; ++jj) {
+      acc[idx] += wi0 * J0[jj] + wi1 * J1[jj];
+      ++idx;
+    }
+    acc[21 + i] += wi0 * r0 + wi1 * r1;
+  }
+}
+
+// the workgroup's 27 sums -> its partial record; FUSED: the last workgroup of the image finalizes, solves and updates the pose
+template <bool FUSED>
+__device__ __forceinline__ void lm_reduce_tail(double (&acc)[NACC], double* __restrict__ partials, const LmTail& tail, int b, int nblk, int bx) {
+  __shared__ double red[LM_THREADS / 64][NACC];
+  __shared__ int is_last;
+  // wave reduction as a butterfly REDUCE-SCATTER (r04): at offset o = 32, 16, 8, 4, 2 a lane keeps the half of its (32, 16, 8, 4,
+  // 2) slots that bit o of its lane number selects, sends the other half to lane ^ o and adds what it receives -- 16 + 8 + 4 + 2 +
+  // 1 exchanged doubles per lane, after which lanes 2k and 2k + 1 hold the two halves of slot k = lane >> 1 (bit order below) and one
+  // last exchange completes it: 32 double exchanges per lane instead of the 27 x 6 = 162 of a full butterfly per accumulator
+  // (the reduction was as long as the fp64 accumulation itself).  Fixed tree: deterministic.  Then across the 4 waves through LDS.
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  {
+    double v[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) v[i] = i < NACC ? acc[i] : 0.0;
+#pragma unroll
+    for (int o = 32, n = 32; o >= 2; o >>= 1, n >>= 1) {         // n slots live before the step, n / 2 after
+      const bool hi = (lane & o) != 0;
+#pragma unroll
+      for (int i = 0; i < n / 2; ++i) {
+        const double send = hi ? v[i] : v[i + n / 2];
+        const double keep = hi ? v[i + n / 2] : v[i];
+        v[i] = keep + rp::shfl_xor_f64(send, o);
+      }
+    }
+    const double tot = v[0] + rp::shfl_xor_f64(v[0], 1);
+    // slot held by this lane pair: bit 5 of the lane chose the upper half of 32, bit 4 of 16, ... bit 1 of 2
+    const int slot = ((lane >> 5) & 1) * 16 + ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+    if (!(lane & 1) && slot < NACC) red[wave][slot] = tot;
+  }
+  __syncthreads();
+  if (threadIdx.x < NACC) {
+    double v = red[0][threadIdx.x];
+#pragma unroll
+    for (int wv = 1; wv < LM_THREADS / 64; ++wv) v += red[wv][threadIdx.x];
+    partials[(static_cast<long long>(b) * nblk + bx) * PSTRIDE + threadIdx.x] = v;
+  }
+  if constexpr (FUSED) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the compiler may drop the wait behind buffer_wbl2: guide, G16 pitfall)
+      const int t = __hip_atomic_fetch_add(&tail.tickets[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      is_last = (t == nblk - 1) ? 1 : 0;
+      if (is_last) {
+        __hip_atomic_store(&tail.tickets[b], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        // ONE agent-scope acquire per workgroup: it invalidates this CU's vector L1 (buffer_inv sc1), which is per CU, not per
+        // thread -- followed by the barrier below before any thread of the block loads the other workgroups' partial records
+        // (cdna_hip_programming.md, Guideline 16: "consumer: one relaxed poll -> one agent acquire -> __syncthreads() -> plain loads")
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+    }
+    __syncthreads();
+    if (!is_last) return;
+    lm_finalize_block_one(partials, nblk, b, tail.Hm, tail.bv);   // (ends with the values in global memory, written by this block)
+    __syncthreads();
+    if (threadIdx.x == 0) lm_solve_one(tail.Hm, tail.bv, tail.G_in, b, tail.ep, tail.lm, tail.max_update, tail.G_out, tail.xi, tail.info);
+  }
+}
 
 template <bool FUSED>
 __global__ __launch_bounds__(LM_THREADS) void lm_normal_eq_kernel(const float* __restrict__ target, int target_mode,
@@ -72,8 +172,6 @@ __global__ __launch_bounds__(LM_THREADS) void lm_normal_eq_kernel(const float* _
                                                                   const float* __restrict__ K,
                                                                   const float* __restrict__ G, int H, int W,
                                                                   double* __restrict__ partials, const LmTail tail) {
-  __shared__ double red[LM_THREADS / 64][NACC];
-  __shared__ int is_last;
   const int b = blockIdx.y;
   const int nblk = gridDim.x;
   const long long P = static_cast<long long>(H) * W;
@@ -118,97 +216,10 @@ __global__ __launch_bounds__(LM_THREADS) void lm_normal_eq_kernel(const float* _
       // lane with a non-finite input keeps its wave in the chain, so that happens here too, whatever the wave is made of.
       const bool skippable = wgt == 0.f && __builtin_isfinite(tx_[j]) && __builtin_isfinite(ty_[j]) && __builtin_isfinite(dep_[j]);
       if (__builtin_amdgcn_ballot_w64(!skippable) == 0ull) continue;
-      const float Z = dep_[j] + eps;
-      float tx = tx_[j], ty = ty_[j];
-      if (target_mode != 0) {
-        tx += static_cast<float>(x);
-        ty += static_cast<float>(y);
-      }
-      const rp::Reproj r = rp::reproject(Z, static_cast<float>(x), static_cast<float>(y), k, g);
-      const bool valid = (r.Z0 > rp::kMinDepthValid) && (r.Z1 > rp::kMinDepthValid);   // transformation.py:289
-      const double vw = valid ? static_cast<double>(wgt) : 0.0;
-      // J_pi in fp32 (projective_ops.py:118-124): zeros where clamped Z <= 0.02
-      const bool tiny = r.Zc <= rp::kMinDepthProj + 0.01f;
-      const float zi1 = tiny ? 0.f : 1.0f / r.Zc;
-      const float zi2 = tiny ? 0.f : 1.0f / (r.Zc * r.Zc);
-      const double a = static_cast<double>(k.fx * zi1);
-      const double c = static_cast<double>(-k.fx * r.X1 * zi2);
-      const double d = static_cast<double>(k.fy * zi1);
-      const double e = static_cast<double>(-k.fy * r.Y1 * zi2);
-      const double X1 = r.X1, Y1 = r.Y1, Z1 = r.Z1;
-      // J = J_pi * J_T with J_T = [I | -[X']x] built from the TRANSFORMED point (transformation.py:27-46,85-90)
-      double J0[6], J1[6];
-      J0[0] = a;   J0[1] = 0.0; J0[2] = c; J0[3] = c * Y1;            J0[4] = a * Z1 + c * (-X1); J0[5] = a * (-Y1);
-      J1[0] = 0.0; J1[1] = d;   J1[2] = e; J1[3] = d * (-Z1) + e * Y1; J1[4] = e * (-X1);          J1[5] = d * X1;
-      const double r0 = static_cast<double>(tx) - static_cast<double>(r.u);
-      const double r1 = static_cast<double>(ty) - static_cast<double>(r.v);
-      int idx = 0;
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        const double wi0 = vw * J0[i], wi1 = vw * J1[i];
-#pragma unroll
-        for (int jj = i; jj < 6; ++jj) {
-          acc[idx] += wi0 * J0[jj] + wi1 * J1[jj];
-          ++idx;
-        }
-        acc[21 + i] += wi0 * r0 + wi1 * r1;
-      }
+      lm_accumulate(acc, wgt, dep_[j], tx_[j], ty_[j], x, y, target_mode, eps, k, g);
     }
   }
-  // wave reduction as a butterfly REDUCE-SCATTER (r04): at offset o = 32, 16, 8, 4, 2 a lane keeps the half of its (32, 16, 8, 4,
-  // 2) slots that bit o of its lane number selects, sends the other half to lane ^ o and adds what it receives -- 16 + 8 + 4 + 2 +
-  // 1 exchanged doubles per lane, after which lanes 2k and 2k + 1 hold the two halves of slot k = lane >> 1 (bit order below) and one
-  // last exchange completes it: 32 double exchanges per lane instead of the 27 x 6 = 162 of a full butterfly per accumulator
-  // (the reduction was as long as the fp64 accumulation itself).  Fixed tree: deterministic.  Then across the 4 waves through LDS.
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  {
-    double v[32];
-#pragma unroll
-    for (int i = 0; i < 32; ++i) v[i] = i < NACC ? acc[i] : 0.0;
-#pragma unroll
-    for (int o = 32, n = 32; o >= 2; o >>= 1, n >>= 1) {         // n slots live before the step, n / 2 after
-      const bool hi = (lane & o) != 0;
-#pragma unroll
-      for (int i = 0; i < n / 2; ++i) {
-        const double send = hi ? v[i] : v[i + n / 2];
-        const double keep = hi ? v[i + n / 2] : v[i];
-        v[i] = keep + rp::shfl_xor_f64(send, o);
-      }
-    }
-    const double tot = v[0] + rp::shfl_xor_f64(v[0], 1);
-    // slot held by this lane pair: bit 5 of the lane chose the upper half of 32, bit 4 of 16, ... bit 1 of 2
-    const int slot = ((lane >> 5) & 1) * 16 + ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
-    if (!(lane & 1) && slot < NACC) red[wave][slot] = tot;
-  }
-  __syncthreads();
-  if (threadIdx.x < NACC) {
-    double v = red[0][threadIdx.x];
-#pragma unroll
-    for (int wv = 1; wv < LM_THREADS / 64; ++wv) v += red[wv][threadIdx.x];
-    partials[(static_cast<long long>(b) * nblk + blockIdx.x) * PSTRIDE + threadIdx.x] = v;
-  }
-  if constexpr (FUSED) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the compiler may drop the wait behind buffer_wbl2: guide, G16 pitfall)
-      const int t = __hip_atomic_fetch_add(&tail.tickets[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      is_last = (t == nblk - 1) ? 1 : 0;
-      if (is_last) {
-        __hip_atomic_store(&tail.tickets[b], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-        // ONE agent-scope acquire per workgroup: it invalidates this CU's vector L1 (buffer_inv sc1), which is per CU, not per
-        // thread -- followed by the barrier below before any thread of the block loads the other workgroups' partial records
-        // (cdna_hip_programming.md, Guideline 16: "consumer: one relaxed poll -> one agent acquire -> __syncthreads() -> plain loads")
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      }
-    }
-    __syncthreads();
-    if (!is_last) return;
-    lm_finalize_block_one(partials, nblk, b, tail.Hm, tail.bv);   // (ends with the values in global memory, written by this block)
-    __syncthreads();
-    if (threadIdx.x == 0) lm_solve_one(tail.Hm, tail.bv, tail.G_in, b, tail.ep, tail.lm, tail.max_update, tail.G_out, tail.xi, tail.info);
-  }
+  lm_reduce_tail<FUSED>(acc, partials, tail, b, nblk, static_cast<int>(blockIdx.x));
 }
 
 // sums the block partials in fixed order and expands to full H (6x6) and b (6)
@@ -295,45 +306,57 @@ __device__ void mat4_mul(const float* A, const float* Bm, float* C) {
 
 // one thread per image: damping, Cholesky, substitutions, guards, exp, left increment
 // damping, 6x6 Cholesky solve, NaN -> 0, clamp, SE(3) exponential and left increment of image b (one thread)
-__device__ void lm_solve_one(const double* Hm, const double* bv, const float* G, int b, double ep, double lm,
-                             double max_update, float* G_new /* may alias G */, float* xi_out, int* info) {
+__device__ __forceinline__ void lm_solve_one(const double* Hm, const double* bv, const float* G, int b, double ep, double lm,
+                                             double max_update, float* G_new /* may alias G */, float* xi_out, int* info) {
   // (the fused tail reads H, b that this very thread's block wrote a barrier ago: same CU, same L1 -- plain loads are current)
-  double A[6][6], L[6][6], rhs[6], yv[6], xv[6];
+  // In place on the lower triangle (21 doubles instead of two 6x6 arrays: this function's registers are the floor of every kernel
+  // that calls it, r04) -- the same operations in the same order as the two-array form.
+  double L[21], xv[6];
+#define LT(i_, j_) L[(i_) * ((i_) + 1) / 2 + (j_)]
+#pragma unroll
   for (int i = 0; i < 6; ++i) {
-    for (int j = 0; j < 6; ++j) {
-      A[i][j] = Hm[b * 36 + i * 6 + j];
-      L[i][j] = 0.0;
-    }
-    rhs[i] = bv[b * 6 + i];
+#pragma unroll
+    for (int j = 0; j <= i; ++j) LT(i, j) = Hm[b * 36 + i * 6 + j];
+    xv[i] = bv[b * 6 + i];
   }
-  for (int i = 0; i < 6; ++i) A[i][i] = A[i][i] + ep + lm * A[i][i];   // H += ep*I + lm*H*I  (transformation.py:300)
+#pragma unroll
+  for (int i = 0; i < 6; ++i) LT(i, i) = LT(i, i) + ep + lm * LT(i, i);   // H += ep*I + lm*H*I  (transformation.py:300)
   int bad = 0;
   const double nan = __longlong_as_double(0x7ff8000000000000LL);
+#pragma unroll
   for (int j = 0; j < 6; ++j) {
-    double s = A[j][j];
-    for (int k = 0; k < j; ++k) s -= L[j][k] * L[j][k];
+    double s = LT(j, j);
+#pragma unroll
+    for (int k = 0; k < j; ++k) s -= LT(j, k) * LT(j, k);
     if (!(s > 0.0)) {
       if (!bad) bad = j + 1;
-      L[j][j] = nan;
+      LT(j, j) = nan;
     } else {
-      L[j][j] = sqrt(s);
+      LT(j, j) = sqrt(s);
     }
+#pragma unroll
     for (int i = j + 1; i < 6; ++i) {
-      double t = A[i][j];
-      for (int k = 0; k < j; ++k) t -= L[i][k] * L[j][k];
-      L[i][j] = t / L[j][j];
+      double t = LT(i, j);
+#pragma unroll
+      for (int k = 0; k < j; ++k) t -= LT(i, k) * LT(j, k);
+      LT(i, j) = t / LT(j, j);
     }
   }
-  for (int i = 0; i < 6; ++i) {
-    double t = rhs[i];
-    for (int k = 0; k < i; ++k) t -= L[i][k] * yv[k];
-    yv[i] = t / L[i][i];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {              // forward substitution, in place (xv: rhs -> y)
+    double t = xv[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) t -= LT(i, k) * xv[k];
+    xv[i] = t / LT(i, i);
   }
-  for (int i = 5; i >= 0; --i) {
-    double t = yv[i];
-    for (int k = i + 1; k < 6; ++k) t -= L[k][i] * xv[k];
-    xv[i] = t / L[i][i];
+#pragma unroll
+  for (int i = 5; i >= 0; --i) {             // back substitution, in place (y -> x)
+    double t = xv[i];
+#pragma unroll
+    for (int k = i + 1; k < 6; ++k) t -= LT(k, i) * xv[k];
+    xv[i] = t / LT(i, i);
   }
+#undef LT
   float xi[6];
   for (int i = 0; i < 6; ++i) {
     double v = xv[i];
@@ -395,13 +418,16 @@ __global__ void se3_inverse_kernel(const float* __restrict__ A, int B, float* __
   for (int i = 0; i < 16; ++i) out[b * 16 + i] = o[i];
 }
 
+// workspace = [B arrival counters, 8 bytes each: zero between launches][partial records]
+inline double* lm_partials(void* workspace, int B) { return static_cast<double*>(workspace) + B; }
+
 // per-workgroup partial sums into `workspace`; -> number of partial records per image
 int launch_normal_eq_partials(const float* target, int target_mode, const float* weight, const float* depth, float eps,
                               const float* K, const float* G, int B, int H, int W, void* workspace, hipStream_t st) {
   const long long P = static_cast<long long>(H) * W;
   const int nblk = lm_blocks_per_image(P);
   hipLaunchKernelGGL(lm_normal_eq_kernel<false>, dim3(nblk, B), dim3(LM_THREADS), 0, st, target, target_mode, weight, depth, eps,
-                     K, G, H, W, static_cast<double*>(workspace), LmTail{});
+                     K, G, H, W, lm_partials(workspace, B), LmTail{});
   return nblk;
 }
 
@@ -412,18 +438,18 @@ void launch_lm_step_fused(const float* target, int target_mode, const float* wei
   const long long P = static_cast<long long>(H) * W;
   const int nblk = lm_blocks_per_image(P);
   LmTail tail{};
-  tail.tickets = reinterpret_cast<int*>(static_cast<double*>(workspace) + static_cast<size_t>(B) * nblk * PSTRIDE);
+  tail.tickets = static_cast<int*>(workspace);
   tail.Hm = Hm; tail.bv = bv; tail.G_in = G_in; tail.G_out = G_out; tail.xi = xi; tail.info = info;
   tail.ep = ep; tail.lm = lm; tail.max_update = max_update;
   hipLaunchKernelGGL(lm_normal_eq_kernel<true>, dim3(nblk, B), dim3(LM_THREADS), 0, st, target, target_mode, weight, depth, eps,
-                     K, G_in, H, W, static_cast<double*>(workspace), tail);
+                     K, G_in, H, W, lm_partials(workspace, B), tail);
 }
 
 int launch_normal_eq(const float* target, int target_mode, const float* weight, const float* depth, float eps,
                      const float* K, const float* G, int B, int H, int W, void* workspace, double* Hm, double* bv,
                      hipStream_t st) {
   const int nblk = launch_normal_eq_partials(target, target_mode, weight, depth, eps, K, G, B, H, W, workspace, st);
-  hipLaunchKernelGGL(lm_finalize_kernel, dim3(B), dim3(256), 0, st, static_cast<const double*>(workspace), nblk, Hm, bv);
+  hipLaunchKernelGGL(lm_finalize_kernel, dim3(B), dim3(256), 0, st, lm_partials(workspace, B), nblk, Hm, bv);
   return 0;
 }
 

@@ -6,6 +6,7 @@
 //   a4  SepConvGRU gate / state update           thirdparty/raft/update.py:45-60
 // Every kernel reads each input byte once with lane-contiguous addresses and writes coalesced rows.
 #include "geometry.cuh"
+#include "descriptor_weight.cuh"
 
 namespace {
 
@@ -250,52 +251,8 @@ __global__ __launch_bounds__(256) void corr_weight_kernel(const float* __restric
     tx = target[(static_cast<long long>(b) * 2 + 0) * P + t] + static_cast<float>(x);
     ty = target[(static_cast<long long>(b) * 2 + 1) * P + t] + static_cast<float>(y);
   }
-  // normalize_coords_grid (align_corners=True formula) then grid_sample's align_corners=False unnormalise
-  const float gx = 2.f * tx / static_cast<float>(W - 1) - 1.f;
-  const float gy = 2.f * ty / static_cast<float>(H - 1) - 1.f;
-  const float px = ((gx + 1.f) * static_cast<float>(W) - 1.f) / 2.f;
-  const float py = ((gy + 1.f) * static_cast<float>(H) - 1.f) / 2.f;
-  const bool sane = (px > -1.0e6f) && (px < 1.0e6f) && (py > -1.0e6f) && (py < 1.0e6f);
-  const float fx0 = floorf(px), fy0 = floorf(py);
-  const int x0 = sane ? static_cast<int>(fx0) : -10, y0 = sane ? static_cast<int>(fy0) : -10;
-  const float ax = px - fx0, ay = py - fy0;
-  const bool vx0 = x0 >= 0 && x0 < W, vx1 = x0 + 1 >= 0 && x0 + 1 < W;
-  const bool vy0 = y0 >= 0 && y0 < H, vy1 = y0 + 1 >= 0 && y0 + 1 < H;
-  const float w00 = (vx0 && vy0) ? (1.f - ax) * (1.f - ay) : 0.f, w10 = (vx1 && vy0) ? ax * (1.f - ay) : 0.f;
-  const float w01 = (vx0 && vy1) ? (1.f - ax) * ay : 0.f, w11 = (vx1 && vy1) ? ax * ay : 0.f;
-  const int cx0 = min(max(x0, 0), W - 1), cx1 = min(max(x0 + 1, 0), W - 1);
-  const int cy0 = min(max(y0, 0), H - 1), cy1 = min(max(y0 + 1, 0), H - 1);
-  const long long o00 = static_cast<long long>(cy0) * W + cx0, o10 = static_cast<long long>(cy0) * W + cx1;
-  const long long o01 = static_cast<long long>(cy1) * W + cx0, o11 = static_cast<long long>(cy1) * W + cx1;
-  const float* a = g1 + static_cast<long long>(b) * D * P + t;
-  const float* q = g2 + static_cast<long long>(b) * D * P;
-  float s = 0.f;
-  int c = 0;
-  // CW_BATCH channels per batch: all their loads are issued before the first use (the fence keeps the compiler from serialising
-  // them behind vmcnt(0) waits, which it does as soon as the surrounding control flow changes: 104 vs 259 us per launch)
-  for (; c + CW_BATCH <= D; c += CW_BATCH) {
-    float av[CW_BATCH], v00[CW_BATCH], v10[CW_BATCH], v01[CW_BATCH], v11[CW_BATCH];
-#pragma unroll
-    for (int j = 0; j < CW_BATCH; ++j) {
-      const float* qc = q + (c + j) * P;
-      av[j] = a[(c + j) * P];
-      v00[j] = qc[o00];
-      v10[j] = qc[o10];
-      v01[j] = qc[o01];
-      v11[j] = qc[o11];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int j = 0; j < CW_BATCH; ++j) {
-      const float wv = ((v00[j] * w00 + v10[j] * w10) + v01[j] * w01) + v11[j] * w11;
-      s += av[j] * wv;
-    }
-  }
-  for (; c < D; ++c) {
-    const float* qc = q + c * P;
-    const float wv = ((qc[o00] * w00 + qc[o10] * w10) + qc[o01] * w01) + qc[o11] * w11;
-    s += a[c * P] * wv;
-  }
+  const rp::DescTaps taps = rp::descriptor_taps(tx, ty, H, W);
+  const float s = rp::descriptor_dot<CW_BATCH>(g1 + static_cast<long long>(b) * D * P + t, g2 + static_cast<long long>(b) * D * P, P, D, taps);
   weight[b * P + t] = expf(-fabsf(1.f - s) / sigma[0]) * fg;
 }
 

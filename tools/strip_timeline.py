@@ -47,12 +47,25 @@ for name, segs, co, kh, kw, hh, ww, hl in cases:
     start = np.sort(last[:, 0])
     # the last launch: stamps within 1 ms of the newest exit
     newest = last[:, 3].max()
-    sel = last[last[:, 0] > newest - 100000 // 100 * 30]      # 300 us window (100 MHz ticks: 100 per us)
+    idx_all = np.nonzero(live)[0]
+    keep = last[:, 0] > newest - 100000 // 100 * 30           # 300 us window (100 MHz ticks: 100 per us)
+    sel = last[keep]
+    wg_id = idx_all[keep]
     pro, loop, epi = (sel[:, 1] - sel[:, 0]) / 100.0, (sel[:, 2] - sel[:, 1]) / 100.0, (sel[:, 3] - sel[:, 2]) / 100.0
     span = (sel[:, 3].max() - sel[:, 0].min()) / 100.0
     life = (sel[:, 3] - sel[:, 0]).sum() / 100.0
     print(f"{name:30s} wgs {len(sel):5d} span {span:7.1f} us | prologue {pro.mean():5.2f} (med {np.median(pro):5.2f}) loop {loop.mean():6.2f} (med {np.median(loop):6.2f}) "
           f"epilogue {epi.mean():5.2f} (med {np.median(epi):5.2f}) us | resident wgs {life / span:6.1f} = {life / span / 256:4.2f} per CU", flush=True)
+    st = np.sort(sel[:, 0] - sel[:, 0].min()) / 100.0
+    en = np.sort(sel[:, 3] - sel[:, 0].min()) / 100.0
+    pc = lambda a, q: a[min(len(a) - 1, int(q * len(a)))]
+    print(f"{'':30s} workgroup entry times (us after the first): 10 % {pc(st, .1):5.1f} | 50 % {pc(st, .5):5.1f} | 90 % {pc(st, .9):5.1f} | last {st[-1]:5.1f};  "
+          f"exits: first {en[0]:5.1f} | 50 % {pc(en, .5):5.1f} | last {en[-1]:5.1f}", flush=True)
+    lifeus = (sel[:, 3] - sel[:, 0]) / 100.0
+    hist = np.histogram(lifeus, bins=8)
+    print(f"{'':30s} lifetime histogram (us): " + " ".join(f"{int(c)}@{e:.0f}" for c, e in zip(hist[0], hist[1][:-1])), flush=True)
+    print(f"{'':30s} mean lifetime by blockIdx % 8 (XCD): " + " ".join(f"{lifeus[wg_id % 8 == x].mean():5.1f}" for x in range(8))
+          + " | by decile of blockIdx: " + " ".join(f"{lifeus[(wg_id * 10 // (wg_id.max() + 1)) == q].mean():5.1f}" for q in range(10)), flush=True)
     if sel[:, 5].max() > 0:      # finer stamps: address set-up done, all prologue requests issued, epilogue set-up done, last store issued
         d = lambda a, b: (sel[:, b] - sel[:, a]).mean() / 100.0
         print(f"{'':30s} prologue: set-up {d(0, 5):5.2f} | requests (+ split of the fp32 forms) {d(5, 6):5.2f} | wait + barrier {d(6, 1):5.2f} us;  "
