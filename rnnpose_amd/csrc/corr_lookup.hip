@@ -90,17 +90,17 @@ __global__ __launch_bounds__(64) void corr_lookup_kernel(const float* __restrict
       const int xa = qbx + tx0, ya = qby + ty0, xb = qbx + tx1, yb = qby + ty1;
       const bool oka = xa >= 0 && xa < wl && ya >= 0 && ya < hl;
       const bool okb = has1 && xb >= 0 && xb < wl && yb >= 0 && yb < hl;
-      if (lvl == 0) {        // j-patch-major: texel (y, x) of pixel i = patch ((y >> 3) n_px + (x >> 4)), row i, cell (y & 7, x & 15)
-        const int qbg = __shfl(bg, qq), qpix = __shfl(pixg, qq);
-        const float* src = lvl_base + (static_cast<long long>(qbg) * info.n_patch * N + qpix) * 128;
-        const long long pstride = static_cast<long long>(N) * 128;
-        v0[j] = src[oka ? ((ya >> 3) * info.n_px + (xa >> 4)) * pstride + (ya & 7) * 16 + (xa & 15) : 0];
-        v1[j] = src[okb ? ((yb >> 3) * info.n_px + (xb >> 4)) * pstride + (yb & 7) * 16 + (xb & 15) : 0];
-      } else {
-        const float* src = lvl_base + (p_off + first + qq) * img;     // p_off: first pyramid row of this launch's images
-        v0[j] = src[oka ? ya * wl + xa : 0];
-        v1[j] = src[okb ? yb * wl + xb : 0];
-      }
+      // level 0 is j-patch-major: texel (y, x) of pixel i = patch ((y >> 3) n_px + (x >> 4)), row i, cell (y & 7, x & 15); the other
+      // levels are row-major maps per pixel.  Both forms as SELECTS on the (block-uniform) level, not as a branch: a branch around the
+      // loads brought the one-wait-per-load form back (tests/test_isa_guard.py: 24 vmcnt(0) waits for 50 loads)
+      const int qbg = __shfl(bg, qq), qpix = __shfl(pixg, qq);
+      const long long pstride = static_cast<long long>(N) * 128;
+      const bool l0 = lvl == 0;
+      const float* src = lvl_base + (l0 ? (static_cast<long long>(qbg) * info.n_patch * N + qpix) * 128 : (p_off + first + qq) * img);
+      const long long ea = l0 ? ((ya >> 3) * info.n_px + (xa >> 4)) * pstride + (ya & 7) * 16 + (xa & 15) : static_cast<long long>(ya * wl + xa);
+      const long long eb = l0 ? ((yb >> 3) * info.n_px + (xb >> 4)) * pstride + (yb & 7) * 16 + (xb & 15) : static_cast<long long>(yb * wl + xb);
+      v0[j] = src[oka ? ea : 0];
+      v1[j] = src[okb ? eb : 0];
       ok |= (oka ? 1u : 0u) << (2 * j) | (okb ? 2u : 0u) << (2 * j);
     }
     __builtin_amdgcn_sched_barrier(0);

@@ -59,7 +59,7 @@ def test_pyramid_layout(lib):
 
 
 def test_workspace_and_argument_validation(lib):
-    assert lib.rnnpose_lm_workspace_bytes(8, 480, 640) == 8 * 150 * 32 * 8 + 8 * 8      # partial records + one arrival counter per image
+    assert lib.rnnpose_lm_workspace_bytes(8, 480, 640) == 8 * 75 * 32 * 8 + 8 * 8       # one arrival counter per image + partial records (4096 pixels each)
     assert lib.rnnpose_lm_workspace_bytes(1, 16, 16) == 32 * 8 + 8
     assert lib.rnnpose_lm_workspace_bytes(0, 16, 16) == 0
     null = C.c_void_p(0)
