@@ -122,6 +122,9 @@ __device__ unsigned long long g_strip_clk[8 * 65536];
 #else
 #define RS_CLK(I_)
 #endif
+#ifndef RS_SLICE_BITS
+#define RS_SLICE_BITS 9    // (100-MHz clock: 2^9 ticks = 5.12 us)
+#endif
 #ifndef RS_VAR
 #define RS_VAR 0          // schedule variants (measurement): 1 s_setprio(1) around a step's MFMAs, 2 fragment reads in front of the
 #endif                    // MFMAs instead of between them, 4 the first read behind the third MFMA
@@ -601,6 +604,12 @@ __global__ __launch_bounds__(NW * 64, NI == 2 ? 1 : 2) void conv_strip_f16x3_ker
     if constexpr (last_ && !(RS_VAR & 8)) {                                                                  \
       wait_lds();                                                                                            \
       if (!(RS_ABL & 32)) wg_barrier();                                                                      \
+      if (RS_VAR & 16) {          /* variant: time-sliced issue priority (the two waves of a SIMD take turns of RS_SLICE_BITS clock bits) */ \
+        unsigned long long t_;                                                                               \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                       \
+        if (((static_cast<unsigned>(t_) >> RS_SLICE_BITS) ^ slotpar_) & 1u) __builtin_amdgcn_s_setprio(2);   \
+        else __builtin_amdgcn_s_setprio(0);                                                                  \
+      }                                                                                                      \
       if (!(RS_ABL & 2)) { if constexpr (MODE == 0) { RS_ISSUE_A(H_) } else { RS_LOAD_A() } }   /* (half block hb+2; past the end: the last one again) */ \
     }                                                                                                        \
     if (!(RS_ABL & 1) && !(RS_VAR & 8)) RS_ISSUE_B((sl_ + NBST - 1) % NBST)                                  \
@@ -627,6 +636,7 @@ __global__ __launch_bounds__(NW * 64, NI == 2 ? 1 : 2) void conv_strip_f16x3_ker
     }                                                                                                        \
     if (RS_VAR & 1) __builtin_amdgcn_s_setprio(0);                                                           \
   }
+  const unsigned slotpar_ = __builtin_amdgcn_s_getreg(6148) & 1u;       // HW_ID.wave_id (bits 3:0): the wave slot on this SIMD
   for (int hbp = 0; hbp < NHB; hbp += 2) {
     if constexpr (TT == 5) {
       RS_STEP(0, 0) RS_STEP(0, 1) RS_STEP(0, 2) RS_STEP(0, 3) RS_STEP(0, 4)
