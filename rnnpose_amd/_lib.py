@@ -8,6 +8,7 @@ import ctypes as C
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
+ABI_VERSION = 2          # include/rnnpose_hip.h: RNNPOSE_ABI_VERSION of the library this front end was written against
 LIB_PATH = os.environ.get("RNNPOSE_LIB") or os.path.join(_PKG, "lib", "librnnpose_hip.so")
 
 _p = C.c_void_p
@@ -145,7 +146,7 @@ def load() -> C.CDLL:
             raise RuntimeError(f"{LIB_PATH} does not export {name}; rebuild it") from e
         fn.restype = res
         fn.argtypes = args
-    if lib.rnnpose_abi_version() != 2:
+    if lib.rnnpose_abi_version() != ABI_VERSION:
         raise RuntimeError("librnnpose_hip.so ABI version mismatch; rebuild it")
     _lib = lib
     return lib

@@ -135,3 +135,15 @@ def test_header_is_plain_c99_and_links_against_the_library(tmp_path):
     ver, total = out.stdout.split()
     n = 2 * 16 * 24
     assert int(ver) == 2 and int(total) == n * (2 * 2 * 128 + 8 * 12 + 4 * 6 + 2 * 3)     # level 0: 2 x 2 whole patches (16 x 24 -> 16 x 32 cells)
+
+
+def test_graft_entry_build_runs():
+    """__graft_entry__.build() (what the driver calls on the CPU box each round): compiles / finds the library, checks its ABI version
+    against the front end's and imports the package -- r04's record pass caught a stale version assert in it."""
+    import importlib
+    import sys
+    sys.path.insert(0, ROOT)
+    ge = importlib.import_module("__graft_entry__")
+    ge.build()
+    from rnnpose_amd import _lib
+    assert _lib.load().rnnpose_abi_version() == _lib.ABI_VERSION == 2
