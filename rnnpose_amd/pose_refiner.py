@@ -234,9 +234,6 @@ class PoseRefiner(nn.Module):
         B = depth.shape[0]
         opt = self.cfg.OPTIM_ITER_COUNT
         Gc = G3[b0:b1]
-        stagger = int(os.environ.get("RNNPOSE_STAGGER_CYCLES", "0"))      # measurement: the later halves start this many GPU clock ticks late
-        if stagger and b0 > 0:
-            torch.cuda._sleep(stagger)
         for i in range(n):
             flow_up, wmap, Gn, Hm, bv, xi, info = (t[b0:b1] for t in bufs["views"][i])
             coords1 = ops.induced_coords_lowres(depth[b0:b1], K[b0:b1], Gc, h, w, EPS, out=bufs["coords"][i, b0:b1])   # :324-328, CFNet.py:136-144
