@@ -252,11 +252,13 @@ typedef struct {
                                   encoder sets it: every convolution input there is an instance-normalised map or a ReLU sum of a few
                                   (|(x - mean) * rstd| <= sqrt(H*W); extractor.py:48-58), two orders below the fp16x3 range */
   int tile;                    /* 0 = automatic; 1 = 128x64, 2 = 128x128 as 4 column waves, 3 = 128x128 as 2x2 waves, 4 = 128x64 with
-                                  a block-deep register pipeline (3, 4: split sources only); 5 = the STRIP kernels (160 output
-                                  pixels x 96 / 128 columns per workgroup, weights and split-tensor activations by LDS-DMA:
+                                  a block-deep register pipeline (3, 4: split sources only); 5 / 6 = the STRIP kernels with 160- / 32-row strips (160 / 32 output
+                                  pixels x 64 / 96 / 128 columns per workgroup, weights and split-tensor activations by LDS-DMA:
                                   stride 1, 3x3 / 1x5 / 5x1, c_out > 32, source channel counts in multiples of 32; a launch with tile_stats / src0_mean_rstd tiles every image into
-                                  rnnpose_conv_tiles_per_image_ex(..., 5) tiles).  The automatic choice takes the strip kernels
-                                  for these layer shapes when the map fills the chip with strips (rnnpose_conv_strip(0): never). */
+                                  rnnpose_conv_tiles_per_image_ex(..., tile, B) tiles).  The automatic choice takes 160-row strips for
+                                  these layer shapes when they give the launch >= 240 workgroups (or >= 24 per image), 32-row strips
+                                  for launches of <= 8192 pixels (single-image crops), else the 128-row kernels
+                                  (rnnpose_conv_strip(0): never strips). */
   void* ksplit_ws;             /* optional (NULL = off): workspace of rnnpose_conv_ksplit_workspace_bytes() bytes, 16-byte aligned,
                                   its first 1024 bytes ZERO before the first launch (the kernel leaves them zero).  With it, a
                                   stride-1 launch of few tiles (B = 1 crops: 8-64 workgroups on 256 CUs) splits its K loop over up
@@ -276,13 +278,14 @@ int rnnpose_conv_ksplit_limits(int max_tiles, int max_splits);   /* measurement:
  * output pixels (ceil(H_out*W_out/128) when tiled per image).  rnnpose_conv_spatial_tiles(0) switches the patch tiling off
  * (measurement: the r02 row-major tiling for 3x3 layers too). */
 int rnnpose_conv_tiles_per_image(int H, int W, int kh, int kw, int stride);
-/* The same for the kernel a launch with this c_out and `tile` request (0 automatic .. 5 strips) will take: the strip kernels
- * tile an image into ceil(W/16) * ceil(H/10) patches of 10 x 16 pixels (3x3) or ceil(H*W/160) runs of 160 pixels. */
-int rnnpose_conv_tiles_per_image_ex(int H, int W, int kh, int kw, int stride, int c_out, int tile);
+/* The same for the kernel a launch of `batch` images with this c_out and `tile` request (0 automatic .. 6) will take: the strip
+ * kernels tile an image into ceil(W/16) * ceil(H/10) patches of 10 x 16 pixels (3x3) or ceil(H*W/160) runs of 160 pixels (32-row
+ * strips: patches of 2 x 16 pixels, runs of 32). */
+int rnnpose_conv_tiles_per_image_ex(int H, int W, int kh, int kw, int stride, int c_out, int tile, int batch);
 int rnnpose_conv_spatial_tiles(int enable);
 int rnnpose_conv_strip(int mode);          /* measurement switch: 0 = the automatic choice never takes the strip kernels, 1 = default,
                                               2 = automatic without the two-wave workgroups of 64-channel layers, 3 = two 32-column
-                                              tiles per wave (one workgroup per CU) */
+                                              tiles per wave (one workgroup per CU), 4 = 160-row strips only (>= 24 per image) */
 /* number of fp16 elements of the packed weight array (hi and lo parts interleaved, in the fragment order of the 128-row kernels
  * followed by the record order of the strip kernels); -1 on bad arguments */
 long long rnnpose_conv_packed_halfs(int c_out, int kh, int kw, const int* h_seg_counts, int n_seg);

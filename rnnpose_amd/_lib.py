@@ -69,7 +69,7 @@ PROTOTYPES = {
     "rnnpose_gru_gate_f32": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p]),
     "rnnpose_gru_update_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _i, _p]),
     "rnnpose_conv_tiles_per_image": (_i, [_i, _i, _i, _i, _i]),
-    "rnnpose_conv_tiles_per_image_ex": (_i, [_i, _i, _i, _i, _i, _i, _i]),
+    "rnnpose_conv_tiles_per_image_ex": (_i, [_i, _i, _i, _i, _i, _i, _i, _i]),
     "rnnpose_conv_spatial_tiles": (_i, [_i]),
     "rnnpose_conv_strip": (_i, [_i]),
     "rnnpose_conv_ksplit": (_i, [_i]),

@@ -96,11 +96,14 @@ struct PackParams {
 int strip_waves(int c_out);                                    // workgroup shape: 16 * (32-column tiles per wave) + waves; 0 = unsupported width
 void strip_allow_two_wave(int on);                             // measurement: two-wave workgroups (c_out <= 64) in the automatic choice (default on)
 void strip_force_ni(int ni);                                   // measurement: 0 automatic, 1 / 2 column tiles per wave
-bool strip_auto(int H, int W, int kh, int kw, int stride, int c_out);      // does the automatic choice take the strip kernel? (shape only)
-int strip_tiles_per_image(int H, int W, int kh, int kw);      // output tiles per image when tiled per image (tile_stats records)
+void strip_allow_small(int on);                                // measurement: 32-row strips in the automatic choice (default on)
+// strip height (160 / 32 rows) a launch of `batch` images takes, 0 = not a strip launch; request: 0 automatic, else the height to force
+int strip_rows(int H, int W, int kh, int kw, int stride, int c_out, int batch, int request);
+int strip_tiles_per_image(int H, int W, int kh, int kw, int rows);      // output tiles per image when tiled per image (tile_stats records)
 // launches the strip kernel for the already filled parameter block (U, V, su, sv, T, dv0, segments, epilogue ...); sets the tiling
 // members.  hlin: split-tensor sources (LDS-DMA); else fp32 sources through registers (+ fused normalisation when p.in_mr).
-int strip_launch(KParams& p, int H, int W, int kh, int kw, bool hlin, bool per_image, hipStream_t st);
+int strip_launch(KParams& p, int H, int W, int kh, int kw, bool hlin, bool per_image, int rows, hipStream_t st);
+int strip_launch_r32(const KParams& p, int nw, int ni, bool spatial, bool hlin, bool norm, unsigned nwg, hipStream_t st);      // conv_strip_r32.hip
 void strip_pack(const float* w, _Float16* pk, const PackParams& q, hipStream_t st);
 
 }  // namespace rpconv

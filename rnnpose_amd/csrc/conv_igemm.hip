@@ -848,11 +848,12 @@ int rnnpose_conv_spatial_tiles(int enable) {     // measurement switch: 0 = the 
 }
 
 int rnnpose_conv_strip(int mode) {               // 0 = never the strip kernels, 1 = automatic (default); measurement: 2 = automatic without
-  if (mode < 0 || mode > 3) {                    // the two-wave workgroups of the 64-channel layers, 3 = two 32-column tiles per wave
-    rp::set_error("rnnpose_conv_strip: mode 0..3");
+  if (mode < 0 || mode > 4) {                    // the two-wave workgroups of the 64-channel layers, 3 = two 32-column tiles per wave,
+    rp::set_error("rnnpose_conv_strip: mode 0..4");      // 4 = 160-row strips only (by the image shape: r04's first rule)
     return 1;
   }
   g_conv_strip = mode != 0;
+  strip_allow_small(mode != 4);
   strip_allow_two_wave(mode != 2);
   strip_force_ni(mode == 3 ? 2 : 1);
   return 0;
@@ -883,10 +884,13 @@ int rnnpose_conv_tiles_per_image(int H, int W, int kh, int kw, int stride) {
   return rp::cdiv(static_cast<long long>(Ho) * Wo, BM);
 }
 
-int rnnpose_conv_tiles_per_image_ex(int H, int W, int kh, int kw, int stride, int c_out, int tile) {
-  if (H <= 0 || W <= 0 || (stride != 1 && stride != 2) || c_out <= 0 || tile < 0 || tile > 5) return -1;
-  const bool strip = tile == 5 || (tile == 0 && g_conv_strip && strip_auto(H, W, kh, kw, stride, c_out));
-  if (strip) return stride == 1 ? strip_tiles_per_image(H, W, kh, kw) : -1;
+int rnnpose_conv_tiles_per_image_ex(int H, int W, int kh, int kw, int stride, int c_out, int tile, int batch) {
+  if (H <= 0 || W <= 0 || (stride != 1 && stride != 2) || c_out <= 0 || tile < 0 || tile > 6 || batch < 1) return -1;
+  int rows = 0;
+  if (tile >= 5) rows = strip_rows(H, W, kh, kw, stride, c_out, batch, tile == 5 ? 160 : 32);
+  else if (tile == 0 && g_conv_strip) rows = strip_rows(H, W, kh, kw, stride, c_out, batch, 0);
+  if (tile >= 5 && rows == 0) return -1;
+  if (rows) return strip_tiles_per_image(H, W, kh, kw, rows);
   return rnnpose_conv_tiles_per_image(H, W, kh, kw, stride);
 }
 
@@ -1032,7 +1036,7 @@ int rnnpose_conv2d_nhwc_f16x3(const rnnpose_conv_desc_t* d, rnnpose_stream_t str
   if (d->dst_split) RP_REQUIRE(d->epilogue != 2 && d->dst_split_c_stride % 8 == 0 && d->dst_split_c_offset % 4 == 0 &&
                                    reinterpret_cast<uintptr_t>(d->dst_split) % 32 == 0, fn,
                                "dst_split: not with the GRU z|r epilogue; channel stride multiple of 8, offset of 4, 32-byte aligned");
-  RP_REQUIRE(d->tile >= 0 && d->tile <= 5, fn, "tile must be 0 (auto), 1 (128x64), 2 (128x128, 4 column waves), 3 (128x128, 2x2 waves), 4 (128x64, deep pipeline) or 5 (160-row strips)");
+  RP_REQUIRE(d->tile >= 0 && d->tile <= 6, fn, "tile must be 0 (auto), 1 (128x64), 2 (128x128, 4 column waves), 3 (128x128, 2x2 waves), 4 (128x64, deep pipeline), 5 / 6 (strips of 160 / 32 rows)");
   if (d->tile_stats) RP_REQUIRE(d->epilogue == 0, fn, "tile_stats needs the linear epilogue");
   const long long Mtot = static_cast<long long>(d->B) * Ho * Wo;
   RP_REQUIRE(Mtot < (1LL << 31) - 256 && static_cast<long long>(d->B) * d->H * d->W < (1LL << 31) - 256, fn, "too many pixels");
@@ -1041,18 +1045,27 @@ int rnnpose_conv2d_nhwc_f16x3(const rnnpose_conv_desc_t* d, rnnpose_stream_t str
     const long long first = static_cast<long long>(d->kh) * d->kw * p.ncb * p.Npad * BK * 2;
     p.wpk_strip = reinterpret_cast<const uint4*>(static_cast<const _Float16*>(d->w_packed) + first);
   }
-  // ---- strip kernels (conv_strip.hip): 160-row strips, operands by LDS-DMA.  tile 5 asks for them; the automatic choice takes
-  // them for the stride-1 3x3 / 1x5 / 5x1 layers of maps that fill the chip with strips (shape only: a launch with tile
-  // statistics must tile like rnnpose_conv_tiles_per_image_ex said it would)
-  if (d->tile == 5 || (d->tile == 0 && g_conv_strip && strip_auto(d->H, d->W, d->kh, d->kw, d->stride, d->c_out))) {
-    bool ok = true;
-    for (int s = 0; s < d->n_src; ++s) ok = ok && d->src[s].c_count % 32 == 0;
-    if (d->src0_mean_rstd && !(d->kh == 3 && d->kw == 3)) ok = false;
+  // ---- strip kernels (conv_strip*.hip): 160- / 32-row strips, operands by LDS-DMA.  tile 5 / 6 ask for them; the automatic choice
+  // takes them for the stride-1 3x3 / 1x5 / 5x1 layers whose launch fills the chip with strips of one of the heights (strip_rows; a
+  // launch with per-image tile records tiles as rnnpose_conv_tiles_per_image_ex says for the same shape and batch)
+  {
     const bool per_image = d->tile_stats || d->src0_mean_rstd;
-    if (ok || d->tile == 5 || per_image) {           // (forced, or the caller sized its statistics for strips: errors surface)
-      if (vertical) { p.G = 1; p.T = d->kh; p.du0 = 0; p.dv0 = -(d->kh / 2); }
-      else { p.G = d->kh; p.T = d->kw; p.du0 = -(d->kh / 2); p.dv0 = -(d->kw / 2); }
-      return strip_launch(p, d->H, d->W, d->kh, d->kw, hlin, per_image, rp::as_stream(stream));
+    int rows = 0;
+    if (d->tile >= 5) {
+      rows = strip_rows(d->H, d->W, d->kh, d->kw, d->stride, d->c_out, d->B, d->tile == 5 ? 160 : 32);
+      RP_REQUIRE(rows != 0, fn, "strip kernels: stride 1, 3x3 / 1x5 / 5x1, c_out > 32 (32-row strips: one column tile per wave)");
+    } else if (d->tile == 0 && g_conv_strip) {
+      rows = strip_rows(d->H, d->W, d->kh, d->kw, d->stride, d->c_out, d->B, 0);
+    }
+    if (rows) {
+      bool ok = true;
+      for (int s = 0; s < d->n_src; ++s) ok = ok && d->src[s].c_count % 32 == 0;
+      if (d->src0_mean_rstd && !(d->kh == 3 && d->kw == 3)) ok = false;
+      if (ok || d->tile >= 5 || per_image) {           // (forced, or the caller sized its statistics for strips: errors surface)
+        if (vertical) { p.G = 1; p.T = d->kh; p.du0 = 0; p.dv0 = -(d->kh / 2); }
+        else { p.G = d->kh; p.T = d->kw; p.du0 = -(d->kh / 2); p.dv0 = -(d->kw / 2); }
+        return strip_launch(p, d->H, d->W, d->kh, d->kw, hlin, per_image, rows, rp::as_stream(stream));
+      }
     }
   }
   p.n_mt = rp::cdiv(Mtot, BM);

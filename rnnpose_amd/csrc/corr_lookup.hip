@@ -17,6 +17,10 @@
 #include "common.hpp"
 
 
+#ifndef RPL_LB
+#define RPL_LB 8          // pixels whose footprint loads are in flight together (measurement: 16)
+#endif
+
 namespace {
 
 constexpr int R = 4;
@@ -76,7 +80,7 @@ __global__ __launch_bounds__(64) void corr_lookup_kernel(const float* __restrict
   // the way into LDS; pixel slots past the end of the batch repeat the last pixel) and the loads of LB pixels are issued
   // before the first LDS store: with the bounds test around the load the compiler waited vmcnt(0) after every pixel --
   // 16 dependent memory round trips per wave (r02: 46 us per half-batch launch, latency-bound).
-  constexpr int LB = 8;
+  constexpr int LB = RPL_LB;
   const bool has1 = t1 < FP * FP;
 #pragma unroll
   for (int qb = 0; qb < PIX; qb += LB) {

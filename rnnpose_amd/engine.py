@@ -438,7 +438,7 @@ class EncoderEngine:
         B, H, W, _ = x.shape
         Ho, Wo = -(-H // stride), -(-W // stride)
         out = torch.empty(B, Ho, Wo, pc.c_out, device=x.device, dtype=torch.float32)
-        ts = torch.empty(B * ops.conv_tiles_per_image(H, W, pc.kh, pc.kw, stride, pc.c_out), pc.c_out, 2, device=x.device, dtype=torch.float64) if stats else None
+        ts = torch.empty(B * ops.conv_tiles_per_image(H, W, pc.kh, pc.kw, stride, pc.c_out, 0, B), pc.c_out, 2, device=x.device, dtype=torch.float64) if stats else None
         # src_bounded: every convolution input of the encoder is an instance-normalised map (|.| <= sqrt(H*W)) or a ReLU sum of a
         # few of them (extractor.py:48-58): two orders of magnitude inside the fp16x3 range, so the in-loop range check is skipped
         # (the stem, which sees the raw image, and the update block keep theirs)

@@ -564,7 +564,7 @@ def conv2d_nhwc(pc: PackedConv, srcs, dst, epilogue: int = EPI_LINEAR, aux0=None
     Writes in place into dst (and dst2); returns nothing.
     src_hl / dst_hl / dst2_hl: the sources / dst / dst2 are SPLIT tensors (fp16 hi|lo per 8-channel group in a buffer of the
     fp32 tensor's shape: include/rnnpose_hip.h; split_hl / unsplit_hl convert); dst_split = (tensor, c_offset): an additional
-    split-form copy of the primary result; tile: 0 auto, 1..4 tile shapes of the 128-row kernels, 5 the strip kernels
+    split-form copy of the primary result; tile: 0 auto, 1..4 tile shapes of the 128-row kernels, 5 / 6 the strip kernels with 160- / 32-row strips
     (160-row strips, operands by LDS-DMA: include/rnnpose_hip.h)."""
     _apply_conv_env()
     d = _lib.ConvDesc()
@@ -601,7 +601,7 @@ def conv2d_nhwc(pc: PackedConv, srcs, dst, epilogue: int = EPI_LINEAR, aux0=None
     d.gru_c = gru_c
     if tile_stats is not None:
         # (B * ceil(HWout/128), c_out, 2) fp32: per-tile column sums / sums of squares for instnorm_tiles_nhwc
-        tpi = conv_tiles_per_image(H, W, pc.kh, pc.kw, stride, pc.c_out, tile)
+        tpi = conv_tiles_per_image(H, W, pc.kh, pc.kw, stride, pc.c_out, tile, B)
         if not (tile_stats.is_cuda and tile_stats.dtype == F64 and tile_stats.is_contiguous()
                 and tile_stats.numel() == B * tpi * pc.c_out * 2):      # exact: the consumer takes the tiling from this shape
             raise ValueError("tile_stats must be a contiguous FP64 CUDA tensor of (B * conv_tiles_per_image(H, W, kh, kw, stride, "
@@ -629,14 +629,14 @@ def conv2d_nhwc(pc: PackedConv, srcs, dst, epilogue: int = EPI_LINEAR, aux0=None
             work=2.0 * B * Ho * Wo * pc.c_out * pc.c_in_real * pc.kh * pc.kw, nbytes=4.0 * nb)
 
 
-def conv_tiles_per_image(H, W, kh, kw, stride=1, c_out=None, tile: int = 0) -> int:
+def conv_tiles_per_image(H, W, kh, kw, stride=1, c_out=None, tile: int = 0, batch: int = 1) -> int:
     """Records per image of a convolution's tile_stats.  128-row kernels: 3x3 stride 1 on 8 x 16 patches, else runs of 128
-    output pixels; with c_out given: for the kernel a launch of that width and `tile` request takes -- the strip kernels
-    (csrc/conv_strip.hip, tile=5 or the automatic choice) tile an image into 10 x 16 patches / runs of 160 pixels."""
+    output pixels; with c_out given: for the kernel a launch of `batch` images of that width and `tile` request takes -- the strip
+    kernels (csrc/conv_strip*.hip, tile=5 / 6 or the automatic choice) tile an image into 10 / 2 x 16 patches or runs of 160 / 32 pixels."""
     _apply_conv_env()
     if c_out is None:
         return int(_lib.load().rnnpose_conv_tiles_per_image(int(H), int(W), int(kh), int(kw), int(stride)))
-    return int(_lib.load().rnnpose_conv_tiles_per_image_ex(int(H), int(W), int(kh), int(kw), int(stride), int(c_out), int(tile)))
+    return int(_lib.load().rnnpose_conv_tiles_per_image_ex(int(H), int(W), int(kh), int(kw), int(stride), int(c_out), int(tile), int(batch)))
 
 
 _conv_env_applied = False
@@ -667,8 +667,8 @@ def conv_spatial_tiles(enable: bool = True):
 
 
 def conv_strip(mode=True):
-    """Measurement switch: False / 0 = the automatic tile choice never takes the strip kernels (RNNPOSE_STRIP=0); 2 / 3 = strips
-    with one / two 32-column tiles per wave only."""
+    """Measurement switch (RNNPOSE_STRIP): False / 0 = the automatic tile choice never takes the strip kernels; 2 = not the two-wave
+    workgroups of 64-channel layers; 3 = two 32-column tiles per wave; 4 = 160-row strips only (no 32-row strips)."""
     _apply_conv_env()
     _lib.call("rnnpose_conv_strip", int(mode))
 

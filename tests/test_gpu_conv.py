@@ -255,7 +255,7 @@ def test_conv_tile_stats_feed_instnorm(ops, B, H, W, cin, cout, k, stride):
     Ho, Wo = -(-H // stride), -(-W // stride)
     assert (Ho * Wo) % 128 == 0
     out = torch.empty(B, Ho, Wo, cout, device="cuda")
-    tpi = ops.conv_tiles_per_image(H, W, k, k, stride, cout)   # 3x3 stride 1: 8 x 16 patches (strips: 10 x 16); else runs of 128 output pixels
+    tpi = ops.conv_tiles_per_image(H, W, k, k, stride, cout, 0, B)   # 3x3 stride 1: 8 x 16 patches (strips: 10 x 16 / 2 x 16); else runs of 128 output pixels
     ts = torch.full((B * tpi, cout, 2), -1.0, device="cuda", dtype=torch.float64)      # fp64 tile statistics
     ops.conv2d_nhwc(pc, [(nhwc(D(x)), 0)], (out, 0), ops.EPI_LINEAR, stride=stride, tile_stats=ts)
     y64 = F.conv2d(D(x).double(), D(w).double(), D(b).double(), stride=stride, padding=k // 2)
@@ -284,7 +284,7 @@ def test_conv_per_image_tiles_and_fused_input_norm(ops, B, H, W, cin, cout):
     w2 = syn.normal("pn.w2", (cout, cin, 3, 3), 5, std=float(np.sqrt(2.0 / (cin * 9))))
     b1, b2 = syn.uniform("pn.b1", (cin,), 4, -0.5, 0.5), syn.uniform("pn.b2", (cout,), 5, -0.5, 0.5)
     p1, p2 = ops.PackedConv(D(w1), D(b1), [cin]), ops.PackedConv(D(w2), D(b2), [cout if False else cin])
-    tpi = ops.conv_tiles_per_image(H, W, 3, 3, 1, cin)          # (60 x 80 x 96: the automatic choice takes the strip kernels)
+    tpi = ops.conv_tiles_per_image(H, W, 3, 3, 1, cin, 0, B)    # (60 x 80 x 96: the automatic choice takes the strip kernels)
     c1 = torch.empty(B, H, W, cin, device="cuda")
     ts = torch.full((B * tpi, cin, 2), -1.0, device="cuda", dtype=torch.float64)
     ops.conv2d_nhwc(p1, [(nhwc(D(x)), 0)], (c1, 0), ops.EPI_LINEAR, tile_stats=ts)
@@ -600,24 +600,25 @@ def test_conv_k_split_matches_single_pass(ops, B, H, W, segs, cout, kh, kw):
 @pytest.mark.gpu
 def test_conv_k_split_with_statistics_norm_and_gru_epilogues(ops):
     """The epilogue variants behind a K split: per-tile statistics + fused input normalisation (encoder layers at 30 x 30) and
-    the GRU gate epilogues (1 x 5) -- all computed by the last-arriving workgroup from the summed accumulators."""
+    the GRU gate epilogues (1 x 5) -- all computed by the last-arriving workgroup from the summed accumulators.  (The 128-row
+    kernels: tile=1 -- the automatic choice takes 32-row strips for a single 30 x 30 crop since r04.)"""
     B, H, W, cin, cout = 1, 30, 30, 128, 128
     x = syn.normal("ks2.x", (B, cin, H, W), 4, std=2.0) + 0.7
     w1 = syn.normal("ks2.w1", (cin, cin, 3, 3), 4, std=float(np.sqrt(2.0 / (cin * 9))))
     w2 = syn.normal("ks2.w2", (cout, cin, 3, 3), 5, std=float(np.sqrt(2.0 / (cin * 9))))
     b1, b2 = syn.uniform("ks2.b1", (cin,), 4, -0.5, 0.5), syn.uniform("ks2.b2", (cout,), 5, -0.5, 0.5)
     p1, p2 = ops.PackedConv(D(w1), D(b1), [cin]), ops.PackedConv(D(w2), D(b2), [cin])
-    tpi = ops.conv_tiles_per_image(H, W, 3, 3, 1)
+    tpi = ops.conv_tiles_per_image(H, W, 3, 3, 1, cin, 1, B)
     ws = ops.conv_ksplit_workspace("cuda")
     res = []
     for k in (None, ws):
         c1 = torch.empty(B, H, W, cin, device="cuda")
         ts = torch.full((B * tpi, cin, 2), -1.0, device="cuda", dtype=torch.float64)
-        ops.conv2d_nhwc(p1, [(nhwc(D(x)), 0)], (c1, 0), ops.EPI_LINEAR, tile_stats=ts, ksplit_ws=k)
+        ops.conv2d_nhwc(p1, [(nhwc(D(x)), 0)], (c1, 0), ops.EPI_LINEAR, tile_stats=ts, ksplit_ws=k, tile=1)
         mr = ops.instnorm_tiles_nhwc(c1, ts, stats_only=True)
         c2 = torch.empty(B, H, W, cout, device="cuda")
         ts2 = torch.full((B * tpi, cout, 2), -1.0, device="cuda", dtype=torch.float64)
-        ops.conv2d_nhwc(p2, [(c1, 0)], (c2, 0), ops.EPI_LINEAR, in_norm=mr, tile_stats=ts2, ksplit_ws=k)
+        ops.conv2d_nhwc(p2, [(c1, 0)], (c2, 0), ops.EPI_LINEAR, in_norm=mr, tile_stats=ts2, ksplit_ws=k, tile=1)
         res.append((c1, ts, c2, ts2))
     for a, bb in zip(res[0], res[1]):
         sc = float(a.abs().max())
@@ -644,10 +645,10 @@ def test_conv_k_split_with_statistics_norm_and_gru_epilogues(ops):
     z = torch.empty(B, H, W, C, device="cuda")
     rh = torch.empty(B, H, W, C, device="cuda")
     hnew = torch.empty(B, H, W, C, device="cuda")
-    ops.conv2d_nhwc(pzr, [(hN, 0), (xN, 0), (xN, C)], (z, 0), ops.EPI_GRU_ZR, aux0=(hN, 0), dst2=(rh, 0), gru_c=C, ksplit_ws=ws)
+    ops.conv2d_nhwc(pzr, [(hN, 0), (xN, 0), (xN, C)], (z, 0), ops.EPI_GRU_ZR, aux0=(hN, 0), dst2=(rh, 0), gru_c=C, ksplit_ws=ws, tile=1)
     assert float((nchw(z).double() - z64).abs().max()) < 2e-6
     assert float((nchw(rh).double() - r64 * hd.double()).abs().max()) < 2e-6
-    ops.conv2d_nhwc(pq, [(rh, 0), (xN, 0), (xN, C)], (hnew, 0), ops.EPI_GRU_Q, aux0=(hN, 0), aux1=(z, 0), ksplit_ws=ws)
+    ops.conv2d_nhwc(pq, [(rh, 0), (xN, 0), (xN, C)], (hnew, 0), ops.EPI_GRU_Q, aux0=(hN, 0), aux1=(z, 0), ksplit_ws=ws, tile=1)
     assert float((nchw(hnew).double() - h64).abs().max()) < 3e-6
     torch.cuda.synchronize()
     assert int(ws[:256].abs().max()) == 0
@@ -667,6 +668,12 @@ STRIP_SHAPES = [
 ]
 
 
+@pytest.fixture(params=[5, 6], ids=["rows160", "rows32"])
+def strip_tile(request):
+    """tile code of the strip height under test: 5 = 160-row strips (10 x 16 patches), 6 = 32 rows (2 x 16)."""
+    return request.param
+
+
 @pytest.fixture(params=[1, 3], ids=["auto", "two-tile-waves"])
 def strip_mode(ops, request):
     """The strip kernels in their automatic shape (one 32-column tile per wave, two workgroups per CU) and with two tiles per
@@ -678,11 +685,11 @@ def strip_mode(ops, request):
 
 @pytest.mark.parametrize("hl", [False, True])
 @pytest.mark.parametrize("B,H,W,segs,cout,kh,kw", STRIP_SHAPES)
-def test_conv_strip_vs_fp64(ops, strip_mode, hl, B, H, W, segs, cout, kh, kw):
+def test_conv_strip_vs_fp64(ops, strip_mode, strip_tile, hl, B, H, W, segs, cout, kh, kw):
     """160-row strips with both operand paths (split-tensor sources by LDS-DMA, fp32 sources through registers) against fp64 and
     against the 128-row kernel on the same operands; fp32 and split-form destinations; bytes around the slice untouched."""
-    if strip_mode == 3 and cout <= 64:
-        pytest.skip("two tiles per wave need more than 64 output channels")
+    if strip_mode == 3 and (cout <= 64 or strip_tile != 5):
+        pytest.skip("two tiles per wave: 160-row strips, more than 64 output channels")
     cin = sum(segs)
     x = syn.normal("sx", (B, cin, H, W), 21, std=1.5)
     w = syn.normal("sw", (cout, cin, kh, kw), 21, std=float(np.sqrt(2.0 / (cin * kh * kw))))
@@ -699,19 +706,19 @@ def test_conv_strip_vs_fp64(ops, strip_mode, hl, B, H, W, segs, cout, kh, kw):
         off += c
     cs = (cout + 23) // 8 * 8
     out = torch.full((B, H, W, cs), 7.0, device="cuda")
-    ops.conv2d_nhwc(pc, xs, (out, 8), ops.EPI_RELU, src_hl=hl, tile=5)
+    ops.conv2d_nhwc(pc, xs, (out, 8), ops.EPI_RELU, src_hl=hl, tile=strip_tile)
     check(nchw(out[..., 8:8 + cout]), y64.clamp(min=0), y32.clamp(min=0), f"strip {kh}x{kw} hl={hl}")
     assert float((out[..., :8] - 7).abs().max()) == 0 and float((out[..., 8 + cout:] - 7).abs().max()) == 0
     ref = torch.full((B, H, W, cs), 7.0, device="cuda")
     ops.conv2d_nhwc(pc, xs, (ref, 8), ops.EPI_RELU, src_hl=hl, tile=1)           # same fp16 operands, other summation order
     assert float((out - ref).abs().max()) <= 2e-6 * float(y64.abs().max())
     again = torch.full((B, H, W, cs), 7.0, device="cuda")
-    ops.conv2d_nhwc(pc, xs, (again, 8), ops.EPI_RELU, src_hl=hl, tile=5)
+    ops.conv2d_nhwc(pc, xs, (again, 8), ops.EPI_RELU, src_hl=hl, tile=strip_tile)
     assert torch.equal(out, again)                                               # deterministic
     outs = torch.zeros(B, H, W, cs, device="cuda")
     extra = torch.zeros(B, H, W, cs, device="cuda")
-    ops.conv2d_nhwc(pc, xs, (outs, 8), ops.EPI_RELU, src_hl=hl, dst_hl=True, tile=5)
-    ops.conv2d_nhwc(pc, xs, (again, 8), ops.EPI_LINEAR, src_hl=hl, dst_split=(extra, 8), tile=5)
+    ops.conv2d_nhwc(pc, xs, (outs, 8), ops.EPI_RELU, src_hl=hl, dst_hl=True, tile=strip_tile)
+    ops.conv2d_nhwc(pc, xs, (again, 8), ops.EPI_LINEAR, src_hl=hl, dst_split=(extra, 8), tile=strip_tile)
     check(nchw(again[..., 8:8 + cout]), y64, y32, f"strip {kh}x{kw} linear")
     full = out[..., 8:8 + cout]
     assert float(((ops.unsplit_hl(outs)[..., 8:8 + cout] - full).abs() / full.abs().clamp(min=1e-2)).max()) < 2.0 ** -20
@@ -721,8 +728,10 @@ def test_conv_strip_vs_fp64(ops, strip_mode, hl, B, H, W, segs, cout, kh, kw):
 
 @pytest.mark.parametrize("hl", [False, True])
 @pytest.mark.parametrize("kh,kw", [(1, 5), (5, 1)])
-def test_conv_strip_gru_epilogues(ops, strip_mode, kh, kw, hl):
+def test_conv_strip_gru_epilogues(ops, strip_mode, strip_tile, kh, kw, hl):
     """GRU gate / state-update epilogues + additive map in the strip kernels (update.py:47-58, hoisted context share)."""
+    if strip_mode == 3 and strip_tile != 5:
+        pytest.skip("two tiles per wave: 160-row strips only")
     B, H, W, C = 2, 11, 19, 128
     h = np.tanh(syn.normal("h", (B, C, H, W), 2))
     x = syn.normal("x", (B, C, H, W), 2)
@@ -745,32 +754,32 @@ def test_conv_strip_gru_epilogues(ops, strip_mode, kh, kw, hl):
     hnew = torch.empty(B, H, W, C, device="cuda")
     hnew_s = torch.empty(B, H, W, C, device="cuda")
     ops.conv2d_nhwc(pzr, [(hS, 0), (xS, 0)], (z, 0), ops.EPI_GRU_ZR, aux0=(hN, 0), dst2=(rh, 0), dst2_hl=hl, gru_c=C, src_hl=hl,
-                    add_map=(aN, 0), tile=5)
+                    add_map=(aN, 0), tile=strip_tile)
     assert float((nchw(z).double() - z64).abs().max()) < 2e-6
     rhd = ops.unsplit_hl(rh) if hl else rh
     assert float((nchw(rhd).double() - r64 * hd.double()).abs().max()) < 2e-6
     ops.conv2d_nhwc(pq, [(rh, 0), (xS, 0)], (hnew, 0), ops.EPI_GRU_Q, aux0=(hN, 0), aux1=(z, 0), src_hl=hl, dst_split=(hnew_s, 0),
-                    add_map=(aN, 2 * C), tile=5)
+                    add_map=(aN, 2 * C), tile=strip_tile)
     assert float((nchw(hnew).double() - h64).abs().max()) < 3e-6
     assert float((ops.unsplit_hl(hnew_s) - hnew).abs().max()) < 2.0 ** -20
 
 
 @pytest.mark.parametrize("B,H,W,cin,cout", [(3, 15, 20, 96, 96), (2, 60, 80, 96, 128), (2, 20, 32, 128, 128), (2, 40, 48, 64, 64)])
-def test_conv_strip_tile_stats_and_fused_input_norm(ops, strip_mode, B, H, W, cin, cout):
+def test_conv_strip_tile_stats_and_fused_input_norm(ops, strip_mode, strip_tile, B, H, W, cin, cout):
     """The encoder's pair (extractor.py:48-58) on strips: conv1 with fp64 tile statistics per 10 x 16 patch, conv2 reading
     relu(norm1(conv1 x)) in its load == the materialised sequence, bit for bit."""
-    if strip_mode == 3 and min(cin, cout) <= 64:
-        pytest.skip("two tiles per wave need more than 64 output channels")
+    if strip_mode == 3 and (min(cin, cout) <= 64 or strip_tile != 5):
+        pytest.skip("two tiles per wave: 160-row strips, more than 64 output channels")
     x = syn.normal("pn.x", (B, cin, H, W), 4, std=2.0) + 0.7
     w1 = syn.normal("pn.w1", (cin, cin, 3, 3), 4, std=float(np.sqrt(2.0 / (cin * 9))))
     w2 = syn.normal("pn.w2", (cout, cin, 3, 3), 5, std=float(np.sqrt(2.0 / (cin * 9))))
     b1, b2 = syn.uniform("pn.b1", (cin,), 4, -0.5, 0.5), syn.uniform("pn.b2", (cout,), 5, -0.5, 0.5)
     p1, p2 = ops.PackedConv(D(w1), D(b1), [cin]), ops.PackedConv(D(w2), D(b2), [cin])
-    tpi = ops.conv_tiles_per_image(H, W, 3, 3, 1, cin, 5)
-    assert tpi == -(-H // 10) * -(-W // 16)
+    tpi = ops.conv_tiles_per_image(H, W, 3, 3, 1, cin, strip_tile, B)
+    assert tpi == -(-H // {5: 10, 6: 2}[strip_tile]) * -(-W // 16)
     c1 = torch.empty(B, H, W, cin, device="cuda")
     ts = torch.full((B * tpi, cin, 2), -1.0, device="cuda", dtype=torch.float64)
-    ops.conv2d_nhwc(p1, [(nhwc(D(x)), 0)], (c1, 0), ops.EPI_LINEAR, tile_stats=ts, tile=5)
+    ops.conv2d_nhwc(p1, [(nhwc(D(x)), 0)], (c1, 0), ops.EPI_LINEAR, tile_stats=ts, tile=strip_tile)
     y64 = F.conv2d(D(x).double(), D(w1).double(), D(b1).double(), padding=1)
     n64 = F.relu(F.instance_norm(y64, eps=1e-5))
     t = ts.view(B, tpi, cin, 2).double().sum(1)
@@ -780,9 +789,9 @@ def test_conv_strip_tile_stats_and_fused_input_norm(ops, strip_mode, B, H, W, ci
     assert float((nchw(got).double() - n64).abs().max()) < 2e-5
     mr = ops.instnorm_tiles_nhwc(c1, ts, stats_only=True)
     fused = torch.empty(B, H, W, cout, device="cuda")
-    ops.conv2d_nhwc(p2, [(c1, 0)], (fused, 0), ops.EPI_LINEAR, in_norm=mr, tile=5)
+    ops.conv2d_nhwc(p2, [(c1, 0)], (fused, 0), ops.EPI_LINEAR, in_norm=mr, tile=strip_tile)
     plain = torch.empty(B, H, W, cout, device="cuda")
-    ops.conv2d_nhwc(p2, [(got, 0)], (plain, 0), ops.EPI_LINEAR, tile=5)
+    ops.conv2d_nhwc(p2, [(got, 0)], (plain, 0), ops.EPI_LINEAR, tile=strip_tile)
     assert torch.equal(fused, plain)
     z64 = F.conv2d(n64, D(w2).double(), D(b2).double(), padding=1)
     z32 = F.conv2d(n64.float(), D(w2), D(b2), padding=1)
@@ -790,10 +799,13 @@ def test_conv_strip_tile_stats_and_fused_input_norm(ops, strip_mode, B, H, W, ci
 
 
 def test_conv_strip_is_the_automatic_choice_at_the_update_block_shape(ops):
-    """60 x 80 maps (the headline's 1/8 resolution): the automatic tile choice takes strips (30 patches per image instead of 40),
-    RNNPOSE_STRIP=0 / ops.conv_strip(False) restores the 128-row kernels; same result to summation order."""
-    assert ops.conv_tiles_per_image(60, 80, 3, 3, 1, 192) == 30 and ops.conv_tiles_per_image(60, 80, 3, 3, 1, 192, 1) == 40
-    assert ops.conv_tiles_per_image(30, 30, 3, 3, 1, 192) == 8            # LINEMOD crops: too ragged / too few strips
+    """60 x 80 maps (the headline's 1/8 resolution), batch 8: the automatic tile choice takes 160-row strips (30 patches per image instead
+    of 40); launches of at most 8192 pixels take 32-row strips (2 x 16 patches) -- a single 60 x 80 map, a single 30 x 30 crop; RNNPOSE_STRIP=0 / ops.conv_strip(False) restores the 128-row kernels; same result bit for bit (the order of
+    the K sum of an output element does not depend on the tile)."""
+    assert ops.conv_tiles_per_image(60, 80, 3, 3, 1, 192, 0, 8) == 30 and ops.conv_tiles_per_image(60, 80, 3, 3, 1, 192, 1, 8) == 40
+    assert ops.conv_tiles_per_image(60, 80, 3, 3, 1, 192, 0, 1) == 150 and ops.conv_tiles_per_image(60, 80, 3, 3, 1, 192, 6, 8) == 150
+    assert ops.conv_tiles_per_image(60, 80, 3, 3, 1, 192, 0, 2) == 30      # (two images: 9600 pixels, 60 strips per image: 160-row strips)
+    assert ops.conv_tiles_per_image(30, 30, 3, 3, 1, 192, 0, 1) == 30      # LINEMOD crops, one image: 15 x 2 patches of 2 x 16
     B, H, W = 2, 60, 80
     x = D(syn.normal("ax", (B, H, W, 256), 31, std=1.2))
     w = D(syn.normal("aw", (192, 256, 3, 3), 31, std=0.02))
@@ -804,7 +816,7 @@ def test_conv_strip_is_the_automatic_choice_at_the_update_block_shape(ops):
     assert torch.equal(a, b)
     try:
         ops.conv_strip(False)
-        assert ops.conv_tiles_per_image(60, 80, 3, 3, 1, 192) == 40
+        assert ops.conv_tiles_per_image(60, 80, 3, 3, 1, 192, 0, 8) == 40
         ops.conv2d_nhwc(pc, [(x, 0)], (a, 0), ops.EPI_RELU)
     finally:
         ops.conv_strip(True)

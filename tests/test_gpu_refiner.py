@@ -300,7 +300,9 @@ def test_k_split_schedule_matches_single_pass(ops, monkeypatch):
 
 def test_two_chains_equal_one_chain(ops, monkeypatch):
     """Small batches run as ONE chain (engine.halves: a chain needs >= 8192 pixels at 1/8 resolution to fill the chip); RNNPOSE_PARTS=2
-    forces the two-stream schedule the large shapes use.  Images are independent: identical results, also through graph replay."""
+    forces the two-stream schedule the large shapes use.  Images are independent: the same results, also through graph replay -- to
+    fp32 round-off, not bit for bit: which convolution kernel a launch takes (K split, 32-row strips, 128-row tiles) depends on how
+    many pixels the launch has, and the families sum K in different orders."""
     from rnnpose_amd import synthetic as syn
     from rnnpose_amd.pose_refiner import PoseRefiner, SyntheticRenderer, default_config
     from rnnpose_amd.transformation import SE3Sequence
@@ -322,4 +324,4 @@ def test_two_chains_equal_one_chain(ops, monkeypatch):
             out = ref(None, SE3Sequence(matrix=D(d["G0"])), D(d["K"]))
         assert len(ref.cf_net.engine().halves(2)) == (1 if parts is None else 2)
         outs.append((out["Ti_pred"].G.clone(), out["flow_last"].clone()))
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert float((outs[0][0] - outs[1][0]).abs().max()) < 1e-6 and float((outs[0][1] - outs[1][1]).abs().max()) < 5e-5

@@ -32,7 +32,6 @@ for name, segs, co, kh, kw, hh, ww, hl in cases:
     for _ in range(5):
         run()
     torch.cuda.synchronize()
-    nw = ops._lib_call("rnnpose_conv_tiles_per_image_ex", hh, ww, kh, kw, 1, co, 5) if hasattr(ops, "_lib_call") else None
     n = 65536
     buf = np.zeros(n * 8, dtype=np.uint64)
     rc = lib.rnnpose_debug_strip_clk(buf.ctypes.data_as(ctypes.c_void_p), n)
