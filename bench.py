@@ -60,6 +60,9 @@ def parse():
     ap.add_argument("--no-encoder", action="store_true", help="feed synthetic feature maps (kernel-only runs)")
     ap.add_argument("--unfused", action="store_true", help="literal reference call sequence through the facade")
     ap.add_argument("--no-graph", action="store_true", help="eager launches only (no hipGraph replay; for counter passes)")
+    ap.add_argument("--mixed-precision", action="store_true",
+                    help="cfg.raft.mixed_precision: single-product fp16 convolutions (the reference's GPU arithmetic) -- NOT the headline "
+                         "arithmetic: the line says so in `dtype` / `config`, and its parity block is a distance, not a gate")
     ap.add_argument("--workload", choices=["cfg1", "cfg4"], default=None,
                     help="a BASELINE.json configuration verbatim: cfg1 = configs[1] (640x480, batch 8/GPU, 3x8: the default), cfg4 = "
                          "configs[4] (1280x960 high-res, batch 8/GPU = batch 64 over 8 GPUs, 3x8)")
@@ -187,6 +190,7 @@ def parity_block(refiner, rend, K, G0, args, want):
     from rnnpose_amd.pose_refiner import PoseRefiner, default_config
     from rnnpose_amd.transformation import SE3Sequence
     cfg = default_config(RENDER_ITER_COUNT=1, ITER_COUNT=args.inner, OPTIM_ITER_COUNT=args.optim_iters)
+    cfg.raft.mixed_precision = bool(args.mixed_precision)
     one = PoseRefiner(cfg, renderer=rend, fused=not args.unfused, use_graph=not args.no_graph).to(K.device).eval()
     one.load_state_dict(refiner.state_dict())
     out = one(rend.views["image_crop"], SE3Sequence(matrix=G0.clone()), K)
@@ -243,6 +247,7 @@ def main():
     torch.manual_seed(0)
     rend, K, G0 = synth_views(B, H, W, device, seed=rank, with_encoder=not args.no_encoder)
     cfg = default_config(RENDER_ITER_COUNT=args.outer, ITER_COUNT=args.inner, OPTIM_ITER_COUNT=args.optim_iters)
+    cfg.raft.mixed_precision = bool(args.mixed_precision)
     refiner = PoseRefiner(cfg, renderer=rend, fused=not args.unfused, use_graph=not args.no_graph).to(device).eval()
 
     def step():
@@ -386,12 +391,14 @@ def main():
         "per_rank_iters_per_sec": [round(v, 2) for v in per_rank], "host_threads_per_rank": host_threads,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32 (convolutions and volume build: fp16x3-split MFMA, fp32-class accuracy; LM: f64)",
+        "dtype": ("f16 products, f32 accumulation in the strip convolutions (cfg.raft.mixed_precision: NOT the headline arithmetic); volume build "
+                  "fp16x3, LM f64") if args.mixed_precision else
+                 "f32 (convolutions and volume build: fp16x3-split MFMA, fp32-class accuracy; LM: f64)",
         "data": "synthetic", "image_iters_per_sec": round(value * B, 2),
         "config": {"workload": f"synthetic {W}x{H} render+target pairs, batch {B}/GPU, {args.outer} outer x "
                                f"{args.inner} inner refinement ({cfg_label}); 1 step = 1 refinement = "
                                f"{iters} iterations", "batch_per_gpu": B, "height": H, "width": W,
-                   "outer": args.outer, "inner": args.inner, "optim_iters": args.optim_iters,
+                   "outer": args.outer, "inner": args.inner, "optim_iters": args.optim_iters, "mixed_precision": bool(args.mixed_precision),
                    "encoder_in_timed_region": not args.no_encoder, "fused_schedule": not args.unfused,
                    "hip_graphs": "encoder+volume build and the inner-iteration body replay as hipGraphs (except in the "
                                  "event-instrumented first outer iteration of the first timed step)" if refiner.use_graph and not args.unfused else "off",
@@ -413,7 +420,9 @@ def main():
     if seen != world:
         raise SystemExit(f"bench.py: the collective reached {seen} ranks, the line would claim {world}")
     print(json.dumps(res))
-    if res["parity"] is not None and not res["parity"]["ok"]:
+    if args.mixed_precision and res["parity"] is not None:
+        res["parity"]["note"] = "mixed precision: distances to the fp32 CPU oracle, reported, not gated (not the headline arithmetic)"
+    if res["parity"] is not None and not res["parity"]["ok"] and not args.mixed_precision:
         raise SystemExit("bench.py: the timed configuration is OUTSIDE the parity tolerances against the CPU oracle "
                          f"({res['parity']}) -- the line above is invalid")
 

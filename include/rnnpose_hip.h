@@ -266,6 +266,12 @@ typedef struct {
                                   (deterministic) and runs the epilogue.  Launches that may run CONCURRENTLY (two streams) need
                                   separate workspaces. */
   size_t ksplit_ws_bytes;
+  int single_product;          /* != 0: ONE fp16 product per multiply-add (a_hi * b_hi, fp32 accumulation) instead of the three of the
+                                  fp16x3 split -- cfg.raft.mixed_precision, the arithmetic the reference runs on a GPU (model/CFNet.py:
+                                  47,126,152: fp16 autocast around encoder and update block).  Honoured by the 160-row strip kernels
+                                  (the layers the automatic choice gives them: the update block and the encoder's residual layers at
+                                  the headline shapes); every other kernel keeps the three-product form.  ~2^-11 relative per product:
+                                  NOT the arithmetic of the parity tolerances. */
 } rnnpose_conv_desc_t;
 
 size_t rnnpose_conv_ksplit_workspace_bytes(void);

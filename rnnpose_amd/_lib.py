@@ -33,7 +33,7 @@ class ConvDesc(C.Structure):       # rnnpose_conv_desc_t
                 ("tile_stats", C.c_void_p), ("add_map", C.c_void_p), ("add_c_stride", C.c_int), ("add_c_offset", C.c_int),
                 ("src0_mean_rstd", C.c_void_p), ("src_hl", C.c_int), ("dst_hl", C.c_int), ("dst2_hl", C.c_int),
                 ("dst_split", C.c_void_p), ("dst_split_c_stride", C.c_int), ("dst_split_c_offset", C.c_int), ("src_bounded", C.c_int),
-                ("tile", C.c_int), ("ksplit_ws", C.c_void_p), ("ksplit_ws_bytes", C.c_size_t)]
+                ("tile", C.c_int), ("ksplit_ws", C.c_void_p), ("ksplit_ws_bytes", C.c_size_t), ("single_product", C.c_int)]
 
 
 # name -> (restype, argtypes); mirrors include/rnnpose_hip.h one to one

@@ -24,7 +24,7 @@ ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall",
          "-Wno-unused-function", "-Wno-unused-variable", "-DNDEBUG"]
 # the MFMA kernels keep their fp32 vector ALU work scalar (csrc/f16x3.cuh: packed fp32 ops are slow next to MFMAs)
-PER_FILE_FLAGS = {"conv_igemm.hip": ["-fno-slp-vectorize"], "conv_strip.hip": ["-fno-slp-vectorize"], "conv_strip_r32.hip": ["-fno-slp-vectorize"], "stem.hip": ["-fno-slp-vectorize"]}
+PER_FILE_FLAGS = {"conv_igemm.hip": ["-fno-slp-vectorize"], "conv_strip.hip": ["-fno-slp-vectorize"], "conv_strip_r32.hip": ["-fno-slp-vectorize"], "conv_strip_p1.hip": ["-fno-slp-vectorize"], "stem.hip": ["-fno-slp-vectorize"]}
 FLAGS += os.environ.get("RNNPOSE_HIPCC_EXTRA", "").split()     # diagnostics builds (e.g. -DRP_ABL=..., tools/conv_ablate.sh), part of the stamp
 
 
@@ -32,7 +32,7 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
-TRAFFIC_KERNEL_FILES = ("conv_igemm.hip", "conv_strip.hip", "conv_strip_r32.hip", "corr_pyramid.hip")      # the kernels whose HBM counters profiles/traffic.json holds
+TRAFFIC_KERNEL_FILES = ("conv_igemm.hip", "conv_strip.hip", "conv_strip_r32.hip", "conv_strip_p1.hip", "corr_pyramid.hip")      # the kernels whose HBM counters profiles/traffic.json holds
 
 
 def source_digest() -> str:

@@ -54,6 +54,7 @@ struct KParams {
   float* ks_ws;              // ksplit partial accumulators: [tile][split][acc register][thread] floats
   unsigned* ks_cnt;          // per-tile arrival counters (zero between launches)
   const uint4* wpk_strip;    // the same weights in the strip kernel's order (conv_strip.hip), behind the first copy in w_packed
+  int single_product;        // strip kernels, 160-row strips, one column tile per wave: a_hi * b_hi only (cfg.raft.mixed_precision)
   int off32;                 // strip kernels: every destination / epilogue operand spans < 2^32 elements (32-bit offsets in the fast epilogue)
 };
 
@@ -104,6 +105,7 @@ int strip_tiles_per_image(int H, int W, int kh, int kw, int rows);      // outpu
 // members.  hlin: split-tensor sources (LDS-DMA); else fp32 sources through registers (+ fused normalisation when p.in_mr).
 int strip_launch(KParams& p, int H, int W, int kh, int kw, bool hlin, bool per_image, int rows, hipStream_t st);
 int strip_launch_r32(const KParams& p, int nw, int ni, bool spatial, bool hlin, bool norm, unsigned nwg, hipStream_t st);      // conv_strip_r32.hip
+int strip_launch_p1(const KParams& p, int nw, int ni, bool spatial, bool hlin, bool norm, unsigned nwg, hipStream_t st);       // conv_strip_p1.hip: 160-row strips, single product
 void strip_pack(const float* w, _Float16* pk, const PackParams& q, hipStream_t st);
 
 }  // namespace rpconv

@@ -1044,6 +1044,7 @@ int rnnpose_conv2d_nhwc_f16x3(const rnnpose_conv_desc_t* d, rnnpose_stream_t str
     // the packed array holds both orders (rnnpose_conv_packed_halfs): the strip kernels' copy sits behind the first one
     const long long first = static_cast<long long>(d->kh) * d->kw * p.ncb * p.Npad * BK * 2;
     p.wpk_strip = reinterpret_cast<const uint4*>(static_cast<const _Float16*>(d->w_packed) + first);
+    p.single_product = d->single_product != 0;
   }
   // ---- strip kernels (conv_strip*.hip): 160- / 32-row strips, operands by LDS-DMA.  tile 5 / 6 ask for them; the automatic choice
   // takes them for the stride-1 3x3 / 1x5 / 5x1 layers whose launch fills the chip with strips of one of the heights (strip_rows; a

@@ -267,7 +267,11 @@ __device__ __forceinline__ void strip_epilogue_fast(const StripEpi p, f32x16 (&a
 // without MFMAs its LDS / DMA stream alone takes 36 of 78 us -- every wave reads the WHOLE activation tile from LDS for its 32
 // columns, 12 ds_read_b128 per 15 MFMAs, and the LDS pipe is a co-bottleneck of the matrix pipe.  With two column tiles per wave
 // an activation fragment feeds twice the MFMAs: 14 reads per 30.
-template <int NW, int TT, int MODE, int NI, int SMI>
+// P1 (r04; cfg.raft.mixed_precision, the reference's GPU arithmetic: model/CFNet.py:47,126,152 run the encoder and the update block under
+// fp16 autocast): ONE product per multiply-add -- a_hi * b_hi on the same MFMA, fp32 accumulation -- instead of three.  The lo planes
+// still arrive (the operands in memory are the same split tensors; activations between layers stay fp32-class, which autocast's are
+// not); their fragments are neither read nor multiplied.  Not the headline arithmetic: narrower than the CPU oracle's fp32.
+template <int NW, int TT, int MODE, int NI, int SMI, bool P1 = false>
 __global__ __launch_bounds__(NW * 64, NI == 2 ? 1 : 2) void conv_strip_f16x3_kernel(const KParams p) {
   constexpr bool SPATIAL = TT == 9;
   constexpr int SM = 32 * SMI;                             // strip rows
@@ -491,13 +495,20 @@ __global__ __launch_bounds__(NW * 64, NI == 2 ? 1 : 2) void conv_strip_f16x3_ker
     if (b_left > 0) { wptr += wstep; --b_left; }                                                             \
   }
   h8 fa_h[2][SMI], fa_l[2][SMI], fb_h[2][NI], fb_l[2][NI];
-  constexpr int NRD = 2 * NI + 2 * SMI;      // fragment reads per step
-  constexpr int NMM = 3 * SMI * NI;          // MFMAs per step
+  constexpr int NRD = P1 ? NI + SMI : 2 * NI + 2 * SMI;      // fragment reads per step
+  constexpr int NMM = (P1 ? 1 : 3) * SMI * NI;               // MFMAs per step
   // fragment K_ (weights hi x NI, activations lo x 5, weights lo x NI, activations hi x 5 -- the order the MFMAs want them) of
   // tap TN_ of activation slot AS_ / weight slot BS_ -> register set SET_
 #define RS_READ1(K_, SET_, TN_, AS_, BS_)                                                                    \
   {                                                                                                          \
     if ((K_) < NI) fb_h[SET_][(K_)] = *reinterpret_cast<const h8*>(sB + (BS_) * BREC + (K_) * 2048 + boff);  \
+    else if (P1) {                 /* (single product: weights hi x NI, activations hi x SMI) */                 \
+      const int mi_ = (K_) - NI;                                                                             \
+      const int dyq_ = (TN_) / 3;                                                                            \
+      const int ad_ = SPATIAL ? aad[mi_][dyq_ == 1 ? 1 : 0] + (dyq_ == 2 ? 2 * SHW * 32 : 0) + ((TN_) - 3 * dyq_) * 32 \
+                              : aad[mi_][SPATIAL ? 0 : (TN_)];                                               \
+      fa_h[SET_][mi_] = *reinterpret_cast<const h8*>(lds + (AS_) * ASLOT + ad_);                             \
+    }                                                                                                        \
     else if ((K_) >= NI + SMI && (K_) < 2 * NI + SMI)                                                        \
       fb_l[SET_][(K_) - NI - SMI] = *reinterpret_cast<const h8*>(sB + (BS_) * BREC + ((K_) - NI - SMI) * 2048 + 1024 + boff); \
     else {                                                                                                   \
@@ -513,7 +524,7 @@ __global__ __launch_bounds__(NW * 64, NI == 2 ? 1 : 2) void conv_strip_f16x3_ker
   // MFMA K_ of a step in term-major order (consecutive MFMAs go to different accumulator tiles): lo x hi, hi x lo, hi x hi
 #define RS_MMA1(K_, SET_)                                                                                    \
   {                                                                                                          \
-    const int term_ = (K_) / (SMI * NI), idx_ = (K_) % (SMI * NI), mi_ = idx_ % SMI, ni_ = idx_ / SMI;       \
+    const int term_ = P1 ? 2 : (K_) / (SMI * NI), idx_ = (K_) % (SMI * NI), mi_ = idx_ % SMI, ni_ = idx_ / SMI; \
     if (term_ == 0) acc[mi_][ni_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_l[SET_][mi_], fb_h[SET_][ni_], acc[mi_][ni_], 0, 0, 0);       \
     else if (term_ == 1) acc[mi_][ni_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_h[SET_][mi_], fb_l[SET_][ni_], acc[mi_][ni_], 0, 0, 0);  \
     else acc[mi_][ni_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_h[SET_][mi_], fb_h[SET_][ni_], acc[mi_][ni_], 0, 0, 0);  \
@@ -814,20 +825,20 @@ __global__ __launch_bounds__(NW * 64, NI == 2 ? 1 : 2) void conv_strip_f16x3_ker
 
 // every kernel of one strip height (SMI_ 32-row tiles per wave): nw waves of ni 32-column tiles, 3x3 (spatial) or 1x5 / 5x1, sources
 // split (hlin) / fp32 / fp32 with the fused normalisation (norm).  Two tiles per wave exist for 160-row strips only.
-template <int SMI_>
+template <int SMI_, bool P1_ = false>
 int strip_launch_height(const KParams& p, int nw, int ni, bool spatial, bool hlin, bool norm, unsigned nwg, hipStream_t st) {
   const dim3 grid(nwg), block(nw * 64);
 #define RS_LAUNCH(NW_, NI_)                                                                                               \
   if (spatial) {                                                                                                          \
-    if (norm) hipLaunchKernelGGL((conv_strip_f16x3_kernel<NW_, 9, 2, NI_, SMI_>), grid, block, 0, st, p);                 \
-    else if (hlin) hipLaunchKernelGGL((conv_strip_f16x3_kernel<NW_, 9, 0, NI_, SMI_>), grid, block, 0, st, p);            \
-    else hipLaunchKernelGGL((conv_strip_f16x3_kernel<NW_, 9, 1, NI_, SMI_>), grid, block, 0, st, p);                      \
+    if (norm) hipLaunchKernelGGL((conv_strip_f16x3_kernel<NW_, 9, 2, NI_, SMI_, P1_>), grid, block, 0, st, p);                 \
+    else if (hlin) hipLaunchKernelGGL((conv_strip_f16x3_kernel<NW_, 9, 0, NI_, SMI_, P1_>), grid, block, 0, st, p);            \
+    else hipLaunchKernelGGL((conv_strip_f16x3_kernel<NW_, 9, 1, NI_, SMI_, P1_>), grid, block, 0, st, p);                      \
   } else {                                                                                                                \
-    if (hlin) hipLaunchKernelGGL((conv_strip_f16x3_kernel<NW_, 5, 0, NI_, SMI_>), grid, block, 0, st, p);                 \
-    else hipLaunchKernelGGL((conv_strip_f16x3_kernel<NW_, 5, 1, NI_, SMI_>), grid, block, 0, st, p);                      \
+    if (hlin) hipLaunchKernelGGL((conv_strip_f16x3_kernel<NW_, 5, 0, NI_, SMI_, P1_>), grid, block, 0, st, p);                 \
+    else hipLaunchKernelGGL((conv_strip_f16x3_kernel<NW_, 5, 1, NI_, SMI_, P1_>), grid, block, 0, st, p);                      \
   }
   if (ni == 2) {
-    if constexpr (SMI_ == 5) {
+    if constexpr (SMI_ == 5 && !P1_) {
       if (nw == 4) { RS_LAUNCH(4, 2) } else if (nw == 3) { RS_LAUNCH(3, 2) } else { RS_LAUNCH(2, 2) }
     } else {
       return 1;

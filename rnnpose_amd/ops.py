@@ -557,7 +557,8 @@ def _nhwc(t, name):
 
 def conv2d_nhwc(pc: PackedConv, srcs, dst, epilogue: int = EPI_LINEAR, aux0=None, aux1=None, dst2=None, gru_c: int = 0,
                 stride: int = 1, tile_stats=None, add_map=None, in_norm=None, src_hl: bool = False, dst_hl: bool = False,
-                dst2_hl: bool = False, dst_split=None, tile: int = 0, src_bounded: bool = False, ksplit_ws=None):
+                dst2_hl: bool = False, dst_split=None, tile: int = 0, src_bounded: bool = False, ksplit_ws=None,
+                single_product=None):
     """srcs: list of (tensor (B,H,W,C), c_offset) matched with pc.seg_counts; dst/aux0/aux1/dst2: (tensor, c_offset).
     ksplit_ws: a conv_ksplit_workspace() buffer -- lets a launch of few tiles (B = 1 crops) split its K loop over several
     workgroups per tile; launches that may run concurrently (two streams) need separate buffers.
@@ -619,6 +620,7 @@ def conv2d_nhwc(pc: PackedConv, srcs, dst, epilogue: int = EPI_LINEAR, aux0=None
         d.dst_split, d.dst_split_c_stride, d.dst_split_c_offset = t.data_ptr(), t.shape[3], off
     if ksplit_ws is not None:
         d.ksplit_ws, d.ksplit_ws_bytes = ksplit_ws.data_ptr(), ksplit_ws.numel() * ksplit_ws.element_size()
+    d.single_product = int(_single_product if single_product is None else bool(single_product))
     Ho, Wo = -(-H // stride), -(-W // stride)
     # algorithmic bytes of the launch: every input element and weight read once, every output written once, the
     # epilogue's operands (additive map; h of the gate, h and z of the state update) read once -- 4 bytes each
@@ -627,6 +629,18 @@ def conv2d_nhwc(pc: PackedConv, srcs, dst, epilogue: int = EPI_LINEAR, aux0=None
     nb += 2 * B * Ho * Wo * pc.c_out * (epilogue == EPI_GRU_Q) + B * Ho * Wo * pc.c_out * (dst_split is not None)
     _launch("rnnpose_conv2d_nhwc_f16x3", C.byref(d), _stream(),
             work=2.0 * B * Ho * Wo * pc.c_out * pc.c_in_real * pc.kh * pc.kw, nbytes=4.0 * nb)
+
+
+_single_product = False
+
+
+def single_product(enable=None) -> bool:
+    """Process-wide default of conv2d_nhwc's `single_product` (cfg.raft.mixed_precision: one fp16 product per multiply-add in the
+    160-row strip kernels instead of three; PoseRefiner sets it from its configuration at every forward).  -> the current value."""
+    global _single_product
+    if enable is not None:
+        _single_product = bool(enable)
+    return _single_product
 
 
 def conv_tiles_per_image(H, W, kh, kw, stride=1, c_out=None, tile: int = 0, batch: int = 1) -> int:

@@ -89,6 +89,7 @@ class PoseRefiner(nn.Module):
         # 240x240) the loop is launch-bound, not GPU-bound.  Falls back to eager launches if capture is refused.
         self.use_graph = use_graph
         self.split_fmaps = os.environ.get("RNNPOSE_SPLIT_FMAPS", "1") != "0"
+        self.mixed_precision = bool(cfg.get("raft", {}).get("mixed_precision", False)) or os.environ.get("RNNPOSE_MIXED_PRECISION", "0") != "0"
         self.profile_rec = None           # set by profile_first_outer(): record of the instrumented first outer iteration
         # inner-iteration graphs, one record PER INPUT SHAPE (a partial last evaluation batch followed by a full one must not
         # evict each other: ADVICE r02): {"gr": graph captured on the caller's tensors (keyed by their addresses), "captures":
@@ -152,7 +153,11 @@ class PoseRefiner(nn.Module):
         """Once per forward(): re-pack weights whose parameters changed (load_state_dict, in-place updates, .to()) and
         return the identity every captured graph depends on -- replay never runs the packing code itself."""
         eng = self.cf_net.engine()
-        key = (eng.refresh(), self.image_fea_enc.engine().refresh(), self.sigma[0].data_ptr(), eng.epoch, ops.range_guard_state())
+        # cfg.raft.mixed_precision (the reference's GPU arithmetic, model/CFNet.py:47,126,152): single-product fp16 convolutions in the
+        # strip kernels; RNNPOSE_MIXED_PRECISION=1 forces it for measurements.  Part of the graph key (graphs bake the kernels in).
+        ops.single_product(self.mixed_precision)
+        key = (eng.refresh(), self.image_fea_enc.engine().refresh(), self.sigma[0].data_ptr(), eng.epoch, ops.range_guard_state(),
+               self.mixed_precision)
         if key != self._wkey:
             if self._wkey is not None:
                 self._drop_graphs()          # graphs hold pointers to the old packed weights / freed activation buffers

@@ -797,6 +797,41 @@ def test_conv_strip_tile_stats_and_fused_input_norm(ops, strip_mode, strip_tile,
     z32 = F.conv2d(n64.float(), D(w2), D(b2), padding=1)
     check(nchw(fused), z64, z32, "strip: fused norm + conv")
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("hl", [False, True])
+@pytest.mark.parametrize("B,H,W,segs,cout,kh,kw", [(2, 20, 32, [128, 128], 256, 1, 5), (2, 20, 32, [256], 192, 3, 3), (1, 40, 48, [64], 64, 3, 3)])
+def test_conv_strip_single_product_is_plain_fp16(ops, hl, B, H, W, segs, cout, kh, kw):
+    """cfg.raft.mixed_precision (single_product=True, 160-row strips): ONE product per multiply-add -- the result is the fp16-rounded
+    operands' convolution in fp32: exact against fp64 on the ROUNDED operands to fp32 round-off, ~2^-11 per product against the
+    unrounded ones; the three-product default on the same inputs is three orders closer.  Other tile requests ignore the flag."""
+    cin = sum(segs)
+    x = syn.normal("sp.x", (B, cin, H, W), 3, std=1.5)
+    w = syn.normal("sp.w", (cout, cin, kh, kw), 3, std=float(np.sqrt(2.0 / (cin * kh * kw))))
+    b = syn.uniform("sp.b", (cout,), 3, -0.5, 0.5)
+    pc = ops.PackedConv(D(w), D(b), segs)
+    xs, o = [], 0
+    for c in segs:
+        t = nhwc(D(x[:, o:o + c]))
+        xs.append((ops.split_hl(t) if hl else t, 0))
+        o += c
+    out1 = torch.empty(B, H, W, cout, device="cuda")
+    out3 = torch.empty(B, H, W, cout, device="cuda")
+    ops.conv2d_nhwc(pc, xs, (out1, 0), ops.EPI_LINEAR, src_hl=hl, tile=5, single_product=True)
+    ops.conv2d_nhwc(pc, xs, (out3, 0), ops.EPI_LINEAR, src_hl=hl, tile=5)
+    pad = (kh // 2, kw // 2)
+    y64 = F.conv2d(D(x).double(), D(w).double(), D(b).double(), padding=pad)
+    # the operands as the kernel rounds them: fp16 of value * scale (activations ops.A_SCALE, weights the packer's power of two)
+    r16 = lambda t, s: (t * s).half().double() / s
+    yr = F.conv2d(r16(D(x), ops.A_SCALE), r16(D(w), pc.w_scale), D(b).double(), padding=pad)
+    scale = float(y64.abs().max())
+    e1, e3 = float((nchw(out1).double() - y64).abs().max()), float((nchw(out3).double() - y64).abs().max())
+    assert e3 < 2e-5 * scale and 20 * e3 < e1 < 4e-3 * scale
+    assert float((nchw(out1).double() - yr).abs().max()) < 1e-2 * e1 + 3e-6 * scale      # (it IS the product of the rounded operands)
+    ref = torch.empty(B, H, W, cout, device="cuda")
+    ops.conv2d_nhwc(pc, xs, (ref, 0), ops.EPI_LINEAR, src_hl=hl, tile=1, single_product=True)        # the 128-row kernels keep three products
+    assert float((nchw(ref).double() - y64).abs().max()) < 2e-5 * scale
+
+
 
 def test_conv_strip_is_the_automatic_choice_at_the_update_block_shape(ops):
     """60 x 80 maps (the headline's 1/8 resolution), batch 8: the automatic tile choice takes 160-row strips (30 patches per image instead

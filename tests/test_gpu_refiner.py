@@ -325,3 +325,39 @@ def test_two_chains_equal_one_chain(ops, monkeypatch):
         assert len(ref.cf_net.engine().halves(2)) == (1 if parts is None else 2)
         outs.append((out["Ti_pred"].G.clone(), out["flow_last"].clone()))
     assert float((outs[0][0] - outs[1][0]).abs().max()) < 1e-6 and float((outs[0][1] - outs[1][1]).abs().max()) < 5e-5
+
+
+def test_mixed_precision_mode_runs_the_single_product_kernels(ops):
+    """cfg.raft.mixed_precision = True (the reference's GPU arithmetic: fp16 autocast around encoder and update block,
+    model/CFNet.py:47,126,152) switches the strip convolutions to ONE fp16 product per multiply-add.  Unpinned against the reference's
+    autocast run (no GPU reference here), so this checks what can be checked: the mode changes the result by the size fp16 operands
+    predict (orders above the default's round-off, far below the signal), hipGraph replay follows the switch, and a default refiner
+    afterwards is bit-identical to one before (the process-wide default is reset at every forward)."""
+    from rnnpose_amd import synthetic as syn
+    from rnnpose_amd.pose_refiner import PoseRefiner, SyntheticRenderer, default_config
+    from rnnpose_amd.transformation import SE3Sequence
+    from oracle import rnnpose_oracle as orc
+    B, H, W = 2, 480, 640                       # (160-row strips need maps that fill the chip: the headline resolution; B = 2 runs as ONE
+                                                #  chain -- the two-chain schedule is not bit-reproducible: profiles/r04_determinism.txt)
+    d = syn.make_inputs(B, H, W, seed=21)
+    D = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    z3 = torch.zeros(B, 3, H, W, device="cuda")
+    kw = dict(syn_img=z3, image_crop=z3, cfea=D(d["ctx"]), geofea1=D(d["g1"]), geofea2_crop=D(d["g2"]), syn_depth=D(d["depth"]),
+              intrinsics_crop=D(d["K"]), fmap1=D(d["fmap1"]), fmap2=D(d["fmap2"]))
+    outs = []
+    try:
+        for mixed in (False, True, False):
+            cfg = default_config(RENDER_ITER_COUNT=1, ITER_COUNT=2, OPTIM_ITER_COUNT=1)
+            cfg.raft.mixed_precision = mixed
+            ref = PoseRefiner(cfg, renderer=SyntheticRenderer(**kw)).cuda().eval()
+            ref.cf_net.update_block.load_state_dict({k: torch.from_numpy(v) for k, v in syn.make_module_weights(orc.UPDATE_BLOCK_SHAPES, seed=0).items()})
+            for _ in range(2):                  # second call replays the captured graphs
+                out = ref(None, SE3Sequence(matrix=D(d["G0"])), D(d["K"]))
+            assert ops.single_product() == mixed
+            outs.append((out["Ti_pred"].G.clone(), out["flow_last"].clone()))
+    finally:
+        ops.single_product(False)
+    assert torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[0][1], outs[2][1])
+    dG, dF = float((outs[0][0] - outs[1][0]).abs().max()), float((outs[0][1] - outs[1][1]).abs().max())
+    fmax = float(outs[0][1].abs().max())
+    assert 1e-6 < dF < 2e-2 * max(fmax, 1.0) and dG < 2e-3, (dG, dF, fmax)

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Run-to-run reproducibility of the refinement loop at the headline shape (B=8, 480x640, feature maps given, 1 outer x 2 inner
+iterations, eager launches): N fresh PoseRefiner instances on identical inputs, every per-iteration output (flow, weight map, G, H,
+b, xi) compared bit for bit with the first instance; for every instance the recorded weight map is also recomputed from the FINAL
+flow of the same iteration (ops.corr_weight) and compared.
+
+r04 finding (profiles/r04_determinism.txt): with the default TWO-chain schedule (two half-batch loops on two streams) every instance
+differs from the first in 15-32 pixels of a weight map -- one or two 64-byte runs of one image row -- and in what follows from them
+(pose 2e-9, flow <= 3.5e-5 px after two iterations); the recorded weight of those pixels is NOT the weight of the final flow: the
+weight kernel saw other (close) flow values in that sector.  With ONE chain (RNNPOSE_SPLIT_BATCH=0) 12 of 12 instances are
+bit-identical.  Root cause open (candidates: cross-XCD L2 visibility between consecutive kernels of a stream while a second stream is
+active; not the allocator, not the launch order).
+    python tools/determinism_probe.py [trials]        (RNNPOSE_SPLIT_BATCH=0 for the one-chain schedule)"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from rnnpose_amd import ops, synthetic as syn  # noqa: E402
+from rnnpose_amd.pose_refiner import PoseRefiner, SyntheticRenderer, default_config  # noqa: E402
+from rnnpose_amd.transformation import SE3Sequence  # noqa: E402
+from oracle import rnnpose_oracle as orc  # noqa: E402  (weights generator only)
+
+trials = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+B, H, W = int(os.environ.get("DET_B", "8")), 480, 640
+d = syn.make_inputs(B, H, W, seed=21)
+D = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+z3 = torch.zeros(B, 3, H, W, device="cuda")
+kw = dict(syn_img=z3, image_crop=z3, cfea=D(d["ctx"]), geofea1=D(d["g1"]), geofea2_crop=D(d["g2"]), syn_depth=D(d["depth"]),
+          intrinsics_crop=D(d["K"]), fmap1=D(d["fmap1"]), fmap2=D(d["fmap2"]))
+wts = {k: torch.from_numpy(v) for k, v in syn.make_module_weights(orc.UPDATE_BLOCK_SHAPES, seed=0).items()}
+G0, K = D(d["G0"]), D(d["K"])
+keep = []           # (keeps the allocator from handing every instance the same blocks)
+
+
+def run(tag):
+    cfg = default_config(RENDER_ITER_COUNT=1, ITER_COUNT=2, OPTIM_ITER_COUNT=1)
+    ref = PoseRefiner(cfg, renderer=SyntheticRenderer(**kw), use_graph=False).cuda().eval()
+    ref.cf_net.update_block.load_state_dict(wts)
+    rec = {}
+    orig = PoseRefiner._loop_buffers
+
+    def spy(self, *a, **k):
+        r = orig(self, *a, **k)
+        r["big"].zero_(), r["small"].zero_(), r["coords"].zero_()
+        rec["bufs"] = r
+        return r
+    PoseRefiner._loop_buffers = spy
+    out = ref(None, SE3Sequence(matrix=G0), K)
+    PoseRefiner._loop_buffers = orig
+    torch.cuda.synchronize()
+    res = {"flow_last": out["flow_last"].clone()}
+    for i, vw in enumerate(rec["bufs"]["views"]):
+        for nm, t in zip(("flow_up", "wmap", "G", "Hm", "bv", "xi", "info"), vw):
+            res[f"it{i}.{nm}"] = t.clone()
+        chk = ops.corr_weight(kw["geofea1"], kw["geofea2_crop"], vw[0], kw["syn_depth"], ref.sigma[0])
+        bad = (chk != vw[1]).nonzero()
+        if len(bad):
+            print(f"  instance {tag} it{i}: recorded weight != corr_weight(final flow) in {len(bad)} pixels, first {bad[0].tolist()}", flush=True)
+    keep.append(torch.full((1 << 26,), float(len(keep)), device="cuda"))
+    return res
+
+
+first = run("first")
+n = 0
+for t in range(trials):
+    cur = run(t)
+    bad = [k for k in first if int((first[k] != cur[k]).sum())]
+    n += bool(bad)
+    if bad:
+        print(f"instance {t}: differs from the first in {bad[:6]}; flow after two iterations by {float((first['flow_last'] - cur['flow_last']).abs().max()):.3g} px, "
+              f"pose by {float((first['it1.G'] - cur['it1.G']).abs().max()):.3g}", flush=True)
+print(f"{n} of {trials} instances differ from the first ({'one chain' if os.environ.get('RNNPOSE_SPLIT_BATCH') == '0' else 'two chains'})")
