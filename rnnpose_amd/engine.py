@@ -29,7 +29,13 @@ class UpdateEngine:
         self._sets = {}           # (B,h,w,device) -> activation buffer set; kept alive because captured hipGraphs hold raw
         self.epoch = 0            # pointers into them.  Bumped whenever a set is freed: graph caches keyed on it are dropped
         import os
-        self.split_batch = os.environ.get("RNNPOSE_SPLIT_BATCH", "1") != "0"   # concurrent part-batch chains
+        # Concurrent part-batch chains on several streams: OFF by default since r04.  (a) With the strip kernels one full-batch chain
+        # is within 1 % of two half-batch chains at the headline (r03's 128-row kernels: 15 % slower); (b) with two streams active,
+        # a kernel's stores were not always visible to the NEXT kernel of its own stream (tools/determinism_probe.py,
+        # profiles/r04_determinism.txt: one 64-byte run of a weight map per forward computed from the flow map as it was before
+        # mask_upsample wrote it; an explicit agent-scope release at the end of the producer cut 14 of 14 differing runs to 0-1 of
+        # 12 at +12 us per launch; one stream: 0 of 12).  RNNPOSE_SPLIT_BATCH=1 (or RNNPOSE_PARTS=n) brings the chains back.
+        self.split_batch = os.environ.get("RNNPOSE_SPLIT_BATCH", "0") != "0"
         self.parts = int(os.environ.get("RNNPOSE_PARTS", "2"))
         self.parts_forced = "RNNPOSE_PARTS" in os.environ                         # explicit part count: no small-batch merging
         self.fused_mask = os.environ.get("RNNPOSE_FUSED_MASK", "1") != "0"       # mask.2 inside the up-sampling kernel
@@ -212,8 +218,9 @@ class UpdateEngine:
         """Image ranges of the concurrent chains: `parts` parts of the batch (one stream each), or the whole batch.
         A chain needs enough pixels to fill the chip on its own launches: B=16 at 240x240 (14400 pixels at 1/8 resolution) runs
         3 % faster as one chain than as two of 7200 (1009 vs 978 iters/s), B=32 (two of 14400) 3 % faster as two, the headline
-        shape (two of 19200) 5 % faster as two (r02); RNNPOSE_PARTS / RNNPOSE_SPLIT_BATCH override."""
-        n = 1 if (B < 2 or not self.split_batch) else min(self.parts, B)
+        shape (two of 19200) 5 % faster as two (r02) -- on the 128-row kernels; r04: ONE chain unless RNNPOSE_SPLIT_BATCH=1 or
+        RNNPOSE_PARTS=n asks for more (see __init__)."""
+        n = 1 if (B < 2 or not (self.split_batch or self.parts_forced)) else min(self.parts, B)
         if n > 1 and not self.parts_forced and self._buf_key is not None:
             _, h, w, _ = self._buf_key
             while n > 1 and B * h * w < n * self.MIN_CHAIN_PIXELS:
@@ -398,7 +405,8 @@ class EncoderEngine:
         self.resident_1x1 = os.environ.get("RNNPOSE_RESIDENT_1X1", "1") != "0"
         self.ksplit = os.environ.get("RNNPOSE_KSPLIT", "1") != "0"
         self.split_batch = os.environ.get("RNNPOSE_SPLIT_ENCODER", "1") != "0"
-        self.parts = int(os.environ.get("RNNPOSE_ENCODER_PARTS", "2"))
+        self.parts = int(os.environ.get("RNNPOSE_ENCODER_PARTS", "1"))
+        self.merge_sets = os.environ.get("RNNPOSE_ENCODER_MERGE", "1") != "0"     # 0: one stream per image set (r02-r03)
 
     def _mine(self):
         f = self.fnet
@@ -491,6 +499,8 @@ class EncoderEngine:
         W = self._weights()
         imgs = [images] if torch.is_tensor(images) else list(images)
         imgs = [ops._chk(t, "image") for t in imgs]
+        if self.merge_sets and len(imgs) > 1:       # r04: the image sets as ONE batch on ONE stream (equal speed; see UpdateEngine.__init__ (b))
+            imgs = [torch.cat(imgs, 0)]
         _, _, H, Wd = imgs[0].shape
         N = sum(t.shape[0] for t in imgs)
         dev = imgs[0].device

@@ -4,13 +4,14 @@ iterations, eager launches): N fresh PoseRefiner instances on identical inputs, 
 b, xi) compared bit for bit with the first instance; for every instance the recorded weight map is also recomputed from the FINAL
 flow of the same iteration (ops.corr_weight) and compared.
 
-r04 finding (profiles/r04_determinism.txt): with the default TWO-chain schedule (two half-batch loops on two streams) every instance
+r04 finding (profiles/r04_determinism.txt): with the TWO-chain schedule (the default until then) (two half-batch loops on two streams) every instance
 differs from the first in 15-32 pixels of a weight map -- one or two 64-byte runs of one image row -- and in what follows from them
 (pose 2e-9, flow <= 3.5e-5 px after two iterations); the recorded weight of those pixels is NOT the weight of the final flow: the
-weight kernel saw other (close) flow values in that sector.  With ONE chain (RNNPOSE_SPLIT_BATCH=0) 12 of 12 instances are
-bit-identical.  Root cause open (candidates: cross-XCD L2 visibility between consecutive kernels of a stream while a second stream is
-active; not the allocator, not the launch order).
-    python tools/determinism_probe.py [trials]        (RNNPOSE_SPLIT_BATCH=0 for the one-chain schedule)"""
+weight kernel saw other (close) flow values in that sector.  With ONE chain 12 of 12 instances are bit-identical; an explicit agent-scope release at the
+end of mask_upsample's workgroups cut the two-chain rate from 14 of 14 to 0-1 of 12 (+12 us per launch): with two streams active, the
+end-of-kernel write-back of one XCD's L2 is not always in time for the next kernel of the same stream on another XCD.  Since then the
+loop runs as one chain and the encoder as one batch by default.
+    python tools/determinism_probe.py [trials]        (RNNPOSE_SPLIT_BATCH=1: the two-chain schedule; DET_ENCODER=1: encoder in the loop)"""
 import os
 import sys
 
@@ -35,7 +36,16 @@ G0, K = D(d["G0"]), D(d["K"])
 keep = []           # (keeps the allocator from handing every instance the same blocks)
 
 
+if os.environ.get("DET_ENCODER", "0") != "0":        # encoder in the loop: images instead of given feature maps
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(5)
+    kw["syn_img"] = torch.rand(B, 3, H, W, device="cuda", generator=gen) * 255
+    kw["image_crop"] = torch.rand(B, 3, H, W, device="cuda", generator=gen) * 255
+    del kw["fmap1"], kw["fmap2"]
+
+
 def run(tag):
+    torch.manual_seed(0)                                # (identical encoder initialisation in every instance)
     cfg = default_config(RENDER_ITER_COUNT=1, ITER_COUNT=2, OPTIM_ITER_COUNT=1)
     ref = PoseRefiner(cfg, renderer=SyntheticRenderer(**kw), use_graph=False).cuda().eval()
     ref.cf_net.update_block.load_state_dict(wts)
@@ -48,7 +58,14 @@ def run(tag):
         rec["bufs"] = r
         return r
     PoseRefiner._loop_buffers = spy
-    out = ref(None, SE3Sequence(matrix=G0), K)
+    if os.environ.get("DET_STREAM", "0") != "0":          # the whole forward on a pool stream instead of the default (null) stream
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            out = ref(None, SE3Sequence(matrix=G0), K)
+        torch.cuda.current_stream().wait_stream(side)
+    else:
+        out = ref(None, SE3Sequence(matrix=G0), K)
     PoseRefiner._loop_buffers = orig
     torch.cuda.synchronize()
     res = {"flow_last": out["flow_last"].clone()}
@@ -72,4 +89,4 @@ for t in range(trials):
     if bad:
         print(f"instance {t}: differs from the first in {bad[:6]}; flow after two iterations by {float((first['flow_last'] - cur['flow_last']).abs().max()):.3g} px, "
               f"pose by {float((first['it1.G'] - cur['it1.G']).abs().max()):.3g}", flush=True)
-print(f"{n} of {trials} instances differ from the first ({'one chain' if os.environ.get('RNNPOSE_SPLIT_BATCH') == '0' else 'two chains'})")
+print(f"{n} of {trials} instances differ from the first ({'two chains' if os.environ.get('RNNPOSE_SPLIT_BATCH', '0') != '0' else 'one chain'})")
