@@ -22,6 +22,8 @@ if [ "$2" != "noprof" ]; then
   python bench.py --steps 10 --warmup 2 --no-cpu-baseline --batch 16 --height 240 --width 240 --inner 4 > $OUT/${TAG}_bench_B16_240.json 2>/dev/null   # configs[2] shape
   python bench.py --steps 10 --warmup 2 --no-cpu-baseline --batch 32 --height 240 --width 240 --inner 4 > $OUT/${TAG}_bench_B32_240.json 2>/dev/null   # configs[3] shape
   RNNPOSE_SPLIT_TENSORS=0 python bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/${TAG}_bench_fp32_activations.json 2>/dev/null
+  RNNPOSE_SPLIT_BATCH=1 RNNPOSE_ENCODER_MERGE=0 RNNPOSE_ENCODER_PARTS=2 python bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/${TAG}_bench_two_chains.json 2>/dev/null   # the r02-r03 schedule (opt-in since r04)
+  python bench.py --steps 20 --warmup 3 --no-cpu-baseline --mixed-precision > $OUT/${TAG}_bench_mixed_precision.json 2>/dev/null
   timeout 600 python tools/error_budget.py > $OUT/${TAG}_error_budget.log 2>&1; cp $OUT/error_budget.json $OUT/${TAG}_error_budget.json
   timeout 900 python tools/parity_probe.py > $OUT/${TAG}_parity_probe.log 2>&1; cp $OUT/parity_probe.json $OUT/${TAG}_parity_probe.json
   if ls gpurun_extra/abl_*.so > /dev/null 2>&1; then     # ablation builds (bash tools/conv_ablate.sh 1 2 4 8 16 32 7 31 in the build container)
@@ -37,7 +39,7 @@ if [ "$2" != "noprof" ]; then
   python tools/drift_probe.py > $OUT/${TAG}_drift.log 2>&1; cp $OUT/drift_probe.json $OUT/${TAG}_drift.json; tail -1 $OUT/${TAG}_drift.log
   ( cd /tmp && export TMPDIR=/tmp
     rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof -o run -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/${TAG}_prof.log 2>&1
-    rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof_unsplit -o run -- env RNNPOSE_SPLIT_BATCH=0 python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph > $OUT/${TAG}_prof_unsplit.log 2>&1
+    rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof_unsplit -o run -- env RNNPOSE_SPLIT_BATCH=1 RNNPOSE_ENCODER_MERGE=0 RNNPOSE_ENCODER_PARTS=2 python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph > $OUT/${TAG}_prof_unsplit.log 2>&1
     rocprofv3 --kernel-trace -d $OUT/${TAG}_prof_convs -o run -- python $R/tools/conv_layers.py 7 > $OUT/${TAG}_prof_convs.log 2>&1 )
   bash tools/pmc_sq.sh ${TAG}_k python tools/pmc_kernels.py 3 > /dev/null 2>&1
   bash tools/pmc_sq.sh ${TAG}_c python tools/conv_layers.py 3 > /dev/null 2>&1

@@ -8,7 +8,7 @@ tools/gpu_round.sh runs it ON the GPU box with outdir = gpurun_out/<tag>_summary
 
   <tag>_bench*.json            the bench lines (default config, --no-graph, S1 / S5 / B16 shapes)
   <tag>_kernel_stats*.csv      per-kernel calls / total / mean / min / max of the rocprofv3 --kernel-trace --stats runs of bench.py
-                               (graph replay, two half-batch chains; and RNNPOSE_SPLIT_BATCH=0 --no-graph)
+                               (graph replay, the default schedule; and the other schedule -- r04: two chains -- with --no-graph)
   <tag>_conv_layers_alone.txt  tools/conv_layers.py: every update-block convolution shape alone on the chip (us, executed TF, % of peak)
   <tag>_conv_layers.csv        the same launches in rocprofv3's kernel trace (keyed by grid size)
   <tag>_pmc_kernels.json       SQ + FETCH/WRITE counters per hand-written kernel (tools/pmc_kernels.py), incl. lm_normal_eq's VALU/LDS
@@ -69,7 +69,7 @@ def tail(src, dst, n=15):
 
 
 os.makedirs(P, exist_ok=True)
-for suffix in ("bench", "bench_nograph", "bench_S1", "bench_S5", "bench_B16", "bench_B16_240", "bench_B32_240", "bench_split_tensors", "drift",
+for suffix in ("bench", "bench_nograph", "bench_S1", "bench_S5", "bench_B16", "bench_B16_240", "bench_B32_240", "bench_split_tensors", "bench_fp32_activations", "bench_two_chains", "bench_mixed_precision", "drift",
                "error_budget", "parity_probe"):
     src = have(f"{TAG}_{suffix}.json")
     if src and os.path.getsize(src):
