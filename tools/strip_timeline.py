@@ -38,12 +38,9 @@ for name, segs, co, kh, kw, hh, ww, hl in cases:
     assert rc == 0, rc
     t = buf.reshape(n, 8).astype(np.int64)
     tpi = ops.conv_tiles_per_image(hh, ww, kh, kw, 1, co, 5)
-    waves = 2 if co <= 64 else None
     # number of workgroups of this launch: entries stamped in the last launch = those whose entry time >= the launch's first entry
-    t0 = t[:, 0]
     live = t[:, 3] > 0
     last = t[live]
-    start = np.sort(last[:, 0])
     # the last launch: stamps within 1 ms of the newest exit
     newest = last[:, 3].max()
     idx_all = np.nonzero(live)[0]
