@@ -345,8 +345,9 @@ def main():
                             "outer iteration every launch goes to ONE stream, so each is timed alone on the chip (the same durations "
                             "rocprofv3's kernel trace reports: profiles/).  traffic = mean HBM bytes per launch of both kernel families from the "
                             "FETCH_SIZE / WRITE_SIZE counter passes over the same command, algorithmic_bytes_per_launch = the mean over the "
-                            "same launches of inputs + weights + outputs + epilogue operands.  The production schedule runs two half-batch "
-                            "chains concurrently on two streams: chip_level is the aggregate over the whole step",
+                            "same launches of inputs + weights + outputs + epilogue operands.  The production schedule is one full-batch chain "
+                            "on one stream (r04; RNNPOSE_SPLIT_BATCH=1: two half-batch chains on two streams): chip_level is the aggregate "
+                            "over the whole step",
                     "fp32_equivalent_over_f32_mfma_peak": round(ach_alg / PEAK_F32_MFMA_TFLOPS, 3),
                     "launches_timed": n,
                     "mean_ms": round(mean_ms, 4), "share_of_step": round(tot_ms / prof_steps / ms_step, 4),
