@@ -407,8 +407,9 @@ def main():
         "roofline": roofline, "chip_level": chip, "correlation_volume_kernel": corr_vol, "kernels": kernels,
         "kernels_note": "HIP events around every C-ABI launch of the first outer iteration of the first timed step (eager); GB/s from "
                         "the ALGORITHMIC bytes each launch declares for its own arguments (SURVEY 8d formulas; half-batch launches "
-                        "declare half the batch); share_of_step = summed launch durations x outer iterations / step time -- launches "
-                        "of the two batch halves overlap on two streams, so the shares add up to more than 1",
+                        "declare half the batch); share_of_step = summed launch durations x outer iterations / step time (under the opt-in "
+                        "two-chain schedule, RNNPOSE_SPLIT_BATCH=1, launches of the two batch halves overlap on two streams and the shares "
+                        "add up to more than 1)",
     }
     if world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"], want = cpu_baseline(refiner, rend, K, G0, args)
