@@ -147,3 +147,18 @@ def test_graft_entry_build_runs():
     ge.build()
     from rnnpose_amd import _lib
     assert _lib.load().rnnpose_abi_version() == _lib.ABI_VERSION == 2
+
+
+def test_conv_tiling_rule_is_a_host_function(lib):
+    """rnnpose_conv_tiles_per_image_ex (records per image of a convolution's tile statistics = how the launch will tile) runs on
+    the host: 160-row strips (10 x 16 patches / runs of 160 pixels) when they give the launch >= 240 workgroups, 32-row strips
+    (2 x 16 / runs of 32) for launches of at most 8192 pixels, else the 128-row kernels (8 x 16 patches / runs of 128)."""
+    f = lib.rnnpose_conv_tiles_per_image_ex
+    assert f(60, 80, 3, 3, 1, 192, 0, 8) == 30 and f(60, 80, 3, 3, 1, 192, 1, 8) == 40       # headline, B = 8: strips / forced 128-row
+    assert f(60, 80, 3, 3, 1, 192, 0, 1) == 150 and f(60, 80, 3, 3, 1, 192, 6, 8) == 150     # one image: 32-row strips / forced
+    assert f(60, 80, 1, 5, 1, 256, 0, 8) == 30 and f(60, 80, 1, 5, 1, 256, 0, 1) == 150      # linear strips: runs of 160 / 32 pixels
+    assert f(30, 30, 1, 5, 1, 256, 0, 1) == 29 and f(30, 30, 3, 3, 1, 128, 0, 1) == 30       # a single LINEMOD crop: 32-row strips
+    assert f(30, 30, 1, 5, 1, 256, 0, 16) == 8 and f(30, 30, 3, 3, 1, 128, 0, 16) == 8       # 16 crops (14 400 pixels): 128-row kernels
+    assert f(240, 320, 3, 3, 1, 64, 0, 8) == 24 * 20                                         # encoder, 64 channels: two-wave strips
+    assert f(60, 80, 3, 3, 2, 128, 0, 8) == lib.rnnpose_conv_tiles_per_image(60, 80, 3, 3, 2)    # stride 2: never strips
+    assert f(60, 80, 3, 3, 1, 32, 5, 8) == -1 and f(60, 80, 3, 3, 1, 192, 7, 8) == -1 and f(60, 80, 3, 3, 1, 192, 0, 0) == -1
