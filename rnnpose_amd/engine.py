@@ -36,6 +36,7 @@ class UpdateEngine:
         # mask_upsample wrote it; an explicit agent-scope release at the end of the producer cut 14 of 14 differing runs to 0-1 of
         # 12 at +12 us per launch; one stream: 0 of 12).  RNNPOSE_SPLIT_BATCH=1 (or RNNPOSE_PARTS=n) brings the chains back.
         self.split_batch = os.environ.get("RNNPOSE_SPLIT_BATCH", "0") != "0"
+        self.side_stream = os.environ.get("RNNPOSE_SIDE_STREAM", "1") != "0"      # one chain: flow-feature / flow-head side chain on a helper stream
         self.parts = int(os.environ.get("RNNPOSE_PARTS", "2"))
         self.parts_forced = "RNNPOSE_PARTS" in os.environ                         # explicit part count: no small-batch merging
         self.fused_mask = os.environ.get("RNNPOSE_FUSED_MASK", "1") != "0"       # mask.2 inside the up-sampling kernel
@@ -239,7 +240,11 @@ class UpdateEngine:
         view["_ksws"], view["_ksws_side"] = self._ksplit_ws(b0, b1, 0), self._ksplit_ws(b0, b1, 1)
         ops.corr_lookup_nhwc_part(corr_fn._buf, coords1_part, view["corr"], B, b0, b1, corr_fn.num_levels, corr_fn.radius)
         yield
-        yield from self._chain_gen(W, view, coords1_part, st, self._stream(coords1_part.device, 2) if single else None)
+        # helper stream for the flow-feature / flow-head side chain: only for a lone SMALL chain (single-image crops: the only concurrency
+        # there is); at the headline it measured equal (695-699 iters/s either way) and a second active queue is what r04's
+        # reproducibility finding is about (see __init__)
+        small = coords1_part.shape[0] * coords1_part.shape[2] * coords1_part.shape[3] < self.MIN_CHAIN_PIXELS
+        yield from self._chain_gen(W, view, coords1_part, st, self._stream(coords1_part.device, 2) if (single and small and self.side_stream) else None)
         if self.fused_mask:         # mask.2 + up-sampling in one kernel (the chain skipped its mask.2 launch)
             ops.mask_upsample(W["mask2u"], view["heads"], 256, view["flow_lr"], out=flow_up_part)
         else:
