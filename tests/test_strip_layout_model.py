@@ -1,4 +1,4 @@
-"""CPU model of the index algebra of csrc/conv_strip.hip (no GPU, no arithmetic): the packed weight order, the lane -> byte
+"""CPU model of the index algebra of csrc/conv_strip_kernel.cuh, both strip heights (no GPU, no arithmetic): the packed weight order, the lane -> byte
 mapping of the LDS-DMA pieces, the XOR swizzle and the fragment read addresses are restated here with the kernel's own integer
 expressions and checked against what the MFMA operands must contain:
 
@@ -11,8 +11,15 @@ import itertools
 
 import pytest
 
-SM, SHALO, SPH, SPW = 160, 4, 10, 16
-SHW, SHR = SPW + 2, (SPH + 2) * (SPW + 2)
+SHALO, SPW = 4, 16
+SHW = SPW + 2
+SM, SPH, SHR, SMI = 160, 10, 12 * SHW, 5          # set per test by geom(): 32 SMI rows per strip (csrc/conv_strip_kernel.cuh: SMI = 5 or 1)
+
+
+def geom(smi):
+    global SM, SPH, SHR, SMI
+    SMI, SM, SPH = smi, 32 * smi, 2 * smi
+    SHR = (SPH + 2) * SHW
 # ds_read_b128 lane groups (MI355X_MICROARCH.md, LDS table)
 GROUPS = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
 GROUPS = GROUPS + [[l + 32 for l in g] for g in GROUPS]
@@ -44,10 +51,12 @@ def a_slot_image(spatial, NW, row_pixel):
     return img, AR * 32
 
 
-@pytest.mark.parametrize("NW", [3, 4])
-def test_spatial_activation_fragments(NW):
+@pytest.mark.parametrize("smi", [5, 1])
+@pytest.mark.parametrize("NW", [2, 3, 4])
+def test_spatial_activation_fragments(NW, smi):
+    geom(smi)
     H, W = 23, 37
-    py0, px0 = 10, 16
+    py0, px0 = SPH, 16
 
     def row_pixel(j):
         hy = j // SHW
@@ -65,7 +74,7 @@ def test_spatial_activation_fragments(NW):
         dy, dx = tap // 3, tap % 3
         return (a1 if dy == 1 else a0) + (2 * SHW * 32 if dy == 2 else 0) + dx * 32
 
-    for tap, mi, lane in itertools.product(range(9), range(5), range(64)):
+    for tap, mi, lane in itertools.product(range(9), range(SMI), range(64)):
         l31, lh = lane & 31, lane >> 5
         r = mi * 32 + l31
         ad = addr(mi, lane, tap)
@@ -75,14 +84,16 @@ def test_spatial_activation_fragments(NW):
             for j in range(8):
                 pix, g, plane, t = img[a + 2 * j]
                 assert pix == want and g == lh and plane == part and t == 2 * j
-    for tap, mi in itertools.product(range(9), range(5)):
+    for tap, mi in itertools.product(range(9), range(SMI)):
         for g in GROUPS:
             slots = {(addr(mi, lane, tap) % 256) // 16 for lane in g}
             assert len(slots) == 16, (tap, mi, g, sorted(slots))      # conflict-free with the line-parity swizzle
 
 
+@pytest.mark.parametrize("smi", [5, 1])
 @pytest.mark.parametrize("vertical", [False, True])
-def test_linear_activation_fragments(vertical):
+def test_linear_activation_fragments(vertical, smi):
+    geom(smi)
     H, W, B = 7, 12, 3
     U, V, su, sv = (W, H, 1, W) if vertical else (H, W, W, 1)
     UV, Mtot = U * V, B * U * V
@@ -97,7 +108,7 @@ def test_linear_activation_fragments(vertical):
             return b * UV + u * su + v * sv
 
         img, PLANE = a_slot_image(False, 4, row_pixel)
-        for tap, mi, lane in itertools.product(range(5), range(5), range(64)):
+        for tap, mi, lane in itertools.product(range(5), range(SMI), range(64)):
             l31, lh = lane & 31, lane >> 5
             r = mi * 32 + l31
             m = m0 + r
@@ -115,7 +126,7 @@ def test_linear_activation_fragments(vertical):
             for part, a in ((0, ad), (1, ad + PLANE)):
                 pix, g, plane, t = img[a]
                 assert pix == want and plane == part and t == 0 and (g == lh or not ok)
-    for tap, mi in itertools.product(range(5), range(5)):
+    for tap, mi in itertools.product(range(5), range(SMI)):
         for g in GROUPS:
             slots = set()
             for lane in g:
