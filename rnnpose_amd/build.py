@@ -21,10 +21,16 @@ LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "librnnpose_hip.so")
 STAMP = os.path.join(LIBDIR, "librnnpose_hip.stamp")
 ARCH = "gfx950"
+# -fno-slp-vectorize for EVERY file (r05): no packed fp32 vector instruction (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32) may exist in
+# this library.  On MI355X such an instruction occasionally returns wrong values for a group of 16 lanes while another wave on the
+# same SIMD issues v_mfma_f32_16x16x32_{f16,bf16} (tools/probes/pk_f32_vs_mfma.hip: plain HIP, two streams -- 694 of 2000 launches
+# differ next to the bf16 form, 2-9 next to the f16 form, 0 for scalar fp32, 0 next to 32x32x16 or 16x16x16 MFMAs, 0 for packed fp16).
+# That was r04's "kernel-to-kernel visibility" finding: corr_weight, SLP-vectorised by plain -O3, running next to mask_upsample /
+# conv1x1_resident of the other stream (profiles/r05_determinism.txt).  tests/test_isa_guard.py fails if one comes back.  (r02 had the
+# flag on the MFMA files only, because packed fp32 next to a wave's OWN MFMAs is slow.)
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall",
-         "-Wno-unused-function", "-Wno-unused-variable", "-DNDEBUG"]
-# the MFMA kernels keep their fp32 vector ALU work scalar (csrc/f16x3.cuh: packed fp32 ops are slow next to MFMAs)
-PER_FILE_FLAGS = {"conv_igemm.hip": ["-fno-slp-vectorize"], "conv_strip.hip": ["-fno-slp-vectorize"], "conv_strip_r32.hip": ["-fno-slp-vectorize"], "conv_strip_p1.hip": ["-fno-slp-vectorize"], "stem.hip": ["-fno-slp-vectorize"]}
+         "-Wno-unused-function", "-Wno-unused-variable", "-DNDEBUG", "-fno-slp-vectorize"]
+PER_FILE_FLAGS = {}
 FLAGS += os.environ.get("RNNPOSE_HIPCC_EXTRA", "").split()     # diagnostics builds (e.g. -DRP_ABL=..., tools/conv_ablate.sh), part of the stamp
 
 

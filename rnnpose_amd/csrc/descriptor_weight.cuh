@@ -4,6 +4,12 @@
 //   dot   s = sum_c g1[c, pixel] * bilinear(g2[c], taps), channels in batches whose 5 loads each are in flight together
 #pragma once
 #include <hip/hip_runtime.h>
+#ifndef RP_CW_WAIT0
+#define RP_CW_WAIT0 0
+#endif
+#ifndef RP_CW_TAPS_SC1
+#define RP_CW_TAPS_SC1 0
+#endif
 
 namespace rp {
 
@@ -51,12 +57,23 @@ __device__ __forceinline__ float descriptor_dot(const float* __restrict__ a, con
     for (int j = 0; j < NB; ++j) {
       const float* qc = q + (c + j) * P;
       av[j] = a[(c + j) * P];
+#if RP_CW_TAPS_SC1   // diagnostics build: the taps through sc1 loads (never served by this CU's L1)
+      v00[j] = __hip_atomic_load(qc + t.o00, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      v10[j] = __hip_atomic_load(qc + t.o10, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      v01[j] = __hip_atomic_load(qc + t.o01, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      v11[j] = __hip_atomic_load(qc + t.o11, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      av[j] = __hip_atomic_load(a + (c + j) * P, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
       v00[j] = qc[t.o00];
       v10[j] = qc[t.o10];
       v01[j] = qc[t.o01];
       v11[j] = qc[t.o11];
+#endif
     }
     __builtin_amdgcn_sched_barrier(0);
+#if RP_CW_WAIT0      // diagnostics build: every load of the batch has returned before the first value is used (no counted waits)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const float wv = ((v00[j] * t.w00 + v10[j] * t.w10) + v01[j] * t.w01) + v11[j] * t.w11;

@@ -29,8 +29,14 @@ constexpr int MQ = 32;          // pixels per workgroup (= threads / 8)
 constexpr int KC = 256;         // input channels (mask.0 output)
 constexpr int NCB = KC / 32;    // 32-channel blocks
 constexpr int NTAP = 9;
-#ifndef MU_NUM_VGPR
-#define MU_NUM_VGPR 160     // register cap: three 4-wave workgroups per CU (the compiler settles at 148, no spills)
+#ifndef MU_STORE_WT
+#define MU_STORE_WT 0
+#endif
+#ifndef MU_RELEASE
+#define MU_RELEASE 0
+#endif
+#ifndef MU_LINE_STORES
+#define MU_LINE_STORES 1    // 0: the r02-r04 epilogue (4-byte stores straight from the softmax registers) for A/B measurements
 #endif
 
 struct MUParams {
@@ -45,7 +51,8 @@ struct MUParams {
   unsigned long long* sat;      // fp16x3 range guard counter (NULL = off)
 };
 
-__global__ __launch_bounds__(8 * MQ) __attribute__((amdgpu_num_vgpr(MU_NUM_VGPR))) void mask_upsample_kernel(const MUParams p) {
+// (launch bounds: three 4-wave workgroups per CU = 3 waves per SIMD: <= 168 registers; the compiler settles at 166, no spills)
+__global__ __launch_bounds__(8 * MQ, 3) void mask_upsample_kernel(const MUParams p) {
   __shared__ __attribute__((aligned(16))) _Float16 sA[NCB][2][MQ * 32];     // [channel block][hi, lo][row * 32 + swizzled chunk * 8 + e]
   __shared__ float2 sF[MQ][NTAP];                                            // 8 * flow of the 3x3 neighbourhood (0 outside the map)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -180,6 +187,60 @@ __global__ __launch_bounds__(8 * MQ) __attribute__((amdgpu_num_vgpr(MU_NUM_VGPR)
 #undef MU_LOADB
   const int si = sub >> 3, sj = sub & 7;
   const long long Wf = 8LL * p.w, Pf = 64LL * n;
+#if MU_LINE_STORES
+  // Epilogue (r05): the 32 x 64 x 2 up-sampled values of the tile go through LDS (the activation tile's space) and leave as WHOLE
+  // 128-byte lines: one wave instruction = one (plane, sub-row) run of 32 pixels x 8 sub-columns = 1 KB of an output row in 16-byte
+  // pieces.  Before, a line was completed piecewise by four 4-byte store instructions of one wave (16 dword stores per lane; now 4
+  // dwordx4) -- the one producer of the loop that handed partially written lines to the memory system.
+  // LDS layout [plane][sub-row si: 336][4-pixel group: 40][pixel & 3: 8][sj] floats: conflict-free for the column-major writes.
+  constexpr int SI_ST = 336, G_ST = 40, PL_ST = 8 * SI_ST;
+  float* sO = reinterpret_cast<float*>(&sA[0][0][0]);
+  static_assert(2 * PL_ST * sizeof(float) <= sizeof(sA), "output staging must fit the activation tile");
+  __syncthreads();                                   // every wave is done reading the activation tile
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int row = 32 * rh + 16 * (r >> 2) + 4 * lq + (r & 3);
+    const int a = si * SI_ST + (row >> 2) * G_ST + (row & 3) * 8 + sj;
+    sO[a] = rax[r] / rden[r];
+    sO[PL_ST + a] = ray[r] / rden[r];
+  }
+  __syncthreads();
+  {
+    const int piece = tid & 63, px = piece >> 1, half = piece & 1;
+    const long long m = m0 + px;
+    if (m < total) {
+      const unsigned mu = static_cast<unsigned>(m);
+      const int b = static_cast<int>(mu / static_cast<unsigned>(n)), pix = static_cast<int>(mu - static_cast<unsigned>(b) * static_cast<unsigned>(n));
+      const int Y = static_cast<int>(static_cast<unsigned>(pix) / static_cast<unsigned>(p.w)), X = pix - Y * p.w;
+      float* dst = p.up + static_cast<long long>(b) * 2 * Pf + 8LL * Y * Wf + 8 * X + 4 * half;
+      const float* src = sO + (px >> 2) * G_ST + (px & 3) * 8 + 4 * half;
+      float4 v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {                  // run = wave + 4 q: plane run >> 3, sub-row run & 7
+        const int run = wave + 4 * q;
+        v[q] = *reinterpret_cast<const float4*>(src + (run >> 3) * PL_ST + (run & 7) * SI_ST);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int run = wave + 4 * q;
+#if MU_STORE_WT     // diagnostics build (tools/det_variants.sh): write-through stores -- the lines never sit dirty in this XCD's L2
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        const f4v vv = {v[q].x, v[q].y, v[q].z, v[q].w};
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst + (run >> 3) * Pf + (run & 7) * Wf), "v"(vv) : "memory");
+#else
+        *reinterpret_cast<float4*>(dst + (run >> 3) * Pf + (run & 7) * Wf) = v[q];
+#endif
+      }
+    }
+  }
+#if MU_STORE_WT
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+#if MU_RELEASE      // diagnostics build: agent-scope release (buffer_wbl2 sc1) by one lane per workgroup behind a barrier
+  __syncthreads();
+  if (tid == 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#endif
+#else
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
     const int row = 32 * rh + 16 * (r >> 2) + 4 * lq + (r & 3);
@@ -193,6 +254,7 @@ __global__ __launch_bounds__(8 * MQ) __attribute__((amdgpu_num_vgpr(MU_NUM_VGPR)
       p.up[(static_cast<long long>(b) * 2 + 1) * Pf + o] = ray[r] / rden[r];
     }
   }
+#endif
 }
 
 // fp32 (576, 256) weights -> [tap k][channel block][column tile ct][hi, lo][lane][8] fp16: lane l of the record carries column
@@ -233,7 +295,8 @@ extern "C" int rnnpose_mask_upsample_f16x3(const float* x, int x_c_stride, int x
   RP_REQUIRE(x_c_offset >= 0 && x_c_offset % 4 == 0 && x_c_stride % 4 == 0 && x_c_offset + KC <= x_c_stride, fn,
              "the 256 input channels must lie inside the row, 16-byte aligned");
   RP_REQUIRE(reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(w_packed) % 16 == 0 &&
-                 reinterpret_cast<uintptr_t>(flow_lr) % 8 == 0, fn, "x / weights must be 16-byte, flow 8-byte aligned");
+                 reinterpret_cast<uintptr_t>(flow_lr) % 8 == 0 && reinterpret_cast<uintptr_t>(flow_up) % 16 == 0, fn,
+             "x / weights / flow_up must be 16-byte, flow 8-byte aligned");
   RP_REQUIRE(a_scale > 0.f && w_scale > 0.f, fn, "scales must be positive");
   MUParams p{};
   p.x = x; p.cs = x_c_stride; p.co = x_c_offset;

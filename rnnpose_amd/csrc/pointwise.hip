@@ -205,6 +205,15 @@ __global__ __launch_bounds__(256) void convex_upsample_kernel(const float* __res
 // ------------------------------------------------------------------------------------------------
 // a8: reliability weight.  One thread per pixel; g1 rows are coalesced, the four g2 taps of neighbouring
 // lanes are neighbouring addresses because the flow is smooth (coalesced in practice).
+#ifndef RP_CW_ACQUIRE
+#define RP_CW_ACQUIRE 0
+#endif
+#ifndef RP_CW_DEBUG
+#define RP_CW_DEBUG 0
+#endif
+#ifndef RP_CW_SC1
+#define RP_CW_SC1 0
+#endif
 #ifndef RP_CW_BATCH
 #define RP_CW_BATCH 4
 #endif
@@ -224,6 +233,10 @@ __global__ __launch_bounds__(256) void corr_weight_kernel(const float* __restric
     const int xcd = bid & 7, idx = bid >> 3;
     bid = xcd * per + (xcd < rem ? xcd : rem) + idx;
   }
+#if RP_CW_ACQUIRE   // diagnostics build (tools/det_variants.sh): agent-scope acquire (buffer_inv sc1) before the first load
+  if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  __syncthreads();
+#endif
   const long long P = static_cast<long long>(H) * W;
   const int bpi = static_cast<int>((P + 255) / 256);       // blocks per image
   const int b = bid / bpi;
@@ -248,12 +261,26 @@ __global__ __launch_bounds__(256) void corr_weight_kernel(const float* __restric
     tx = tt.x;
     ty = tt.y;
   } else {
+#if RP_CW_SC1       // diagnostics build: the flow map through sc1 loads (served by L2 / memory, never by this CU's L1)
+    tx = __hip_atomic_load(target + (static_cast<long long>(b) * 2 + 0) * P + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + static_cast<float>(x);
+    ty = __hip_atomic_load(target + (static_cast<long long>(b) * 2 + 1) * P + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + static_cast<float>(y);
+#else
     tx = target[(static_cast<long long>(b) * 2 + 0) * P + t] + static_cast<float>(x);
     ty = target[(static_cast<long long>(b) * 2 + 1) * P + t] + static_cast<float>(y);
+#endif
   }
+#if RP_CW_DEBUG == 3   // diagnostics: the descriptor path alone (the target is the pixel itself, the flow map is read and ignored)
+  tx = static_cast<float>(x) + 0.f * tx; ty = static_cast<float>(y) + 0.f * ty;
+#endif
   const rp::DescTaps taps = rp::descriptor_taps(tx, ty, H, W);
   const float s = rp::descriptor_dot<CW_BATCH>(g1 + static_cast<long long>(b) * D * P + t, g2 + static_cast<long long>(b) * D * P, P, D, taps);
+#if RP_CW_DEBUG == 1   // diagnostics: what this thread read from the flow map (x / y plane)
+  weight[b * P + t] = tx + 0.f * s;
+#elif RP_CW_DEBUG == 2
+  weight[b * P + t] = ty + 0.f * s;
+#else
   weight[b * P + t] = expf(-fabsf(1.f - s) / sigma[0]) * fg;
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -7,10 +7,10 @@ Per step and batch part: lookup (NHWC) -> convc1 -> convc2 | flow features (coor
 kernel) -> convf2 -> conv -> z|r (1x5) -> q (1x5) -> z|r (5x1) -> q (5x1)  [the context input's share of the GRU gates is
 hoisted: computed once per outer iteration and added in the epilogues] -> flow/mask heads (one 128->512 conv) ->
 flow_head.conv2 + coords update -> mask.2 + convex up-sampling in ONE kernel (csrc/mask_upsample.hip; the 576-channel
-mask only exists for the BasicUpdateBlock facade): 14 launches, no ATen elementwise / cat / clone kernels.  The batch is
-cut into parts (default 2) that run their chains on separate streams.  The module's parameters stay the single source of
-truth:
-packed fp16 hi/lo copies are rebuilt whenever a parameter's version or storage changes.
+mask only exists for the BasicUpdateBlock facade): 14 launches, no ATen elementwise / cat / clone kernels.  By default the whole
+batch runs as ONE chain on the caller's stream; RNNPOSE_SPLIT_BATCH=1 cuts it into two half-batch chains on two streams (see
+__init__).  The module's parameters stay the single source of truth: packed fp16 hi/lo copies are rebuilt whenever a parameter's
+version or storage changes.
 """
 from __future__ import annotations
 
@@ -29,14 +29,17 @@ class UpdateEngine:
         self._sets = {}           # (B,h,w,device) -> activation buffer set; kept alive because captured hipGraphs hold raw
         self.epoch = 0            # pointers into them.  Bumped whenever a set is freed: graph caches keyed on it are dropped
         import os
-        # Concurrent part-batch chains on several streams: OFF by default since r04.  (a) With the strip kernels one full-batch chain
-        # is within 1 % of two half-batch chains at the headline (r03's 128-row kernels: 15 % slower); (b) with two streams active,
-        # a kernel's stores were not always visible to the NEXT kernel of its own stream (tools/determinism_probe.py,
-        # profiles/r04_determinism.txt: one 64-byte run of a weight map per forward computed from the flow map as it was before
-        # mask_upsample wrote it; an explicit agent-scope release at the end of the producer cut 14 of 14 differing runs to 0-1 of
-        # 12 at +12 us per launch; one stream: 0 of 12).  RNNPOSE_SPLIT_BATCH=1 (or RNNPOSE_PARTS=n) brings the chains back.
+        # Concurrent part-batch chains on several streams: opt-in (RNNPOSE_SPLIT_BATCH=1 / RNNPOSE_PARTS=n).  r04 switched them off because
+        # fresh instances differed in 64-byte runs of a weight map whenever two streams were active.  r05 found the cause
+        # (profiles/r05_determinism.txt): corr_weight, compiled into PACKED fp32 instructions by plain -O3, computed other values for
+        # groups of 16 lanes while a v_mfma_f32_16x16x32_f16 kernel (mask_upsample, conv1x1_resident) of the other stream shared its
+        # SIMDs -- a property of the chip that a plain-HIP probe reproduces (tools/probes/pk_f32_vs_mfma.hip), not a visibility problem.
+        # The library is built without packed fp32 since (build.py) and both schedules are bit-reproducible
+        # (tests/test_gpu_reproducibility.py); with the strip kernels one full-batch chain is within 1-4 % of two half-batch chains.
         self.split_batch = os.environ.get("RNNPOSE_SPLIT_BATCH", "0") != "0"
-        self.side_stream = os.environ.get("RNNPOSE_SIDE_STREAM", "1") != "0"      # one chain: flow-feature / flow-head side chain on a helper stream
+        # flow-feature / flow-head side chain of a lone SMALL chain on a helper stream: off by default since r05 (B = 1, 240 x 240:
+        # 4.25 ms per refinement without it, 4.49 with it -- hipGraph replay runs the two-branch graph no faster than the linear one)
+        self.side_stream = os.environ.get("RNNPOSE_SIDE_STREAM", "0") != "0"
         self.parts = int(os.environ.get("RNNPOSE_PARTS", "2"))
         self.parts_forced = "RNNPOSE_PARTS" in os.environ                         # explicit part count: no small-batch merging
         self.fused_mask = os.environ.get("RNNPOSE_FUSED_MASK", "1") != "0"       # mask.2 inside the up-sampling kernel
@@ -240,9 +243,8 @@ class UpdateEngine:
         view["_ksws"], view["_ksws_side"] = self._ksplit_ws(b0, b1, 0), self._ksplit_ws(b0, b1, 1)
         ops.corr_lookup_nhwc_part(corr_fn._buf, coords1_part, view["corr"], B, b0, b1, corr_fn.num_levels, corr_fn.radius)
         yield
-        # helper stream for the flow-feature / flow-head side chain: only for a lone SMALL chain (single-image crops: the only concurrency
-        # there is); at the headline it measured equal (695-699 iters/s either way) and a second active queue is what r04's
-        # reproducibility finding is about (see __init__)
+        # helper stream for the flow-feature / flow-head side chain: opt-in (RNNPOSE_SIDE_STREAM=1), and only for a lone SMALL chain; it
+        # measured equal at the headline (695-699 iters/s either way) and slower at B = 1 (see __init__)
         small = coords1_part.shape[0] * coords1_part.shape[2] * coords1_part.shape[3] < self.MIN_CHAIN_PIXELS
         yield from self._chain_gen(W, view, coords1_part, st, self._stream(coords1_part.device, 2) if (single and small and self.side_stream) else None)
         if self.fused_mask:         # mask.2 + up-sampling in one kernel (the chain skipped its mask.2 launch)
@@ -411,7 +413,11 @@ class EncoderEngine:
         self.ksplit = os.environ.get("RNNPOSE_KSPLIT", "1") != "0"
         self.split_batch = os.environ.get("RNNPOSE_SPLIT_ENCODER", "1") != "0"
         self.parts = int(os.environ.get("RNNPOSE_ENCODER_PARTS", "1"))
-        self.merge_sets = os.environ.get("RNNPOSE_ENCODER_MERGE", "1") != "0"     # 0: one stream per image set (r02-r03)
+        # one stream per image set (rendered | observed) -- the r02-r03 schedule, the default again since r05: one set's HBM-bound
+        # normalisation passes and latency-bound finalize launches run under the other set's convolutions (+2 % on the headline step).
+        # r04 had merged the sets into one batch on one stream because runs with two active streams were not bit-reproducible; r05 found
+        # and removed the cause (packed fp32 instructions next to 16x16x32 MFMAs: UpdateEngine.__init__).  RNNPOSE_ENCODER_MERGE=1: one batch.
+        self.merge_sets = os.environ.get("RNNPOSE_ENCODER_MERGE", "0") != "0"
 
     def _mine(self):
         f = self.fnet
@@ -497,14 +503,14 @@ class EncoderEngine:
 
     @torch.no_grad()
     def __call__(self, images, normalize=True, split_out=False):
-        """images: one (N,3,H,W) tensor or a list of them (rendered, observed: processed as one batch, no concatenation)
+        """images: one (N,3,H,W) tensor or a list of them (rendered, observed: one stream each; RNNPOSE_ENCODER_MERGE=1: concatenated into one batch)
         -> (sum N, 256, H/8, W/8) NCHW.  normalize: apply 2*(x/255)-1 in the stem's load (model/CFNet.py:42-43).
         split_out: return an ops.SplitTensor instead (pixel-major fp16 hi|lo, written by the output convolution itself) --
         the operand format of the volume build, which then needs neither the NCHW transposition nor its split pre-pass."""
         W = self._weights()
         imgs = [images] if torch.is_tensor(images) else list(images)
         imgs = [ops._chk(t, "image") for t in imgs]
-        if self.merge_sets and len(imgs) > 1:       # r04: the image sets as ONE batch on ONE stream (equal speed; see UpdateEngine.__init__ (b))
+        if self.merge_sets and len(imgs) > 1:       # opt-in (r04's default): the image sets as ONE batch on ONE stream
             imgs = [torch.cat(imgs, 0)]
         _, _, H, Wd = imgs[0].shape
         N = sum(t.shape[0] for t in imgs)

@@ -11,6 +11,9 @@ weight kernel saw other (close) flow values in that sector.  With ONE chain 12 o
 end of mask_upsample's workgroups cut the two-chain rate from 14 of 14 to 0-1 of 12 (+12 us per launch): with two streams active, the
 end-of-kernel write-back of one XCD's L2 is not always in time for the next kernel of the same stream on another XCD.  Since then the
 loop runs as one chain and the encoder as one batch by default.
+r05: shapes and launch modes by environment -- DET_B / DET_H / DET_W (default 8 x 480 x 640; DET_B=1 DET_H=240 DET_W=240 is the reference's
+own working size, where the flow-feature / flow-head side chain may run on a helper stream: RNNPOSE_SIDE_STREAM), DET_ITERS inner
+iterations (2), DET_GRAPH=1 hipGraph replay instead of eager launches.
     python tools/determinism_probe.py [trials]        (RNNPOSE_SPLIT_BATCH=1: the two-chain schedule; DET_ENCODER=1: encoder in the loop)"""
 import os
 import sys
@@ -25,7 +28,8 @@ from rnnpose_amd.transformation import SE3Sequence  # noqa: E402
 from oracle import rnnpose_oracle as orc  # noqa: E402  (weights generator only)
 
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 12
-B, H, W = int(os.environ.get("DET_B", "8")), 480, 640
+B, H, W = int(os.environ.get("DET_B", "8")), int(os.environ.get("DET_H", "480")), int(os.environ.get("DET_W", "640"))
+ITERS, GRAPH = int(os.environ.get("DET_ITERS", "2")), os.environ.get("DET_GRAPH", "0") != "0"
 d = syn.make_inputs(B, H, W, seed=21)
 D = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
 z3 = torch.zeros(B, 3, H, W, device="cuda")
@@ -46,8 +50,8 @@ if os.environ.get("DET_ENCODER", "0") != "0":        # encoder in the loop: imag
 
 def run(tag):
     torch.manual_seed(0)                                # (identical encoder initialisation in every instance)
-    cfg = default_config(RENDER_ITER_COUNT=1, ITER_COUNT=2, OPTIM_ITER_COUNT=1)
-    ref = PoseRefiner(cfg, renderer=SyntheticRenderer(**kw), use_graph=False).cuda().eval()
+    cfg = default_config(RENDER_ITER_COUNT=1, ITER_COUNT=ITERS, OPTIM_ITER_COUNT=1)
+    ref = PoseRefiner(cfg, renderer=SyntheticRenderer(**kw), use_graph=GRAPH).cuda().eval()
     ref.cf_net.update_block.load_state_dict(wts)
     rec = {}
     orig = PoseRefiner._loop_buffers
@@ -88,5 +92,7 @@ for t in range(trials):
     n += bool(bad)
     if bad:
         print(f"instance {t}: differs from the first in {bad[:6]}; flow after two iterations by {float((first['flow_last'] - cur['flow_last']).abs().max()):.3g} px, "
-              f"pose by {float((first['it1.G'] - cur['it1.G']).abs().max()):.3g}", flush=True)
-print(f"{n} of {trials} instances differ from the first ({'two chains' if os.environ.get('RNNPOSE_SPLIT_BATCH', '0') != '0' else 'one chain'})")
+              f"pose by {float((first[f'it{ITERS - 1}.G'] - cur[f'it{ITERS - 1}.G']).abs().max()):.3g}", flush=True)
+print(f"{n} of {trials} instances differ from the first (B={B} {H}x{W}, {ITERS} iterations, {'graph replay' if GRAPH else 'eager'}, "
+      f"{'two chains' if os.environ.get('RNNPOSE_SPLIT_BATCH', '0') != '0' else 'one chain'}, side stream {os.environ.get('RNNPOSE_SIDE_STREAM', '1')}, "
+      f"lib {os.path.basename(os.environ.get('RNNPOSE_LIB', 'in-tree'))}, AMD_OPT_FLUSH={os.environ.get('AMD_OPT_FLUSH', 'default')})", flush=True)
