@@ -143,6 +143,12 @@ def cpu_baseline(refiner, rend, K, G0, args):
     outputs = {"G": warm["G"], "Tij": [tr["Tij"] for tr in warm["trace"]], "flow_first": warm["trace"][0]["flow_up"],
                "flow_last": warm["flow_up"], "weight_last": warm["weight"]}
     del warm
+    # the same unit started the reference's LITERAL way, Tij = Ti * Ti^-1 (model/PoseRefiner.py:243-244), for parity.literal_legacy
+    t0 = time.perf_counter()
+    leg = orc.refine(inp, W, outer=1, inner=args.inner, optim_iters=args.optim_iters, fast=True, capture=True, literal_legacy_pose=True)
+    outputs["legacy"] = {"G": leg["G"], "Tij": [tr["Tij"] for tr in leg["trace"]], "flow_first": leg["trace"][0]["flow_up"],
+                         "flow_last": leg["flow_up"], "seconds": time.perf_counter() - t0}
+    del leg
     # the same arithmetic in fp64 for the FIRST iteration: what both fp32 evaluations (this oracle's, the GPU's) approximate
     t0 = time.perf_counter()
     with orc.precision(torch.float64):
@@ -212,7 +218,27 @@ def parity_block(refiner, rend, K, G0, args, want):
     ok_fp64 = bool(d_gpu64 <= max(FLOW_TOL, 2.0 * d_cpu64))
     leg = "literal" if ok_literal else ("fp64" if ok_fp64 else "none")
     ok = bool(max(dG, dT) <= POSE_TOL and ok_literal)
-    return {"max_abs_dpose": max(dG, dT), "max_abs_dpose_final": dG, "max_abs_dflow_first": d_first,
+    # The same comparison with BOTH sides started from the reference's literal product Tij = Ti * Ti^-1: what the
+    # reference computes, where the default pair above shares the exact-identity deviation.  Reported next to it.
+    legacy = None
+    if want.get("legacy") is not None:
+        wl = want["legacy"]
+        two = PoseRefiner(cfg, renderer=rend, fused=not args.unfused, use_graph=not args.no_graph, literal_legacy_pose=True).to(K.device).eval()
+        two.load_state_dict(refiner.state_dict())
+        o2 = two(rend.views["image_crop"], SE3Sequence(matrix=G0.clone()), K)
+        torch.cuda.synchronize()
+        lG = float((o2["Ti_pred"].G.reshape(-1, 4, 4) - T(wl["G"]).reshape(-1, 4, 4)).abs().max())
+        lT = max(float((t.G.reshape(-1, 4, 4) - T(w_).reshape(-1, 4, 4)).abs().max()) for t, w_ in zip(two.residual_pose_history, wl["Tij"]))
+        l_first = float((o2["flow"][0] - T(wl["flow_first"])).abs().max())
+        l_last = float((o2["flow_last"] - T(wl["flow_last"])).abs().max())
+        legacy = {"max_abs_dpose": max(lG, lT), "max_abs_dflow_first": l_first, "max_abs_dflow_last": l_last,
+                  "ok": bool(max(lG, lT) <= POSE_TOL and l_first <= FLOW_TOL), "drift_ok": bool(l_last <= 5e-4),
+                  "default_vs_literal_start_gpu_dflow_first": float((o2["flow"][0] - gf).abs().max()),
+                  "oracle_seconds": round(wl["seconds"], 1),
+                  "what": "GPU PoseRefiner(literal_legacy_pose=True) vs oracle.refine(literal_legacy_pose=True) on the timed inputs: every outer "
+                          "iteration starts from Tij = Ti * Ti^-1 as model/PoseRefiner.py:243-244 forms it, not from the exact identity"}
+        del two, o2
+    return {"max_abs_dpose": max(dG, dT), "max_abs_dpose_final": dG, "max_abs_dflow_first": d_first, "literal_legacy": legacy,
             "first_iteration_vs_fp64": {"gpu": d_gpu64, "cpu_oracle_fp32": d_cpu64, "fp64_oracle_seconds": round(want["fp64_seconds"], 1)},
             "max_abs_dflow_last": d_last, "max_abs_dweight_last": d_w, "max_abs_flow_first": flow_mag,
             "tol": {"pose": POSE_TOL, "flow_first_iteration": f"|gpu - cpu| <= {FLOW_TOL} (literal: the gate); diagnostic leg: |gpu - fp64| <= max({FLOW_TOL}, 2 |cpu - fp64|)",
@@ -345,9 +371,9 @@ def main():
                             "outer iteration every launch goes to ONE stream, so each is timed alone on the chip (the same durations "
                             "rocprofv3's kernel trace reports: profiles/).  traffic = mean HBM bytes per launch of both kernel families from the "
                             "FETCH_SIZE / WRITE_SIZE counter passes over the same command, algorithmic_bytes_per_launch = the mean over the "
-                            "same launches of inputs + weights + outputs + epilogue operands.  The production schedule is one full-batch chain "
-                            "on one stream (r04; RNNPOSE_SPLIT_BATCH=1: two half-batch chains on two streams): chip_level is the aggregate "
-                            "over the whole step",
+                            "same launches of inputs + weights + outputs + epilogue operands.  The production schedule (r05) is one full-batch "
+                            "loop chain on the caller's stream and one encoder stream per image set (RNNPOSE_SPLIT_BATCH=1: two half-batch loop "
+                            "chains as well; RNNPOSE_ENCODER_MERGE=1: one encoder batch on one stream): chip_level is the aggregate over the whole step",
                     "fp32_equivalent_over_f32_mfma_peak": round(ach_alg / PEAK_F32_MFMA_TFLOPS, 3),
                     "launches_timed": n,
                     "mean_ms": round(mean_ms, 4), "share_of_step": round(tot_ms / prof_steps / ms_step, 4),
@@ -403,13 +429,15 @@ def main():
                    "encoder_in_timed_region": not args.no_encoder, "fused_schedule": not args.unfused,
                    "hip_graphs": "encoder+volume build and the inner-iteration body replay as hipGraphs (except in the "
                                  "event-instrumented first outer iteration of the first timed step)" if refiner.use_graph and not args.unfused else "off",
+                   "schedule": {"loop_chains": len(refiner.cf_net.engine().halves(B)) if hasattr(refiner.cf_net.engine(), "halves") else 1,
+                                "encoder_streams": 1 if (args.no_encoder or refiner.image_fea_enc.engine().merge_sets) else 2},
                    "weights": "random init", "lm_accumulation": "f64", "sharding": f"dp{world} (independent images, no collective in the path)"},
         "roofline": roofline, "chip_level": chip, "correlation_volume_kernel": corr_vol, "kernels": kernels,
         "kernels_note": "HIP events around every C-ABI launch of the first outer iteration of the first timed step (eager); GB/s from "
                         "the ALGORITHMIC bytes each launch declares for its own arguments (SURVEY 8d formulas; half-batch launches "
-                        "declare half the batch); share_of_step = summed launch durations x outer iterations / step time (under the opt-in "
-                        "two-chain schedule, RNNPOSE_SPLIT_BATCH=1, launches of the two batch halves overlap on two streams and the shares "
-                        "add up to more than 1)",
+                        "declare half the batch); share_of_step = summed launch durations x outer iterations / step time (the two image sets of the "
+                        "encoder run on two streams in the timed steps -- and so do the two batch halves under RNNPOSE_SPLIT_BATCH=1 --, so the "
+                        "shares, measured launch by launch on one stream, can add up to more than 1)",
     }
     if world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"], want = cpu_baseline(refiner, rend, K, G0, args)

@@ -26,10 +26,12 @@ extern "C" {
 
 typedef void* rnnpose_stream_t;
 
-/* 2 (round 4): rnnpose_conv_desc_t grew the split-tensor / K-split members, the packed weight array holds two orders
+/* 3 (round 5): rnnpose_conv_desc_t ends with tile_stats_records (the launch checks the statistics buffer it is given);
+ * rnnpose_conv_tiles_per_image_desc sizes it from the descriptor itself.
+ * 2 (round 4): rnnpose_conv_desc_t grew the split-tensor / K-split members, the packed weight array holds two orders
  * (rnnpose_conv_packed_halfs doubled), tile statistics are fp64, rnnpose_lm_step_* needs a zero-filled workspace: a consumer
  * built against version 1 must not pass the check. */
-#define RNNPOSE_ABI_VERSION 2
+#define RNNPOSE_ABI_VERSION 3
 #define RNNPOSE_MAX_LEVELS 4
 
 int rnnpose_abi_version(void);
@@ -272,6 +274,10 @@ typedef struct {
                                   (the layers the automatic choice gives them: the update block and the encoder's residual layers at
                                   the headline shapes); every other kernel keeps the three-product form.  ~2^-11 relative per product:
                                   NOT the arithmetic of the parity tolerances. */
+  int tile_stats_records;      /* with tile_stats: how many (c_out, 2) records the buffer holds.  The launch REFUSES a buffer smaller
+                                  than B * rnnpose_conv_tiles_per_image_desc(this descriptor) -- which kernel family a launch takes
+                                  (and with it the tile count: 32-row strips write four times the records of 128-row tiles) is the
+                                  library's choice, so the buffer is checked where the choice is made. */
 } rnnpose_conv_desc_t;
 
 size_t rnnpose_conv_ksplit_workspace_bytes(void);
@@ -283,10 +289,16 @@ int rnnpose_conv_ksplit_limits(int max_tiles, int max_splits);   /* measurement:
  * image PATCHES (ceil(W/16) * ceil(H/8) tiles per image, nine taps on one staged halo tile), everything else on runs of 128
  * output pixels (ceil(H_out*W_out/128) when tiled per image).  rnnpose_conv_spatial_tiles(0) switches the patch tiling off
  * (measurement: the r02 row-major tiling for 3x3 layers too). */
-int rnnpose_conv_tiles_per_image(int H, int W, int kh, int kw, int stride);
+int rnnpose_conv_tiles_per_image(int H, int W, int kh, int kw, int stride);      /* (the 128-row kernels' rule only: it does NOT size
+                                                                                      tile_stats of a tile = 0 launch since ABI 2) */
+/* Records per image of `tile_stats` for exactly the launch this descriptor describes -- the kernel choice looks at B, H, W, kh, kw,
+ * stride, c_out, tile, the sources' channel counts and whether src0_mean_rstd is set (pointers are not dereferenced, dst / weights
+ * may be NULL): the one sizing rule that cannot disagree with rnnpose_conv2d_nhwc_f16x3.  -1 on bad arguments. */
+int rnnpose_conv_tiles_per_image_desc(const rnnpose_conv_desc_t* h_desc);
 /* The same for the kernel a launch of `batch` images with this c_out and `tile` request (0 automatic .. 6) will take: the strip
  * kernels tile an image into ceil(W/16) * ceil(H/10) patches of 10 x 16 pixels (3x3) or ceil(H*W/160) runs of 160 pixels (32-row
- * strips: patches of 2 x 16 pixels, runs of 32). */
+ * strips: patches of 2 x 16 pixels, runs of 32).  Shape-only: it assumes source channel counts in multiples of 32 (launches whose
+ * sources are not fall back to the 128-row kernels: use rnnpose_conv_tiles_per_image_desc). */
 int rnnpose_conv_tiles_per_image_ex(int H, int W, int kh, int kw, int stride, int c_out, int tile, int batch);
 int rnnpose_conv_spatial_tiles(int enable);
 int rnnpose_conv_strip(int mode);          /* measurement switch: 0 = the automatic choice never takes the strip kernels, 1 = default,

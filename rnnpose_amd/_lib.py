@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 2          # include/rnnpose_hip.h: RNNPOSE_ABI_VERSION of the library this front end was written against
+ABI_VERSION = 3          # include/rnnpose_hip.h: RNNPOSE_ABI_VERSION of the library this front end was written against
 LIB_PATH = os.environ.get("RNNPOSE_LIB") or os.path.join(_PKG, "lib", "librnnpose_hip.so")
 
 _p = C.c_void_p
@@ -33,7 +33,8 @@ class ConvDesc(C.Structure):       # rnnpose_conv_desc_t
                 ("tile_stats", C.c_void_p), ("add_map", C.c_void_p), ("add_c_stride", C.c_int), ("add_c_offset", C.c_int),
                 ("src0_mean_rstd", C.c_void_p), ("src_hl", C.c_int), ("dst_hl", C.c_int), ("dst2_hl", C.c_int),
                 ("dst_split", C.c_void_p), ("dst_split_c_stride", C.c_int), ("dst_split_c_offset", C.c_int), ("src_bounded", C.c_int),
-                ("tile", C.c_int), ("ksplit_ws", C.c_void_p), ("ksplit_ws_bytes", C.c_size_t), ("single_product", C.c_int)]
+                ("tile", C.c_int), ("ksplit_ws", C.c_void_p), ("ksplit_ws_bytes", C.c_size_t), ("single_product", C.c_int),
+                ("tile_stats_records", C.c_int)]
 
 
 # name -> (restype, argtypes); mirrors include/rnnpose_hip.h one to one
@@ -70,6 +71,7 @@ PROTOTYPES = {
     "rnnpose_gru_update_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _i, _p]),
     "rnnpose_conv_tiles_per_image": (_i, [_i, _i, _i, _i, _i]),
     "rnnpose_conv_tiles_per_image_ex": (_i, [_i, _i, _i, _i, _i, _i, _i, _i]),
+    "rnnpose_conv_tiles_per_image_desc": (_i, [C.POINTER(ConvDesc)]),
     "rnnpose_conv_spatial_tiles": (_i, [_i]),
     "rnnpose_conv_strip": (_i, [_i]),
     "rnnpose_conv_ksplit": (_i, [_i]),

@@ -884,6 +884,30 @@ int rnnpose_conv_tiles_per_image(int H, int W, int kh, int kw, int stride) {
   return rp::cdiv(static_cast<long long>(Ho) * Wo, BM);
 }
 
+// Strip height of the launch `d` describes (0: the 128-row kernels).  tile 5 / 6 force a height (errors surface in the launch); the
+// automatic choice takes strips only when the sources qualify -- whole 32-channel blocks, the fused normalisation only for 3x3 --
+// and otherwise falls back, with or without tile statistics (r04 raised an error there: ADVICE).  The ONE place this is decided.
+static int desc_strip_rows(const rnnpose_conv_desc_t* d) {
+  if (d->tile >= 5) return strip_rows(d->H, d->W, d->kh, d->kw, d->stride, d->c_out, d->B, d->tile == 5 ? 160 : 32);
+  if (d->tile != 0 || !g_conv_strip) return 0;
+  const int rows = strip_rows(d->H, d->W, d->kh, d->kw, d->stride, d->c_out, d->B, 0);
+  if (!rows) return 0;
+  for (int s = 0; s < d->n_src; ++s)
+    if (d->src[s].c_count % 32 != 0) return 0;
+  if (d->src0_mean_rstd && !(d->kh == 3 && d->kw == 3)) return 0;
+  return rows;
+}
+
+int rnnpose_conv_tiles_per_image_desc(const rnnpose_conv_desc_t* d) {
+  if (!d || d->H <= 0 || d->W <= 0 || (d->stride != 1 && d->stride != 2) || d->c_out <= 0 || d->tile < 0 || d->tile > 6 || d->B < 1 ||
+      d->n_src < 1 || d->n_src > 4)
+    return -1;
+  const int rows = desc_strip_rows(d);
+  if (d->tile >= 5 && rows == 0) return -1;
+  if (rows) return strip_tiles_per_image(d->H, d->W, d->kh, d->kw, rows);
+  return rnnpose_conv_tiles_per_image(d->H, d->W, d->kh, d->kw, d->stride);
+}
+
 int rnnpose_conv_tiles_per_image_ex(int H, int W, int kh, int kw, int stride, int c_out, int tile, int batch) {
   if (H <= 0 || W <= 0 || (stride != 1 && stride != 2) || c_out <= 0 || tile < 0 || tile > 6 || batch < 1) return -1;
   int rows = 0;
@@ -1049,24 +1073,20 @@ int rnnpose_conv2d_nhwc_f16x3(const rnnpose_conv_desc_t* d, rnnpose_stream_t str
   // ---- strip kernels (conv_strip*.hip): 160- / 32-row strips, operands by LDS-DMA.  tile 5 / 6 ask for them; the automatic choice
   // takes them for the stride-1 3x3 / 1x5 / 5x1 layers whose launch fills the chip with strips of one of the heights (strip_rows; a
   // launch with per-image tile records tiles as rnnpose_conv_tiles_per_image_ex says for the same shape and batch)
+  if (d->tile_stats) {     // the buffer is checked against the tiling of the kernel THIS launch takes (ABI 3)
+    const int tpi = rnnpose_conv_tiles_per_image_desc(d);
+    RP_REQUIRE(tpi > 0 && static_cast<long long>(d->tile_stats_records) >= static_cast<long long>(d->B) * tpi, fn,
+               "tile_stats_records is smaller than B * rnnpose_conv_tiles_per_image_desc(desc): size the statistics buffer with that call");
+  }
   {
     const bool per_image = d->tile_stats || d->src0_mean_rstd;
-    int rows = 0;
-    if (d->tile >= 5) {
-      rows = strip_rows(d->H, d->W, d->kh, d->kw, d->stride, d->c_out, d->B, d->tile == 5 ? 160 : 32);
+    const int rows = desc_strip_rows(d);
+    if (d->tile >= 5)
       RP_REQUIRE(rows != 0, fn, "strip kernels: stride 1, 3x3 / 1x5 / 5x1, c_out > 32 (32-row strips: one column tile per wave)");
-    } else if (d->tile == 0 && g_conv_strip) {
-      rows = strip_rows(d->H, d->W, d->kh, d->kw, d->stride, d->c_out, d->B, 0);
-    }
-    if (rows) {
-      bool ok = true;
-      for (int s = 0; s < d->n_src; ++s) ok = ok && d->src[s].c_count % 32 == 0;
-      if (d->src0_mean_rstd && !(d->kh == 3 && d->kw == 3)) ok = false;
-      if (ok || d->tile >= 5 || per_image) {           // (forced, or the caller sized its statistics for strips: errors surface)
-        if (vertical) { p.G = 1; p.T = d->kh; p.du0 = 0; p.dv0 = -(d->kh / 2); }
-        else { p.G = d->kh; p.T = d->kw; p.du0 = -(d->kh / 2); p.dv0 = -(d->kw / 2); }
-        return strip_launch(p, d->H, d->W, d->kh, d->kw, hlin, per_image, rows, rp::as_stream(stream));
-      }
+    if (rows) {          // (a forced strip launch whose sources do not fit surfaces its error in strip_launch)
+      if (vertical) { p.G = 1; p.T = d->kh; p.du0 = 0; p.dv0 = -(d->kh / 2); }
+      else { p.G = d->kh; p.T = d->kw; p.du0 = -(d->kh / 2); p.dv0 = -(d->kw / 2); }
+      return strip_launch(p, d->H, d->W, d->kh, d->kw, hlin, per_image, rows, rp::as_stream(stream));
     }
   }
   p.n_mt = rp::cdiv(Mtot, BM);

@@ -52,6 +52,9 @@ class UpdateEngine:
         # at 4-6 us per workgroup: +2-3 % on the step (profiles/r04_ab_split_tensors.txt, same box: 724 vs 690-713 iters/s).  ON by
         # default; RNNPOSE_SPLIT_TENSORS=0 restores fp32 activations everywhere (tests cover both).
         self.hl = os.environ.get("RNNPOSE_SPLIT_TENSORS", "1") != "0"
+        # cfg.raft.mixed_precision: one fp16 product per multiply-add in the 160-row strip kernels.  Carried by the ENGINE its PoseRefiner
+        # configures (r04 used a process-wide default that direct callers of ops / cf_net inherited from the last refiner: ADVICE r04)
+        self.single_product = False
         # tile-shape override per layer for measurements: RNNPOSE_CONV_TILE="zr=3,q=1,heads=2" (0 auto, see conv2d_nhwc)
         self.tile = {}
         for kv in filter(None, os.environ.get("RNNPOSE_CONV_TILE", "").split(",")):
@@ -188,8 +191,8 @@ class UpdateEngine:
         if self.hl:
             ops.split_hl(b["hA"], b["hA_s"])
             src = ops.split_hl(b["inp"], b["inp_s"])
-        ops.conv2d_nhwc(W["inp1"], [(src, 0)], (b["inp1"], 0), ops.EPI_LINEAR, src_hl=self.hl, tile=self.tile.get("inp", 0))
-        ops.conv2d_nhwc(W["inp2"], [(src, 0)], (b["inp2"], 0), ops.EPI_LINEAR, src_hl=self.hl, tile=self.tile.get("inp", 0))
+        ops.conv2d_nhwc(W["inp1"], [(src, 0)], (b["inp1"], 0), ops.EPI_LINEAR, src_hl=self.hl, tile=self.tile.get("inp", 0), single_product=self.single_product)
+        ops.conv2d_nhwc(W["inp2"], [(src, 0)], (b["inp2"], 0), ops.EPI_LINEAR, src_hl=self.hl, tile=self.tile.get("inp", 0), single_product=self.single_product)
 
     def hidden_nchw(self):
         return ops.nhwc_to_nchw(self._b["hA"])
@@ -325,7 +328,7 @@ class UpdateEngine:
             """One implicit-GEMM launch; with split tensors every source is in split form and hl_out says the result only
             feeds further convolutions (written split).  ks: K-split workspace of the stream the launch goes to."""
             ops.conv2d_nhwc(W[name], srcs, dst, epi, src_hl=hl, dst_hl=hl and hl_out, tile=tl(name, 0),
-                            ksplit_ws=ks_main if ks is None else ks, **kw)
+                            ksplit_ws=ks_main if ks is None else ks, single_product=self.single_product, **kw)
         # Two independent chains feed the motion encoder's last convolution (update.py:89-92): correlation features
         # (convc1 -> convc2) and flow features (flow_prep -> convf1 -> convf2).  With a helper stream the second one runs
         # there (a parallel branch when the step is captured into a hipGraph).  Same for flow_head.conv2 next to mask.2.
@@ -352,7 +355,7 @@ class UpdateEngine:
         if self.resident_1x1 and W["convc1r"] is not None:
             ops.conv1x1_resident(W["convc1r"], (b["corr"], 0), (b["cor1"], 0), relu=True, dst_split=hl)   # update.py:89 (LDS-resident tile)
         else:                                                                       # (the looked-up correlation features are fp32)
-            ops.conv2d_nhwc(W["convc1"], [(b["corr"], 0)], (b["cor1"], 0), R, dst_hl=hl)                  # update.py:89
+            ops.conv2d_nhwc(W["convc1"], [(b["corr"], 0)], (b["cor1"], 0), R, dst_hl=hl, single_product=self.single_product)   # update.py:89
         yield
         c("convc2", [(b["cor1"], 0)], (b["corflo"], 0), R, hl_out=True)             # :90
         yield
@@ -381,7 +384,7 @@ class UpdateEngine:
             head()
             yield
             if mask_here:
-                ops.conv2d_nhwc(W["mask2"], [(b["heads"], 256)], (b["mask"], 0), ops.EPI_LINEAR)  # 0.25 * mask.2(relu(mask.0(h)))
+                ops.conv2d_nhwc(W["mask2"], [(b["heads"], 256)], (b["mask"], 0), ops.EPI_LINEAR, single_product=self.single_product)  # 0.25 * mask.2(relu(mask.0(h)))
                 yield
             return
         fork2 = torch.cuda.Event()
@@ -392,7 +395,7 @@ class UpdateEngine:
             join2 = torch.cuda.Event()
             join2.record(side)
         if mask_here:
-            ops.conv2d_nhwc(W["mask2"], [(b["heads"], 256)], (b["mask"], 0), ops.EPI_LINEAR)      # 0.25 * mask.2(relu(mask.0(h)))
+            ops.conv2d_nhwc(W["mask2"], [(b["heads"], 256)], (b["mask"], 0), ops.EPI_LINEAR, single_product=self.single_product)      # 0.25 * mask.2(relu(mask.0(h)))
         main.wait_event(join2)
         yield
 
@@ -411,6 +414,7 @@ class EncoderEngine:
         self._side = None
         self.resident_1x1 = os.environ.get("RNNPOSE_RESIDENT_1X1", "1") != "0"
         self.ksplit = os.environ.get("RNNPOSE_KSPLIT", "1") != "0"
+        self.single_product = False                   # cfg.raft.mixed_precision, set by the PoseRefiner that owns the encoder (see UpdateEngine)
         self.split_batch = os.environ.get("RNNPOSE_SPLIT_ENCODER", "1") != "0"
         self.parts = int(os.environ.get("RNNPOSE_ENCODER_PARTS", "1"))
         # one stream per image set (rendered | observed) -- the r02-r03 schedule, the default again since r05: one set's HBM-bound
@@ -450,23 +454,24 @@ class EncoderEngine:
         return self._w
 
     @staticmethod
-    def _conv(pc, x, stride=1, stats=True, in_norm=None, ks=None):
+    def _conv(pc, x, stride=1, stats=True, in_norm=None, ks=None, sp=False):
         """-> (out, tile_stats or None): the convolution's epilogue also emits the per-tile column statistics the following
         instance norm needs (saves re-reading the tensor once; output rows are tiled per image for that).
         in_norm: mean / rstd of `x`, which is then a RAW convolution output normalised (+ ReLU) in this convolution's load."""
         B, H, W, _ = x.shape
         Ho, Wo = -(-H // stride), -(-W // stride)
         out = torch.empty(B, Ho, Wo, pc.c_out, device=x.device, dtype=torch.float32)
-        ts = torch.empty(B * ops.conv_tiles_per_image(H, W, pc.kh, pc.kw, stride, pc.c_out, 0, B), pc.c_out, 2, device=x.device, dtype=torch.float64) if stats else None
+        ts = torch.empty(B * ops.conv_tiles_per_image(H, W, pc.kh, pc.kw, stride, pc.c_out, 0, B, src_counts=pc.seg_counts, fused_norm=in_norm is not None),
+                         pc.c_out, 2, device=x.device, dtype=torch.float64) if stats else None
         # src_bounded: every convolution input of the encoder is an instance-normalised map (|.| <= sqrt(H*W)) or a ReLU sum of a
         # few of them (extractor.py:48-58): two orders of magnitude inside the fp16x3 range, so the in-loop range check is skipped
         # (the stem, which sees the raw image, and the update block keep theirs)
         ops.conv2d_nhwc(pc, [(x, 0)], (out, 0), ops.EPI_LINEAR, stride=stride, tile_stats=ts, in_norm=in_norm, src_bounded=True,
-                        ksplit_ws=ks)
+                        ksplit_ws=ks, single_product=sp)
         return out, ts
 
     @staticmethod
-    def _block_gen(W, name, blk, x, x_norm=None, ks=None):
+    def _block_gen(W, name, blk, x, x_norm=None, ks=None, sp=False):
         """ResidualBlock (extractor.py:48-58) on an NHWC tensor, as a generator (yields after every launch, returns the block
         output).  Instance norms are never materialised on their own: norm1 + ReLU happens in conv2's load, the residual's
         norm (x_norm = (mean_rstd, relu) when `x` is the RAW stem output; norm3 of the down-sampling branch) inside the one
@@ -474,18 +479,18 @@ class EncoderEngine:
         convolution outputs."""
         E = EncoderEngine
         st = blk.conv1.stride[0]
-        c1, ts1 = E._conv(W[name + ".c1"], x, st, in_norm=None if x_norm is None else x_norm[0], ks=ks)
+        c1, ts1 = E._conv(W[name + ".c1"], x, st, in_norm=None if x_norm is None else x_norm[0], ks=ks, sp=sp)
         yield
         mr1 = ops.instnorm_tiles_nhwc(c1, ts1, stats_only=True)          # relu(norm1(conv1 x)): applied in conv2's load
         yield
         res, res_norm = x, x_norm
         if blk.downsample is not None:
             assert x_norm is None
-            res, tsd = E._conv(W[name + ".down"], x, st, ks=ks)
+            res, tsd = E._conv(W[name + ".down"], x, st, ks=ks, sp=sp)
             yield
             res_norm = (ops.instnorm_tiles_nhwc(res, tsd, stats_only=True), False)            # norm3, no ReLU
             yield
-        c2, ts2 = E._conv(W[name + ".c2"], c1, in_norm=mr1, ks=ks)
+        c2, ts2 = E._conv(W[name + ".c2"], c1, in_norm=mr1, ks=ks, sp=sp)
         yield
         out = ops.instnorm_tiles_nhwc(c2, ts2, relu=True, residual=res, residual_norm=None if res_norm is None else res_norm[0],
                                       residual_relu=bool(res_norm and res_norm[1]))               # relu(x + relu(IN(.)))
@@ -598,7 +603,7 @@ class EncoderEngine:
         yield
         for li, layer in enumerate((f.layer1, f.layer2, f.layer3), start=1):
             for bi, blk in enumerate(layer):
-                x = yield from E._block_gen(W, f"l{li}.{bi}", blk, x, x_norm, ks=ks)
+                x = yield from E._block_gen(W, f"l{li}.{bi}", blk, x, x_norm, ks=ks, sp=self.single_product)
                 x_norm = None
         if W["outr"] is not None and self.resident_1x1:
             if split_out:                # the volume build's operand, written in place (a batch slice of NHWC is contiguous)
@@ -608,7 +613,7 @@ class EncoderEngine:
             o = torch.empty(*x.shape[:3], 256, device=x.device, dtype=torch.float32)
             ops.conv1x1_resident(W["outr"], (x, 0), (o, 0), relu=False)
         else:
-            o, _ = E._conv(W["out"], x, stats=False, ks=ks)
+            o, _ = E._conv(W["out"], x, stats=False, ks=ks, sp=self.single_product)
         yield
         if split_out:
             ops.split_hl(o, dst=out, a_scale=ops.A_SCALE)

@@ -382,10 +382,13 @@ _ws_cache = {}
 def _workspace(B, H, W, device, slot=0):
     """slot: calls that may run concurrently on different streams (the two batch halves) need distinct workspaces."""
     n = int(_lib.load().rnnpose_lm_workspace_bytes(B, H, W))
-    key = (device, n, slot)
+    # keyed on the SHAPE, not on the byte count: the first B doubles are the arrival counters of the fused LM step (zero between
+    # launches), the partial records follow -- two shapes of equal size would find each other's partial sums where their counters
+    # should be zero and the fused tail would never fire (ADVICE r04)
+    key = (device, int(B), int(H), int(W), slot)
     ws = _ws_cache.get(key)
     if ws is None:
-        ws = torch.zeros(n // 8, device=device, dtype=F64)      # (zero: the arrival counters of the fused LM step live at its end)
+        ws = torch.zeros(n // 8, device=device, dtype=F64)      # (zero: the arrival counters live in the first B doubles)
         _ws_cache[key] = ws
     return ws, n
 
@@ -600,19 +603,20 @@ def conv2d_nhwc(pc: PackedConv, srcs, dst, epilogue: int = EPI_LINEAR, aux0=None
         _nhwc(t, "add_map")
         d.add_map, d.add_c_stride, d.add_c_offset = t.data_ptr(), t.shape[3], off
     d.gru_c = gru_c
-    if tile_stats is not None:
-        # (B * ceil(HWout/128), c_out, 2) fp32: per-tile column sums / sums of squares for instnorm_tiles_nhwc
-        tpi = conv_tiles_per_image(H, W, pc.kh, pc.kw, stride, pc.c_out, tile, B)
-        if not (tile_stats.is_cuda and tile_stats.dtype == F64 and tile_stats.is_contiguous()
-                and tile_stats.numel() == B * tpi * pc.c_out * 2):      # exact: the consumer takes the tiling from this shape
-            raise ValueError("tile_stats must be a contiguous FP64 CUDA tensor of (B * conv_tiles_per_image(H, W, kh, kw, stride, "
-                             f"c_out, tile) = {B * tpi}, c_out, 2): the tile count depends on the kernel the launch takes")
-        d.tile_stats = tile_stats.data_ptr()
     if in_norm is not None:          # (B, C_src, 2) mean / rstd of source 0: read relu((x - mean) * rstd) instead of x
         if not (in_norm.is_cuda and in_norm.dtype == F32 and in_norm.is_contiguous() and tuple(in_norm.shape) == (B, srcs[0][0].shape[3], 2)):
             raise ValueError("in_norm must be a contiguous fp32 CUDA tensor of (B, C_source, 2)")
         d.src0_mean_rstd = in_norm.data_ptr()
     d.src_hl, d.dst_hl, d.dst2_hl, d.tile = int(bool(src_hl)), int(bool(dst_hl)), int(bool(dst2_hl)), int(tile)
+    if tile_stats is not None:
+        # (B * tiles per image, c_out, 2) fp64 per-tile column sums / sums of squares for instnorm_tiles_nhwc.  The tile count is the one
+        # of the kernel THIS launch takes: asked from the library with the descriptor itself (the launch checks it again)
+        tpi = int(_lib.load().rnnpose_conv_tiles_per_image_desc(C.byref(d)))
+        if not (tile_stats.is_cuda and tile_stats.dtype == F64 and tile_stats.is_contiguous()
+                and tile_stats.numel() == B * tpi * pc.c_out * 2):      # exact: the consumer takes the tiling from this shape
+            raise ValueError("tile_stats must be a contiguous FP64 CUDA tensor of (B * conv_tiles_per_image(H, W, kh, kw, stride, c_out, tile, B, "
+                             f"src_counts, fused_norm) = {B * tpi}, c_out, 2): the tile count depends on the kernel the launch takes")
+        d.tile_stats, d.tile_stats_records = tile_stats.data_ptr(), B * tpi
     d.src_bounded = int(bool(src_bounded))      # caller's guarantee that the sources cannot leave the fp16x3 range: no range check
     if dst_split is not None:
         t, off = dst_split
@@ -635,21 +639,32 @@ _single_product = False
 
 
 def single_product(enable=None) -> bool:
-    """Process-wide default of conv2d_nhwc's `single_product` (cfg.raft.mixed_precision: one fp16 product per multiply-add in the
-    160-row strip kernels instead of three; PoseRefiner sets it from its configuration at every forward).  -> the current value."""
+    """Process-wide default of conv2d_nhwc's `single_product` for callers that do not pass it (measurement scripts).  The package itself
+    never sets it: since r05 the mode is carried by the engines a PoseRefiner configures (engine.UpdateEngine / EncoderEngine
+    .single_product) and passed explicitly with every launch.  -> the current value."""
     global _single_product
     if enable is not None:
         _single_product = bool(enable)
     return _single_product
 
 
-def conv_tiles_per_image(H, W, kh, kw, stride=1, c_out=None, tile: int = 0, batch: int = 1) -> int:
+def conv_tiles_per_image(H, W, kh, kw, stride=1, c_out=None, tile: int = 0, batch: int = 1, src_counts=None, fused_norm: bool = False) -> int:
     """Records per image of a convolution's tile_stats.  128-row kernels: 3x3 stride 1 on 8 x 16 patches, else runs of 128
     output pixels; with c_out given: for the kernel a launch of `batch` images of that width and `tile` request takes -- the strip
-    kernels (csrc/conv_strip*.hip, tile=5 / 6 or the automatic choice) tile an image into 10 / 2 x 16 patches or runs of 160 / 32 pixels."""
+    kernels (csrc/conv_strip*.hip, tile=5 / 6 or the automatic choice) tile an image into 10 / 2 x 16 patches or runs of 160 / 32 pixels.
+    src_counts (channel counts of the sources) and fused_norm (the launch passes in_norm) complete the description: sources that are
+    not whole 32-channel blocks send an automatic launch to the 128-row kernels (rnnpose_conv_tiles_per_image_desc)."""
     _apply_conv_env()
     if c_out is None:
         return int(_lib.load().rnnpose_conv_tiles_per_image(int(H), int(W), int(kh), int(kw), int(stride)))
+    if src_counts is not None:
+        d = _lib.ConvDesc()
+        for i, c in enumerate(src_counts):
+            d.src[i] = _lib.ConvSrc(None, int(c), 0, int(c))
+        d.n_src = len(src_counts)
+        d.B, d.H, d.W, d.kh, d.kw, d.stride, d.c_out, d.tile = int(batch), int(H), int(W), int(kh), int(kw), int(stride), int(c_out), int(tile)
+        d.src0_mean_rstd = 16 if fused_norm else None        # (only its null-ness is looked at)
+        return int(_lib.load().rnnpose_conv_tiles_per_image_desc(C.byref(d)))
     return int(_lib.load().rnnpose_conv_tiles_per_image_ex(int(H), int(W), int(kh), int(kw), int(stride), int(c_out), int(tile), int(batch)))
 
 

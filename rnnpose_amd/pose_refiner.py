@@ -90,6 +90,12 @@ class PoseRefiner(nn.Module):
         self.use_graph = use_graph
         self.split_fmaps = os.environ.get("RNNPOSE_SPLIT_FMAPS", "1") != "0"
         self.mixed_precision = bool(cfg.get("raft", {}).get("mixed_precision", False)) or os.environ.get("RNNPOSE_MIXED_PRECISION", "0") != "0"
+        if self.mixed_precision:
+            # the reference's YAMLs set raft.mixed_precision: True (config/linemod/template_fw0.5.yml:88): loading one changes the arithmetic
+            import warnings
+            warnings.warn("cfg.raft.mixed_precision: the 160-row strip convolutions run ONE fp16 product per multiply-add (the reference's GPU "
+                          "autocast arithmetic, ~2^-11 per product).  The parity tolerances (1e-4 flow / 1e-5 pose against the fp32 CPU path) "
+                          "are stated for mixed_precision = False; this mode is not pinned against the reference's autocast run.")
         self.profile_rec = None           # set by profile_first_outer(): record of the instrumented first outer iteration
         # inner-iteration graphs, one record PER INPUT SHAPE (a partial last evaluation batch followed by a full one must not
         # evict each other: ADVICE r02): {"gr": graph captured on the caller's tensors (keyed by their addresses), "captures":
@@ -155,8 +161,11 @@ class PoseRefiner(nn.Module):
         eng = self.cf_net.engine()
         # cfg.raft.mixed_precision (the reference's GPU arithmetic, model/CFNet.py:47,126,152): single-product fp16 convolutions in the
         # strip kernels; RNNPOSE_MIXED_PRECISION=1 forces it for measurements.  Part of the graph key (graphs bake the kernels in).
-        ops.single_product(self.mixed_precision)
-        key = (eng.refresh(), self.image_fea_enc.engine().refresh(), self.sigma[0].data_ptr(), eng.epoch, ops.range_guard_state(),
+        # The mode lives on THIS refiner's engines, not in a process-wide default: direct calls of ops / another refiner's modules are
+        # not affected by what this one ran last.
+        enc = self.image_fea_enc.engine()
+        eng.single_product = enc.single_product = self.mixed_precision
+        key = (eng.refresh(), enc.refresh(), self.sigma[0].data_ptr(), eng.epoch, ops.range_guard_state(),
                self.mixed_precision)
         if key != self._wkey:
             if self._wkey is not None:

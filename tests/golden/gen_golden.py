@@ -276,11 +276,11 @@ def g_loop480():
     Poses in full; the fields sub-sampled ::8 (reading every pixel of the 1/8-resolution grid once).
     Two fixtures: encoder weights at kaiming gain 1 (feature maps of magnitude ~31, correlation values ~900: the harshest fp32
     conditioning this path sees -- the reference's CPU result is itself ~2e-4 px away from its own fp64 evaluation there) and at
-    gain 0.25 (|f| ~ 8, |corr| ~ 60)."""
+    gain 0.25 (|f| ~ 8, |corr| ~ 60); r05: a third one at gain 0.5, between the two (where does the literal 1e-4 stop holding?)."""
     torch.set_num_threads(min(os.cpu_count() or 1, 64))
     net = make_cfnet()
     dt = syn.make_inputs_t(2, 480, 640, seed=51, device="cpu", with_images=True)
-    for name, gain in (("loop_480", 1.0), ("loop_480_g25", 0.25)):
+    for name, gain in (("loop_480", 1.0), ("loop_480_g25", 0.25), ("loop_480_g50", 0.5)):
         enc = object.__new__(cf.ImageFeaEncoder)
         torch.nn.Module.__init__(enc)
         enc.fnet = BasicEncoder(output_dim=256, norm_fn="instance", dropout=False, input_dim=3)
@@ -297,8 +297,32 @@ def g_loop480():
              max_abs_fmap=np.array([float(f1.abs().max()), float(f2.abs().max())]), max_abs_flow=np.array(float(it[0]["flow"].abs().max())))
 
 
+def g_loop960():
+    """BASELINE config 5's per-GPU image size against the reference itself: ONE image of 960 x 1280 (N = 19 200
+    correlation columns, a 1.47-GB volume), the reference's BasicEncoder at kaiming gain 0.25 + GRU_CFUpdator + reprojction_optim, 1 outer
+    x 2 inner iterations, legacy start pose.  Fields sub-sampled ::16."""
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    net = make_cfnet()
+    dt = syn.make_inputs_t(1, 960, 1280, seed=61, device="cpu", with_images=True)
+    gain = 0.25
+    enc = object.__new__(cf.ImageFeaEncoder)
+    torch.nn.Module.__init__(enc)
+    enc.fnet = BasicEncoder(output_dim=256, norm_fn="instance", dropout=False, input_dim=3)
+    enc.eval()
+    shapes = {k: tuple(v.shape) for k, v in enc.fnet.state_dict().items()}
+    enc.fnet.load_state_dict({k: T(v) for k, v in syn.make_module_weights(shapes, seed=3, gain=gain).items()}, strict=True)
+    d = {k: v.numpy() for k, v in dt.items()}
+    f1, f2 = enc(dt["img_render"], dt["img_target"])
+    d["fmap1"], d["fmap2"] = f1.float().numpy(), f2.float().numpy()
+    Gf, it, first = run_loop(d, net, outer=1, inner=2, optim_iters=1, sigma=1.0)
+    save("loop_960", G_final=Gf, G_iters=torch.stack([x["G"] for x in it]), flow_first=it[0]["flow"][:, :, ::16, ::16],
+         flow_last=it[-1]["flow"][:, :, ::16, ::16], w_first=it[0]["w"][:, 0, ::16, ::16, 0], w_last=it[-1]["w"][:, 0, ::16, ::16, 0],
+         fmap1_sub=f1.float()[:, ::16, ::10, ::10], fmap2_sub=f2.float()[:, ::16, ::10, ::10], enc_gain=np.array(gain),
+         max_abs_fmap=np.array([float(f1.abs().max()), float(f2.abs().max())]), max_abs_flow=np.array(float(it[0]["flow"].abs().max())))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["corr", "update", "upsample_ctx", "geometry", "encoder", "loop", "loop480"]
+    which = sys.argv[1:] or ["corr", "update", "upsample_ctx", "geometry", "encoder", "loop", "loop480", "loop960"]
     for nm in which:
         print("generating", nm)
         globals()["g_" + nm]()

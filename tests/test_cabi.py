@@ -30,7 +30,7 @@ def test_header_symbols_exported_and_typed(lib):
         assert hasattr(lib, n), f"{n} declared in the header but not exported"
         assert n in _lib.PROTOTYPES, f"{n} has no ctypes prototype"
     assert sorted(_lib.PROTOTYPES) == names
-    assert lib.rnnpose_abi_version() == 2
+    assert lib.rnnpose_abi_version() == 3
 
 
 def test_gfx950_code_object_present():
@@ -134,7 +134,7 @@ def test_header_is_plain_c99_and_links_against_the_library(tmp_path):
     assert out.returncode == 0, out.stderr
     ver, total = out.stdout.split()
     n = 2 * 16 * 24
-    assert int(ver) == 2 and int(total) == n * (2 * 2 * 128 + 8 * 12 + 4 * 6 + 2 * 3)     # level 0: 2 x 2 whole patches (16 x 24 -> 16 x 32 cells)
+    assert int(ver) == 3 and int(total) == n * (2 * 2 * 128 + 8 * 12 + 4 * 6 + 2 * 3)     # level 0: 2 x 2 whole patches (16 x 24 -> 16 x 32 cells)
 
 
 def test_graft_entry_build_runs():
@@ -146,7 +146,7 @@ def test_graft_entry_build_runs():
     ge = importlib.import_module("__graft_entry__")
     ge.build()
     from rnnpose_amd import _lib
-    assert _lib.load().rnnpose_abi_version() == _lib.ABI_VERSION == 2
+    assert _lib.load().rnnpose_abi_version() == _lib.ABI_VERSION == 3
 
 
 def test_conv_tiling_rule_is_a_host_function(lib):

@@ -99,3 +99,81 @@ def test_two_rank_rccl_on_two_devices():
         assert p.exitcode == 0
     for rank, seen, vals, t, add, n in outs:
         assert seen == 2 and vals == [10.0, 11.0] and t == 2.0 and n == 2 and abs(add - 0.5) < 1e-12
+
+
+# ---- r05: readiness for the driver's 8-GPU run (no multi-GPU box is reachable from the build side) ----------
+def _lazy_load_worker(rank, world, port, q):
+    """What bench.py does on every rank, in bench.py's order: import the package and its ops BEFORE distributed.build_once.  The
+    shared library must not be dlopen'ed by that (ranks > 0 would map a file rank 0 is still writing): _lib.load() is lazy."""
+    import time
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from rnnpose_amd import distributed as D
+    D.init_from_env(backend="gloo")
+    from rnnpose_amd import _lib, build, ops  # noqa: F401  (bench.py:240: `from rnnpose_amd import build, ops`)
+    from rnnpose_amd.pose_refiner import PoseRefiner, default_config  # noqa: F401
+    mapped = lambda: any("librnnpose_hip" in line for line in open("/proc/self/maps"))
+    before = (_lib._lib is None, mapped())
+    stamp = {}
+
+    def fake_build():                      # rank 0 "compiles" for a while; the others must still be waiting when it returns
+        if rank == 0:
+            time.sleep(1.0)
+        stamp["t"] = time.time()
+        return build.LIB
+    t_enter = time.time()
+    path = D.build_once(fake_build)
+    after = (_lib._lib is None, mapped())
+    q.put((rank, before, after, path == build.LIB, stamp["t"] - t_enter))
+    torch.distributed.destroy_process_group()
+
+
+def test_ranks_do_not_dlopen_the_library_before_build_once_returns():
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_lazy_load_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, before, after, same, waited in outs:
+        assert before == (True, False), f"rank {rank} loaded the library while importing the package"
+        assert after == (True, False) and same                 # build_once itself does not load it either
+        assert waited >= 0.9, f"rank {rank} ran its build step {waited:.2f} s after entering build_once: it did not wait for rank 0"
+
+
+def test_bench_argument_plumbing_for_the_driver_launch(monkeypatch):
+    """`python bench.py --gpus 8 --workload cfg4 ...` outside torchrun re-launches itself as 8 ranks on 127.0.0.1 with the arguments
+    passed through; under torchrun (RANK / WORLD_SIZE set) main() must not spawn again.  cfg4 = BASELINE.json configs[4]."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    argv = ["bench.py", "--gpus", "8", "--steps", "5", "--warmup", "1", "--workload", "cfg4"]
+    monkeypatch.setattr(sys, "argv", argv)
+    args = bench.parse()
+    assert (args.gpus, args.steps, args.warmup) == (8, 5, 1)
+    assert (args.batch, args.height, args.width, args.outer, args.inner) == (8, 960, 1280, 3, 8)
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    with pytest.raises(SystemExit) as e:
+        bench.spawn_ranks(8)
+    assert e.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-len(argv):] == [os.path.join(root, "bench.py")] + argv[1:]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    with pytest.raises(SystemExit) as e:                      # fewer devices than ranks: refuse instead of oversubscribing
+        bench.spawn_ranks(8)
+    assert "only 1 GPU" in str(e.value.code)

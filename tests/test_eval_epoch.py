@@ -117,6 +117,19 @@ def test_two_rank_epoch_equals_single_process():
     assert sum(single["refined"][c]["n"] for c in models) == N_ITEMS
 
 
+def test_eight_rank_epoch_equals_single_process():
+    """The driver's scaling run is 8 ranks (one per GPU); no such box is reachable from the build side, so the 8-rank form of the epoch
+    -- 13 items over 8 ranks: three wrap-around duplicates, ranks whose shard holds a single class, ragged one-class batches -- runs
+    here on gloo.  Every rank must end with the single-process table."""
+    models, items = _setup()
+    single = ee.run_epoch(items, models, _halfway, _oracle_metrics(models), batch_size=BATCH, symmetric=("glue",))
+    outs = _spawn(_cpu_worker, world=8)
+    assert sorted(outs) == list(range(8))
+    for r in range(1, 8):
+        _same(outs[0], outs[r])
+    _same(outs[0], single, 1e-12)
+
+
 # ---- GPU: the real thing ---------------------------------------------------------------------------------------------
 def _gpu_epoch(rank, world, reduce_device=None):
     from oracle import rnnpose_oracle as orc

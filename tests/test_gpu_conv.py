@@ -856,3 +856,44 @@ def test_conv_strip_is_the_automatic_choice_at_the_update_block_shape(ops):
     finally:
         ops.conv_strip(True)
     assert not torch.equal(a, b) and float((a - b).abs().max()) < 2e-6 * float(b.abs().max())
+
+
+@pytest.mark.parametrize("cin", [16, 48])
+def test_conv_tile_stats_with_narrow_sources_fall_back_to_the_128_row_kernels(ops, cin):
+    """a launch whose shape would get strips (3x3, 96 columns, a map that fills the chip) but whose source is not whole
+    32-channel blocks.  r04 raised an error as soon as tile statistics were asked for (the strip path was taken because the caller had
+    "sized its buffer for strips"); since ABI 3 the choice is made in ONE place, from the descriptor, the query
+    rnnpose_conv_tiles_per_image_desc answers for exactly that launch, and the launch checks the record count it is given."""
+    B, H, W, cout = 2, 60, 80, 96
+    x = syn.normal("nf.x", (B, cin, H, W), 3, std=1.5)
+    w = syn.normal("nf.w", (cout, cin, 3, 3), 3, std=float(np.sqrt(2.0 / (cin * 9))))
+    b = syn.uniform("nf.b", (cout,), 3, -0.5, 0.5)
+    pc = ops.PackedConv(D(w), D(b), [cin])
+    tpi_strips = ops.conv_tiles_per_image(H, W, 3, 3, 1, cout, 0, B)                       # shape-only rule: 10 x 16 patches
+    tpi = ops.conv_tiles_per_image(H, W, 3, 3, 1, cout, 0, B, src_counts=[cin])           # this launch: 8 x 16 patches of the 128-row kernel
+    assert tpi_strips == 6 * 5 and tpi == 8 * 5
+    out = torch.empty(B, H, W, cout, device="cuda")
+    ts = torch.full((B * tpi, cout, 2), -1.0, device="cuda", dtype=torch.float64)
+    ops.conv2d_nhwc(pc, [(nhwc(D(x)), 0)], (out, 0), ops.EPI_LINEAR, tile_stats=ts)
+    y64 = F.conv2d(D(x).double(), D(w).double(), D(b).double(), padding=1)
+    assert float((nchw(out).double() - y64).abs().max()) < 2e-5 * float(y64.abs().max())
+    want = torch.stack([y64.sum((2, 3)), (y64 * y64).sum((2, 3))], -1)
+    assert float((ts.view(B, tpi, cout, 2).sum(1) - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    with pytest.raises(ValueError):                                                       # a buffer sized by the shape-only rule is refused
+        ops.conv2d_nhwc(pc, [(nhwc(D(x)), 0)], (out, 0), ops.EPI_LINEAR, tile_stats=torch.zeros(B * tpi_strips, cout, 2, device="cuda", dtype=torch.float64))
+    # ... and by the C entry point itself when a caller bypasses the wrapper's check (tile_stats_records too small)
+    from rnnpose_amd import _lib
+    import ctypes as C
+    d = _lib.ConvDesc()
+    xs = nhwc(D(x))
+    d.src[0] = _lib.ConvSrc(xs.data_ptr(), cin, 0, cin)
+    d.n_src, d.B, d.H, d.W, d.kh, d.kw, d.stride = 1, B, H, W, 3, 3, 1
+    d.w_packed, d.bias, d.c_out, d.a_scale, d.w_scale, d.epilogue = pc.w_packed.data_ptr(), pc.bias.data_ptr(), cout, pc.a_scale, pc.w_scale, 0
+    d.dst, d.dst_c_stride, d.dst_c_offset = out.data_ptr(), cout, 0
+    d.tile_stats, d.tile_stats_records = ts.data_ptr(), B * tpi - 1
+    lib = _lib.load()
+    assert lib.rnnpose_conv_tiles_per_image_desc(C.byref(d)) == tpi
+    assert lib.rnnpose_conv2d_nhwc_f16x3(C.byref(d), None) != 0 and b"tile_stats_records" in lib.rnnpose_last_error()
+    d.tile_stats_records = B * tpi
+    assert lib.rnnpose_conv2d_nhwc_f16x3(C.byref(d), None) == 0
+    torch.cuda.synchronize()

@@ -332,13 +332,13 @@ def test_mixed_precision_mode_runs_the_single_product_kernels(ops):
     model/CFNet.py:47,126,152) switches the strip convolutions to ONE fp16 product per multiply-add.  Unpinned against the reference's
     autocast run (no GPU reference here), so this checks what can be checked: the mode changes the result by the size fp16 operands
     predict (orders above the default's round-off, far below the signal), hipGraph replay follows the switch, and a default refiner
-    afterwards is bit-identical to one before (the process-wide default is reset at every forward)."""
+    afterwards is bit-identical to one before.  The mode lives on the refiner's own engines: the process-wide default of
+    ops.conv2d_nhwc stays False, so direct callers of ops / cf_net are not affected by what a refiner ran last."""
     from rnnpose_amd import synthetic as syn
     from rnnpose_amd.pose_refiner import PoseRefiner, SyntheticRenderer, default_config
     from rnnpose_amd.transformation import SE3Sequence
     from oracle import rnnpose_oracle as orc
-    B, H, W = 2, 480, 640                       # (160-row strips need maps that fill the chip: the headline resolution; B = 2 runs as ONE
-                                                #  chain -- the two-chain schedule is not bit-reproducible: profiles/r04_determinism.txt)
+    B, H, W = 2, 480, 640                       # (160-row strips need maps that fill the chip: the headline resolution)
     d = syn.make_inputs(B, H, W, seed=21)
     D = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
     z3 = torch.zeros(B, 3, H, W, device="cuda")
@@ -353,7 +353,7 @@ def test_mixed_precision_mode_runs_the_single_product_kernels(ops):
             ref.cf_net.update_block.load_state_dict({k: torch.from_numpy(v) for k, v in syn.make_module_weights(orc.UPDATE_BLOCK_SHAPES, seed=0).items()})
             for _ in range(2):                  # second call replays the captured graphs
                 out = ref(None, SE3Sequence(matrix=D(d["G0"])), D(d["K"]))
-            assert ops.single_product() == mixed
+            assert ops.single_product() is False and ref.cf_net.engine().single_product == mixed == ref.image_fea_enc.engine().single_product
             outs.append((out["Ti_pred"].G.clone(), out["flow_last"].clone()))
     finally:
         ops.single_product(False)

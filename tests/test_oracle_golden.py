@@ -222,7 +222,7 @@ def loop480_inputs(device="cpu"):
     return syn.make_inputs_t(c["B"], c["H"], c["W"], seed=c["seed"], device=device, with_images=True)
 
 
-@pytest.mark.parametrize("fixture", ["loop_480", "loop_480_g25"])
+@pytest.mark.parametrize("fixture", ["loop_480", "loop_480_g25", "loop_480_g50"])
 def test_loop_480_oracle_pinned_at_the_headline_resolution(golden, fixture):
     """the oracle against the REFERENCE ITSELF at 480 x 640 with the encoder in the loop (B = 2, 1 outer x 2
     inner iterations, reference BasicEncoder + GRU_CFUpdator + reprojction_optim, its literal legacy start pose Ti * Ti.inv()):
@@ -257,6 +257,41 @@ def test_loop_480_oracle_pinned_at_the_headline_resolution(golden, fixture):
     # features (|f| ~ 31, |corr| ~ 900) turn that into 1e-4-level field differences at this resolution.  This
     # leg is a sensitivity record with a documented bound, not the parity gate.
     assert dist[False]["pose"] < 1e-5 and dist[False]["w_first"] < 1e-4 and dist[False]["flow_first"] < 5e-4 and dist[False]["flow_last"] < 1e-3, dist[False]
+
+
+LOOP960 = dict(B=1, H=960, W=1280, seed=61, inner=2)
+
+
+def loop960_inputs(device="cpu"):
+    """The inputs tests/golden/gen_golden.py g_loop960 fed the reference."""
+    c = LOOP960
+    return syn.make_inputs_t(c["B"], c["H"], c["W"], seed=c["seed"], device=device, with_images=True)
+
+
+def test_loop_960_oracle_pinned_at_config5_image_size(golden):
+    """BASELINE config 5's per-GPU image size (960 x 1280: 120 x 160 feature maps, N = 19 200 correlation
+    columns, a 1.47-GB volume) against the REFERENCE ITSELF -- its BasicEncoder (kaiming gain 0.25) + GRU_CFUpdator +
+    reprojction_optim on one image, legacy start pose.  Until r05 the oracle was pinned up to 480 x 640 only, while
+    test_full_shape_short_horizon_vs_oracle[1-960-1280] used it at this size.  First iteration only here (the CPU suite's time budget);
+    the GPU test compares both iterations with the fixture directly."""
+    import os
+    g = golden("loop_960")
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    dt = loop960_inputs()
+    d = {k: v.numpy() for k, v in dt.items()}
+    d.pop("fmap1"), d.pop("fmap2")
+    W = {"upd": upd_weights(), "enc": syn.make_module_weights(orc.encoder_shapes(), seed=3, gain=float(g["enc_gain"]))}
+    f1, f2 = orc.image_encoder(W["enc"], d["img_render"], d["img_target"])
+    fmax = float(g["max_abs_fmap"].max())
+    assert maxdiff(f1[:, ::16, ::10, ::10], g["fmap1_sub"]) < 1e-5 * max(fmax, 1.0) and maxdiff(f2[:, ::16, ::10, ::10], g["fmap2_sub"]) < 1e-5 * max(fmax, 1.0)
+    d["fmap1"], d["fmap2"] = f1.numpy(), f2.numpy()              # (the encoder is checked above: the loop takes its maps as given)
+    d.pop("img_render"), d.pop("img_target")
+    res = orc.refine(d, {"upd": W["upd"]}, outer=1, inner=1, optim_iters=1, capture=True, fast=True, literal_legacy_pose=True)
+    dist = dict(pose=maxdiff(res["trace"][0]["Tij"], g["G_iters"][0]),
+                flow_first=maxdiff(res["trace"][0]["flow_up"][:, :, ::16, ::16], g["flow_first"]),
+                w_first=maxdiff(res["trace"][0]["weight"][:, ::16, ::16], g["w_first"]))
+    print("loop_960 oracle vs reference (max |feature map| %.1f, max |flow| %.2f):" % (fmax, float(g["max_abs_flow"])), dist)
+    assert dist["pose"] < 1e-5 and dist["flow_first"] < 1e-4 and dist["w_first"] < 1e-4, dist
 
 
 # ---- row f2: evaluator arithmetic pinned to the reference's own utils/eval_metric.py (tests/golden/gen_golden_eval.py) ----
