@@ -339,10 +339,11 @@ def main():
             e["GBps"] = round(nbytes / (tot_ms * 1e-3) / 1e9, 1)
             e["hbm_frac"] = round(e["GBps"] / PEAK_HBM_GBS, 4)
         if work and name in MFMA3:
+            ex = (rec.get("_exec") or {}).get(name) or 3 * work     # executed fp16 flops: 3 products per multiply-add, 1 for single-product launches (--mixed-precision)
             e["fp32_equivalent_TFLOPps"] = round(work / (tot_ms * 1e-3) / 1e12, 2)
-            e["executed_fp16_TFLOPps"] = round(3 * work / (tot_ms * 1e-3) / 1e12, 1)
-            e["fp16_mfma_frac"] = round(3 * work / (tot_ms * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4)
-            exec_flops_step += 3 * work / prof_steps
+            e["executed_fp16_TFLOPps"] = round(ex / (tot_ms * 1e-3) / 1e12, 1)
+            e["fp16_mfma_frac"] = round(ex / (tot_ms * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4)
+            exec_flops_step += ex / prof_steps
         elif work and name == "rnnpose_corr_pyramid_f32":
             e["TFLOPps"] = round(work / (tot_ms * 1e-3) / 1e12, 2)
             e["f32_mfma_frac"] = round(e["TFLOPps"] / PEAK_F32_MFMA_TFLOPS, 4)
@@ -354,7 +355,7 @@ def main():
     if dom == "rnnpose_conv2d_nhwc_f16x3":
         n, mean_ms, tot_ms, work, nbytes = prof[dom]
         ach_alg = work / (tot_ms * 1e-3) / 1e12                   # 2 * MAC of every launch / its duration
-        ach_exec = 3 * ach_alg                                    # one algorithmic multiply-add = three fp16 MFMA products (fp16x3 split)
+        ach_exec = ((rec.get("_exec") or {}).get(dom) or 3 * work) / (tot_ms * 1e-3) / 1e12    # three fp16 MFMA products per multiply-add (one in single-product launches)
         roofline = {"kernel": "conv_strip_f16x3_kernel + conv_igemm_f16x3_kernel (NHWC implicit-GEMM convolutions, fp16x3-split MFMA = fp32-class "
                               "accuracy: csrc/conv_strip.hip takes the stride-1 3x3 / 1x5 / 5x1 layers of maps that fill the chip with 160-row "
                               "strips, csrc/conv_igemm.hip the rest; all update-block and encoder convolutions but the stem)",
@@ -362,7 +363,7 @@ def main():
                     "frac": round(ach_alg / PEAK_F16_MFMA_TFLOPS, 4),
                     "frac_label": "ALGORITHMIC flops (SURVEY 8d: 2 * multiply-adds of the convolution) / duration / fp16 dense MFMA peak",
                     "pipe_util": round(ach_exec / PEAK_F16_MFMA_TFLOPS, 4),
-                    "pipe_util_label": "EXECUTED fp16 MFMA flops (3 products per algorithmic multiply-add) / duration / fp16 dense peak",
+                    "pipe_util_label": "EXECUTED fp16 MFMA flops (3 products per algorithmic multiply-add; 1 in the single-product launches of --mixed-precision) / duration / fp16 dense peak",
                     "executed_fp16_TFLOPps": round(ach_exec, 1),
                     "traffic": tr("conv"), "traffic_note": traffic_note,
                     "algorithmic_bytes_per_launch": int(nbytes / n) if nbytes else None,

@@ -295,6 +295,9 @@ int rnnpose_conv_tiles_per_image(int H, int W, int kh, int kw, int stride);     
  * stride, c_out, tile, the sources' channel counts and whether src0_mean_rstd is set (pointers are not dereferenced, dst / weights
  * may be NULL): the one sizing rule that cannot disagree with rnnpose_conv2d_nhwc_f16x3.  -1 on bad arguments. */
 int rnnpose_conv_tiles_per_image_desc(const rnnpose_conv_desc_t* h_desc);
+/* fp16 MFMA products per multiply-add the launch this descriptor describes executes: 3 (fp16x3 split) or 1 (single_product honoured:
+ * 160-row strips with one column tile per wave).  For flop accounting (bench.py's pipe_util); -1 on bad arguments. */
+int rnnpose_conv_products_desc(const rnnpose_conv_desc_t* h_desc);
 /* The same for the kernel a launch of `batch` images with this c_out and `tile` request (0 automatic .. 6) will take: the strip
  * kernels tile an image into ceil(W/16) * ceil(H/10) patches of 10 x 16 pixels (3x3) or ceil(H*W/160) runs of 160 pixels (32-row
  * strips: patches of 2 x 16 pixels, runs of 32).  Shape-only: it assumes source channel counts in multiples of 32 (launches whose

@@ -72,6 +72,7 @@ PROTOTYPES = {
     "rnnpose_conv_tiles_per_image": (_i, [_i, _i, _i, _i, _i]),
     "rnnpose_conv_tiles_per_image_ex": (_i, [_i, _i, _i, _i, _i, _i, _i, _i]),
     "rnnpose_conv_tiles_per_image_desc": (_i, [C.POINTER(ConvDesc)]),
+    "rnnpose_conv_products_desc": (_i, [C.POINTER(ConvDesc)]),
     "rnnpose_conv_spatial_tiles": (_i, [_i]),
     "rnnpose_conv_strip": (_i, [_i]),
     "rnnpose_conv_ksplit": (_i, [_i]),

@@ -908,6 +908,12 @@ int rnnpose_conv_tiles_per_image_desc(const rnnpose_conv_desc_t* d) {
   return rnnpose_conv_tiles_per_image(d->H, d->W, d->kh, d->kw, d->stride);
 }
 
+int rnnpose_conv_products_desc(const rnnpose_conv_desc_t* d) {
+  if (!d || rnnpose_conv_tiles_per_image_desc(d) < 0) return -1;
+  const int rows = desc_strip_rows(d);
+  return (d->single_product && rows == 160 && (strip_waves(d->c_out) >> 4) == 1) ? 1 : 3;      // (the rule of strip_launch: P1 = 160-row strips, one column tile per wave)
+}
+
 int rnnpose_conv_tiles_per_image_ex(int H, int W, int kh, int kw, int stride, int c_out, int tile, int batch) {
   if (H <= 0 || W <= 0 || (stride != 1 && stride != 2) || c_out <= 0 || tile < 0 || tile > 6 || batch < 1) return -1;
   int rows = 0;

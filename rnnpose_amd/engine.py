@@ -8,8 +8,8 @@ kernel) -> convf2 -> conv -> z|r (1x5) -> q (1x5) -> z|r (5x1) -> q (5x1)  [the 
 hoisted: computed once per outer iteration and added in the epilogues] -> flow/mask heads (one 128->512 conv) ->
 flow_head.conv2 + coords update -> mask.2 + convex up-sampling in ONE kernel (csrc/mask_upsample.hip; the 576-channel
 mask only exists for the BasicUpdateBlock facade): 14 launches, no ATen elementwise / cat / clone kernels.  By default the whole
-batch runs as ONE chain on the caller's stream; RNNPOSE_SPLIT_BATCH=1 cuts it into two half-batch chains on two streams (see
-__init__).  The module's parameters stay the single source of truth: packed fp16 hi/lo copies are rebuilt whenever a parameter's
+batch is cut into two half-batch chains on two streams when every chain still fills the chip (RNNPOSE_SPLIT_BATCH=0: ONE chain on
+the caller's stream; see __init__).  The module's parameters stay the single source of truth: packed fp16 hi/lo copies are rebuilt whenever a parameter's
 version or storage changes.
 """
 from __future__ import annotations
@@ -29,14 +29,17 @@ class UpdateEngine:
         self._sets = {}           # (B,h,w,device) -> activation buffer set; kept alive because captured hipGraphs hold raw
         self.epoch = 0            # pointers into them.  Bumped whenever a set is freed: graph caches keyed on it are dropped
         import os
-        # Concurrent part-batch chains on several streams: opt-in (RNNPOSE_SPLIT_BATCH=1 / RNNPOSE_PARTS=n).  r04 switched them off because
-        # fresh instances differed in 64-byte runs of a weight map whenever two streams were active.  r05 found the cause
-        # (profiles/r05_determinism.txt): corr_weight, compiled into PACKED fp32 instructions by plain -O3, computed other values for
-        # groups of 16 lanes while a v_mfma_f32_16x16x32_f16 kernel (mask_upsample, conv1x1_resident) of the other stream shared its
-        # SIMDs -- a property of the chip that a plain-HIP probe reproduces (tools/probes/pk_f32_vs_mfma.hip), not a visibility problem.
-        # The library is built without packed fp32 since (build.py) and both schedules are bit-reproducible
-        # (tests/test_gpu_reproducibility.py); with the strip kernels one full-batch chain is within 1-4 % of two half-batch chains.
-        self.split_batch = os.environ.get("RNNPOSE_SPLIT_BATCH", "0") != "0"
+        # Two half-batch chains on two streams (RNNPOSE_SPLIT_BATCH, default 1 again since r05; 0: ONE full-batch chain on the caller's
+        # stream).  Images are independent, so each half of the batch runs its complete inner loop on its own stream: one chain's
+        # latency-bound tail kernels and kernel boundaries run under the other chain's convolutions (+2 % on the headline step next to
+        # two encoder streams, +4-5 % for both together: profiles/r05_schedules.txt).  r04 had switched this off because fresh instances
+        # differed in 64-byte runs of a weight map whenever two streams were active.  r05 found the cause (profiles/r05_determinism.txt):
+        # corr_weight, compiled into PACKED fp32 instructions by plain -O3, computed other values for groups of 16 lanes while a
+        # v_mfma_f32_16x16x32_f16 kernel (mask_upsample, conv1x1_resident) of the other stream shared its SIMDs -- a property of the chip
+        # that a plain-HIP probe reproduces (tools/probes/pk_f32_vs_mfma.hip), not a visibility problem.  The library is built without
+        # packed fp32 since (build.py, tests/test_isa_guard.py) and every schedule is bit-reproducible and bit-identical to the others
+        # (tests/test_gpu_reproducibility.py).
+        self.split_batch = os.environ.get("RNNPOSE_SPLIT_BATCH", "1") != "0"
         # flow-feature / flow-head side chain of a lone SMALL chain on a helper stream: off by default since r05 (B = 1, 240 x 240:
         # 4.25 ms per refinement without it, 4.49 with it -- hipGraph replay runs the two-branch graph no faster than the linear one)
         self.side_stream = os.environ.get("RNNPOSE_SIDE_STREAM", "0") != "0"
@@ -225,8 +228,8 @@ class UpdateEngine:
         """Image ranges of the concurrent chains: `parts` parts of the batch (one stream each), or the whole batch.
         A chain needs enough pixels to fill the chip on its own launches: B=16 at 240x240 (14400 pixels at 1/8 resolution) runs
         3 % faster as one chain than as two of 7200 (1009 vs 978 iters/s), B=32 (two of 14400) 3 % faster as two, the headline
-        shape (two of 19200) 5 % faster as two (r02) -- on the 128-row kernels; r04: ONE chain unless RNNPOSE_SPLIT_BATCH=1 or
-        RNNPOSE_PARTS=n asks for more (see __init__)."""
+        shape (two of 19200) 5 % faster as two (r02) -- on the 128-row kernels; with the strip kernels (r04-r05): 2-3.5 % at the
+        headline.  RNNPOSE_SPLIT_BATCH=0: always one chain; RNNPOSE_PARTS=n: exactly n (see __init__)."""
         n = 1 if (B < 2 or not (self.split_batch or self.parts_forced)) else min(self.parts, B)
         if n > 1 and not self.parts_forced and self._buf_key is not None:
             _, h, w, _ = self._buf_key

@@ -68,9 +68,13 @@ def summarize(rec) -> dict:
     return out
 
 
-def _launch(name, *args, work=0, nbytes=0):
+def _launch(name, *args, work=0, nbytes=0, products=3):
+    """products: fp16 MFMA products per algorithmic multiply-add this launch executes (3 = fp16x3 split; 1 = a single-product
+    strip launch) -- summed into rec["_exec"][name] as EXECUTED flops next to the algorithmic `work`."""
     rec = _prof
     if rec is not None and (rec["_only"] is None or name in rec["_only"]):
+        ex = rec.setdefault("_exec", {})
+        ex[name] = ex.get(name, 0.0) + products * work
         i = rec["_next"]
         rec["_next"] = i + 2
         while len(_event_pool) < i + 2:
@@ -631,8 +635,11 @@ def conv2d_nhwc(pc: PackedConv, srcs, dst, epilogue: int = EPI_LINEAR, aux0=None
     nb = B * H * W * pc.c_in_real + pc.c_out * pc.c_in_real * pc.kh * pc.kw + B * Ho * Wo * pc.c_out
     nb += B * Ho * Wo * pc.c_out * (add_map is not None) + B * Ho * Wo * (gru_c if epilogue == EPI_GRU_ZR else 0)
     nb += 2 * B * Ho * Wo * pc.c_out * (epilogue == EPI_GRU_Q) + B * Ho * Wo * pc.c_out * (dst_split is not None)
+    products = 3
+    if d.single_product and _prof is not None:       # (flop accounting only: which launches the library runs single-product)
+        products = int(_lib.load().rnnpose_conv_products_desc(C.byref(d)))
     _launch("rnnpose_conv2d_nhwc_f16x3", C.byref(d), _stream(),
-            work=2.0 * B * Ho * Wo * pc.c_out * pc.c_in_real * pc.kh * pc.kw, nbytes=4.0 * nb)
+            work=2.0 * B * Ho * Wo * pc.c_out * pc.c_in_real * pc.kh * pc.kw, nbytes=4.0 * nb, products=products)
 
 
 _single_product = False

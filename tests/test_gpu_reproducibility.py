@@ -99,9 +99,10 @@ SHAPES = {
 
 @pytest.mark.parametrize("name", list(SHAPES))
 def test_default_schedule_is_bit_reproducible(ops, monkeypatch, name):
-    """>= 8 fresh instances on identical inputs: every output of every iteration bit-identical to the first instance's -- for the
-    default schedule at the headline shape and at the reference's own working size (B = 1, 240 x 240), eager and replayed, and for
-    the opt-in schedules that keep a second stream busy (two half-batch chains, two encoder streams, the single-image helper stream)."""
+    """8 fresh instances after the first on identical inputs: every output of every iteration bit-identical to the first instance's --
+    for the default schedule (two half-batch chains + one encoder stream per image set at the headline shape; one chain at the
+    reference's own working size, B = 1, 240 x 240), eager and replayed, for the one-stream schedule, and for the single-image helper
+    stream."""
     B, H, W, iters, graph, enc, env = SHAPES[name]
     for k, v in env.items():
         monkeypatch.setenv(k, v)

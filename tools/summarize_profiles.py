@@ -69,17 +69,18 @@ def tail(src, dst, n=15):
 
 
 os.makedirs(P, exist_ok=True)
-for suffix in ("bench", "bench_nograph", "bench_S1", "bench_S5", "bench_B16", "bench_B16_240", "bench_B32_240", "bench_split_tensors", "bench_fp32_activations", "bench_two_chains", "bench_mixed_precision", "drift",
+for suffix in ("bench", "bench_nograph", "bench_S1", "bench_S5", "bench_B16", "bench_B16_240", "bench_B32_240", "bench_split_tensors", "bench_fp32_activations", "bench_two_chains", "bench_one_stream", "bench_mixed_precision", "drift",
                "error_budget", "parity_probe"):
     src = have(f"{TAG}_{suffix}.json")
     if src and os.path.getsize(src):
         shutil.copy(src, os.path.join(P, f"{TAG}_{suffix}.json"))
-for suffix, n in (("pytest_gpu.log", 12), ("smoke.log", 4), ("device.txt", 5), ("conv_layers_alone.txt", 40), ("drift.log", 60),
+for suffix, n in (("pytest_gpu.log", 12), ("smoke.log", 4), ("device.txt", 40), ("conv_layers_alone.txt", 40), ("drift.log", 60),
                   ("conv_ablation.txt", 200), ("corr_ablation.txt", 60), ("corr_store_patterns.txt", 40)):
     src = have(f"{TAG}_{suffix}")
     if src:
         tail(src, os.path.join(P, f"{TAG}_{suffix.replace('.log', '.txt')}"), n)
 for d, name, by_grid in ((f"{TAG}_prof", f"{TAG}_kernel_stats.csv", False), (f"{TAG}_prof_unsplit", f"{TAG}_kernel_stats_unsplit_nograph.csv", False),
+                         (f"{TAG}_prof_serial", f"{TAG}_kernel_stats_serialized.csv", False), (f"{TAG}_prof_one_stream", f"{TAG}_kernel_stats_one_stream.csv", False),
                          (f"{TAG}_prof_convs", f"{TAG}_conv_layers.csv", True)):
     src = have(d, "run_results.db")
     if src:
