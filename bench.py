@@ -431,7 +431,8 @@ def main():
                    "hip_graphs": "encoder+volume build and the inner-iteration body replay as hipGraphs (except in the "
                                  "event-instrumented first outer iteration of the first timed step)" if refiner.use_graph and not args.unfused else "off",
                    "schedule": {"loop_chains": len(refiner.cf_net.engine().halves(B)) if hasattr(refiner.cf_net.engine(), "halves") else 1,
-                                "encoder_streams": 1 if (args.no_encoder or refiner.image_fea_enc.engine().merge_sets) else 2},
+                                "encoder_streams": 1 if (args.no_encoder or refiner.image_fea_enc.engine().merge_sets or
+                                                          (refiner.image_fea_enc.engine().merge_sets is None and B * H * W < refiner.image_fea_enc.engine().MIN_SET_PIXELS)) else 2},
                    "weights": "random init", "lm_accumulation": "f64", "sharding": f"dp{world} (independent images, no collective in the path)"},
         "roofline": roofline, "chip_level": chip, "correlation_volume_kernel": corr_vol, "kernels": kernels,
         "kernels_note": "HIP events around every C-ABI launch of the first outer iteration of the first timed step (eager); GB/s from "

@@ -94,6 +94,9 @@ __device__ unsigned long long g_strip_clk[8 * 65536];
 #ifndef RS_SLICE_BITS
 #define RS_SLICE_BITS 9    // (100-MHz clock: 2^9 ticks = 5.12 us)
 #endif
+#ifndef RS_RING3
+#define RS_RING3 1        // 0: the two-wave 3x3 workgroups keep the 6-slot weight ring (r04; same-box A/B)
+#endif
 #ifndef RS_VAR
 #define RS_VAR 0          // schedule variants (measurement): 1 s_setprio(1) around a step's MFMAs, 2 fragment reads in front of the
 #endif                    // MFMAs instead of between them, 4 the first read behind the third MFMA
@@ -278,7 +281,11 @@ __global__ __launch_bounds__(NW * 64, NI == 2 ? 1 : 2) void conv_strip_f16x3_ker
   constexpr int SPH = 2 * SMI;                             // 3x3: patch lines (10 x 16, 4 x 16, 2 x 16 pixels)
   constexpr int SHR = (SPH + 2) * SHW;                     // staged rows of a patch with its halo (216 / 108 / 72)
   constexpr int BREC = 2048 * NI;                          // weight record of one wave and step
-  constexpr int NBST = SPATIAL ? 6 : 5;                    // weight ring slots per wave: 2 TT is a multiple (slots are compile-time)
+  // weight ring slots per wave: 2 TT is a multiple (slots are compile-time).  r05: the TWO-wave 3x3 workgroups (64-column layers: the
+  // encoder's 240 x 320 residual blocks) take a 3-slot ring -- 40 KB of LDS per workgroup instead of 52: FOUR workgroups per CU = two
+  // waves per SIMD instead of three = 1.5.  Their records are requested two steps ahead (L2-resident weights: 36 K values per layer).
+  constexpr bool RING3 = RS_RING3 && SPATIAL && NW == 2 && NI == 1 && SMI == 5;
+  constexpr int NBST = SPATIAL ? (RING3 ? 3 : 6) : 5;
   static_assert((2 * TT) % NBST == 0 && NBST - 2 < TT - 1, "ring period");
   constexpr int NT_ = NW * 64;
   constexpr int ARV = SPATIAL ? SHR : SM + 2 * SHALO;      // staged rows that carry data (216 / 168)
@@ -582,7 +589,8 @@ __global__ __launch_bounds__(NW * 64, NI == 2 ? 1 : 2) void conv_strip_f16x3_ker
     constexpr int set_ = q_ & 1, sl_ = q_ % NBST;                                                            \
     constexpr bool last_ = (T_) == TT - 1;                                                                   \
     constexpr int tn_ = last_ ? 0 : (T_) + 1, asn_ = last_ ? 1 - (H_) : (H_);                                \
-    if (!(RS_ABL & 64)) wait_vm<2 * NI * (NBST - 3) + ((T_) <= NBST - 4 ? PAW : 0)>();                       \
+    /* (3-slot ring: the record of step s+1 is the newest request but for the activation half block that follows it in the queue) */ \
+    if (!(RS_ABL & 64)) wait_vm<RING3 ? ((T_) == 0 ? PAW : 0) : 2 * NI * (NBST - 3) + ((T_) <= NBST - 4 ? PAW : 0)>();  \
     if constexpr (MODE != 0 && (T_) == NBST - 2) { RS_STORE_A(1 - (H_)) }    /* (requested at the last boundary; landed: (a)) */ \
     if constexpr (last_ && !(RS_VAR & 8)) {                                                                  \
       wait_lds();                                                                                            \
@@ -593,9 +601,10 @@ __global__ __launch_bounds__(NW * 64, NI == 2 ? 1 : 2) void conv_strip_f16x3_ker
         if (((static_cast<unsigned>(t_) >> RS_SLICE_BITS) ^ slotpar_) & 1u) __builtin_amdgcn_s_setprio(2);   \
         else __builtin_amdgcn_s_setprio(0);                                                                  \
       }                                                                                                      \
+      if constexpr (RING3) { RS_ISSUE_B((sl_ + NBST - 1) % NBST) }     /* (3-slot ring: the weight record FIRST, so that the next step can wait for it and leave the half block in flight) */ \
       if (!(RS_ABL & 2)) { if constexpr (MODE == 0) { RS_ISSUE_A(H_) } else { RS_LOAD_A() } }   /* (half block hb+2; past the end: the last one again) */ \
     }                                                                                                        \
-    if (!(RS_ABL & 1) && !(RS_VAR & 8)) RS_ISSUE_B((sl_ + NBST - 1) % NBST)                                  \
+    if (!(RS_ABL & 1) && !(RS_VAR & 8) && !(RING3 && last_)) RS_ISSUE_B((sl_ + NBST - 1) % NBST)             \
     __builtin_amdgcn_sched_barrier(0);                                                                       \
     if (RS_VAR & 2) {              /* variant: all fragment reads of the next step in front of the MFMAs */    \
       _Pragma("unroll") for (int k = 0; k < NRD; ++k) RS_READ1(k, 1 - set_, tn_, asn_, (sl_ + 1) % NBST)     \
@@ -643,6 +652,11 @@ __global__ __launch_bounds__(NW * 64, NI == 2 ? 1 : 2) void conv_strip_f16x3_ker
   // map, h, z) are requested before the block goes through LDS (conv_igemm.hip has the history of this order).
   constexpr int ES = 32 * NI + 4, F4 = 8 * NI, KG = 4 * NI;       // row stride of the staging tile (floats), float4 per row, row groups per block
   float* S_ = reinterpret_cast<float*>(sB);              // 32 x ES floats = 4.5 / 8.5 KB <= the ring's 10 / 24 KB
+  if constexpr (RING3) {                                 // (a 6-KB ring does not hold the fast epilogue's two staging tiles: 9 KB per wave
+    wg_barrier();                                        //  from the activation slots, once every wave is done reading them)
+    S_ = reinterpret_cast<float*>(lds + wave * (2 * 32 * ES * 4));
+    static_assert(!RING3 || NW * 2 * 32 * (32 * NI + 4) * 4 <= 2 * ASLOT, "epilogue staging in the activation slots");
+  }
   const int colw = ct32 * 32;
   const int colq = colw + (lane % F4) * 4;
   const bool colok = colq < p.Cout;

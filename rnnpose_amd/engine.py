@@ -420,11 +420,17 @@ class EncoderEngine:
         self.single_product = False                   # cfg.raft.mixed_precision, set by the PoseRefiner that owns the encoder (see UpdateEngine)
         self.split_batch = os.environ.get("RNNPOSE_SPLIT_ENCODER", "1") != "0"
         self.parts = int(os.environ.get("RNNPOSE_ENCODER_PARTS", "1"))
-        # one stream per image set (rendered | observed) -- the r02-r03 schedule, the default again since r05: one set's HBM-bound
-        # normalisation passes and latency-bound finalize launches run under the other set's convolutions (+2 % on the headline step).
-        # r04 had merged the sets into one batch on one stream because runs with two active streams were not bit-reproducible; r05 found
-        # and removed the cause (packed fp32 instructions next to 16x16x32 MFMAs: UpdateEngine.__init__).  RNNPOSE_ENCODER_MERGE=1: one batch.
-        self.merge_sets = os.environ.get("RNNPOSE_ENCODER_MERGE", "0") != "0"
+        # one stream per image set (rendered | observed) -- the r02-r03 schedule, the default again since r05 for image sets that fill
+        # the chip: one set's HBM-bound normalisation passes and latency-bound finalize launches run under the other set's convolutions
+        # (+1-2 % on the headline step, +2 % at B = 16 240 x 240).  Small sets run as ONE concatenated batch on one stream: the fork / join
+        # and half-empty launches cost more than the overlap gives (B = 1 240 x 240: 4.19 vs 4.53 ms per refinement, B = 4: 5.33 vs 5.55;
+        # B = 2 480 x 640: equal; profiles/r05_ab_encoder_streams_small.txt).  r04 had merged ALL sets because runs with two active
+        # streams were not bit-reproducible; r05 found and removed the cause (UpdateEngine.__init__).
+        # RNNPOSE_ENCODER_MERGE=1 / 0: always one batch / always one stream per set.
+        m = os.environ.get("RNNPOSE_ENCODER_MERGE")
+        self.merge_sets = None if m is None else (m != "0")
+
+    MIN_SET_PIXELS = 800_000      # full-resolution pixels per image set from which the sets get their own streams
 
     def _mine(self):
         f = self.fnet
@@ -518,7 +524,10 @@ class EncoderEngine:
         W = self._weights()
         imgs = [images] if torch.is_tensor(images) else list(images)
         imgs = [ops._chk(t, "image") for t in imgs]
-        if self.merge_sets and len(imgs) > 1:       # opt-in (r04's default): the image sets as ONE batch on ONE stream
+        merge = self.merge_sets
+        if merge is None and len(imgs) > 1:          # automatic: small image sets as ONE batch on ONE stream
+            merge = min(t.shape[0] * t.shape[2] * t.shape[3] for t in imgs) < self.MIN_SET_PIXELS
+        if merge and len(imgs) > 1:
             imgs = [torch.cat(imgs, 0)]
         _, _, H, Wd = imgs[0].shape
         N = sum(t.shape[0] for t in imgs)

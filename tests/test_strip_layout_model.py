@@ -164,3 +164,81 @@ def test_packed_weight_record():
     for g in GROUPS:
         slots = {((l & 31) * 32 + (((l >> 5) ^ (((l & 31) >> 3) & 1)) << 4)) % 256 // 16 for l in g}
         assert len(slots) == 16
+
+
+# ---- the weight ring and the hand-counted s_waitcnt vmcnt(N) of the main loop (r05: the 3-slot ring of the two-wave 3x3 workgroups) ----
+def _simulate_ring(TT, NBST, ring3, PAW, NI, NHB, mode0, swap=None):
+    """A wave's vector-memory queue (in-order completion, as vmcnt counts it) through prologue and main loop of
+    csrc/conv_strip_kernel.cuh, with the kernel's own wait expressions.  Checks, at every step s = (half block hb, tap T):
+      * weight record s+1 has landed before its fragments are read (during the MFMAs of step s),
+      * activation half block hb+1 has landed before it is published: the barrier of the last tap (DMA path) or the register ->
+        LDS store at tap NBST-2 (register path),
+      * the slot a record is requested into is the slot of a record whose fragments were consumed a step ago."""
+    swap = ring3 if swap is None else swap
+    q = []                                             # outstanding requests, oldest first: ("A", hb) x PAW or ("B", s) x 2 NI
+    landed = set()
+
+    def issue(kind, idx, n):
+        q.extend([(kind, idx)] * n)
+
+    def wait(n):
+        while len(q) > n:
+            landed.add(q.pop(0))
+    S = NHB * TT
+    slot_of = {}
+    issue("A", 0, PAW), issue("A", 1, PAW)
+    for i in range(NBST - 1):
+        issue("B", i, 2 * NI)
+        slot_of[i] = i
+    wait(0)
+    b_next = NBST - 1                                  # next record to request (past the end: the last one again -> same counts)
+    for hb in range(NHB):
+        for T in range(TT):
+            s = hb * TT + T
+            last = T == TT - 1
+            n = (PAW if T == 0 else 0) if ring3 else 2 * NI * (NBST - 3) + (PAW if T <= NBST - 4 else 0)
+            wait(n)
+            if s + 1 < S:
+                assert ("B", s + 1) in landed, f"step {s}: record {s + 1} still in flight behind wait({n})"
+            if not mode0 and T == NBST - 2 and hb + 1 < NHB:
+                assert ("A", hb + 1) in landed, f"step {s}: half block {hb + 1} stored before it landed"
+            sl = ((hb & 1) * TT + T) % NBST
+
+            def issue_b():
+                nonlocal b_next
+                dst = (sl + NBST - 1) % NBST
+                if b_next < S:
+                    # the slot being overwritten held record b_next - NBST: read during step b_next - NBST - 1, consumed in the step after
+                    assert b_next - NBST <= s - 1, (s, b_next)
+                    assert slot_of.get(b_next - NBST, dst) == dst
+                    slot_of[b_next] = dst
+                issue("B", min(b_next, S - 1) if b_next < S else ("pad", s), 2 * NI)
+                b_next += 1
+            if last:
+                if mode0 and hb + 1 < NHB:
+                    assert ("A", hb + 1) in landed, f"step {s}: barrier publishes half block {hb + 1} before it landed"
+                if swap:
+                    issue_b()
+                issue("A", hb + 2 if hb + 2 < NHB else ("pad", s), PAW)
+            if not (swap and last):
+                issue_b()
+            assert len(q) <= 63, "vmcnt is a 6-bit counter"
+    return True
+
+
+@pytest.mark.parametrize("TT,NBST,ring3,PAW,NI", [(9, 6, False, 4, 1), (9, 6, False, 7, 1), (9, 6, False, 7, 2), (5, 5, False, 3, 1), (5, 5, False, 6, 2),
+                                                  (9, 3, True, 7, 1), (9, 3, True, 9, 1)])
+@pytest.mark.parametrize("mode0", [True, False])
+def test_weight_ring_wait_counts(TT, NBST, ring3, PAW, NI, mode0):
+    """The counted waits of RS_STEP for every ring the kernel instantiates: 6 slots (3x3), 5 (1x5 / 5x1) and -- r05 -- 3 slots for the
+    two-wave 3x3 workgroups, whose last tap requests the weight record BEFORE the activation half block so that the next step can wait
+    for the record (vmcnt(PAW)) and leave the half block in flight."""
+    assert (2 * TT) % NBST == 0 and NBST - 2 < TT - 1
+    assert _simulate_ring(TT, NBST, ring3, PAW, NI, NHB=8, mode0=mode0)
+
+
+def test_three_slot_ring_needs_the_swapped_request_order():
+    """The model is sensitive to what it checks: the 3-slot wait rule (vmcnt(PAW) at the first tap of a half block) with r04's request
+    order -- the activation half block BEFORE the weight record at the last tap -- reads a record that is still in flight."""
+    with pytest.raises(AssertionError):
+        _simulate_ring(9, 3, True, 7, 1, NHB=4, mode0=False, swap=False)
