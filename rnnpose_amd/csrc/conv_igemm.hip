@@ -848,12 +848,13 @@ int rnnpose_conv_spatial_tiles(int enable) {     // measurement switch: 0 = the 
 }
 
 int rnnpose_conv_strip(int mode) {               // 0 = never the strip kernels, 1 = automatic (default); measurement: 2 = automatic without
-  if (mode < 0 || mode > 4) {                    // the two-wave workgroups of the 64-channel layers, 3 = two 32-column tiles per wave,
-    rp::set_error("rnnpose_conv_strip: mode 0..4");      // 4 = 160-row strips only (by the image shape: r04's first rule)
-    return 1;
+  if (mode < 0 || mode > 5) {                    // the two-wave workgroups of the 64-channel layers, 3 = two 32-column tiles per wave,
+    rp::set_error("rnnpose_conv_strip: mode 0..5");      // 4 = 160-row strips only (by the image shape: r04's first rule),
+    return 1;                                    // 5 = automatic without the stride-2 form (r05)
   }
   g_conv_strip = mode != 0;
   strip_allow_small(mode != 4);
+  strip_allow_s2(mode != 5);
   strip_allow_two_wave(mode != 2);
   strip_force_ni(mode == 3 ? 2 : 1);
   return 0;
@@ -888,6 +889,9 @@ int rnnpose_conv_tiles_per_image(int H, int W, int kh, int kw, int stride) {
 // automatic choice takes strips only when the sources qualify -- whole 32-channel blocks, the fused normalisation only for 3x3 --
 // and otherwise falls back, with or without tile statistics (r04 raised an error there: ADVICE).  The ONE place this is decided.
 static int desc_strip_rows(const rnnpose_conv_desc_t* d) {
+  if (d->stride == 2) {      // the parity-plane form: ONE fp32 source of whole 32-channel blocks, no fused normalisation, <= MAX_CB blocks over the four planes
+    if (d->n_src != 1 || d->src[0].c_count % 32 != 0 || d->src_hl || d->src0_mean_rstd || 4 * (d->src[0].c_count / 32) > MAX_CB || d->tile == 6) return 0;
+  }
   if (d->tile >= 5) return strip_rows(d->H, d->W, d->kh, d->kw, d->stride, d->c_out, d->B, d->tile == 5 ? 160 : 32);
   if (d->tile != 0 || !g_conv_strip) return 0;
   const int rows = strip_rows(d->H, d->W, d->kh, d->kw, d->stride, d->c_out, d->B, 0);
@@ -904,7 +908,7 @@ int rnnpose_conv_tiles_per_image_desc(const rnnpose_conv_desc_t* d) {
     return -1;
   const int rows = desc_strip_rows(d);
   if (d->tile >= 5 && rows == 0) return -1;
-  if (rows) return strip_tiles_per_image(d->H, d->W, d->kh, d->kw, rows);
+  if (rows) return strip_tiles_per_image(d->H / d->stride, d->W / d->stride, d->kh, d->kw, rows);       // (tiles of the OUTPUT grid; stride 2: even sizes only)
   return rnnpose_conv_tiles_per_image(d->H, d->W, d->kh, d->kw, d->stride);
 }
 
@@ -920,7 +924,7 @@ int rnnpose_conv_tiles_per_image_ex(int H, int W, int kh, int kw, int stride, in
   if (tile >= 5) rows = strip_rows(H, W, kh, kw, stride, c_out, batch, tile == 5 ? 160 : 32);
   else if (tile == 0 && g_conv_strip) rows = strip_rows(H, W, kh, kw, stride, c_out, batch, 0);
   if (tile >= 5 && rows == 0) return -1;
-  if (rows) return strip_tiles_per_image(H, W, kh, kw, rows);
+  if (rows) return strip_tiles_per_image(H / stride, W / stride, kh, kw, rows);
   return rnnpose_conv_tiles_per_image(H, W, kh, kw, stride);
 }
 
@@ -931,8 +935,9 @@ long long rnnpose_conv_packed_halfs(int c_out, int kh, int kw, const int* h_seg_
   const int ncb = fill_cb_tables(h_seg_counts, n_seg, cs, c0);
   if (ncb < 0) return -1;
   const long long Npad = static_cast<long long>(rp::cdiv(c_out, BN)) * BN;
-  // hi and lo parts interleaved; TWO copies: the 128-row kernels' fragment order, then the strip kernels' record order
-  return 2 * static_cast<long long>(kh) * kw * ncb * Npad * BK * 2;
+  // hi and lo parts interleaved; TWO copies: the 128-row kernels' fragment order, then the strip kernels' record order -- and for a 3x3
+  // layer with one source of whole 32-channel blocks a THIRD one: the stride-2 form over parity planes (conv_strip.hip, r05)
+  return 2 * static_cast<long long>(kh) * kw * ncb * Npad * BK * 2 + strip_s2_halfs(h_seg_counts[0], kh, kw, ncb, static_cast<int>(Npad), n_seg);
 }
 
 int rnnpose_conv_pack_weights_f16x3(const float* w_oihw, int c_out, int c_in, int kh, int kw, const int* h_seg_counts,
@@ -1089,6 +1094,22 @@ int rnnpose_conv2d_nhwc_f16x3(const rnnpose_conv_desc_t* d, rnnpose_stream_t str
     const int rows = desc_strip_rows(d);
     if (d->tile >= 5)
       RP_REQUIRE(rows != 0, fn, "strip kernels: stride 1, 3x3 / 1x5 / 5x1, c_out > 32 (32-row strips: one column tile per wave)");
+    if (rows && d->stride == 2) {
+      // stride-2 3x3 layer on strips (r05): the four parity planes of the source as four segments of a virtual concatenation -- strided
+      // views (pixel stride 2, row stride 2 W) starting at pixels (0,0), (0,1), (1,0), (1,1) -- on the half-resolution output grid,
+      // 2 x 2 taps per plane (conv_strip.hip: pack_strip_s2_kernel has the tap table).  p.U / p.V are the output extents already.
+      const rnnpose_conv_src_t& sr = d->src[0];
+      const int nb = sr.c_count / BK;
+      for (int k = 0; k < 4; ++k) {
+        const Seg sg{sr.ptr + (static_cast<long long>(k >> 1) * d->W + (k & 1)) * sr.c_stride, sr.c_stride, sr.c_offset, sr.c_count};
+        (k == 0 ? p.seg0 : k == 1 ? p.seg1 : k == 2 ? p.seg2 : p.seg3) = sg;
+      }
+      p.cb1 = nb; p.cb2 = 2 * nb; p.cb3 = 3 * nb; p.ncb = 4 * nb;
+      p.su = 2 * d->W; p.sv = 2; p.Uin = d->H; p.Vin = d->W;
+      p.G = 1; p.du0 = 0; p.dv0 = 0;
+      p.wpk_strip = reinterpret_cast<const uint4*>(reinterpret_cast<const _Float16*>(p.wpk_strip) + static_cast<long long>(nb) * 2 * 9 * p.Npad * 32);   // behind the stride-1 strip copy
+      return strip_launch(p, Ho, Wo, d->kh, d->kw, false, per_image, rows, rp::as_stream(stream));
+    }
     if (rows) {          // (a forced strip launch whose sources do not fit surfaces its error in strip_launch)
       if (vertical) { p.G = 1; p.T = d->kh; p.du0 = 0; p.dv0 = -(d->kh / 2); }
       else { p.G = d->kh; p.T = d->kw; p.du0 = -(d->kh / 2); p.dv0 = -(d->kw / 2); }

@@ -69,6 +69,39 @@ __global__ void pack_strip_kernel(const float* __restrict__ w, _Float16* __restr
   pk[i] = part == 0 ? h : static_cast<_Float16>(v - static_cast<float>(h));
 }
 
+// r05: the STRIDE-2 form of a 3x3 layer (one source of whole 32-channel blocks).  out(Y, X) = sum w(dy, dx) in(2Y + dy, 2X + dx) is a
+// stride-1 layer on the half-resolution grid over the FOUR PARITY PLANES of the input -- plane (py, px) pixel (y, x) = in(2y + py,
+// 2x + px), a strided view of the NHWC source, no copy -- with 2 x 2 taps (ty, tx), offsets (ty - 1, tx - 1) in {-1, 0}:
+//     dy = -1 -> plane row 1 at y - 1 (ty 0),  dy = 0 -> plane row 0 at y (ty 1),  dy = +1 -> plane row 1 at y (ty 1);  likewise dx.
+// Nine of the sixteen (plane, tap) pairs carry a weight, seven are zero.  Packed order = the strip order with K running over
+// [plane p = 2 py + px][channel]: [half block of 4 Cin channels][tap t = 2 ty + tx][32-column tile] records of 2 KB.
+__global__ void pack_strip_s2_kernel(const float* __restrict__ w, _Float16* __restrict__ pk, const PackParams q) {
+  const int nt32 = q.Npad / 32;
+  const long long total = static_cast<long long>(4 * q.ncb) * 2 * 4 * q.Npad * 32;
+  const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int j8 = static_cast<int>(i & 7);
+  const int pos = static_cast<int>((i >> 3) & 1);
+  const int n32 = static_cast<int>((i >> 4) & 31);
+  const int part = static_cast<int>((i >> 9) & 1);
+  const int ctile = static_cast<int>((i >> 10) % nt32);
+  const long long st = (i >> 10) / nt32;
+  const int tap = static_cast<int>(st % 4);
+  const int hbk = static_cast<int>(st / 4);
+  const int blk4 = hbk >> 1, kk = hbk & 1;
+  const int plane = blk4 / q.ncb, blk = blk4 - plane * q.ncb;
+  const int py = plane >> 1, px = plane & 1, ty = tap >> 1, tx = tap & 1;
+  const int ky = py == 0 ? (ty == 1 ? 1 : -1) : (ty == 0 ? 0 : 2);
+  const int kx = px == 0 ? (tx == 1 ? 1 : -1) : (tx == 0 ? 0 : 2);
+  const int g = pos ^ ((n32 >> 3) & 1);
+  const int ci = blk * 32 + kk * 16 + g * 8 + j8;
+  const int n = ctile * 32 + n32;
+  float v = 0.f;
+  if (n < q.Cout && ci < q.Cin && ky >= 0 && kx >= 0) v = w[((static_cast<long long>(n) * q.Cin + ci) * 3 + ky) * 3 + kx] * q.w_scale;
+  const _Float16 h = static_cast<_Float16>(v);
+  pk[i] = part == 0 ? h : static_cast<_Float16>(v - static_cast<float>(h));
+}
+
 bool strip_kernel_shape(int kh, int kw) { return (kh == 3 && kw == 3) || (kh == 1 && kw == 5) || (kh == 5 && kw == 1); }
 
 }  // namespace
@@ -109,6 +142,8 @@ int strip_tiles_per_image(int H, int W, int kh, int kw, int rows) {
 
 static int g_strip_small = 1;        // 32-row strips in the automatic choice (strip_allow_small)
 void strip_allow_small(int on) { g_strip_small = on; }
+static int g_strip_s2 = 1;           // stride-2 3x3 layers as strips over parity planes (strip_allow_s2; 0: the 128-row kernel's tap-per-staging mode)
+void strip_allow_s2(int on) { g_strip_s2 = on; }
 
 // Strip height for a launch of `batch` images: 160 or 32 rows -- or 0: not a strip launch.  request: 0 = automatic, else that height
 // (tests, measurement).  160-row strips when they give the launch >= 240 workgroups (about one per CU) or, failing that, >= 24 per
@@ -118,8 +153,12 @@ void strip_allow_small(int on) { g_strip_small = on; }
 // the 128-row kernel, 30-48 on 160-row strips; at 14 400 pixels (16 crops) the 128-row kernel is 0.5-1 % ahead of 32-row strips on
 // the step, at 19 200 (B = 4 of the headline) they are equal.  (64-row strips were built too: never the best of the three.)
 int strip_rows(int H, int W, int kh, int kw, int stride, int c_out, int batch, int request) {
-  if (stride != 1 || !strip_kernel_shape(kh, kw) || strip_waves(c_out) == 0) return 0;
+  if ((stride != 1 && stride != 2) || !strip_kernel_shape(kh, kw) || strip_waves(c_out) == 0) return 0;
   const int cfg = strip_waves(c_out), ni = cfg >> 4, nwt = (cfg & 15) * ni;         // 32-column wave tiles per workgroup
+  if (stride == 2) {      // r05: the 2x2-tap form over the parity planes: 3x3, even input size, 160-row strips on the OUTPUT grid, one tile per wave
+    if (!g_strip_s2 || !(kh == 3 && kw == 3) || (H & 1) || (W & 1) || ni != 1 || request == 32) return 0;
+    H >>= 1; W >>= 1;
+  }
   if (request != 0) return (request == 160 || (request == 32 && ni == 1)) ? request : 0;
   if ((cfg & 15) == 2 && ni == 1 && g_strip_two_wave == 0) return 0;      // (two-wave workgroups, c_out <= 64: see strip_allow_two_wave)
   auto fits = [&](int rows) {
@@ -138,6 +177,7 @@ int strip_rows(int H, int W, int kh, int kw, int stride, int c_out, int batch, i
   const long long t160 = strip_tiles_per_image(H, W, kh, kw, 160) * static_cast<long long>(ncol);
   const long long npix = nb * H * W;
   if (fits(160) && (t160 * nb >= 240 || (t160 >= 24 && npix > 8192))) return 160;
+  if (stride == 2) return 0;
   if (fits(32) && npix <= 8192 && strip_tiles_per_image(H, W, kh, kw, 32) * ncol * nb >= 24) return 32;
   return 0;
 }
@@ -147,11 +187,19 @@ void strip_pack(const float* w, _Float16* pk, const PackParams& q, hipStream_t s
   const int TT = q.kh * q.kw;
   const long long total = static_cast<long long>(q.ncb) * 2 * TT * q.Npad * 32;
   hipLaunchKernelGGL(pack_strip_kernel, dim3(rp::cdiv(total, 256)), dim3(256), 0, st, w, pk, q, TT, (q.kh == 3 && q.kw == 3) ? 1 : 0);
+  const long long t2 = strip_s2_halfs(q.Cin, q.kh, q.kw, q.ncb, q.Npad, q.seg_count[1] == 0 && q.seg_count[2] == 0 && q.seg_count[3] == 0 ? 1 : 2);
+  if (t2 > 0) hipLaunchKernelGGL(pack_strip_s2_kernel, dim3(rp::cdiv(t2, 256)), dim3(256), 0, st, w, pk + total, q);     // (third copy: the stride-2 form)
+}
+
+// fp16 elements of the stride-2 copy of a layer's packed weights (0: the layer has none): 3x3, ONE source of whole 32-channel blocks
+long long strip_s2_halfs(int c_in, int kh, int kw, int ncb, int Npad, int n_seg) {
+  if (!(kh == 3 && kw == 3) || n_seg != 1 || c_in % 32 != 0 || 4 * ncb > MAX_CB) return 0;
+  return static_cast<long long>(4 * ncb) * 2 * 4 * Npad * 32;
 }
 
 int strip_launch(KParams& p, int H, int W, int kh, int kw, bool hlin, bool per_image, int rows, hipStream_t st) {
   const char* fn = "rnnpose_conv2d_nhwc_f16x3";
-  RP_REQUIRE(strip_kernel_shape(kh, kw) && p.stride == 1, fn, "strip kernel: 3x3, 1x5 or 5x1, stride 1");
+  RP_REQUIRE(strip_kernel_shape(kh, kw) && (p.stride == 1 || (p.stride == 2 && kh == 3 && kw == 3)), fn, "strip kernel: 3x3, 1x5 or 5x1, stride 1 (3x3: also stride 2)");
   const int cfg = strip_waves(p.Cout);
   RP_REQUIRE(cfg != 0, fn, "strip kernel: c_out must exceed 32");
   const int ni = cfg >> 4, nw = cfg & 15;
@@ -181,7 +229,8 @@ int strip_launch(KParams& p, int H, int W, int kh, int kw, bool hlin, bool per_i
   p.n_nt = rp::cdiv(p.Cout, 32 * ni * nw);
   RP_REQUIRE(p.n_nt * ni * nw * 32 <= p.Npad, fn, "strip kernel: column tiles exceed the packed width");
   if (spatial) {
-    p.T = 9; p.dv0 = 0;
+    p.T = p.stride == 2 ? 4 : 9; p.dv0 = 0;
+    if (p.stride == 1) { p.Uin = p.U; p.Vin = p.V; p.su = p.V; p.sv = 1; }      // (source pixel of a staged row: RS_ROW_PIXEL; stride 2: set by the caller)
     p.sp_tx = rp::cdiv(W, SPW); p.sp_ty = rp::cdiv(H, rows / 16);
     p.tpi = p.sp_tx * p.sp_ty;
     p.n_mt = p.B * p.tpi;

@@ -276,7 +276,8 @@ __device__ __forceinline__ void strip_epilogue_fast(const StripEpi p, f32x16 (&a
 // not); their fragments are neither read nor multiplied.  Not the headline arithmetic: narrower than the CPU oracle's fp32.
 template <int NW, int TT, int MODE, int NI, int SMI, bool P1 = false>
 __global__ __launch_bounds__(NW * 64, NI == 2 ? 1 : 2) void conv_strip_f16x3_kernel(const KParams p) {
-  constexpr bool SPATIAL = TT == 9;
+  constexpr bool SPATIAL = TT == 9 || TT == 4;             // TT = 4 (r05): a STRIDE-2 3x3 layer as a 2x2-tap layer over the four parity planes
+  constexpr bool S2 = TT == 4;                             // of its input (strided views of the NHWC source: conv_strip.hip, strip_launch)
   constexpr int SM = 32 * SMI;                             // strip rows
   constexpr int SPH = 2 * SMI;                             // 3x3: patch lines (10 x 16, 4 x 16, 2 x 16 pixels)
   constexpr int SHR = (SPH + 2) * SHW;                     // staged rows of a patch with its halo (216 / 108 / 72)
@@ -284,8 +285,8 @@ __global__ __launch_bounds__(NW * 64, NI == 2 ? 1 : 2) void conv_strip_f16x3_ker
   // weight ring slots per wave: 2 TT is a multiple (slots are compile-time).  r05: the TWO-wave 3x3 workgroups (64-column layers: the
   // encoder's 240 x 320 residual blocks) take a 3-slot ring -- 40 KB of LDS per workgroup instead of 52: FOUR workgroups per CU = two
   // waves per SIMD instead of three = 1.5.  Their records are requested two steps ahead (L2-resident weights: 36 K values per layer).
-  constexpr bool RING3 = RS_RING3 && SPATIAL && NW == 2 && NI == 1 && SMI == 5;
-  constexpr int NBST = SPATIAL ? (RING3 ? 3 : 6) : 5;
+  constexpr bool RING3 = RS_RING3 && TT == 9 && NW == 2 && NI == 1 && SMI == 5;
+  constexpr int NBST = SPATIAL ? (RING3 ? 3 : (S2 ? 4 : 6)) : 5;
   static_assert((2 * TT) % NBST == 0 && NBST - 2 < TT - 1, "ring period");
   constexpr int NT_ = NW * 64;
   constexpr int ARV = SPATIAL ? SHR : SM + 2 * SHALO;      // staged rows that carry data (216 / 168)
@@ -338,7 +339,7 @@ __global__ __launch_bounds__(NW * 64, NI == 2 ? 1 : 2) void conv_strip_f16x3_ker
       const int hy_ = j_ / SHW, y_ = py0_ - 1 + hy_, x_ = px0_ - 1 + (j_ - hy_ * SHW);                       \
       const bool ok_ = j_ < SHR && static_cast<unsigned>(y_) < static_cast<unsigned>(p.U) &&                 \
                        static_cast<unsigned>(x_) < static_cast<unsigned>(p.V);                               \
-      OUT_ = ok_ ? img_ * UV + y_ * p.V + x_ : -1;                                                           \
+      OUT_ = ok_ ? img_ * (p.Uin * p.Vin) + y_ * p.su + x_ * p.sv : -1;    /* (stride 1: Uin x Vin = U x V, su = V, sv = 1; stride 2: a parity plane) */ \
     } else {                                                                                                 \
       const int m_ = m0 - SHALO + j_;                                                                        \
       const bool ok_ = j_ < ARV && m_ >= 0 && m_ < Mtot;                                                     \
@@ -511,8 +512,9 @@ __global__ __launch_bounds__(NW * 64, NI == 2 ? 1 : 2) void conv_strip_f16x3_ker
     if ((K_) < NI) fb_h[SET_][(K_)] = *reinterpret_cast<const h8*>(sB + (BS_) * BREC + (K_) * 2048 + boff);  \
     else if (P1) {                 /* (single product: weights hi x NI, activations hi x SMI) */                 \
       const int mi_ = (K_) - NI;                                                                             \
-      const int dyq_ = (TN_) / 3;                                                                            \
-      const int ad_ = SPATIAL ? aad[mi_][dyq_ == 1 ? 1 : 0] + (dyq_ == 2 ? 2 * SHW * 32 : 0) + ((TN_) - 3 * dyq_) * 32 \
+      const int tn9_ = S2 ? ((TN_) >> 1) * 3 + ((TN_) & 1) : (TN_);     /* 2x2 taps (dy, dx) in {0, 1}^2 of the 3x3 halo geometry */ \
+      const int dyq_ = tn9_ / 3;                                                                             \
+      const int ad_ = SPATIAL ? aad[mi_][dyq_ == 1 ? 1 : 0] + (dyq_ == 2 ? 2 * SHW * 32 : 0) + (tn9_ - 3 * dyq_) * 32 \
                               : aad[mi_][SPATIAL ? 0 : (TN_)];                                               \
       fa_h[SET_][mi_] = *reinterpret_cast<const h8*>(lds + (AS_) * ASLOT + ad_);                             \
     }                                                                                                        \
@@ -521,8 +523,9 @@ __global__ __launch_bounds__(NW * 64, NI == 2 ? 1 : 2) void conv_strip_f16x3_ker
     else {                                                                                                   \
       const bool lo_ = (K_) < NI + SMI;                                                                      \
       const int mi_ = lo_ ? (K_) - NI : (K_) - 2 * NI - SMI;                                                 \
-      const int dyq_ = (TN_) / 3;                                                                            \
-      const int ad_ = SPATIAL ? aad[mi_][dyq_ == 1 ? 1 : 0] + (dyq_ == 2 ? 2 * SHW * 32 : 0) + ((TN_) - 3 * dyq_) * 32 \
+      const int tn9_ = S2 ? ((TN_) >> 1) * 3 + ((TN_) & 1) : (TN_);                                          \
+      const int dyq_ = tn9_ / 3;                                                                             \
+      const int ad_ = SPATIAL ? aad[mi_][dyq_ == 1 ? 1 : 0] + (dyq_ == 2 ? 2 * SHW * 32 : 0) + (tn9_ - 3 * dyq_) * 32 \
                               : aad[mi_][SPATIAL ? 0 : (TN_)];                                               \
       if (lo_) fa_l[SET_][mi_] = *reinterpret_cast<const h8*>(lds + (AS_) * ASLOT + PLANE + ad_);            \
       else fa_h[SET_][mi_] = *reinterpret_cast<const h8*>(lds + (AS_) * ASLOT + ad_);                        \
@@ -637,6 +640,9 @@ __global__ __launch_bounds__(NW * 64, NI == 2 ? 1 : 2) void conv_strip_f16x3_ker
     if constexpr (TT == 5) {
       RS_STEP(0, 0) RS_STEP(0, 1) RS_STEP(0, 2) RS_STEP(0, 3) RS_STEP(0, 4)
       RS_STEP(1, 0) RS_STEP(1, 1) RS_STEP(1, 2) RS_STEP(1, 3) RS_STEP(1, 4)
+    } else if constexpr (TT == 4) {
+      RS_STEP(0, 0) RS_STEP(0, 1) RS_STEP(0, 2) RS_STEP(0, 3)
+      RS_STEP(1, 0) RS_STEP(1, 1) RS_STEP(1, 2) RS_STEP(1, 3)
     } else {
       RS_STEP(0, 0) RS_STEP(0, 1) RS_STEP(0, 2) RS_STEP(0, 3) RS_STEP(0, 4) RS_STEP(0, 5) RS_STEP(0, 6) RS_STEP(0, 7) RS_STEP(0, 8)
       RS_STEP(1, 0) RS_STEP(1, 1) RS_STEP(1, 2) RS_STEP(1, 3) RS_STEP(1, 4) RS_STEP(1, 5) RS_STEP(1, 6) RS_STEP(1, 7) RS_STEP(1, 8)
@@ -652,10 +658,11 @@ __global__ __launch_bounds__(NW * 64, NI == 2 ? 1 : 2) void conv_strip_f16x3_ker
   // map, h, z) are requested before the block goes through LDS (conv_igemm.hip has the history of this order).
   constexpr int ES = 32 * NI + 4, F4 = 8 * NI, KG = 4 * NI;       // row stride of the staging tile (floats), float4 per row, row groups per block
   float* S_ = reinterpret_cast<float*>(sB);              // 32 x ES floats = 4.5 / 8.5 KB <= the ring's 10 / 24 KB
-  if constexpr (RING3) {                                 // (a 6-KB ring does not hold the fast epilogue's two staging tiles: 9 KB per wave
-    wg_barrier();                                        //  from the activation slots, once every wave is done reading them)
+  constexpr bool EPI_IN_ASLOTS = NBST * BREC < 2 * 32 * ES * 4;      // a 3- / 4-slot ring (6 / 8 KB) does not hold the fast epilogue's two staging
+  if constexpr (EPI_IN_ASLOTS) {                                      // tiles (9 KB per wave): they are laid over the whole LDS block from its start
+    wg_barrier();                                                     // (activation slots, then rings) once EVERY wave has left the main loop
     S_ = reinterpret_cast<float*>(lds + wave * (2 * 32 * ES * 4));
-    static_assert(!RING3 || NW * 2 * 32 * (32 * NI + 4) * 4 <= 2 * ASLOT, "epilogue staging in the activation slots");
+    static_assert(!EPI_IN_ASLOTS || NW * 2 * 32 * (32 * NI + 4) * 4 <= LDSB, "epilogue staging inside the workgroup's LDS block");
   }
   const int colw = ct32 * 32;
   const int colq = colw + (lane % F4) * 4;
@@ -842,6 +849,17 @@ __global__ __launch_bounds__(NW * 64, NI == 2 ? 1 : 2) void conv_strip_f16x3_ker
 template <int SMI_, bool P1_ = false>
 int strip_launch_height(const KParams& p, int nw, int ni, bool spatial, bool hlin, bool norm, unsigned nwg, hipStream_t st) {
   const dim3 grid(nwg), block(nw * 64);
+  if (p.stride == 2) {          // the 2x2-tap form of a stride-2 3x3 layer: fp32 source through registers, 160-row strips, one tile per wave
+    if constexpr (SMI_ == 5 && !P1_) {
+      if (ni != 1 || hlin || norm || !spatial) return 1;
+      if (nw == 2) hipLaunchKernelGGL((conv_strip_f16x3_kernel<2, 4, 1, 1, SMI_, false>), grid, block, 0, st, p);
+      else if (nw == 3) hipLaunchKernelGGL((conv_strip_f16x3_kernel<3, 4, 1, 1, SMI_, false>), grid, block, 0, st, p);
+      else hipLaunchKernelGGL((conv_strip_f16x3_kernel<4, 4, 1, 1, SMI_, false>), grid, block, 0, st, p);
+      return 0;
+    } else {
+      return 1;
+    }
+  }
 #define RS_LAUNCH(NW_, NI_)                                                                                               \
   if (spatial) {                                                                                                          \
     if (norm) hipLaunchKernelGGL((conv_strip_f16x3_kernel<NW_, 9, 2, NI_, SMI_, P1_>), grid, block, 0, st, p);                 \

@@ -897,3 +897,40 @@ def test_conv_tile_stats_with_narrow_sources_fall_back_to_the_128_row_kernels(op
     d.tile_stats_records = B * tpi
     assert lib.rnnpose_conv2d_nhwc_f16x3(C.byref(d), None) == 0
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout,stats", [(8, 240, 320, 64, 96, True), (8, 120, 160, 96, 128, True), (2, 240, 320, 64, 96, False),
+                                                     (3, 96, 160, 32, 64, True), (2, 100, 112, 64, 96, True)])
+def test_conv_stride2_strips_over_parity_planes(ops, B, H, W, cin, cout, stats):
+    """r05: a stride-2 3x3 layer as a stride-1 layer with 2 x 2 taps over the four parity planes of its input --
+    strided views of the NHWC source -- on 160-row strips (csrc/conv_strip.hip).  The encoder's l2.0.c1 / l3.0.c1 shapes at the headline
+    resolution, a smaller batch, a two-wave shape and a ragged patch grid: against torch in fp64, against the 128-row kernel's stride-2
+    mode (same products, another summation order), with the fp64 tile statistics the following instance norm consumes."""
+    x = syn.normal("s2.x", (B, cin, H, W), 6, std=1.5) + 0.3
+    w = syn.normal("s2.w", (cout, cin, 3, 3), 6, std=float(np.sqrt(2.0 / (cin * 9))))
+    b = syn.uniform("s2.b", (cout,), 6, -0.5, 0.5)
+    pc = ops.PackedConv(D(w), D(b), [cin])
+    xs = nhwc(D(x))
+    Ho, Wo = H // 2, W // 2
+    y64 = F.conv2d(D(x).double(), D(w).double(), D(b).double(), stride=2, padding=1)
+    outs = {}
+    try:
+        for mode in (1, 5):                                   # 1: automatic (the strip form where it applies), 5: without the stride-2 form
+            ops.conv_strip(mode)
+            tpi = ops.conv_tiles_per_image(H, W, 3, 3, 2, cout, 0, B, src_counts=[cin])
+            out = torch.full((B, Ho, Wo, cout), 7.0, device="cuda")
+            ts = torch.full((B * tpi, cout, 2), -1.0, device="cuda", dtype=torch.float64) if stats else None
+            ops.conv2d_nhwc(pc, [(xs, 0)], (out, 0), ops.EPI_LINEAR, stride=2, tile_stats=ts, src_bounded=True)
+            outs[mode] = (out, ts, tpi)
+    finally:
+        ops.conv_strip(1)
+    if H >= 120 and W >= 160:       # the encoder's shapes: the strip form must actually be taken (10 x 16 patches of the OUTPUT grid)
+        assert outs[1][2] == -(-Ho // 10) * -(-Wo // 16) and outs[5][2] == -(-(Ho * Wo) // 128), (outs[1][2], outs[5][2])
+    scale = float(y64.abs().max())
+    for mode, (out, ts, tpi) in outs.items():
+        err = float((nchw(out).double() - y64).abs().max())
+        assert err <= 3e-6 * scale + 1e-6, (mode, err, scale)
+        if stats:
+            want = torch.stack([y64.sum((2, 3)), (y64 * y64).sum((2, 3))], -1)
+            assert float((ts.view(B, tpi, cout, 2).sum(1) - want).abs().max()) <= 2e-5 * float(want.abs().max()), mode
+    assert float((outs[1][0] - outs[5][0]).abs().max()) <= 2e-6 * scale + 1e-6

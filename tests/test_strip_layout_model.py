@@ -227,11 +227,11 @@ def _simulate_ring(TT, NBST, ring3, PAW, NI, NHB, mode0, swap=None):
 
 
 @pytest.mark.parametrize("TT,NBST,ring3,PAW,NI", [(9, 6, False, 4, 1), (9, 6, False, 7, 1), (9, 6, False, 7, 2), (5, 5, False, 3, 1), (5, 5, False, 6, 2),
-                                                  (9, 3, True, 7, 1), (9, 3, True, 9, 1)])
+                                                  (9, 3, True, 7, 1), (9, 3, True, 9, 1), (4, 4, False, 4, 1), (4, 4, False, 5, 1), (4, 4, False, 7, 1)])
 @pytest.mark.parametrize("mode0", [True, False])
 def test_weight_ring_wait_counts(TT, NBST, ring3, PAW, NI, mode0):
-    """The counted waits of RS_STEP for every ring the kernel instantiates: 6 slots (3x3), 5 (1x5 / 5x1) and -- r05 -- 3 slots for the
-    two-wave 3x3 workgroups, whose last tap requests the weight record BEFORE the activation half block so that the next step can wait
+    """The counted waits of RS_STEP for every ring the kernel instantiates: 6 slots (3x3), 5 (1x5 / 5x1) and -- r05 -- 4 slots for the
+    2x2-tap form of the stride-2 layers and 3 slots for the two-wave 3x3 workgroups, whose last tap requests the weight record BEFORE the activation half block so that the next step can wait
     for the record (vmcnt(PAW)) and leave the half block in flight."""
     assert (2 * TT) % NBST == 0 and NBST - 2 < TT - 1
     assert _simulate_ring(TT, NBST, ring3, PAW, NI, NHB=8, mode0=mode0)
