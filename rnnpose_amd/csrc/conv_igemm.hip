@@ -891,6 +891,7 @@ int rnnpose_conv_tiles_per_image(int H, int W, int kh, int kw, int stride) {
 static int desc_strip_rows(const rnnpose_conv_desc_t* d) {
   if (d->stride == 2) {      // the parity-plane form: ONE fp32 source of whole 32-channel blocks, no fused normalisation, <= MAX_CB blocks over the four planes
     if (d->n_src != 1 || d->src[0].c_count % 32 != 0 || d->src_hl || d->src0_mean_rstd || 4 * (d->src[0].c_count / 32) > MAX_CB || d->tile == 6) return 0;
+    if (!((d->kh == 3 && d->kw == 3) || (d->kh == 1 && d->kw == 1))) return 0;
   }
   if (d->tile >= 5) return strip_rows(d->H, d->W, d->kh, d->kw, d->stride, d->c_out, d->B, d->tile == 5 ? 160 : 32);
   if (d->tile != 0 || !g_conv_strip) return 0;
@@ -908,7 +909,8 @@ int rnnpose_conv_tiles_per_image_desc(const rnnpose_conv_desc_t* d) {
     return -1;
   const int rows = desc_strip_rows(d);
   if (d->tile >= 5 && rows == 0) return -1;
-  if (rows) return strip_tiles_per_image(d->H / d->stride, d->W / d->stride, d->kh, d->kw, rows);       // (tiles of the OUTPUT grid; stride 2: even sizes only)
+  if (rows) return d->stride == 2 ? strip_tiles_per_image(d->H / 2, d->W / 2, 3, 3, rows)      // (tiles of the OUTPUT grid, 10 x 16 patches; even sizes only)
+                                  : strip_tiles_per_image(d->H, d->W, d->kh, d->kw, rows);
   return rnnpose_conv_tiles_per_image(d->H, d->W, d->kh, d->kw, d->stride);
 }
 
@@ -924,7 +926,7 @@ int rnnpose_conv_tiles_per_image_ex(int H, int W, int kh, int kw, int stride, in
   if (tile >= 5) rows = strip_rows(H, W, kh, kw, stride, c_out, batch, tile == 5 ? 160 : 32);
   else if (tile == 0 && g_conv_strip) rows = strip_rows(H, W, kh, kw, stride, c_out, batch, 0);
   if (tile >= 5 && rows == 0) return -1;
-  if (rows) return strip_tiles_per_image(H / stride, W / stride, kh, kw, rows);
+  if (rows) return stride == 2 ? strip_tiles_per_image(H / 2, W / 2, 3, 3, rows) : strip_tiles_per_image(H, W, kh, kw, rows);
   return rnnpose_conv_tiles_per_image(H, W, kh, kw, stride);
 }
 
@@ -1100,14 +1102,16 @@ int rnnpose_conv2d_nhwc_f16x3(const rnnpose_conv_desc_t* d, rnnpose_stream_t str
       // 2 x 2 taps per plane (conv_strip.hip: pack_strip_s2_kernel has the tap table).  p.U / p.V are the output extents already.
       const rnnpose_conv_src_t& sr = d->src[0];
       const int nb = sr.c_count / BK;
-      for (int k = 0; k < 4; ++k) {
-        const Seg sg{sr.ptr + (static_cast<long long>(k >> 1) * d->W + (k & 1)) * sr.c_stride, sr.c_stride, sr.c_offset, sr.c_count};
-        (k == 0 ? p.seg0 : k == 1 ? p.seg1 : k == 2 ? p.seg2 : p.seg3) = sg;
-      }
-      p.cb1 = nb; p.cb2 = 2 * nb; p.cb3 = 3 * nb; p.ncb = 4 * nb;
+      if (d->kh == 3) {
+        for (int k = 0; k < 4; ++k) {
+          const Seg sg{sr.ptr + (static_cast<long long>(k >> 1) * d->W + (k & 1)) * sr.c_stride, sr.c_stride, sr.c_offset, sr.c_count};
+          (k == 0 ? p.seg0 : k == 1 ? p.seg1 : k == 2 ? p.seg2 : p.seg3) = sg;
+        }
+        p.cb1 = nb; p.cb2 = 2 * nb; p.cb3 = 3 * nb; p.ncb = 4 * nb;
+        p.wpk_strip = reinterpret_cast<const uint4*>(reinterpret_cast<const _Float16*>(p.wpk_strip) + static_cast<long long>(nb) * 2 * 9 * p.Npad * 32);   // behind the stride-1 strip copy
+      }                        // (1x1: plane (0, 0) = segment 0 as it stands, one tap in four; its packed copy sits right behind the first one)
       p.su = 2 * d->W; p.sv = 2; p.Uin = d->H; p.Vin = d->W;
       p.G = 1; p.du0 = 0; p.dv0 = 0;
-      p.wpk_strip = reinterpret_cast<const uint4*>(reinterpret_cast<const _Float16*>(p.wpk_strip) + static_cast<long long>(nb) * 2 * 9 * p.Npad * 32);   // behind the stride-1 strip copy
       return strip_launch(p, Ho, Wo, d->kh, d->kw, false, per_image, rows, rp::as_stream(stream));
     }
     if (rows) {          // (a forced strip launch whose sources do not fit surfaces its error in strip_launch)

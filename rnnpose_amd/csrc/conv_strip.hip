@@ -77,7 +77,7 @@ __global__ void pack_strip_kernel(const float* __restrict__ w, _Float16* __restr
 // [plane p = 2 py + px][channel]: [half block of 4 Cin channels][tap t = 2 ty + tx][32-column tile] records of 2 KB.
 __global__ void pack_strip_s2_kernel(const float* __restrict__ w, _Float16* __restrict__ pk, const PackParams q) {
   const int nt32 = q.Npad / 32;
-  const long long total = static_cast<long long>(4 * q.ncb) * 2 * 4 * q.Npad * 32;
+  const long long total = static_cast<long long>((q.kh == 1 ? 1 : 4) * q.ncb) * 2 * 4 * q.Npad * 32;
   const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int j8 = static_cast<int>(i & 7);
@@ -97,7 +97,9 @@ __global__ void pack_strip_s2_kernel(const float* __restrict__ w, _Float16* __re
   const int ci = blk * 32 + kk * 16 + g * 8 + j8;
   const int n = ctile * 32 + n32;
   float v = 0.f;
-  if (n < q.Cout && ci < q.Cin && ky >= 0 && kx >= 0) v = w[((static_cast<long long>(n) * q.Cin + ci) * 3 + ky) * 3 + kx] * q.w_scale;
+  if (q.kh == 1) {        // 1x1 stride 2 (the encoder's down-sampling branches): plane (0, 0) only, the centre tap only
+    if (n < q.Cout && ci < q.Cin && tap == 3) v = w[static_cast<long long>(n) * q.Cin + ci] * q.w_scale;
+  } else if (n < q.Cout && ci < q.Cin && ky >= 0 && kx >= 0) v = w[((static_cast<long long>(n) * q.Cin + ci) * 3 + ky) * 3 + kx] * q.w_scale;
   const _Float16 h = static_cast<_Float16>(v);
   pk[i] = part == 0 ? h : static_cast<_Float16>(v - static_cast<float>(h));
 }
@@ -153,11 +155,13 @@ void strip_allow_s2(int on) { g_strip_s2 = on; }
 // the 128-row kernel, 30-48 on 160-row strips; at 14 400 pixels (16 crops) the 128-row kernel is 0.5-1 % ahead of 32-row strips on
 // the step, at 19 200 (B = 4 of the headline) they are equal.  (64-row strips were built too: never the best of the three.)
 int strip_rows(int H, int W, int kh, int kw, int stride, int c_out, int batch, int request) {
-  if ((stride != 1 && stride != 2) || !strip_kernel_shape(kh, kw) || strip_waves(c_out) == 0) return 0;
+  const bool s2_1x1 = stride == 2 && kh == 1 && kw == 1;
+  if ((stride != 1 && stride != 2) || !(strip_kernel_shape(kh, kw) || s2_1x1) || strip_waves(c_out) == 0) return 0;
   const int cfg = strip_waves(c_out), ni = cfg >> 4, nwt = (cfg & 15) * ni;         // 32-column wave tiles per workgroup
-  if (stride == 2) {      // r05: the 2x2-tap form over the parity planes: 3x3, even input size, 160-row strips on the OUTPUT grid, one tile per wave
-    if (!g_strip_s2 || !(kh == 3 && kw == 3) || (H & 1) || (W & 1) || ni != 1 || request == 32) return 0;
+  if (stride == 2) {      // r05: the 2x2-tap form over the parity planes: 3x3 (or 1x1: one plane), even input size, 160-row strips on the OUTPUT grid, one tile per wave
+    if (!g_strip_s2 || !((kh == 3 && kw == 3) || s2_1x1) || (H & 1) || (W & 1) || ni != 1 || request == 32) return 0;
     H >>= 1; W >>= 1;
+    kh = kw = 3;          // (tiled like a 3x3 layer: 10 x 16 patches)
   }
   if (request != 0) return (request == 160 || (request == 32 && ni == 1)) ? request : 0;
   if ((cfg & 15) == 2 && ni == 1 && g_strip_two_wave == 0) return 0;      // (two-wave workgroups, c_out <= 64: see strip_allow_two_wave)
@@ -183,6 +187,11 @@ int strip_rows(int H, int W, int kh, int kw, int stride, int c_out, int batch, i
 }
 
 void strip_pack(const float* w, _Float16* pk, const PackParams& q, hipStream_t st) {
+  if (q.kh == 1 && q.kw == 1) {       // 1x1: no stride-1 strip form; the stride-2 form (one plane, one tap in four) right behind the first copy
+    const long long t1 = strip_s2_halfs(q.Cin, 1, 1, q.ncb, q.Npad, q.seg_count[1] == 0 && q.seg_count[2] == 0 && q.seg_count[3] == 0 ? 1 : 2);
+    if (t1 > 0) hipLaunchKernelGGL(pack_strip_s2_kernel, dim3(rp::cdiv(t1, 256)), dim3(256), 0, st, w, pk, q);
+    return;
+  }
   if (!strip_kernel_shape(q.kh, q.kw)) return;        // (the second copy stays unwritten: never read for other shapes)
   const int TT = q.kh * q.kw;
   const long long total = static_cast<long long>(q.ncb) * 2 * TT * q.Npad * 32;
@@ -193,13 +202,17 @@ void strip_pack(const float* w, _Float16* pk, const PackParams& q, hipStream_t s
 
 // fp16 elements of the stride-2 copy of a layer's packed weights (0: the layer has none): 3x3, ONE source of whole 32-channel blocks
 long long strip_s2_halfs(int c_in, int kh, int kw, int ncb, int Npad, int n_seg) {
-  if (!(kh == 3 && kw == 3) || n_seg != 1 || c_in % 32 != 0 || 4 * ncb > MAX_CB) return 0;
+  if (n_seg != 1 || c_in % 32 != 0) return 0;
+  if (kh == 1 && kw == 1) return static_cast<long long>(ncb) * 2 * 4 * Npad * 32;          // one plane
+  if (!(kh == 3 && kw == 3) || 4 * ncb > MAX_CB) return 0;
   return static_cast<long long>(4 * ncb) * 2 * 4 * Npad * 32;
 }
 
 int strip_launch(KParams& p, int H, int W, int kh, int kw, bool hlin, bool per_image, int rows, hipStream_t st) {
   const char* fn = "rnnpose_conv2d_nhwc_f16x3";
-  RP_REQUIRE(strip_kernel_shape(kh, kw) && (p.stride == 1 || (p.stride == 2 && kh == 3 && kw == 3)), fn, "strip kernel: 3x3, 1x5 or 5x1, stride 1 (3x3: also stride 2)");
+  RP_REQUIRE((strip_kernel_shape(kh, kw) && p.stride == 1) || (p.stride == 2 && ((kh == 3 && kw == 3) || (kh == 1 && kw == 1))), fn,
+             "strip kernel: 3x3, 1x5 or 5x1, stride 1; 3x3 or 1x1, stride 2");
+  if (p.stride == 2) kh = kw = 3;        // (the stride-2 forms run the 3x3 geometry: 10 x 16 patches, 2 x 2 taps)
   const int cfg = strip_waves(p.Cout);
   RP_REQUIRE(cfg != 0, fn, "strip kernel: c_out must exceed 32");
   const int ni = cfg >> 4, nw = cfg & 15;

@@ -899,25 +899,27 @@ def test_conv_tile_stats_with_narrow_sources_fall_back_to_the_128_row_kernels(op
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("k", [3, 1])
 @pytest.mark.parametrize("B,H,W,cin,cout,stats", [(8, 240, 320, 64, 96, True), (8, 120, 160, 96, 128, True), (2, 240, 320, 64, 96, False),
                                                      (3, 96, 160, 32, 64, True), (2, 100, 112, 64, 96, True)])
-def test_conv_stride2_strips_over_parity_planes(ops, B, H, W, cin, cout, stats):
+def test_conv_stride2_strips_over_parity_planes(ops, B, H, W, cin, cout, stats, k):
     """r05: a stride-2 3x3 layer as a stride-1 layer with 2 x 2 taps over the four parity planes of its input --
     strided views of the NHWC source -- on 160-row strips (csrc/conv_strip.hip).  The encoder's l2.0.c1 / l3.0.c1 shapes at the headline
     resolution, a smaller batch, a two-wave shape and a ragged patch grid: against torch in fp64, against the 128-row kernel's stride-2
-    mode (same products, another summation order), with the fp64 tile statistics the following instance norm consumes."""
+    mode (same products, another summation order), with the fp64 tile statistics the following instance norm consumes.  k = 1: the 1x1
+    stride-2 down-sampling branches (extractor.py:36-39) in the same form -- plane (0, 0) only, one tap in four."""
     x = syn.normal("s2.x", (B, cin, H, W), 6, std=1.5) + 0.3
-    w = syn.normal("s2.w", (cout, cin, 3, 3), 6, std=float(np.sqrt(2.0 / (cin * 9))))
+    w = syn.normal("s2.w", (cout, cin, k, k), 6, std=float(np.sqrt(2.0 / (cin * k * k))))
     b = syn.uniform("s2.b", (cout,), 6, -0.5, 0.5)
     pc = ops.PackedConv(D(w), D(b), [cin])
     xs = nhwc(D(x))
     Ho, Wo = H // 2, W // 2
-    y64 = F.conv2d(D(x).double(), D(w).double(), D(b).double(), stride=2, padding=1)
+    y64 = F.conv2d(D(x).double(), D(w).double(), D(b).double(), stride=2, padding=k // 2)
     outs = {}
     try:
         for mode in (1, 5):                                   # 1: automatic (the strip form where it applies), 5: without the stride-2 form
             ops.conv_strip(mode)
-            tpi = ops.conv_tiles_per_image(H, W, 3, 3, 2, cout, 0, B, src_counts=[cin])
+            tpi = ops.conv_tiles_per_image(H, W, k, k, 2, cout, 0, B, src_counts=[cin])
             out = torch.full((B, Ho, Wo, cout), 7.0, device="cuda")
             ts = torch.full((B * tpi, cout, 2), -1.0, device="cuda", dtype=torch.float64) if stats else None
             ops.conv2d_nhwc(pc, [(xs, 0)], (out, 0), ops.EPI_LINEAR, stride=2, tile_stats=ts, src_bounded=True)
