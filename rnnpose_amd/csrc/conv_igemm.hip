@@ -917,7 +917,7 @@ int rnnpose_conv_tiles_per_image_desc(const rnnpose_conv_desc_t* d) {
 int rnnpose_conv_products_desc(const rnnpose_conv_desc_t* d) {
   if (!d || rnnpose_conv_tiles_per_image_desc(d) < 0) return -1;
   const int rows = desc_strip_rows(d);
-  return (d->single_product && rows == 160 && (strip_waves(d->c_out) >> 4) == 1) ? 1 : 3;      // (the rule of strip_launch: P1 = 160-row strips, one column tile per wave)
+  return (d->single_product && rows == 160 && d->stride == 1 && (strip_waves(d->c_out) >> 4) == 1) ? 1 : 3;      // (the rule of strip_launch: P1 = 160-row strips, one column tile per wave)
 }
 
 int rnnpose_conv_tiles_per_image_ex(int H, int W, int kh, int kw, int stride, int c_out, int tile, int batch) {

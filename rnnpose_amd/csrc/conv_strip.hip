@@ -256,7 +256,7 @@ int strip_launch(KParams& p, int H, int W, int kh, int kw, bool hlin, bool per_i
   }
   const unsigned nwg = static_cast<unsigned>(p.n_mt) * p.n_nt;
   int bad;
-  if (rows == 160 && p.single_product && ni == 1) bad = strip_launch_p1(p, nw, ni, spatial, hlin, norm, nwg, st);
+  if (rows == 160 && p.single_product && ni == 1 && p.stride == 1) bad = strip_launch_p1(p, nw, ni, spatial, hlin, norm, nwg, st);      // (the stride-2 forms keep three products)
   else if (rows == 160) bad = strip_launch_height<5>(p, nw, ni, spatial, hlin, norm, nwg, st);
   else bad = strip_launch_r32(p, nw, ni, spatial, hlin, norm, nwg, st);
   RP_REQUIRE(!bad, fn, "strip kernel: no kernel for this workgroup shape and strip height");

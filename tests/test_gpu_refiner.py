@@ -361,3 +361,37 @@ def test_mixed_precision_mode_runs_the_single_product_kernels(ops):
     dG, dF = float((outs[0][0] - outs[1][0]).abs().max()), float((outs[0][1] - outs[1][1]).abs().max())
     fmax = float(outs[0][1].abs().max())
     assert 1e-6 < dF < 2e-2 * max(fmax, 1.0) and dG < 2e-3, (dG, dF, fmax)
+
+
+def test_mixed_precision_with_the_encoder_in_the_loop(ops):
+    """cfg.raft.mixed_precision through EVERY convolution family the loop launches, the encoder included: single-product 160-row strips
+    where they exist, three products elsewhere -- in particular the stride-2 strip forms (r05), which have no single-product
+    instantiation (a launch that asked for one failed the whole forward until the dispatch learned that)."""
+    from rnnpose_amd.pose_refiner import PoseRefiner, SyntheticRenderer, default_config
+    from rnnpose_amd.transformation import SE3Sequence
+    B, H, W = 8, 480, 640
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    r = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    g1, g2 = r(B, 32, H, W), r(B, 32, H, W)
+    g1 /= g1.norm(dim=1, keepdim=True)
+    g2 /= g2.norm(dim=1, keepdim=True)
+    depth = torch.rand(B, 1, H, W, device="cuda", generator=g) * 0.3 + 0.9
+    depth[:, :, : H // 4] = 0
+    K = torch.tensor([[572.4114, 0, W / 2], [0, 573.57043, H / 2], [0, 0, 1]], device="cuda").repeat(B, 1, 1)
+    G0 = T(syn.se3_exp_np(syn.normal("g0", (B, 6), 4, std=0.02)).astype(np.float32)).cuda()[:, None]
+    rend = SyntheticRenderer(syn_img=torch.rand(B, 3, H, W, device="cuda", generator=g) * 255, image_crop=torch.rand(B, 3, H, W, device="cuda", generator=g) * 255,
+                             cfea=0.1 * r(B, 256, H, W), geofea1=g1, geofea2_crop=g2, syn_depth=depth, intrinsics_crop=K)
+    outs = []
+    for mixed in (False, True):
+        cfg = default_config(RENDER_ITER_COUNT=1, ITER_COUNT=2, OPTIM_ITER_COUNT=1)
+        cfg.raft.mixed_precision = mixed
+        torch.manual_seed(0)
+        ref = PoseRefiner(cfg, renderer=rend).cuda().eval()
+        ref.cf_net.update_block.load_state_dict({k: T(v) for k, v in syn.make_module_weights(orc.UPDATE_BLOCK_SHAPES, seed=0).items()})
+        for _ in range(2):
+            out = ref(None, SE3Sequence(matrix=G0.clone()), K)
+        outs.append(out["flow_last"].clone())
+    assert torch.isfinite(outs[1]).all()
+    d = float((outs[0] - outs[1]).abs().max())
+    assert 1e-6 < d < 5e-2 * max(1.0, float(outs[0].abs().max())), d
