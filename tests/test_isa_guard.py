@@ -23,7 +23,17 @@ EXPECT = {
 }
 
 
+_ISA_CACHE = {}
+
+
 def _isa(src, tmp_path):
+    """-> (ISA text, {kernel symbol: spilled VGPRs}) of one source file under the library's own flags; compiled once per session."""
+    if src not in _ISA_CACHE:
+        _ISA_CACHE[src] = _isa_compile(src, tmp_path)
+    return _ISA_CACHE[src]
+
+
+def _isa_compile(src, tmp_path):
     from rnnpose_amd import build
     out = tmp_path / (os.path.basename(src) + ".s")
     flags = [f for f in build.FLAGS if f not in ("-shared", "-fPIC")] + build.PER_FILE_FLAGS.get(os.path.basename(src), [])
