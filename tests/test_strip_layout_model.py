@@ -242,3 +242,76 @@ def test_three_slot_ring_needs_the_swapped_request_order():
     order -- the activation half block BEFORE the weight record at the last tap -- reads a record that is still in flight."""
     with pytest.raises(AssertionError):
         _simulate_ring(9, 3, True, 7, 1, NHB=4, mode0=False, swap=False)
+
+
+# ---- r05: the stride-2 form (TT = 4): packed order of pack_strip_s2_kernel + the kernel's tap / plane algebra == a stride-2 3x3 convolution ----
+def _pack_s2(w, Npad):
+    """csrc/conv_strip.hip pack_strip_s2_kernel, index decode restated: -> {(half block, tap, column, k in 0..15): weight} with
+    half blocks running over [plane p = 2 py + px][32-channel block][kk]."""
+    import numpy as np
+    Cout, Cin, kh, _ = w.shape
+    ncb = Cin // 32
+    planes = 1 if kh == 1 else 4
+    nt32 = Npad // 32
+    total = planes * ncb * 2 * 4 * Npad * 32
+    out = {}
+    for i in range(0, total, 1):
+        j8, pos, n32, part = i & 7, (i >> 3) & 1, (i >> 4) & 31, (i >> 9) & 1
+        if part:                       # (lo plane: the same value's remainder)
+            continue
+        ctile = (i >> 10) % nt32
+        st = (i >> 10) // nt32
+        tap, hbk = st % 4, st // 4
+        blk4, kk = hbk >> 1, hbk & 1
+        plane, blk = blk4 // ncb, blk4 % ncb
+        py, px, ty, tx = plane >> 1, plane & 1, tap >> 1, tap & 1
+        ky = (1 if ty == 1 else -1) if py == 0 else (0 if ty == 0 else 2)
+        kx = (1 if tx == 1 else -1) if px == 0 else (0 if tx == 0 else 2)
+        g = pos ^ ((n32 >> 3) & 1)
+        ci = blk * 32 + kk * 16 + g * 8 + j8
+        n = ctile * 32 + n32
+        v = 0.0
+        if kh == 1:
+            if n < Cout and tap == 3:
+                v = w[n, ci, 0, 0]
+        elif n < Cout and ky >= 0 and kx >= 0:
+            v = w[n, ci, ky, kx]
+        out[(hbk, tap, n, g * 8 + j8)] = v
+    return out, planes * ncb * 2
+
+
+@pytest.mark.parametrize("k", [3, 1])
+def test_stride2_form_is_the_stride2_convolution(k):
+    """What the TT = 4 instantiation computes, restated with its own integer expressions: for every half block hb (16 channels of
+    parity plane p = (hb / 2) / ncb) and tap t = 2 ty + tx, the staged tile of plane p is read at offset (ty - 1, tx - 1) of the
+    half-resolution grid (RS_READ1: 2x2 taps (dy, dx) in {0, 1}^2 of the 3x3 halo geometry), plane (py, px) pixel (y, x) being
+    source pixel (2 y + py, 2 x + px) (RS_ROW_PIXEL with su = 2 W, sv = 2 and the segment's start pixel) -- summed with the packed
+    weights it must be torch's stride-2 convolution with padding k // 2."""
+    import numpy as np
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(0)
+    B, Cin, Cout, H, W = 1, 32, 5, 8, 12
+    x = rng.standard_normal((B, Cin, H, W))
+    w = rng.standard_normal((Cout, Cin, k, k))
+    ref = F.conv2d(torch.from_numpy(x), torch.from_numpy(w), stride=2, padding=k // 2).numpy()
+    pk, nhb = _pack_s2(w, Npad=32)
+    ncb = Cin // 32
+    U, V = H // 2, W // 2
+    out = np.zeros((B, Cout, U, V))
+    for hb in range(nhb):
+        plane, blk, kk = (hb >> 1) // ncb, (hb >> 1) % ncb, hb & 1
+        py, px = plane >> 1, plane & 1
+        for t in range(4):
+            tn9 = (t >> 1) * 3 + (t & 1)                    # the kernel's tap index in the 3x3 halo geometry
+            dy, dx = tn9 // 3 - 1, tn9 % 3 - 1              # offset on the half-resolution grid: {-1, 0}
+            for y in range(U):
+                for xx in range(V):
+                    ys, xs = y + dy, xx + dx
+                    if not (0 <= ys < U and 0 <= xs < V):    # (halo rows outside the plane stage zeros)
+                        continue
+                    src = x[0, blk * 32 + kk * 16: blk * 32 + kk * 16 + 16, 2 * ys + py, 2 * xs + px]
+                    for n in range(Cout):
+                        wv = np.array([pk[(hb, t, n, c)] for c in range(16)])
+                        out[0, n, y, xx] += float(src @ wv)
+    assert np.abs(out - ref).max() < 1e-10
