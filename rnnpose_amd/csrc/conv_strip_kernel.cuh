@@ -94,6 +94,10 @@ __device__ unsigned long long g_strip_clk[8 * 65536];
 #ifndef RS_SLICE_BITS
 #define RS_SLICE_BITS 9    // (100-MHz clock: 2^9 ticks = 5.12 us)
 #endif
+#ifndef RS_S2_SKIP
+#define RS_S2_SKIP 0      // 1: the stride-2 form skips the MFMAs of its seven empty (plane, tap) slots instead of multiplying by their zero records.
+#endif                    // Built, right, and SLOWER (profiles/r05_ab_s2_skip.txt: l2.0.c1 139 vs 116 us, step 733 vs 745 iters/s): the branch takes the
+                          // fragment reads out from between the MFMAs and costs 21-41 spilled registers; the kernel is not MFMA-bound there
 #ifndef RS_RING3
 #define RS_RING3 1        // 0: the two-wave 3x3 workgroups keep the 6-slot weight ring (r04; same-box A/B)
 #endif
@@ -614,6 +618,13 @@ __global__ __launch_bounds__(NW * 64, NI == 2 ? 1 : 2) void conv_strip_f16x3_ker
       __builtin_amdgcn_sched_barrier(0);                                                                     \
     }                                                                                                        \
     if (RS_VAR & 1) __builtin_amdgcn_s_setprio(1);                                                           \
+    /* stride-2 form: a (plane, tap) slot that carries no weight (its packed record is zero) runs no MFMAs -- one wave-uniform branch \
+       around the step's MFMA block; the next step's fragment reads then stand in front of it instead of between the MFMAs */ \
+    if (S2 && RS_S2_SKIP) {                                                                                  \
+      _Pragma("unroll") for (int k = 0; k < NRD; ++k) RS_READ1(k, 1 - set_, tn_, asn_, (sl_ + 1) % NBST)     \
+      __builtin_amdgcn_sched_barrier(0);                                                                     \
+    }                                                                                                        \
+    if (!(S2 && RS_S2_SKIP) || ((s2_taps_ >> (T_)) & 1u)) {                                                  \
     _Pragma("unroll") for (int k = 0; k < NMM; ++k) {                                                        \
       if (!(RS_ABL & 8)) RS_MMA1(k, set_)                                                                    \
       if (RS_VAR & 8) {            /* variant: the step's bookkeeping between its last MFMAs instead of in front of the first */ \
@@ -621,7 +632,7 @@ __global__ __launch_bounds__(NW * 64, NI == 2 ? 1 : 2) void conv_strip_f16x3_ker
         if (last_ && k == 2 * SMI * NI + 1) { if (!(RS_ABL & 2)) { if constexpr (MODE == 0) { RS_ISSUE_A(H_) } else { RS_LOAD_A() } } } \
         if (k == 2 * SMI * NI + 2) { if (!(RS_ABL & 1)) RS_ISSUE_B((sl_ + NBST - 1) % NBST) }                \
       }                                                                                                      \
-      if (!(RS_VAR & 2)) {                                                                                   \
+      if (!(RS_VAR & 2) && !(S2 && RS_S2_SKIP)) {                                                           \
         constexpr int kr0_ = (RS_VAR & 4) ? 2 : 0;        /* variant: the first reads behind the third MFMA */ \
         const bool isb_ = (k - kr0_ < NI) || (k - kr0_ >= NI + SMI && k - kr0_ < 2 * NI + SMI);              \
         if (k >= kr0_ && k - kr0_ < NRD && !(RS_ABL & 4) && !((RS_ABL & 128) && !isb_) && !((RS_ABL & 256) && isb_)) \
@@ -629,14 +640,25 @@ __global__ __launch_bounds__(NW * 64, NI == 2 ? 1 : 2) void conv_strip_f16x3_ker
       }                                                                                                      \
       __builtin_amdgcn_sched_barrier(0);                                                                     \
     }                                                                                                        \
-    if constexpr (NRD > NMM && !(RS_VAR & 2)) {      /* (32-row strips: four fragment reads for three MFMAs) */   \
+    }                                                                                                        \
+    if constexpr (NRD > NMM && !(RS_VAR & 2) && !S2) {      /* (32-row strips: four fragment reads for three MFMAs) */   \
       _Pragma("unroll") for (int k = NMM; k < NRD; ++k) { if (!(RS_ABL & 4)) RS_READ1(k, 1 - set_, tn_, asn_, (sl_ + 1) % NBST) } \
       __builtin_amdgcn_sched_barrier(0);                                                                     \
     }                                                                                                        \
     if (RS_VAR & 1) __builtin_amdgcn_s_setprio(0);                                                           \
   }
   const unsigned slotpar_ = __builtin_amdgcn_s_getreg(6148) & 1u;       // HW_ID.wave_id (bits 3:0): the wave slot on this SIMD
+  // stride-2 form: which of the four 2x2 taps of the current parity plane carry a weight (bit t = 2 ty + tx).  Plane (py, px): row
+  // tap ty = 0 (offset -1) only for py = 1, column tap tx = 0 only for px = 1; the 1x1 form (p.gkw == 1): the centre tap of plane (0, 0).
+  // Both half blocks of a pair lie in one 32-channel block, i.e. in one plane.
+  unsigned s2_taps_ = 15u;
+  const int s2_nb_ = S2 ? (p.cb1 < p.ncb ? p.cb1 : p.ncb) : 1;          // 32-channel blocks per plane
   for (int hbp = 0; hbp < NHB; hbp += 2) {
+    if constexpr (S2) {
+      const int plane_ = (hbp >> 1) / s2_nb_;
+      const unsigned rows_ = (plane_ >> 1) ? 3u : 2u, cols_ = (plane_ & 1) ? 3u : 2u;     // valid ty / tx bits
+      s2_taps_ = p.gkw == 1 ? 8u : ((((rows_ & 1u) && (cols_ & 1u)) ? 1u : 0u) | ((rows_ & 1u) ? 2u : 0u) | ((cols_ & 1u) ? 4u : 0u) | 8u);
+    }
     if constexpr (TT == 5) {
       RS_STEP(0, 0) RS_STEP(0, 1) RS_STEP(0, 2) RS_STEP(0, 3) RS_STEP(0, 4)
       RS_STEP(1, 0) RS_STEP(1, 1) RS_STEP(1, 2) RS_STEP(1, 3) RS_STEP(1, 4)
