@@ -890,7 +890,7 @@ int rnnpose_conv_tiles_per_image(int H, int W, int kh, int kw, int stride) {
 // and otherwise falls back, with or without tile statistics (r04 raised an error there: ADVICE).  The ONE place this is decided.
 static int desc_strip_rows(const rnnpose_conv_desc_t* d) {
   if (d->stride == 2) {      // the parity-plane form: ONE fp32 source of whole 32-channel blocks, no fused normalisation, <= MAX_CB blocks over the four planes
-    if (d->n_src != 1 || d->src[0].c_count % 32 != 0 || d->src_hl || d->src0_mean_rstd || 4 * (d->src[0].c_count / 32) > MAX_CB || d->tile == 6) return 0;
+    if (d->n_src != 1 || d->src[0].c_count % 32 != 0 || d->src_hl || d->src0_mean_rstd || 4 * (d->src[0].c_count / 32) > MAX_CB) return 0;
     if (!((d->kh == 3 && d->kw == 3) || (d->kh == 1 && d->kw == 1))) return 0;
   }
   if (d->tile >= 5) return strip_rows(d->H, d->W, d->kh, d->kw, d->stride, d->c_out, d->B, d->tile == 5 ? 160 : 32);

@@ -159,7 +159,7 @@ int strip_rows(int H, int W, int kh, int kw, int stride, int c_out, int batch, i
   if ((stride != 1 && stride != 2) || !(strip_kernel_shape(kh, kw) || s2_1x1) || strip_waves(c_out) == 0) return 0;
   const int cfg = strip_waves(c_out), ni = cfg >> 4, nwt = (cfg & 15) * ni;         // 32-column wave tiles per workgroup
   if (stride == 2) {      // r05: the 2x2-tap form over the parity planes: 3x3 (or 1x1: one plane), even input size, 160-row strips on the OUTPUT grid, one tile per wave
-    if (!g_strip_s2 || !((kh == 3 && kw == 3) || s2_1x1) || (H & 1) || (W & 1) || ni != 1 || request == 32) return 0;
+    if (!g_strip_s2 || !((kh == 3 && kw == 3) || s2_1x1) || (H & 1) || (W & 1) || ni != 1) return 0;
     H >>= 1; W >>= 1;
     kh = kw = 3;          // (tiled like a 3x3 layer: 10 x 16 patches)
   }
@@ -181,7 +181,6 @@ int strip_rows(int H, int W, int kh, int kw, int stride, int c_out, int batch, i
   const long long t160 = strip_tiles_per_image(H, W, kh, kw, 160) * static_cast<long long>(ncol);
   const long long npix = nb * H * W;
   if (fits(160) && (t160 * nb >= 240 || (t160 >= 24 && npix > 8192))) return 160;
-  if (stride == 2) return 0;
   if (fits(32) && npix <= 8192 && strip_tiles_per_image(H, W, kh, kw, 32) * ncol * nb >= 24) return 32;
   return 0;
 }

@@ -641,7 +641,7 @@ __global__ __launch_bounds__(NW * 64, NI == 2 ? 1 : 2) void conv_strip_f16x3_ker
       __builtin_amdgcn_sched_barrier(0);                                                                     \
     }                                                                                                        \
     }                                                                                                        \
-    if constexpr (NRD > NMM && !(RS_VAR & 2) && !S2) {      /* (32-row strips: four fragment reads for three MFMAs) */   \
+    if constexpr (NRD > NMM && !(RS_VAR & 2) && !(S2 && RS_S2_SKIP)) {      /* (32-row strips: four fragment reads for three MFMAs) */   \
       _Pragma("unroll") for (int k = NMM; k < NRD; ++k) { if (!(RS_ABL & 4)) RS_READ1(k, 1 - set_, tn_, asn_, (sl_ + 1) % NBST) } \
       __builtin_amdgcn_sched_barrier(0);                                                                     \
     }                                                                                                        \
@@ -871,8 +871,8 @@ __global__ __launch_bounds__(NW * 64, NI == 2 ? 1 : 2) void conv_strip_f16x3_ker
 template <int SMI_, bool P1_ = false>
 int strip_launch_height(const KParams& p, int nw, int ni, bool spatial, bool hlin, bool norm, unsigned nwg, hipStream_t st) {
   const dim3 grid(nwg), block(nw * 64);
-  if (p.stride == 2) {          // the 2x2-tap form of a stride-2 3x3 layer: fp32 source through registers, 160-row strips, one tile per wave
-    if constexpr (SMI_ == 5 && !P1_) {
+  if (p.stride == 2) {          // the 2x2-tap form of a stride-2 3x3 / 1x1 layer: fp32 source through registers, one tile per wave, either strip height
+    if constexpr (!P1_) {
       if (ni != 1 || hlin || norm || !spatial) return 1;
       if (nw == 2) hipLaunchKernelGGL((conv_strip_f16x3_kernel<2, 4, 1, 1, SMI_, false>), grid, block, 0, st, p);
       else if (nw == 3) hipLaunchKernelGGL((conv_strip_f16x3_kernel<3, 4, 1, 1, SMI_, false>), grid, block, 0, st, p);

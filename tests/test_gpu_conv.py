@@ -901,11 +901,11 @@ def test_conv_tile_stats_with_narrow_sources_fall_back_to_the_128_row_kernels(op
 
 @pytest.mark.parametrize("k", [3, 1])
 @pytest.mark.parametrize("B,H,W,cin,cout,stats", [(8, 240, 320, 64, 96, True), (8, 120, 160, 96, 128, True), (2, 240, 320, 64, 96, False),
-                                                     (3, 96, 160, 32, 64, True), (2, 100, 112, 64, 96, True)])
+                                                     (3, 96, 160, 32, 64, True), (2, 100, 112, 64, 96, True), (2, 120, 120, 64, 96, True), (1, 60, 60, 96, 128, True)])
 def test_conv_stride2_strips_over_parity_planes(ops, B, H, W, cin, cout, stats, k):
     """r05: a stride-2 3x3 layer as a stride-1 layer with 2 x 2 taps over the four parity planes of its input --
     strided views of the NHWC source -- on 160-row strips (csrc/conv_strip.hip).  The encoder's l2.0.c1 / l3.0.c1 shapes at the headline
-    resolution, a smaller batch, a two-wave shape and a ragged patch grid: against torch in fp64, against the 128-row kernel's stride-2
+    resolution, a smaller batch, a two-wave shape, a ragged patch grid and the single-image crop's shapes (32-row strips): against torch in fp64, against the 128-row kernel's stride-2
     mode (same products, another summation order), with the fp64 tile statistics the following instance norm consumes.  k = 1: the 1x1
     stride-2 down-sampling branches (extractor.py:36-39) in the same form -- plane (0, 0) only, one tap in four."""
     x = syn.normal("s2.x", (B, cin, H, W), 6, std=1.5) + 0.3
