@@ -327,6 +327,10 @@ def main():
             traffic_note = ("profiles/traffic.json was measured on other kernel sources (digest "
                             f"{str(traffic.get('csrc_digest'))[:12]} != {build.source_digest()[:12]}): refused")
             traffic = {}
+        elif traffic.get("carried_over"):              # measured on an earlier commit whose measured kernels are the same machine code (tools/isa_equal.py)
+            co = traffic["carried_over"]
+            traffic_note = (f"counters measured at commit {co.get('measured_at')} (source digest {str(co.get('measured_on_digest'))[:12]}); "
+                            f"carried to this digest by {co.get('check')}")
     tr = lambda k: (traffic.get(k) or {}).get("bytes_per_launch") if isinstance(traffic.get(k), dict) else None
 
     MFMA3 = ("rnnpose_conv2d_nhwc_f16x3", "rnnpose_stem_conv7x7_s2_f16x3", "rnnpose_corr_pyramid_f16x3", "rnnpose_corr_pyramid_split")   # 3 fp16 products per multiply-add
@@ -372,9 +376,10 @@ def main():
                             "outer iteration every launch goes to ONE stream, so each is timed alone on the chip (the same durations "
                             "rocprofv3's kernel trace reports: profiles/).  traffic = mean HBM bytes per launch of both kernel families from the "
                             "FETCH_SIZE / WRITE_SIZE counter passes over the same command, algorithmic_bytes_per_launch = the mean over the "
-                            "same launches of inputs + weights + outputs + epilogue operands.  The production schedule (r05) is one full-batch "
-                            "loop chain on the caller's stream and one encoder stream per image set (RNNPOSE_SPLIT_BATCH=1: two half-batch loop "
-                            "chains as well; RNNPOSE_ENCODER_MERGE=1: one encoder batch on one stream): chip_level is the aggregate over the whole step",
+                            "same launches of inputs + weights + outputs + epilogue operands.  The production schedule (r05) is two half-batch "
+                            "loop chains on two streams and one encoder stream per image set (RNNPOSE_SPLIT_BATCH=0: one full-batch loop chain on "
+                            "the caller's stream; RNNPOSE_ENCODER_MERGE=1: one encoder batch on one stream; bit-identical results either way: "
+                            "tests/test_gpu_reproducibility.py): chip_level is the aggregate over the whole step",
                     "fp32_equivalent_over_f32_mfma_peak": round(ach_alg / PEAK_F32_MFMA_TFLOPS, 3),
                     "launches_timed": n,
                     "mean_ms": round(mean_ms, 4), "share_of_step": round(tot_ms / prof_steps / ms_step, 4),
@@ -438,7 +443,7 @@ def main():
         "kernels_note": "HIP events around every C-ABI launch of the first outer iteration of the first timed step (eager); GB/s from "
                         "the ALGORITHMIC bytes each launch declares for its own arguments (SURVEY 8d formulas; half-batch launches "
                         "declare half the batch); share_of_step = summed launch durations x outer iterations / step time (the two image sets of the "
-                        "encoder run on two streams in the timed steps -- and so do the two batch halves under RNNPOSE_SPLIT_BATCH=1 --, so the "
+                        "encoder run on two streams in the timed steps, and so do the two batch halves of the loop, so the "
                         "shares, measured launch by launch on one stream, can add up to more than 1)",
     }
     if world == 1 and not args.no_cpu_baseline:

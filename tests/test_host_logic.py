@@ -228,3 +228,20 @@ def test_bench_spawns_its_own_ranks(monkeypatch):
     with pytest.raises(SystemExit) as e:
         bench.spawn_ranks(4)
     assert "only 1 GPU" in str(e.value.code)
+
+
+def test_traffic_record_belongs_to_the_kernel_sources_in_the_tree():
+    """bench.py quotes profiles/traffic.json (HBM counters per launch) only when the record carries the digest of the kernel sources
+    in the tree, and prints `traffic: null` otherwise.  The record is either measured on these sources or carried over from the commit
+    it was measured on by tools/isa_equal.py (byte-identical ISA of every measured kernel + identical tiling of every headline launch):
+    an edit of csrc/ without either makes this fail here, not silently blank the roofline line on the driver's box."""
+    import json
+    from rnnpose_amd import build
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    t = json.load(open(os.path.join(root, "profiles", "traffic.json")))
+    assert t["csrc_digest"] == build.source_digest()
+    for k in ("conv", "corr_pyramid_h3"):
+        assert t[k]["bytes_per_launch"] > 0 and t[k]["launches"] > 0
+    co = t.get("carried_over")
+    if co is not None:
+        assert co["measured_on_digest"] != t["csrc_digest"] and "isa_equal" in co["check"] and co["measured_at"]
