@@ -1,0 +1,104 @@
+"""TEST INFRASTRUCTURE: builds `librnnpose_hostexec.so` -- the library's kernel sources compiled as plain C++ over
+tests/host_exec/harness.hpp, so that their C-ABI entry points run on host memory (tests/test_kernels_on_host.py).
+
+Sources are compiled WHERE THEY LIE (rnnpose_amd/csrc); the few statements a host compiler cannot take are rewritten in a scratch copy
+by the PATCHES table below -- every rewrite is listed with the number of places it must hit, so a source edit that changes one of them
+fails the build here instead of silently testing something else.  Nothing of this is reachable from the product path."""
+from __future__ import annotations
+
+import hashlib
+import os
+import re
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "rnnpose_amd", "csrc")
+
+# file -> [(regex, replacement, expected hits)]
+PATCHES = {
+    # `extern __shared__` (dynamic LDS): the harness hands out the launch's dynamic allocation
+    "nhwc_ops.hip": [(r"extern __shared__ float wl\[\];", "float* wl = reinterpret_cast<float*>(hostexec::dyn_lds());", 1)],
+    # hardware waits around the arrival counter of the fused LM tail: no meaning on the host (stores are visible in program order)
+    "lm.hip": [(r'asm volatile\("s_waitcnt vmcnt\(0\)" ::: "memory"\);', ";", 2)],
+    # WAVE-SYNCHRONOUS LDS: the epilogue passes the accumulators through a wave-private LDS tile -- every lane writes its 16 values,
+    # then reads rows other lanes wrote, with no barrier in between: a wave's LDS operations execute in program order on the GPU.
+    # Fibers of a wave do not run in lock step, so the scratch copy gets a wave synchronisation after the writes (RAW) and at the
+    # end of the row-block iteration (WAR: the next iteration overwrites the tile).
+    "conv_igemm.hip": [
+        (r"(S\[\(\(r & 3\) \+ 8 \* \(r >> 2\) \+ 4 \* lh\) \* ES \+ ni \* 32 \+ l31\] = acc\[mi\]\[ni\]\[r\] \* p\.out_scale;)",
+         r"\1\n    __builtin_amdgcn_wave_barrier();", 1),
+        (r"(if \(p\.dsth\) store_quad_hl\(p\.dsth \+ pix \* p\.dsth_cs, p\.dsth_co \+ col, y\[0\], y\[1\], y\[2\], y\[3\], nv, p\.a_scale, sat_n\);\n    \})",
+         r"\1\n    __builtin_amdgcn_wave_barrier();", 1),
+    ],
+    # an empty asm that only makes a value opaque to the optimiser: AMDGPU register class "v" -> a host register
+    "mask_upsample.hip": [(r'asm volatile\("" : "\+v"\(aoff\)\);', 'asm volatile("" : "+r"(aoff));', 1)],
+}
+
+# sources of the host library (csrc/conv_strip*.hip -- LDS-DMA inline assembly -- are replaced by strip_stubs.cpp: the automatic
+# kernel choice then always takes the 128-row kernels of conv_igemm.hip)
+SOURCES = ["pointwise.hip", "corr_pyramid.hip", "corr_lookup.hip", "corr_alt.hip", "conv_igemm.hip", "conv1x1_resident.hip", "stem.hip",
+           "nhwc_ops.hip", "eval_metrics.hip", "zoom_crop.hip", "raster.hip", "lm.hip", "mask_upsample.hip"]
+EXTRA = ["runtime_host.cpp", "strip_stubs.cpp"]
+
+
+def clang() -> str:
+    for c in (os.environ.get("HOSTEXEC_CXX"), "/opt/rocm/lib/llvm/bin/clang++", "/opt/rocm/llvm/bin/clang++"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("no clang++ of the ROCm toolchain found (needed for _Float16 vectors and the HIP headers)")
+
+
+def _digest() -> str:
+    h = hashlib.sha256()
+    for d, names in ((CSRC, sorted(os.listdir(CSRC))), (HERE, sorted(os.listdir(HERE)))):
+        for n in names:
+            p = os.path.join(d, n)
+            if os.path.isfile(p) and not n.endswith((".pyc", ".so")):
+                h.update(n.encode())
+                h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def build(outdir: str) -> str:
+    """-> path of the host library (built once per source digest inside outdir)."""
+    os.makedirs(outdir, exist_ok=True)
+    lib = os.path.join(outdir, f"librnnpose_hostexec_{_digest()}.so")
+    if os.path.exists(lib):
+        return lib
+    flags = ["-x", "c++", "-std=c++20", "-O1", "-fPIC", "-pthread", "-D__HIP_PLATFORM_AMD__", "-DNDEBUG", "-w", "-I", outdir, "-I", "/opt/rocm/include",
+             "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-I", HERE]
+    units = []
+    for name in SOURCES:
+        src = os.path.join(CSRC, name)
+        if name in PATCHES:
+            txt = open(src).read()
+            for rx, rep, hits in PATCHES[name]:
+                txt, n = re.subn(rx, rep if '\\1' in rep else (lambda m, rep=rep: rep), txt)
+                if n != hits:
+                    raise RuntimeError(f"host-exec patch of {name}: {rx!r} matched {n} places, expected {hits}")
+            src = os.path.join(outdir, "patched_" + name)
+            open(src, "w").write(txt)
+        tu = os.path.join(outdir, name + ".host.cpp")
+        open(tu, "w").write(f'#include "harness.hpp"\n#include "{src}"\n')
+        units.append(tu)
+    units += [os.path.join(HERE, n) for n in EXTRA]
+
+    def cc(tu):
+        obj = os.path.join(outdir, os.path.basename(tu) + ".o")
+        r = subprocess.run([clang(), "-c", tu, "-o", obj] + flags, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"host build of {tu} failed:\n{r.stderr[-4000:]}")
+        return obj
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        objs = list(ex.map(cc, units))
+    r = subprocess.run([clang(), "-shared", "-pthread", "-o", lib] + objs, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("host link failed:\n" + r.stderr[-4000:])
+    return lib
+
+
+if __name__ == "__main__":
+    import sys
+    print(build(sys.argv[1] if len(sys.argv) > 1 else "/tmp/rnnpose_hostexec"))

@@ -1,0 +1,350 @@
+// TEST INFRASTRUCTURE (never linked into librnnpose_hip.so): runs the library's HIP kernels ON THE HOST, lane by lane.
+//
+// A .hip source of rnnpose_amd/csrc is compiled as PLAIN C++ (hip's host_defines.h leaves __device__ / __host__ empty outside a HIP
+// compile; this header supplies __global__, __shared__, threadIdx / blockIdx, __syncthreads, the wave-level operations and
+// hipLaunchKernelGGL).  A launch runs every workgroup as a set of FIBERS (ucontext), one per GPU thread, scheduled round-robin by one
+// OS thread: deterministic, no data races of the emulation's own.  `__shared__` arrays become thread_local statics (one copy per OS
+// thread = per workgroup in flight), `__syncthreads()` and the wave collectives are yield points that release when every LIVE thread of
+// the workgroup / wave has arrived (a thread that returned no longer takes part, as on the GPU).  Wave collectives: shuffles, ballot,
+// and the MFMA instructions the kernels issue -- each lane deposits its operand fragment, the wave synchronises, each lane computes
+// the elements of D it owns in the gfx950 register layout (MI355X_MICROARCH.md / cdna_hip_programming.md), fp32 accumulation.
+// `__builtin_amdgcn_wave_barrier()` -- a compiler-only fence on the GPU, where a wave's LDS operations execute in order -- is a real
+// wave synchronisation here, because lanes of a wave do not run in lock step.
+//
+// The C-ABI entry points of the source therefore run unchanged -- argument checks, launch geometry, kernel code -- on host pointers,
+// and tests/test_kernels_on_host.py compares what they compute with the CPU oracle and the reference-generated golden vectors in the
+// `-m "not gpu"` tier.  Not runnable this way: sources with gfx950 inline assembly (the strip convolution kernels, mask_upsample,
+// lm.hip).  Host libm replaces the device's expf / tanhf (1-ulp differences); the MFMA's internal summation order is not modelled
+// (fp32 sequential accumulation: differences at the 1e-7 relative level).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <ucontext.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <thread>
+#include <vector>
+
+#define __global__
+#define __launch_bounds__(...)
+#define __shared__ static thread_local
+#define amdgpu_num_vgpr(...)                 // (inside __attribute__((...)) of a kernel: kernel-only attributes are dropped)
+#define amdgpu_waves_per_eu(...)
+#define amdgpu_flat_work_group_size(...)
+#ifndef __HIP_MEMORY_SCOPE_AGENT
+#define __HIP_MEMORY_SCOPE_SINGLETHREAD 1
+#define __HIP_MEMORY_SCOPE_WAVEFRONT 2
+#define __HIP_MEMORY_SCOPE_WORKGROUP 3
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __HIP_MEMORY_SCOPE_SYSTEM 5
+#endif
+#define __hip_atomic_fetch_add(p, v, order, scope) __atomic_fetch_add((p), (v), __ATOMIC_SEQ_CST)
+#define __hip_atomic_load(p, order, scope) __atomic_load_n((p), __ATOMIC_SEQ_CST)
+#define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), __ATOMIC_SEQ_CST)
+
+struct host_idx3 {
+  unsigned x, y, z;
+};
+// ONE instance per process (inline variables): inline functions of the sources' shared headers are merged across translation units
+inline thread_local host_idx3 threadIdx, blockIdx;
+inline host_idx3 blockDim, gridDim;
+
+namespace hostexec {
+
+constexpr int kWaveSize = 64;
+constexpr size_t kStack = 256 * 1024;
+
+struct Wave {
+  int live = 0, arrived = 0;
+  unsigned gen = 0;
+  alignas(64) unsigned char buf[kWaveSize][256];       // one operand fragment per lane
+};
+
+struct Fiber {
+  ucontext_t ctx;
+  std::unique_ptr<char[]> stack;
+  host_idx3 tid;
+  int lane = 0, wave = 0;
+  bool done = false;
+};
+
+struct Block {
+  std::vector<Fiber> fibers;
+  std::vector<Wave> waves;
+  ucontext_t sched;
+  Fiber* cur = nullptr;
+  int live = 0, arrived = 0;
+  unsigned gen = 0;
+  unsigned long long progress = 0;
+  const std::function<void()>* body = nullptr;
+};
+
+inline thread_local Block* g_blk = nullptr;
+
+inline void yield() {
+  Block* b = g_blk;
+  Fiber* me = b->cur;
+  swapcontext(&me->ctx, &b->sched);
+}
+
+inline void block_sync() {
+  Block* b = g_blk;
+  const unsigned g = b->gen;
+  ++b->progress;
+  if (++b->arrived == b->live) {
+    b->arrived = 0;
+    ++b->gen;
+  } else {
+    while (b->gen == g) yield();
+  }
+}
+
+inline Wave& my_wave() { return g_blk->waves[g_blk->cur->wave]; }
+inline int my_lane() { return g_blk->cur->lane; }
+
+inline void wave_sync() {
+  Block* b = g_blk;
+  Wave& w = my_wave();
+  const unsigned g = w.gen;
+  ++b->progress;
+  if (++w.arrived == w.live) {
+    w.arrived = 0;
+    ++w.gen;
+  } else {
+    while (w.gen == g) yield();
+  }
+}
+
+inline void fiber_main() {
+  Block* b = g_blk;
+  (*b->body)();
+  // this GPU thread has returned: it no longer takes part in barriers / collectives
+  Fiber* me = b->cur;
+  me->done = true;
+  ++b->progress;
+  Wave& w = b->waves[me->wave];
+  --w.live;
+  if (w.live > 0 && w.arrived == w.live) { w.arrived = 0; ++w.gen; }
+  --b->live;
+  if (b->live > 0 && b->arrived == b->live) { b->arrived = 0; ++b->gen; }
+  // (returning resumes uc_link = the scheduler)
+}
+
+inline void run_block(Block& blk, unsigned nt, dim3 block, const std::function<void()>& body) {
+  g_blk = &blk;
+  blk.body = &body;
+  blk.live = static_cast<int>(nt);
+  blk.arrived = 0;
+  const int nw = static_cast<int>((nt + kWaveSize - 1) / kWaveSize);
+  blk.waves.assign(0, Wave());
+  blk.waves.resize(nw);
+  if (blk.fibers.size() != nt) {
+    blk.fibers.clear();
+    blk.fibers.resize(nt);
+    for (auto& f : blk.fibers) f.stack.reset(new char[kStack]);
+  }
+  for (unsigned t = 0; t < nt; ++t) {
+    Fiber& f = blk.fibers[t];
+    f.tid = {t % block.x, (t / block.x) % block.y, t / (block.x * block.y)};
+    f.lane = static_cast<int>(t % kWaveSize);
+    f.wave = static_cast<int>(t / kWaveSize);
+    f.done = false;
+    ++blk.waves[f.wave].live;
+    getcontext(&f.ctx);
+    f.ctx.uc_stack.ss_sp = f.stack.get();
+    f.ctx.uc_stack.ss_size = kStack;
+    f.ctx.uc_link = &blk.sched;
+    makecontext(&f.ctx, fiber_main, 0);
+  }
+  while (blk.live > 0) {
+    const unsigned long long before = blk.progress;
+    for (unsigned t = 0; t < nt; ++t) {
+      Fiber& f = blk.fibers[t];
+      if (f.done) continue;
+      blk.cur = &f;
+      threadIdx = f.tid;
+      swapcontext(&blk.sched, &f.ctx);
+    }
+    if (blk.progress == before && blk.live > 0) {
+      std::fprintf(stderr, "hostexec: deadlock (a barrier or wave collective that not every live thread reaches)\n");
+      std::abort();
+    }
+  }
+}
+
+inline thread_local std::vector<unsigned char> g_dyn_lds;       // `extern __shared__` of the workgroup in flight (see the test's source patch)
+inline void* dyn_lds() { return g_dyn_lds.data(); }
+
+template <class Body>
+inline void launch(dim3 grid, dim3 block, size_t shmem, Body body) {
+  blockDim = {block.x, block.y, block.z};
+  gridDim = {grid.x, grid.y, grid.z};
+  const unsigned nt = block.x * block.y * block.z;
+  const unsigned long long nb = static_cast<unsigned long long>(grid.x) * grid.y * grid.z;
+  const std::function<void()> fn = body;
+  std::atomic<unsigned long long> next{0};
+  const unsigned nthr = static_cast<unsigned>(std::min<unsigned long long>(nb, std::max(1u, std::thread::hardware_concurrency())));
+  std::vector<std::thread> pool;
+  for (unsigned i = 0; i < nthr; ++i)
+    pool.emplace_back([&] {
+      Block blk;
+      g_dyn_lds.assign(shmem + 64, 0);
+      for (;;) {
+        const unsigned long long k = next.fetch_add(1);
+        if (k >= nb) break;
+        blockIdx = {static_cast<unsigned>(k % grid.x), static_cast<unsigned>((k / grid.x) % grid.y),
+                    static_cast<unsigned>(k / (static_cast<unsigned long long>(grid.x) * grid.y))};
+        run_block(blk, nt, block, fn);
+      }
+    });
+  for (auto& th : pool) th.join();
+}
+
+// ---- wave collectives ---------------------------------------------------------------------------------------------------
+template <class T>
+inline T exchange(T mine, int src_lane) {
+  static_assert(sizeof(T) <= 256, "fragment too large");
+  Wave& w = my_wave();
+  std::memcpy(w.buf[my_lane()], &mine, sizeof(T));
+  wave_sync();
+  T r;
+  std::memcpy(&r, w.buf[src_lane & (kWaveSize - 1)], sizeof(T));
+  wave_sync();
+  return r;
+}
+
+// ballot: LANE-LOCAL here ("does any lane of my wave ..." answered as "do I").  A true wave ballot would be a collective, and the
+// sources call it inside divergent control flow (lanes that left a loop do not take part; the hardware masks them, fibers cannot
+// know who will arrive).  Both uses in csrc (pointwise.hip corr_weight, lm.hip normal equations) are early exits that skip work
+// whose contribution is exactly zero, so the per-lane answer changes no result.
+inline unsigned long long ballot(bool pred) { return pred ? 1ull << my_lane() : 0ull; }
+
+// D = A * B + C of one wave.  Register layouts (gfx950):
+//   32x32xK : A row i = lane % 32, K slice kpl * (lane / 32) .. + kpl - 1;  B column j = lane % 32, same K slice;
+//             D register v of lane l: row 8 * (v / 4) + 4 * (l / 32) + v % 4, column l % 32
+//   16x16xK : A row i = lane % 16, K slice kpl * (lane / 16) ..;  B column j = lane % 16;  D register v: row 4 * (l / 16) + v, column l % 16
+template <int MN, int KPL, class AV, class CV>
+inline CV mfma(AV a, AV b, CV c) {
+  Wave& w = my_wave();
+  const int lane = my_lane();
+  float af[KPL], bf[KPL];
+  for (int k = 0; k < KPL; ++k) { af[k] = static_cast<float>(a[k]); bf[k] = static_cast<float>(b[k]); }
+  std::memcpy(w.buf[lane], af, sizeof af);
+  std::memcpy(w.buf[lane] + 128, bf, sizeof bf);
+  wave_sync();
+  constexpr int G = kWaveSize / MN;           // lane groups along K
+  constexpr int NV = MN * MN / kWaveSize;     // D registers per lane
+  const int j = lane % MN;
+  for (int v = 0; v < NV; ++v) {
+    const int i = MN == 32 ? 8 * (v / 4) + 4 * (lane / 32) + v % 4 : 4 * (lane / 16) + v;
+    float s = c[v];
+    for (int g = 0; g < G; ++g) {
+      const float* ar = reinterpret_cast<const float*>(w.buf[g * MN + i]);
+      const float* bc = reinterpret_cast<const float*>(w.buf[g * MN + j] + 128);
+      for (int k = 0; k < KPL; ++k) s += ar[k] * bc[k];
+    }
+    c[v] = s;
+  }
+  wave_sync();
+  return c;
+}
+
+template <class CV>
+inline CV mfma_32x32x2f32(float a, float b, CV c) {
+  struct S { float v[1]; float operator[](int) const { return v[0]; } };
+  return mfma<32, 1>(S{{a}}, S{{b}}, c);
+}
+
+}  // namespace hostexec
+
+inline void __syncthreads() { hostexec::block_sync(); }
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) hostexec::launch((grid), (block), (shmem), [=] { kernel(__VA_ARGS__); })
+
+#define __builtin_amdgcn_ballot_w64(pred) hostexec::ballot(pred)
+#define __builtin_amdgcn_sched_barrier(mask) ((void)0)
+#define __builtin_amdgcn_wave_barrier() hostexec::wave_sync()
+#define __builtin_amdgcn_fence(...) __atomic_thread_fence(__ATOMIC_SEQ_CST)
+#define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) hostexec::mfma<32, 8>((a), (b), (c))
+#define __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z) hostexec::mfma<16, 8>((a), (b), (c))
+#define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) hostexec::mfma_32x32x2f32((a), (b), (c))
+
+template <class T> inline T __shfl_xor(T v, int m, int = 64) { return hostexec::exchange(v, hostexec::my_lane() ^ m); }
+template <class T> inline T __shfl_down(T v, unsigned d, int = 64) {
+  const int s = hostexec::my_lane() + static_cast<int>(d);
+  return hostexec::exchange(v, s < hostexec::kWaveSize ? s : hostexec::my_lane());
+}
+template <class T> inline T __shfl_up(T v, unsigned d, int = 64) {
+  const int s = hostexec::my_lane() - static_cast<int>(d);
+  return hostexec::exchange(v, s >= 0 ? s : hostexec::my_lane());
+}
+template <class T> inline T __shfl(T v, int src, int = 64) { return hostexec::exchange(v, src); }
+
+inline int __double2loint(double v) { long long b; std::memcpy(&b, &v, 8); return static_cast<int>(b); }
+inline int __double2hiint(double v) { long long b; std::memcpy(&b, &v, 8); return static_cast<int>(b >> 32); }
+inline double __hiloint2double(int hi, int lo) {
+  const long long b = (static_cast<long long>(hi) << 32) | static_cast<unsigned>(lo);
+  double v; std::memcpy(&v, &b, 8); return v;
+}
+
+// global-memory atomics (workgroups run on several OS threads)
+inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+inline float atomicAdd(float* p, float v) {
+  float old = *p, want;
+  do { want = old + v; } while (!__atomic_compare_exchange(p, &old, &want, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
+  return old;
+}
+inline double atomicAdd(double* p, double v) {
+  double old = *p, want;
+  do { want = old + v; } while (!__atomic_compare_exchange(p, &old, &want, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
+  return old;
+}
+inline unsigned long long atomicMin(unsigned long long* p, unsigned long long v) {
+  unsigned long long old = *p;
+  while (v < old && !__atomic_compare_exchange_n(p, &old, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+  return old;
+}
+inline unsigned long long atomicMax(unsigned long long* p, unsigned long long v) {
+  unsigned long long old = *p;
+  while (v > old && !__atomic_compare_exchange_n(p, &old, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+  return old;
+}
+inline int atomicMin(int* p, int v) {
+  int old = *p;
+  while (v < old && !__atomic_compare_exchange_n(p, &old, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+  return old;
+}
+inline int atomicMax(int* p, int v) {
+  int old = *p;
+  while (v > old && !__atomic_compare_exchange_n(p, &old, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+  return old;
+}
+inline unsigned atomicMin(unsigned* p, unsigned v) {
+  unsigned old = *p;
+  while (v < old && !__atomic_compare_exchange_n(p, &old, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+  return old;
+}
+inline unsigned atomicMax(unsigned* p, unsigned v) {
+  unsigned old = *p;
+  while (v > old && !__atomic_compare_exchange_n(p, &old, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+  return old;
+}
+inline double __longlong_as_double(long long b) { double v; std::memcpy(&v, &b, 8); return v; }
+inline long long __double_as_longlong(double v) { long long b; std::memcpy(&b, &v, 8); return b; }
+inline float rsqrtf(float v) { return 1.0f / sqrtf(v); }
+inline unsigned __float_as_uint(float v) { unsigned u; std::memcpy(&u, &v, 4); return u; }
+inline float __uint_as_float(unsigned u) { float v; std::memcpy(&v, &u, 4); return v; }
+inline int __float_as_int(float v) { int u; std::memcpy(&u, &v, 4); return u; }
+inline float __int_as_float(int u) { float v; std::memcpy(&v, &u, 4); return v; }
+using std::max;
+using std::min;
+
+#include "common.hpp"      // (rp::set_error / fail_arg / check_launch / sat_counter: runtime_host.cpp compiles csrc/runtime.hip itself)
