@@ -67,7 +67,7 @@ def build(outdir: str) -> str:
     lib = os.path.join(outdir, f"librnnpose_hostexec_{_digest()}.so")
     if os.path.exists(lib):
         return lib
-    flags = ["-x", "c++", "-std=c++20", "-O1", "-fPIC", "-pthread", "-D__HIP_PLATFORM_AMD__", "-DNDEBUG", "-w", "-I", outdir, "-I", "/opt/rocm/include",
+    flags = ["-x", "c++", "-std=c++20", "-O2", "-fPIC", "-pthread", "-D__HIP_PLATFORM_AMD__", "-DNDEBUG", "-U_FORTIFY_SOURCE", "-w", "-I", outdir, "-I", "/opt/rocm/include",
              "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-I", HERE]
     units = []
     for name in SOURCES:

@@ -7,7 +7,7 @@
 // thread = per workgroup in flight), `__syncthreads()` and the wave collectives are yield points that release when every LIVE thread of
 // the workgroup / wave has arrived (a thread that returned no longer takes part, as on the GPU).  Wave collectives: shuffles, ballot,
 // and the MFMA instructions the kernels issue -- each lane deposits its operand fragment, the wave synchronises, each lane computes
-// the elements of D it owns in the gfx950 register layout (MI355X_MICROARCH.md / cdna_hip_programming.md), fp32 accumulation.
+// the elements of D it owns in the gfx950 register layout (MI355X_MICROARCH.md / cdna_hip_programming.md).
 // `__builtin_amdgcn_wave_barrier()` -- a compiler-only fence on the GPU, where a wave's LDS operations execute in order -- is a real
 // wave synchronisation here, because lanes of a wave do not run in lock step.
 //
@@ -15,9 +15,10 @@
 // and tests/test_kernels_on_host.py compares what they compute with the CPU oracle and the reference-generated golden vectors in the
 // `-m "not gpu"` tier.  Not runnable this way: sources with gfx950 inline assembly (the strip convolution kernels, mask_upsample,
 // lm.hip).  Host libm replaces the device's expf / tanhf (1-ulp differences); the MFMA's internal summation order is not modelled
-// (fp32 sequential accumulation: differences at the 1e-7 relative level).
+// (the products of one instruction are summed exactly and rounded to fp32 once).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <setjmp.h>
 #include <ucontext.h>
 
 #include <algorithm>
@@ -29,6 +30,7 @@
 #include <cstring>
 #include <functional>
 #include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -68,7 +70,9 @@ struct Wave {
 };
 
 struct Fiber {
-  ucontext_t ctx;
+  ucontext_t ctx;               // first entry only (makecontext); every later switch is _setjmp / _longjmp: no signal-mask system calls
+  jmp_buf env;
+  bool started = false;
   std::unique_ptr<char[]> stack;
   host_idx3 tid;
   int lane = 0, wave = 0;
@@ -78,7 +82,7 @@ struct Fiber {
 struct Block {
   std::vector<Fiber> fibers;
   std::vector<Wave> waves;
-  ucontext_t sched;
+  jmp_buf sched_env;
   Fiber* cur = nullptr;
   int live = 0, arrived = 0;
   unsigned gen = 0;
@@ -91,7 +95,7 @@ inline thread_local Block* g_blk = nullptr;
 inline void yield() {
   Block* b = g_blk;
   Fiber* me = b->cur;
-  swapcontext(&me->ctx, &b->sched);
+  if (_setjmp(me->env) == 0) _longjmp(b->sched_env, 1);
 }
 
 inline void block_sync() {
@@ -134,7 +138,7 @@ inline void fiber_main() {
   if (w.live > 0 && w.arrived == w.live) { w.arrived = 0; ++w.gen; }
   --b->live;
   if (b->live > 0 && b->arrived == b->live) { b->arrived = 0; ++b->gen; }
-  // (returning resumes uc_link = the scheduler)
+  _longjmp(b->sched_env, 1);      // back to the scheduler for good (this stack is never resumed)
 }
 
 inline void run_block(Block& blk, unsigned nt, dim3 block, const std::function<void()>& body) {
@@ -145,10 +149,10 @@ inline void run_block(Block& blk, unsigned nt, dim3 block, const std::function<v
   const int nw = static_cast<int>((nt + kWaveSize - 1) / kWaveSize);
   blk.waves.assign(0, Wave());
   blk.waves.resize(nw);
-  if (blk.fibers.size() != nt) {
-    blk.fibers.clear();
+  if (blk.fibers.size() < nt) {
+    const size_t have = blk.fibers.size();
     blk.fibers.resize(nt);
-    for (auto& f : blk.fibers) f.stack.reset(new char[kStack]);
+    for (size_t t = have; t < nt; ++t) blk.fibers[t].stack.reset(new char[kStack]);
   }
   for (unsigned t = 0; t < nt; ++t) {
     Fiber& f = blk.fibers[t];
@@ -156,11 +160,12 @@ inline void run_block(Block& blk, unsigned nt, dim3 block, const std::function<v
     f.lane = static_cast<int>(t % kWaveSize);
     f.wave = static_cast<int>(t / kWaveSize);
     f.done = false;
+    f.started = false;
     ++blk.waves[f.wave].live;
     getcontext(&f.ctx);
     f.ctx.uc_stack.ss_sp = f.stack.get();
     f.ctx.uc_stack.ss_size = kStack;
-    f.ctx.uc_link = &blk.sched;
+    f.ctx.uc_link = nullptr;
     makecontext(&f.ctx, fiber_main, 0);
   }
   while (blk.live > 0) {
@@ -170,7 +175,15 @@ inline void run_block(Block& blk, unsigned nt, dim3 block, const std::function<v
       if (f.done) continue;
       blk.cur = &f;
       threadIdx = f.tid;
-      swapcontext(&blk.sched, &f.ctx);
+      if (_setjmp(blk.sched_env) == 0) {
+        if (!f.started) {
+          f.started = true;
+          setcontext(&f.ctx);
+        } else {
+          _longjmp(f.env, 1);
+        }
+      }
+      // (here again when the fiber yielded or finished)
     }
     if (blk.progress == before && blk.live > 0) {
       std::fprintf(stderr, "hostexec: deadlock (a barrier or wave collective that not every live thread reaches)\n");
@@ -181,6 +194,21 @@ inline void run_block(Block& blk, unsigned nt, dim3 block, const std::function<v
 
 inline thread_local std::vector<unsigned char> g_dyn_lds;       // `extern __shared__` of the workgroup in flight (see the test's source patch)
 inline void* dyn_lds() { return g_dyn_lds.data(); }
+
+// workgroup contexts (256 fiber stacks each) are kept across launches: allocating them per launch was most of the system time
+inline std::mutex g_pool_mu;
+inline std::vector<std::unique_ptr<Block>> g_pool;
+inline std::unique_ptr<Block> pool_get() {
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  if (g_pool.empty()) return std::unique_ptr<Block>(new Block());
+  std::unique_ptr<Block> b = std::move(g_pool.back());
+  g_pool.pop_back();
+  return b;
+}
+inline void pool_put(std::unique_ptr<Block> b) {
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  g_pool.push_back(std::move(b));
+}
 
 template <class Body>
 inline void launch(dim3 grid, dim3 block, size_t shmem, Body body) {
@@ -194,15 +222,16 @@ inline void launch(dim3 grid, dim3 block, size_t shmem, Body body) {
   std::vector<std::thread> pool;
   for (unsigned i = 0; i < nthr; ++i)
     pool.emplace_back([&] {
-      Block blk;
+      std::unique_ptr<Block> blk = pool_get();
       g_dyn_lds.assign(shmem + 64, 0);
       for (;;) {
         const unsigned long long k = next.fetch_add(1);
         if (k >= nb) break;
         blockIdx = {static_cast<unsigned>(k % grid.x), static_cast<unsigned>((k / grid.x) % grid.y),
                     static_cast<unsigned>(k / (static_cast<unsigned long long>(grid.x) * grid.y))};
-        run_block(blk, nt, block, fn);
+        run_block(*blk, nt, block, fn);
       }
+      pool_put(std::move(blk));
     });
   for (auto& th : pool) th.join();
 }
@@ -234,8 +263,8 @@ template <int MN, int KPL, class AV, class CV>
 inline CV mfma(AV a, AV b, CV c) {
   Wave& w = my_wave();
   const int lane = my_lane();
-  float af[KPL], bf[KPL];
-  for (int k = 0; k < KPL; ++k) { af[k] = static_cast<float>(a[k]); bf[k] = static_cast<float>(b[k]); }
+  double af[KPL], bf[KPL];
+  for (int k = 0; k < KPL; ++k) { af[k] = static_cast<double>(a[k]); bf[k] = static_cast<double>(b[k]); }
   std::memcpy(w.buf[lane], af, sizeof af);
   std::memcpy(w.buf[lane] + 128, bf, sizeof bf);
   wave_sync();
@@ -244,13 +273,13 @@ inline CV mfma(AV a, AV b, CV c) {
   const int j = lane % MN;
   for (int v = 0; v < NV; ++v) {
     const int i = MN == 32 ? 8 * (v / 4) + 4 * (lane / 32) + v % 4 : 4 * (lane / 16) + v;
-    float s = c[v];
+    double s = c[v];                          // products of the instruction summed exactly, ONE rounding to fp32 per MFMA
     for (int g = 0; g < G; ++g) {
-      const float* ar = reinterpret_cast<const float*>(w.buf[g * MN + i]);
-      const float* bc = reinterpret_cast<const float*>(w.buf[g * MN + j] + 128);
+      const double* ar = reinterpret_cast<const double*>(w.buf[g * MN + i]);
+      const double* bc = reinterpret_cast<const double*>(w.buf[g * MN + j] + 128);
       for (int k = 0; k < KPL; ++k) s += ar[k] * bc[k];
     }
-    c[v] = s;
+    c[v] = static_cast<float>(s);
   }
   wave_sync();
   return c;

@@ -3,9 +3,11 @@
 `host_mode(lib_path)` is a context manager that, for its duration only and in this process only,
   * makes rnnpose_amd._lib.load() return the host library built by tests/host_exec/build_host.py (same 80 C-ABI entry points, the
     product's own prototypes),
-  * replaces the front end's "must be a GPU tensor" guards (ops._chk, ops._nhwc) by their dtype / contiguity half,
-  * maps the device "cuda" to the CPU for tensor factories and .to() / .cuda() (a TorchFunctionMode), and gives torch.cuda's stream /
-    event / synchronize calls inert stand-ins (work is synchronous on the host).
+  * maps the device "cuda" to the CPU for tensor factories and .to() / .cuda() and answers `tensor.is_cuda` with True (a
+    TorchFunctionMode): the front end itself -- ops.py, the engines, the module classes with their "GPU tensors only" guards -- runs
+    UNMODIFIED,
+  * gives torch.cuda's stream / event / synchronize calls inert stand-ins (work is synchronous on the host) and refuses hipGraph
+    capture (PoseRefiner then takes its eager path).
 Nothing here is imported by the package; outside the context the front end refuses CPU tensors as before (tests/test_host_logic.py
 ::test_ops_refuse_cpu_tensors keeps checking that)."""
 from __future__ import annotations
@@ -39,6 +41,8 @@ class CudaIsCpu(TorchFunctionMode):
         if "device" in kwargs:
             kwargs["device"] = _map(kwargs["device"])
         name = getattr(func, "__name__", "")
+        if name == "__get__" and getattr(getattr(func, "__self__", None), "__name__", None) == "is_cuda":
+            return True                                      # the front end's "GPU tensors only" guards (ops._chk, module forwards)
         if name == "cuda":                                   # Tensor.cuda()
             return args[0]
         if name == "to" or name == "empty_like" or name == "zeros_like":
@@ -79,26 +83,14 @@ def host_mode(lib_path: str):
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
     assert lib.rnnpose_abi_version() == _lib.ABI_VERSION
-    saved = {"lib": _lib._lib, "chk": ops._chk, "nhwc": ops._nhwc, "stream": ops._stream, "arm": ops.range_guard_arm,
-             "cuda": {k: getattr(torch.cuda, k) for k in ("synchronize", "current_stream", "Stream", "Event", "stream", "is_available",
-                                                          "current_device", "device", "set_device", "device_count")}}
+    names = ("synchronize", "current_stream", "Stream", "Event", "stream", "is_available", "current_device", "device", "set_device",
+             "device_count", "CUDAGraph", "graph")
+    saved_lib, saved_cuda = _lib._lib, {k: getattr(torch.cuda, k) for k in names}
 
-    def chk(t, name, dtype=ops.F32):
-        if not isinstance(t, torch.Tensor):
-            raise TypeError(f"{name} must be a torch.Tensor")
-        return (t if t.dtype == dtype else t.to(dtype)).contiguous()
-
-    def nhwc(t, name):
-        if not (t.dtype == ops.F32 and t.is_contiguous() and t.dim() == 4):
-            raise ValueError(f"{name} must be a contiguous fp32 tensor shaped (B,H,W,C)")
-        return t
-
-    def arm(device=None):
-        _lib.call("rnnpose_f16x3_saturation_check", 1)
-        ops._guard_on = True
+    def no_graphs(*a, **k):
+        raise RuntimeError("host execution: no hipGraph capture (callers fall back to eager launches)")
 
     _lib._lib = lib
-    ops._chk, ops._nhwc, ops._stream, ops.range_guard_arm = chk, nhwc, (lambda: C.c_void_p(0)), arm
     torch.cuda.synchronize = lambda *a, **k: None
     torch.cuda.current_stream = lambda *a, **k: _Inert()
     torch.cuda.Stream = _Inert
@@ -109,11 +101,12 @@ def host_mode(lib_path: str):
     torch.cuda.device = lambda *a, **k: _Inert()
     torch.cuda.set_device = lambda *a, **k: None
     torch.cuda.device_count = lambda: 1
+    torch.cuda.CUDAGraph = no_graphs
+    torch.cuda.graph = no_graphs
     try:
         with CudaIsCpu():
             yield ops
     finally:
-        _lib._lib = saved["lib"]
-        ops._chk, ops._nhwc, ops._stream, ops.range_guard_arm = saved["chk"], saved["nhwc"], saved["stream"], saved["arm"]
-        for k, v in saved["cuda"].items():
+        _lib._lib = saved_lib
+        for k, v in saved_cuda.items():
             setattr(torch.cuda, k, v)

@@ -156,20 +156,27 @@ def test_metric_accumulator_single_process():
 
 
 def test_concurrent_build_calls_are_serialised(tmp_path):
-    """One process per GPU: every rank calls build.build() at start-up.  Two processes forcing a rebuild at the same time
-    must both succeed and leave a loadable library (the file lock makes the loser wait and re-check the stamp)."""
+    """One process per GPU: every rank calls build.build() at start-up.  Two processes forcing / checking a build at the same time
+    must both succeed and leave a loadable library (the file lock makes the loser wait and re-check the stamp).  Run on a scratch
+    library directory with two small sources (the locking is what is tested; a forced rebuild of all 17 files took this test 70 s
+    and re-wrote the in-tree library under the other tests)."""
     import subprocess
     import sys
-    code = ("import sys; sys.path.insert(0, %r); from rnnpose_amd import build; "
-            "p = build.build(force=(sys.argv[1] == 'force')); print(p)") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, os; sys.path.insert(0, %r); from rnnpose_amd import build; d = %r; "
+            "build.LIBDIR = d; build.LIB = os.path.join(d, 'librnnpose_hip.so'); build.STAMP = os.path.join(d, 'librnnpose_hip.stamp'); "
+            "build.sources = lambda: [os.path.join(build.CSRC, f) for f in ('runtime.hip', 'raster.hip')]; "
+            "p = build.build(force=(sys.argv[1] == 'force')); print(p)") % (root, str(tmp_path / "lib"))
     procs = [subprocess.Popen([sys.executable, "-c", code, mode], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-             for mode in ("force", "check")]
+             for mode in ("force", "check", "check")]
     outs = [p.communicate(timeout=900) for p in procs]
     for p, (out, err) in zip(procs, outs):
         assert p.returncode == 0, err[-2000:]
         assert out.strip().endswith("librnnpose_hip.so")
+    assert os.path.exists(str(tmp_path / "lib" / "librnnpose_hip.stamp"))
     import ctypes
-    ctypes.CDLL(outs[0][0].strip())
+    lib = ctypes.CDLL(outs[0][0].strip())
+    assert lib.rnnpose_abi_version() >= 3
 
 
 def test_torch_library_ops_registered_with_fake_kernels():
