@@ -36,11 +36,39 @@ PATCHES = {
     "mask_upsample.hip": [(r'asm volatile\("" : "\+v"\(aoff\)\);', 'asm volatile("" : "+r"(aoff));', 1)],
 }
 
-# sources of the host library (csrc/conv_strip*.hip -- LDS-DMA inline assembly -- are replaced by strip_stubs.cpp: the automatic
-# kernel choice then always takes the 128-row kernels of conv_igemm.hip)
+# The strip convolution kernels request their operands by LDS-DMA (inline assembly).  Their scratch copy gets host versions of the
+# three request / wait helpers -- a request copies each lane's 16 bytes to LDS at once (the hardware completes it later and the kernel
+# waits with counted s_waitcnt: instant completion is one of the timings a correct kernel must tolerate) and synchronises the wave
+# around the copy (the hardware issues it for all lanes at one program point) -- and an LDS base that maps the kernel's numeric LDS
+# addresses back to the host array.
+HEADER_PATCHES = {
+    "conv_strip_kernel.cuh": [
+        (r"__device__ __forceinline__ void glds16\(const void\* g, unsigned dst\) \{.*?\n\}\n",
+         "__device__ __forceinline__ void glds16(const void* g, unsigned dst) { hostexec::lds_dma(g, dst, 1); }\n", 1),
+        (r"template <int NI>\n__device__ __forceinline__ void glds_rec\(const void\* base, unsigned voff, unsigned dst\) \{.*?\n  \}\n\}\n",
+         "template <int NI>\n__device__ __forceinline__ void glds_rec(const void* base, unsigned voff, unsigned dst) {\n"
+         "  hostexec::lds_dma(static_cast<const unsigned char*>(base) + voff, dst, 2 * NI);\n}\n", 1),
+        (r'asm volatile\("s_waitcnt vmcnt\(%0\)" ::"n"\(N\) : "memory"\);', ";", 1),
+        (r'asm volatile\("s_waitcnt lgkmcnt\(0\)" ::: "memory"\);', ";", 1),
+        (r'asm volatile\("s_memrealtime %0\\n\\ts_waitcnt lgkmcnt\(0\)" : "=s"\(t_\)::"memory"\);', "t_ = 0;", 1),
+        # wave-synchronous LDS staging of the two epilogues (as in conv_igemm.hip): a wave synchronisation before and after every
+        # staging write
+        (r"\n  stage\(0, acc\[0\]\[0\]\);", "\n  __builtin_amdgcn_wave_barrier(); stage(0, acc[0][0]); __builtin_amdgcn_wave_barrier();", 1),
+        (r"\n    if \(mi \+ 1 < NBLK\) stage\(mi \+ 1, acc\[mi \+ 1 < NBLK \? mi \+ 1 : mi\]\[0\]\);",
+         "\n    __builtin_amdgcn_wave_barrier();\n    if (mi + 1 < NBLK) stage(mi + 1, acc[mi + 1 < NBLK ? mi + 1 : mi][0]);\n    __builtin_amdgcn_wave_barrier();", 1),
+        (r"(S_\[\(\(r & 3\) \+ 8 \* \(r >> 2\) \+ 4 \* lh\) \* ES \+ ni \* 32 \+ l31\] = at\[ni\]\[r\] \* p\.out_scale;)",
+         "BACKREF1\n    __builtin_amdgcn_wave_barrier();", 1),
+        (r"(if \(p\.dsth\) store_quad_hl\(p\.dsth \+ pix \* p\.dsth_cs, p\.dsth_co \+ colq, y\[0\], y\[1\], y\[2\], y\[3\], nv, p\.a_scale, sat_n\);\n    \})",
+         "BACKREF1\n    __builtin_amdgcn_wave_barrier();", 1),
+        (r"const unsigned lds0 = static_cast<unsigned>\(reinterpret_cast<size_t>\(\(__attribute__\(\(address_space\(3\)\)\) unsigned char\*\)lds\)\);",
+         "const unsigned lds0 = hostexec::lds_register(lds);", 1),
+    ],
+}
+STRIP_SOURCES = ["conv_strip.hip", "conv_strip_r32.hip", "conv_strip_p1.hip"]      # copied next to the patched header (quote includes look there first)
+
 SOURCES = ["pointwise.hip", "corr_pyramid.hip", "corr_lookup.hip", "corr_alt.hip", "conv_igemm.hip", "conv1x1_resident.hip", "stem.hip",
            "nhwc_ops.hip", "eval_metrics.hip", "zoom_crop.hip", "raster.hip", "lm.hip", "mask_upsample.hip"]
-EXTRA = ["runtime_host.cpp", "strip_stubs.cpp"]
+EXTRA = ["runtime_host.cpp"]
 
 
 def clang() -> str:
@@ -67,7 +95,7 @@ def build(outdir: str) -> str:
     lib = os.path.join(outdir, f"librnnpose_hostexec_{_digest()}.so")
     if os.path.exists(lib):
         return lib
-    flags = ["-x", "c++", "-std=c++20", "-O2", "-fPIC", "-pthread", "-D__HIP_PLATFORM_AMD__", "-DNDEBUG", "-U_FORTIFY_SOURCE", "-w", "-I", outdir, "-I", "/opt/rocm/include",
+    flags = ["-x", "c++", "-std=c++20", "-O1", "-fPIC", "-pthread", "-D__HIP_PLATFORM_AMD__", "-DNDEBUG", "-U_FORTIFY_SOURCE", "-w", "-I", outdir, "-I", "/opt/rocm/include",
              "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-I", HERE]
     units = []
     for name in SOURCES:
@@ -83,11 +111,25 @@ def build(outdir: str) -> str:
         tu = os.path.join(outdir, name + ".host.cpp")
         open(tu, "w").write(f'#include "harness.hpp"\n#include "{src}"\n')
         units.append(tu)
+    for name, patches in HEADER_PATCHES.items():
+        txt = open(os.path.join(CSRC, name)).read()
+        for rx, rep, hits in patches:
+            txt, n = re.subn(rx, lambda m, rep=rep: rep.replace("BACKREF1", m.group(1) if m.groups() else ""), txt, flags=re.S)
+            if n != hits:
+                raise RuntimeError(f"host-exec patch of {name}: {rx!r} matched {n} places, expected {hits}")
+        open(os.path.join(outdir, name), "w").write(txt)
+    for name in STRIP_SOURCES:
+        cp = os.path.join(outdir, name)
+        open(cp, "w").write(open(os.path.join(CSRC, name)).read())
+        tu = os.path.join(outdir, name + ".host.cpp")
+        open(tu, "w").write(f'#include "harness.hpp"\n#include "{cp}"\n')
+        units.append(tu)
     units += [os.path.join(HERE, n) for n in EXTRA]
 
     def cc(tu):
         obj = os.path.join(outdir, os.path.basename(tu) + ".o")
-        r = subprocess.run([clang(), "-c", tu, "-o", obj] + flags, capture_output=True, text=True)
+        fl = [("-O0" if (f == "-O1" and "conv_strip" in os.path.basename(tu)) else f) for f in flags]     # (the strip units: 68 kernel instantiations, compile time over run time)
+        r = subprocess.run([clang(), "-c", tu, "-o", obj] + fl, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"host build of {tu} failed:\n{r.stderr[-4000:]}")
         return obj

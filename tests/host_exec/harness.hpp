@@ -249,6 +249,20 @@ inline T exchange(T mine, int src_lane) {
   return r;
 }
 
+// LDS-DMA of the strip kernels (global_load_lds_dwordx4): `pieces` requests of one wave, request k moves 16 bytes per lane from
+// g + 1024 k (g is per lane) to LDS bytes [dst + 1024 k + 16 lane, + 16) -- dst is the wave-uniform M0 base, a numeric LDS address.
+// The kernel's LDS array is registered once per thread (lds_register) under a fixed fake base, which maps such addresses back.
+constexpr unsigned kLdsFakeBase = 0x10000u;
+inline thread_local unsigned char* g_lds_host = nullptr;
+inline unsigned lds_register(unsigned char* lds) { g_lds_host = lds; return kLdsFakeBase; }
+inline void lds_dma(const void* g, unsigned dst, int pieces) {
+  wave_sync();                         // every lane of the wave has passed its reads of what the slot held (the hardware issues the request
+  unsigned char* d = g_lds_host + (dst - kLdsFakeBase) + 16 * my_lane();      //  for all lanes at one program point)
+  const unsigned char* s = static_cast<const unsigned char*>(g);
+  for (int k = 0; k < pieces; ++k) std::memcpy(d + 1024 * k, s + 1024 * k, 16);
+  wave_sync();
+}
+
 // ballot: LANE-LOCAL here ("does any lane of my wave ..." answered as "do I").  A true wave ballot would be a collective, and the
 // sources call it inside divergent control flow (lanes that left a loop do not take part; the hardware masks them, fibers cannot
 // know who will arrive).  Both uses in csrc (pointwise.hip corr_weight, lm.hip normal equations) are early exits that skip work
@@ -300,6 +314,12 @@ inline void __syncthreads() { hostexec::block_sync(); }
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
 #define __builtin_amdgcn_wave_barrier() hostexec::wave_sync()
 #define __builtin_amdgcn_fence(...) __atomic_thread_fence(__ATOMIC_SEQ_CST)
+#define __builtin_amdgcn_s_barrier() hostexec::block_sync()
+#define __builtin_amdgcn_readfirstlane(v) (v)          // (used on wave-uniform values only: it makes them scalar registers)
+#define __builtin_amdgcn_s_setprio(n) ((void)0)
+#define __builtin_amdgcn_s_getreg(r) 0u
+#define __builtin_amdgcn_exp2f(v) exp2f(v)
+#define __builtin_amdgcn_rcpf(v) (1.0f / (v))
 #define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) hostexec::mfma<32, 8>((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z) hostexec::mfma<16, 8>((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) hostexec::mfma_32x32x2f32((a), (b), (c))
