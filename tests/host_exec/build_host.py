@@ -80,6 +80,7 @@ def clang() -> str:
 
 def _digest() -> str:
     h = hashlib.sha256()
+    h.update(os.environ.get("HOSTEXEC_CXXFLAGS", "").encode())
     for d, names in ((CSRC, sorted(os.listdir(CSRC))), (HERE, sorted(os.listdir(HERE)))):
         for n in names:
             p = os.path.join(d, n)
@@ -95,7 +96,8 @@ def build(outdir: str) -> str:
     lib = os.path.join(outdir, f"librnnpose_hostexec_{_digest()}.so")
     if os.path.exists(lib):
         return lib
-    flags = ["-x", "c++", "-std=c++20", "-O1", "-fPIC", "-pthread", "-D__HIP_PLATFORM_AMD__", "-DNDEBUG", "-U_FORTIFY_SOURCE", "-w", "-I", outdir, "-I", "/opt/rocm/include",
+    extra = os.environ.get("HOSTEXEC_CXXFLAGS", "").split()       # e.g. -fsanitize=address -fno-omit-frame-pointer (see tests/host_exec/README.md)
+    flags = extra + ["-x", "c++", "-std=c++20", "-O1", "-fPIC", "-pthread", "-D__HIP_PLATFORM_AMD__", "-DNDEBUG", "-U_FORTIFY_SOURCE", "-w", "-I", outdir, "-I", "/opt/rocm/include",
              "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-I", HERE]
     units = []
     for name in SOURCES:
@@ -135,7 +137,7 @@ def build(outdir: str) -> str:
         return obj
     with ThreadPoolExecutor(max_workers=8) as ex:
         objs = list(ex.map(cc, units))
-    r = subprocess.run([clang(), "-shared", "-pthread", "-o", lib] + objs, capture_output=True, text=True)
+    r = subprocess.run([clang(), "-shared", "-pthread", "-o", lib] + [f for f in extra if f.startswith("-fsanitize")] + objs, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("host link failed:\n" + r.stderr[-4000:])
     return lib
