@@ -245,3 +245,41 @@ def test_gpu_parity_tests_pass_on_the_host_executed_kernels(host_lib):
     b = _subset(host_lib, STRIP_IDS)
     _passed(b, len(STRIP_IDS))
     _passed(a, 95)
+
+
+def test_harness_model(tmp_path):
+    """The execution model of tests/host_exec/harness.hpp on kernels of its own (tests/host_exec/selftest_kernels.hip): one MFMA tile in
+    the gfx950 register layout against a matrix product, threads that return before a barrier, shuffles among the remaining lanes,
+    dynamic LDS, atomics across workgroups."""
+    import build_host
+    try:
+        cxx = build_host.clang()
+    except RuntimeError as e:
+        pytest.skip(str(e))
+    here = os.path.join(ROOT, "tests", "host_exec")
+    src = open(os.path.join(here, "selftest_kernels.hip")).read().replace("extern __shared__ float buf[];", "float* buf = reinterpret_cast<float*>(hostexec::dyn_lds());")
+    (tmp_path / "selftest.hip").write_text(src)
+    (tmp_path / "tu.cpp").write_text(f'#include "harness.hpp"\n#include "{tmp_path / "selftest.hip"}"\n')
+    lib = str(tmp_path / "selftest.so")
+    r = subprocess.run([cxx, "-x", "c++", "-std=c++20", "-O1", "-fPIC", "-shared", "-pthread", "-D__HIP_PLATFORM_AMD__", "-w", "-I", "/opt/rocm/include",
+                        "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "rnnpose_amd", "csrc"), "-I", here, str(tmp_path / "tu.cpp"),
+                        os.path.join(here, "runtime_host.cpp"), "-o", lib], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    st = C.CDLL(lib)
+    rng = np.random.default_rng(0)
+    a = np.ascontiguousarray(rng.standard_normal((32, 16)).astype(np.float16).astype(np.float32))
+    b = np.ascontiguousarray(rng.standard_normal((16, 32)).astype(np.float16).astype(np.float32))
+    d = np.zeros((32, 32), np.float32)
+    st.selftest_mfma(P(a), P(b), P(d))
+    assert np.array_equal(d, (a.astype(np.float64) @ b.astype(np.float64) + 1.0).astype(np.float32))      # exact products, one rounding
+    nblk = 5
+    x = np.ascontiguousarray(rng.integers(-100, 100, nblk * 128).astype(np.int32))
+    out = np.zeros(nblk * 2, np.int32)
+    st.selftest_barrier_exit(P(x), P(out), nblk)
+    xs = x.reshape(nblk, 128)
+    want = np.array([[sum(int(xs[k, (t + 2) % 128]) for t in range(w * 64, w * 64 + 64, 2)) for w in (0, 1)] for k in range(nblk)], np.int32)
+    assert np.array_equal(out.reshape(nblk, 2), want)
+    f = np.ascontiguousarray(rng.standard_normal(7 * 64).astype(np.float32))
+    y, cnt = np.zeros_like(f), np.zeros(1, np.uint64)
+    st.selftest_dyn_lds(P(f), P(cnt), P(y), 7)
+    assert np.array_equal(y.reshape(7, 64), f.reshape(7, 64)[:, ::-1]) and int(cnt[0]) == int((f > 0).sum())
