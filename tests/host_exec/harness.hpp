@@ -168,22 +168,32 @@ inline void run_block(Block& blk, unsigned nt, dim3 block, const std::function<v
     f.ctx.uc_link = nullptr;
     makecontext(&f.ctx, fiber_main, 0);
   }
+  // Wave by wave: a wave keeps the processor while any of its lanes makes progress (its collectives release among its own 64
+  // fibers: cycling all 256 fibers of the workgroup through every wave-level step was most of the switching); lanes that wait at a
+  // workgroup barrier are polled once per pass over the waves.
+  auto resume = [&](Fiber& f) {
+    blk.cur = &f;
+    threadIdx = f.tid;
+    if (_setjmp(blk.sched_env) == 0) {
+      if (!f.started) {
+        f.started = true;
+        setcontext(&f.ctx);
+      } else {
+        _longjmp(f.env, 1);
+      }
+    }
+    // (here again when the fiber yielded or finished)
+  };
   while (blk.live > 0) {
     const unsigned long long before = blk.progress;
-    for (unsigned t = 0; t < nt; ++t) {
-      Fiber& f = blk.fibers[t];
-      if (f.done) continue;
-      blk.cur = &f;
-      threadIdx = f.tid;
-      if (_setjmp(blk.sched_env) == 0) {
-        if (!f.started) {
-          f.started = true;
-          setcontext(&f.ctx);
-        } else {
-          _longjmp(f.env, 1);
-        }
+    for (int w = 0; w < nw; ++w) {
+      const unsigned t0 = static_cast<unsigned>(w) * kWaveSize, t1 = std::min(nt, t0 + kWaveSize);
+      for (;;) {
+        const unsigned long long wbefore = blk.progress;
+        for (unsigned t = t0; t < t1; ++t)
+          if (!blk.fibers[t].done) resume(blk.fibers[t]);
+        if (blk.progress == wbefore) break;          // every live lane of this wave waits for another wave (or the wave is done)
       }
-      // (here again when the fiber yielded or finished)
     }
     if (blk.progress == before && blk.live > 0) {
       std::fprintf(stderr, "hostexec: deadlock (a barrier or wave collective that not every live thread reaches)\n");
