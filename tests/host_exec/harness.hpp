@@ -13,8 +13,9 @@
 //
 // The C-ABI entry points of the source therefore run unchanged -- argument checks, launch geometry, kernel code -- on host pointers,
 // and tests/test_kernels_on_host.py compares what they compute with the CPU oracle and the reference-generated golden vectors in the
-// `-m "not gpu"` tier.  Not runnable this way: sources with gfx950 inline assembly (the strip convolution kernels, mask_upsample,
-// lm.hip).  Host libm replaces the device's expf / tanhf (1-ulp differences); the MFMA's internal summation order is not modelled
+// `-m "not gpu"` tier.  gfx950 inline assembly (the LDS-DMA requests and counted waits of the strip convolution kernels, two waits in
+// lm.hip, one register constraint) is rewritten in a scratch copy by build_host.py, as are the four places where an epilogue relies on
+// a wave's LDS operations executing in order (lanes of a wave are independent fibers between collectives).  Host libm replaces the device's expf / tanhf (1-ulp differences); the MFMA's internal summation order is not modelled
 // (the products of one instruction are summed exactly and rounded to fp32 once).
 #pragma once
 #include <hip/hip_runtime.h>

@@ -176,7 +176,7 @@ def test_gru_pointwise_stages(host):
 
 # ---- the `-m gpu` parity tests themselves, against the host-executed kernels -------------------------------------------------------
 # Excluded: sizes that take the emulation minutes (full BASELINE shapes, the long refinement loops but one), tests of hipGraph replay
-# (no capture on the host), tests that REQUIRE the strip kernels (inline assembly: GPU only) or a real torch.cuda allocator.
+# (no capture on the host) or of a real torch.cuda allocator; the strip-kernel tests are the second set (STRIP_IDS).
 PARITY_K = ("not (full_size or full_shape or loop_480 or timed_configuration or config3 or linemod_crop or graph_replay or "
             "alternate_corr_block_vs_oracle or alternate_corr_odd or teacher or facade_stateful or context_prep_and_flow_to_coords or "
             "strip or stride2_strips or patch_tiling_equals_row_major or range_guard_is_visible or per_image_tiles or "
