@@ -80,7 +80,7 @@ def clang() -> str:
 
 def _digest() -> str:
     h = hashlib.sha256()
-    h.update(os.environ.get("HOSTEXEC_CXXFLAGS", "").encode())
+    h.update((os.environ.get("HOSTEXEC_CXXFLAGS", "") + os.environ.get("HOSTEXEC_MUTATE", "")).encode())
     for d, names in ((CSRC, sorted(os.listdir(CSRC))), (HERE, sorted(os.listdir(HERE)))):
         for n in names:
             p = os.path.join(d, n)
@@ -113,8 +113,16 @@ def build(outdir: str) -> str:
         tu = os.path.join(outdir, name + ".host.cpp")
         open(tu, "w").write(f'#include "harness.hpp"\n#include "{src}"\n')
         units.append(tu)
+    # HOSTEXEC_MUTATE="file::regex::replacement": one extra rewrite of a header's scratch copy -- mutation checks ("does the tier see this
+    # bug?"), e.g. the round-5 fourth-fragment bug of the 32-row stride-2 strips (profiles/r05_hostexec_mutation.txt)
+    mutate = os.environ.get("HOSTEXEC_MUTATE", "")
     for name, patches in HEADER_PATCHES.items():
         txt = open(os.path.join(CSRC, name)).read()
+        if mutate and mutate.split("::")[0] == name:
+            _, rx, rep = mutate.split("::")
+            txt, n = re.subn(rx, lambda m: rep, txt)
+            if n != 1:
+                raise RuntimeError(f"HOSTEXEC_MUTATE matched {n} places")
         for rx, rep, hits in patches:
             txt, n = re.subn(rx, lambda m, rep=rep: rep.replace("BACKREF1", m.group(1) if m.groups() else ""), txt, flags=re.S)
             if n != hits:
