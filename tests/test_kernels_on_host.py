@@ -248,7 +248,7 @@ def test_gpu_parity_tests_pass_on_the_host_executed_kernels(host_lib):
 
 
 def test_harness_model(tmp_path):
-    """The execution model of tests/host_exec/harness.hpp on kernels of its own (tests/host_exec/selftest_kernels.hip): one MFMA tile in
+    """The execution model of tests/host_exec/harness.hpp on kernels of its own (tests/host_exec/selftest_kernels.hip.inc): one MFMA tile in
     the gfx950 register layout against a matrix product, threads that return before a barrier, shuffles among the remaining lanes,
     dynamic LDS, atomics across workgroups."""
     import build_host
@@ -257,7 +257,7 @@ def test_harness_model(tmp_path):
     except RuntimeError as e:
         pytest.skip(str(e))
     here = os.path.join(ROOT, "tests", "host_exec")
-    src = open(os.path.join(here, "selftest_kernels.hip")).read().replace("extern __shared__ float buf[];", "float* buf = reinterpret_cast<float*>(hostexec::dyn_lds());")
+    src = open(os.path.join(here, "selftest_kernels.hip.inc")).read().replace("extern __shared__ float buf[];", "float* buf = reinterpret_cast<float*>(hostexec::dyn_lds());")
     (tmp_path / "selftest.hip").write_text(src)
     (tmp_path / "tu.cpp").write_text(f'#include "harness.hpp"\n#include "{tmp_path / "selftest.hip"}"\n')
     lib = str(tmp_path / "selftest.so")
