@@ -557,14 +557,14 @@ _FAST = {"corr_lookup": corr_lookup_fast, "corr_weight": corr_weight_fast, "conv
 # a12: the loop                                                     model/PoseRefiner.py:239-365
 # --------------------------------------------------------------------------------------------------
 def refine(inp: dict, W: dict, outer: int = 3, inner: int = 8, optim_iters: int = 1,
-           capture: bool = False, stage_timer=None, fast: bool = False, literal_legacy_pose: bool = False):
+           capture: bool = False, stage_timer=None, fast: bool = False, literal_legacy_pose: bool = True):
     """One batched refinement on STATIC synthetic renderings (the renderer is out of scope, so depth /
     ctx / g1 / fmaps are not re-rendered between outer iterations).
     inp: dict from rnnpose_amd.synthetic.make_inputs (fmap1,fmap2,ctx,g1,g2,depth,K,G0,sigma) --
     if it holds img_render/img_target and W holds 'enc' weights the encoder runs per outer iteration.
-    literal_legacy_pose: start every outer iteration from Tij = Ti * Ti.inv() as the reference's legacy branch literally does
-    (model/PoseRefiner.py:243-244; geometry/se3.py:194-208: inverse = [R^T | -R^T t], product = 4x4 matmul) instead of the
-    exact identity that product stands for.
+    literal_legacy_pose (default True since r06: it is what the reference computes): start every outer iteration from
+    Tij = Ti * Ti.inv() as the reference's legacy branch literally does (model/PoseRefiner.py:243-244; geometry/se3.py:194-208:
+    inverse = [R^T | -R^T t], product = 4x4 matmul); False: the exact identity that product stands for.
     Returns dict(G=(B,1,4,4) final Ti, flow_up=last, weight=last, trace=[per-iteration captures])."""
     import time
     tm = stage_timer if stage_timer is not None else {}

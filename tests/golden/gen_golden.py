@@ -321,8 +321,37 @@ def g_loop960():
          max_abs_fmap=np.array([float(f1.abs().max()), float(f2.abs().max())]), max_abs_flow=np.array(float(it[0]["flow"].abs().max())))
 
 
+def g_loopS1enc():
+    """BASELINE configs[0]'s shape at the SHIPPED schedule against the reference itself: ONE 240 x 240 crop
+    (30 x 30 feature maps), the reference's BasicEncoder (kaiming gain 0.5) + GRU_CFUpdator + reprojction_optim, RENDER_ITER_COUNT = 3
+    outer x ITER_COUNT = 4 inner iterations (config/linemod/template_fw0.5.yml:76-81), every outer iteration started from the legacy
+    product Ti * Ti.inv() and accumulated Ti <- Tij * Ti (model/PoseRefiner.py:241-244,365).  All 12 relative poses, the final pose,
+    the first field of every outer iteration and the last field / weight (::4)."""
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    net = make_cfnet()
+    dt = syn.make_inputs_t(1, 240, 240, seed=71, device="cpu", with_images=True)
+    gain = 0.5
+    enc = object.__new__(cf.ImageFeaEncoder)
+    torch.nn.Module.__init__(enc)
+    enc.fnet = BasicEncoder(output_dim=256, norm_fn="instance", dropout=False, input_dim=3)
+    enc.eval()
+    shapes = {k: tuple(v.shape) for k, v in enc.fnet.state_dict().items()}
+    enc.fnet.load_state_dict({k: T(v) for k, v in syn.make_module_weights(shapes, seed=3, gain=gain).items()}, strict=True)
+    d = {k: v.numpy() for k, v in dt.items()}
+    f1, f2 = enc(dt["img_render"], dt["img_target"])
+    d["fmap1"], d["fmap2"] = f1.float().numpy(), f2.float().numpy()
+    outer, inner = 3, 4
+    Gf, it, first = run_loop(d, net, outer=outer, inner=inner, optim_iters=1, sigma=1.0)
+    save("loop_S1_enc", G_final=Gf, G_iters=torch.stack([x["G"] for x in it]),
+         flow_outer_first=torch.stack([it[o * inner]["flow"][:, :, ::4, ::4] for o in range(outer)]),
+         flow_last=it[-1]["flow"][:, :, ::4, ::4], w_last=it[-1]["w"][:, 0, ::4, ::4, 0],
+         fmap1_sub=f1.float()[:, ::16, ::3, ::3], fmap2_sub=f2.float()[:, ::16, ::3, ::3], enc_gain=np.array(gain),
+         schedule=np.array([outer, inner]), max_abs_fmap=np.array([float(f1.abs().max()), float(f2.abs().max())]),
+         max_abs_flow=np.array(float(it[0]["flow"].abs().max())))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["corr", "update", "upsample_ctx", "geometry", "encoder", "loop", "loop480", "loop960"]
+    which = sys.argv[1:] or ["corr", "update", "upsample_ctx", "geometry", "encoder", "loop", "loop480", "loop960", "loopS1enc"]
     for nm in which:
         print("generating", nm)
         globals()["g_" + nm]()

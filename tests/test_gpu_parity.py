@@ -1024,6 +1024,44 @@ def test_loop_480_vs_reference_fixture(ops, golden, fixture):
         assert dist[lit]["pose"] < 1e-5 and dist[lit]["flow_first"] < 5e-4 and dist[lit]["flow_last"] < 1e-3, (lit, dist[lit])
 
 
+@pytest.mark.parametrize("lit", [True, False])
+def test_loop_S1_shipped_schedule_vs_reference_fixture(ops, golden, lit):
+    """BASELINE configs[0]'s shape at the SHIPPED schedule against the REFERENCE ITSELF -- one 240 x 240 crop, the
+    encoder in the loop, RENDER_ITER_COUNT = 3 x ITER_COUNT = 4 (tests/golden/gen_golden.py g_loopS1enc: the reference's BasicEncoder +
+    GRU_CFUpdator + reprojction_optim, every outer iteration started from Ti * Ti.inv() and accumulated Ti <- Tij * Ti,
+    model/PoseRefiner.py:241-244,365).  The free-running PoseRefiner (graphs, default schedule) with the shipped default start pose
+    (lit = True: the literal product, formed by the device kernels) holds all 12 relative poses and the final pose at 1e-5 and the
+    first field at 1e-4; the later fields see the pose fed back (drift bound 5e-4).  lit = False: the exact-identity option, same bounds
+    but 5e-4 on the first field (a sensitivity record: DESIGN section 2)."""
+    from rnnpose_amd.pose_refiner import PoseRefiner, SyntheticRenderer, default_config
+    from rnnpose_amd.transformation import SE3Sequence
+    from test_oracle_golden import LOOPS1ENC, loopS1enc_inputs
+    g = golden("loop_S1_enc")
+    c = LOOPS1ENC
+    dt = loopS1enc_inputs("cuda")
+    encW, updW = syn.make_module_weights(orc.encoder_shapes(), seed=3, gain=float(g["enc_gain"])), upd_weights()
+    rend = SyntheticRenderer(syn_img=dt["img_render"], image_crop=dt["img_target"], cfea=dt["ctx"], geofea1=dt["g1"], geofea2_crop=dt["g2"],
+                             syn_depth=dt["depth"], intrinsics_crop=dt["K"])
+    cfg = default_config(RENDER_ITER_COUNT=c["outer"], ITER_COUNT=c["inner"], OPTIM_ITER_COUNT=1)
+    ref = PoseRefiner(cfg, renderer=rend, fused=True, literal_legacy_pose=lit).cuda().eval()
+    assert PoseRefiner(cfg, renderer=rend).literal_legacy_pose is True          # the shipped default is the reference's product
+    ref.cf_net.update_block.load_state_dict({k: T(v) for k, v in updW.items()}, strict=True)
+    ref.image_fea_enc.fnet.load_state_dict({k: T(v) for k, v in encW.items()}, strict=True)
+    md = lambda a, b: float((a.double().cpu() - torch.from_numpy(np.asarray(b)).double()).abs().max())
+    for rep in range(2):                                        # second call: hipGraph replay of everything
+        out = ref(dt["img_target"], SE3Sequence(matrix=dt["G0"].clone()), dt["K"])
+        Gi = torch.stack([t.G for t in ref.residual_pose_history]).cpu()
+        assert Gi.shape[0] == c["outer"] * c["inner"]
+        dist = dict(pose=max(md(Gi, g["G_iters"]), md(out["Ti_pred"].G, g["G_final"])),
+                    flow_outer_first=[md(ref.flow_history[o * c["inner"]][-1][:, :, ::4, ::4], g["flow_outer_first"][o]) for o in range(c["outer"])],
+                    flow_last=md(out["flow_last"][:, :, ::4, ::4], g["flow_last"]), w_last=md(out["weight"][:, 0, 0, ::4, ::4], g["w_last"]))
+        print(f"loop_S1_enc, literal start {lit}, call {rep}: free-running GPU refiner vs the reference:", dist)
+        assert dist["pose"] < 1e-5, dist
+        assert dist["flow_outer_first"][0] < (1e-4 if lit else 5e-4), dist
+        assert max(dist["flow_outer_first"]) < 5e-4 and dist["flow_last"] < 5e-4 and dist["w_last"] < 5e-4, dist
+        assert int(out["f16x3_range_events"].item()) == 0
+
+
 @pytest.mark.parametrize("B", [16, 32])
 def test_linemod_crop_shape_loops_vs_oracle(ops, B):
     """BASELINE configs[2] / configs[3] at THEIR shape: LINEMOD / LM-O run 240x240 zoom crops (30x30

@@ -294,6 +294,42 @@ def test_loop_960_oracle_pinned_at_config5_image_size(golden):
     assert dist["pose"] < 1e-5 and dist["flow_first"] < 1e-4 and dist["w_first"] < 1e-4, dist
 
 
+LOOPS1ENC = dict(B=1, H=240, W=240, seed=71, outer=3, inner=4)
+
+
+def loopS1enc_inputs(device="cpu"):
+    """The inputs tests/golden/gen_golden.py g_loopS1enc fed the reference."""
+    c = LOOPS1ENC
+    return syn.make_inputs_t(c["B"], c["H"], c["W"], seed=c["seed"], device=device, with_images=True)
+
+
+def test_loop_S1_shipped_schedule_oracle_pinned(golden):
+    """BASELINE configs[0]'s shape at the SHIPPED schedule (one 240 x 240 crop, 3 outer x 4 inner iterations,
+    config/linemod/template_fw0.5.yml:76-81) against the REFERENCE ITSELF with its encoder in the loop: pins the multi-outer
+    accumulation Ti <- Tij * Ti with the literal start Tij = Ti * Ti.inv() of every outer iteration (model/PoseRefiner.py:241-244,365)
+    end to end -- all 12 relative poses and the final pose at 1e-5, the first field of the first outer iteration at 1e-4 (identical
+    inputs), the later fields (free-running: poses fed back) at the drift bound 5e-4."""
+    import os
+    g = golden("loop_S1_enc")
+    c = LOOPS1ENC
+    assert tuple(g["schedule"]) == (c["outer"], c["inner"])
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    d = {k: v.numpy() for k, v in loopS1enc_inputs().items()}
+    d.pop("fmap1"), d.pop("fmap2")
+    W = {"upd": upd_weights(), "enc": syn.make_module_weights(orc.encoder_shapes(), seed=3, gain=float(g["enc_gain"]))}
+    f1, f2 = orc.image_encoder(W["enc"], d["img_render"], d["img_target"])
+    fmax = float(g["max_abs_fmap"].max())
+    assert maxdiff(f1[:, ::16, ::3, ::3], g["fmap1_sub"]) < 1e-5 * max(fmax, 1.0) and maxdiff(f2[:, ::16, ::3, ::3], g["fmap2_sub"]) < 1e-5 * max(fmax, 1.0)
+    res = orc.refine(d, W, outer=c["outer"], inner=c["inner"], optim_iters=1, capture=True, fast=True)        # (default: the literal start)
+    Gi = torch.stack([t["Tij"] for t in res["trace"]])
+    dist = dict(pose=max(maxdiff(Gi, g["G_iters"]), maxdiff(res["G"], g["G_final"])),
+                flow_outer_first=[maxdiff(res["trace"][o * c["inner"]]["flow_up"][:, :, ::4, ::4], g["flow_outer_first"][o]) for o in range(c["outer"])],
+                flow_last=maxdiff(res["flow_up"][:, :, ::4, ::4], g["flow_last"]), w_last=maxdiff(res["weight"][:, ::4, ::4], g["w_last"]))
+    print("loop_S1_enc oracle vs reference (max |feature map| %.1f, max |flow| %.2f):" % (fmax, float(g["max_abs_flow"])), dist)
+    assert dist["pose"] < 1e-5 and dist["flow_outer_first"][0] < 1e-4, dist
+    assert max(dist["flow_outer_first"]) < 5e-4 and dist["flow_last"] < 5e-4 and dist["w_last"] < 5e-4, dist
+
+
 # ---- row f2: evaluator arithmetic pinned to the reference's own utils/eval_metric.py (tests/golden/gen_golden_eval.py) ----
 EVAL_SETS = [("cat_", False), ("driller_", False), ("sym_eggbox_", True)]
 
