@@ -99,6 +99,7 @@ void strip_allow_two_wave(int on);                             // measurement: t
 void strip_force_ni(int ni);                                   // measurement: 0 automatic, 1 / 2 column tiles per wave
 void strip_allow_small(int on);                                // measurement: 32-row strips in the automatic choice (default on)
 void strip_allow_s2(int on);                                   // measurement: stride-2 3x3 layers on strips over parity planes (default on)
+void strip_allow_small32(int on);                              // measurement: 32-row strips for launches of <= 256 waves of 160-row strips (default on)
 long long strip_s2_halfs(int c_in, int kh, int kw, int ncb, int Npad, int n_seg);   // size of the stride-2 copy of a layer's packed weights (0: none)
 // strip height (160 / 32 rows) a launch of `batch` images takes, 0 = not a strip launch; request: 0 automatic, else the height to force
 int strip_rows(int H, int W, int kh, int kw, int stride, int c_out, int batch, int request);

@@ -144,8 +144,13 @@ int strip_tiles_per_image(int H, int W, int kh, int kw, int rows) {
 
 static int g_strip_small = 1;        // 32-row strips in the automatic choice (strip_allow_small)
 void strip_allow_small(int on) { g_strip_small = on; }
+#ifndef RS_SMALL32_WAVES
+#define RS_SMALL32_WAVES 256         // (measurement: -DRS_SMALL32_WAVES=512 also moves the GRU's q and the motion encoder's last layer at B = 4)
+#endif
+static int g_strip_small32 = 1;      // r06: 32-row strips for launches of <= 256 waves of 160-row strips (rnnpose_conv_strip(6): off)
 static int g_strip_s2 = 1;           // stride-2 3x3 layers as strips over parity planes (strip_allow_s2; 0: the 128-row kernel's tap-per-staging mode)
 void strip_allow_s2(int on) { g_strip_s2 = on; }
+void strip_allow_small32(int on) { g_strip_small32 = on; }
 
 // Strip height for a launch of `batch` images: 160 or 32 rows -- or 0: not a strip launch.  request: 0 = automatic, else that height
 // (tests, measurement).  160-row strips when they give the launch >= 240 workgroups (about one per CU) or, failing that, >= 24 per
@@ -180,7 +185,12 @@ int strip_rows(int H, int W, int kh, int kw, int stride, int c_out, int batch, i
     return fits(160) && strip_tiles_per_image(H, W, kh, kw, 160) * ncol >= 24 ? 160 : 0;
   const long long t160 = strip_tiles_per_image(H, W, kh, kw, 160) * static_cast<long long>(ncol);
   const long long npix = nb * H * W;
-  if (fits(160) && (t160 * nb >= 240 || (t160 >= 24 && npix > 8192))) return 160;
+  if (fits(160) && (t160 * nb >= 240 || (t160 >= 24 && npix > 8192))) {
+    // r06: a launch whose 160-row strips are at most 256 WAVES (a quarter of the chip's SIMDs: convf2 128 -> 64 of a half-batch chain =
+    // 120 two-wave workgroups) takes 32-row strips instead -- five times the waves; 15 vs 26 us (profiles/r05_conv_layers_alone.txt hl6 / hl5)
+    if (g_strip_small32 && stride == 1 && t160 * nb * (cfg & 15) <= RS_SMALL32_WAVES && fits(32)) return 32;
+    return 160;
+  }
   if (fits(32) && npix <= 8192 && strip_tiles_per_image(H, W, kh, kw, 32) * ncol * nb >= 24) return 32;
   return 0;
 }
