@@ -254,12 +254,13 @@ typedef struct {
                                   encoder sets it: every convolution input there is an instance-normalised map or a ReLU sum of a few
                                   (|(x - mean) * rstd| <= sqrt(H*W); extractor.py:48-58), two orders below the fp16x3 range */
   int tile;                    /* 0 = automatic; 1 = 128x64, 2 = 128x128 as 4 column waves, 3 = 128x128 as 2x2 waves, 4 = 128x64 with
-                                  a block-deep register pipeline (3, 4: split sources only); 5 / 6 = the STRIP kernels with 160- / 32-row strips (160 / 32 output
+                                  a block-deep register pipeline (3, 4: split sources only); 5 / 6 / 7 = the STRIP kernels with 160- / 32- / 96-row strips (160 / 32 / 96 output
                                   pixels x 64 / 96 / 128 columns per workgroup, weights and split-tensor activations by LDS-DMA:
                                   stride 1, 3x3 / 1x5 / 5x1, c_out > 32, source channel counts in multiples of 32; a launch with tile_stats / src0_mean_rstd tiles every image into
                                   rnnpose_conv_tiles_per_image_ex(..., tile, B) tiles).  The automatic choice takes 160-row strips for
-                                  these layer shapes when they give the launch >= 240 workgroups (or >= 24 per image), 32-row strips
-                                  for launches of <= 8192 pixels (single-image crops), else the 128-row kernels
+                                  these layer shapes when they give the launch >= 240 workgroups (or >= 24 per image) -- r06: 32-row strips
+                                  instead when those are at most 256 waves, 96-row strips when at most 512 (the thin layers of a
+                                  half-batch chain) --, 32-row strips for launches of <= 8192 pixels (single-image crops), else the 128-row kernels
                                   (rnnpose_conv_strip(0): never strips). */
   void* ksplit_ws;             /* optional (NULL = off): workspace of rnnpose_conv_ksplit_workspace_bytes() bytes, 16-byte aligned,
                                   its first 1024 bytes ZERO before the first launch (the kernel leaves them zero).  With it, a
@@ -298,8 +299,8 @@ int rnnpose_conv_tiles_per_image_desc(const rnnpose_conv_desc_t* h_desc);
 /* fp16 MFMA products per multiply-add the launch this descriptor describes executes: 3 (fp16x3 split) or 1 (single_product honoured:
  * 160-row strips with one column tile per wave).  For flop accounting (bench.py's pipe_util); -1 on bad arguments. */
 int rnnpose_conv_products_desc(const rnnpose_conv_desc_t* h_desc);
-/* The same for the kernel a launch of `batch` images with this c_out and `tile` request (0 automatic .. 6) will take: the strip
- * kernels tile an image into ceil(W/16) * ceil(H/10) patches of 10 x 16 pixels (3x3) or ceil(H*W/160) runs of 160 pixels (32-row
+/* The same for the kernel a launch of `batch` images with this c_out and `tile` request (0 automatic .. 7) will take: the strip
+ * kernels tile an image into ceil(W/16) * ceil(H/10) patches of 10 x 16 pixels (3x3) or ceil(H*W/160) runs of 160 pixels (96-row strips: patches of 6 x 16 pixels, runs of 96; 32-row
  * strips: patches of 2 x 16 pixels, runs of 32).  Shape-only: it assumes source channel counts in multiples of 32 (launches whose
  * sources are not fall back to the 128-row kernels: use rnnpose_conv_tiles_per_image_desc). */
 int rnnpose_conv_tiles_per_image_ex(int H, int W, int kh, int kw, int stride, int c_out, int tile, int batch);

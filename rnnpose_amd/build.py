@@ -38,7 +38,7 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
-TRAFFIC_KERNEL_FILES = ("conv_igemm.hip", "conv_strip.hip", "conv_strip_r32.hip", "conv_strip_p1.hip", "corr_pyramid.hip")      # the kernels whose HBM counters profiles/traffic.json holds
+TRAFFIC_KERNEL_FILES = ("conv_igemm.hip", "conv_strip.hip", "conv_strip_r32.hip", "conv_strip_r96.hip", "conv_strip_p1.hip", "corr_pyramid.hip")      # the kernels whose HBM counters profiles/traffic.json holds
 
 
 def source_digest() -> str:

@@ -108,6 +108,7 @@ int strip_tiles_per_image(int H, int W, int kh, int kw, int rows);      // outpu
 // members.  hlin: split-tensor sources (LDS-DMA); else fp32 sources through registers (+ fused normalisation when p.in_mr).
 int strip_launch(KParams& p, int H, int W, int kh, int kw, bool hlin, bool per_image, int rows, hipStream_t st);
 int strip_launch_r32(const KParams& p, int nw, int ni, bool spatial, bool hlin, bool norm, unsigned nwg, hipStream_t st);      // conv_strip_r32.hip
+int strip_launch_r96(const KParams& p, int nw, int ni, bool spatial, bool hlin, bool norm, unsigned nwg, hipStream_t st);      // conv_strip_r96.hip (r06)
 int strip_launch_p1(const KParams& p, int nw, int ni, bool spatial, bool hlin, bool norm, unsigned nwg, hipStream_t st);       // conv_strip_p1.hip: 160-row strips, single product
 void strip_pack(const float* w, _Float16* pk, const PackParams& q, hipStream_t st);
 

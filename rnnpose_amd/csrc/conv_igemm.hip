@@ -889,12 +889,13 @@ int rnnpose_conv_tiles_per_image(int H, int W, int kh, int kw, int stride) {
 // Strip height of the launch `d` describes (0: the 128-row kernels).  tile 5 / 6 force a height (errors surface in the launch); the
 // automatic choice takes strips only when the sources qualify -- whole 32-channel blocks, the fused normalisation only for 3x3 --
 // and otherwise falls back, with or without tile statistics (r04 raised an error there: ADVICE).  The ONE place this is decided.
+static int strip_tile_rows(int tile) { return tile == 5 ? 160 : (tile == 6 ? 32 : 96); }      // tile codes of the strip heights (7: r06)
 static int desc_strip_rows(const rnnpose_conv_desc_t* d) {
   if (d->stride == 2) {      // the parity-plane form: ONE fp32 source of whole 32-channel blocks, no fused normalisation, <= MAX_CB blocks over the four planes
     if (d->n_src != 1 || d->src[0].c_count % 32 != 0 || d->src_hl || d->src0_mean_rstd || 4 * (d->src[0].c_count / 32) > MAX_CB) return 0;
     if (!((d->kh == 3 && d->kw == 3) || (d->kh == 1 && d->kw == 1))) return 0;
   }
-  if (d->tile >= 5) return strip_rows(d->H, d->W, d->kh, d->kw, d->stride, d->c_out, d->B, d->tile == 5 ? 160 : 32);
+  if (d->tile >= 5) return strip_rows(d->H, d->W, d->kh, d->kw, d->stride, d->c_out, d->B, strip_tile_rows(d->tile));
   if (d->tile != 0 || !g_conv_strip) return 0;
   const int rows = strip_rows(d->H, d->W, d->kh, d->kw, d->stride, d->c_out, d->B, 0);
   if (!rows) return 0;
@@ -905,7 +906,7 @@ static int desc_strip_rows(const rnnpose_conv_desc_t* d) {
 }
 
 int rnnpose_conv_tiles_per_image_desc(const rnnpose_conv_desc_t* d) {
-  if (!d || d->H <= 0 || d->W <= 0 || (d->stride != 1 && d->stride != 2) || d->c_out <= 0 || d->tile < 0 || d->tile > 6 || d->B < 1 ||
+  if (!d || d->H <= 0 || d->W <= 0 || (d->stride != 1 && d->stride != 2) || d->c_out <= 0 || d->tile < 0 || d->tile > 7 || d->B < 1 ||
       d->n_src < 1 || d->n_src > 4)
     return -1;
   const int rows = desc_strip_rows(d);
@@ -922,9 +923,9 @@ int rnnpose_conv_products_desc(const rnnpose_conv_desc_t* d) {
 }
 
 int rnnpose_conv_tiles_per_image_ex(int H, int W, int kh, int kw, int stride, int c_out, int tile, int batch) {
-  if (H <= 0 || W <= 0 || (stride != 1 && stride != 2) || c_out <= 0 || tile < 0 || tile > 6 || batch < 1) return -1;
+  if (H <= 0 || W <= 0 || (stride != 1 && stride != 2) || c_out <= 0 || tile < 0 || tile > 7 || batch < 1) return -1;
   int rows = 0;
-  if (tile >= 5) rows = strip_rows(H, W, kh, kw, stride, c_out, batch, tile == 5 ? 160 : 32);
+  if (tile >= 5) rows = strip_rows(H, W, kh, kw, stride, c_out, batch, strip_tile_rows(tile));
   else if (tile == 0 && g_conv_strip) rows = strip_rows(H, W, kh, kw, stride, c_out, batch, 0);
   if (tile >= 5 && rows == 0) return -1;
   if (rows) return stride == 2 ? strip_tiles_per_image(H / 2, W / 2, 3, 3, rows) : strip_tiles_per_image(H, W, kh, kw, rows);
@@ -1074,7 +1075,7 @@ int rnnpose_conv2d_nhwc_f16x3(const rnnpose_conv_desc_t* d, rnnpose_stream_t str
   if (d->dst_split) RP_REQUIRE(d->epilogue != 2 && d->dst_split_c_stride % 8 == 0 && d->dst_split_c_offset % 4 == 0 &&
                                    reinterpret_cast<uintptr_t>(d->dst_split) % 32 == 0, fn,
                                "dst_split: not with the GRU z|r epilogue; channel stride multiple of 8, offset of 4, 32-byte aligned");
-  RP_REQUIRE(d->tile >= 0 && d->tile <= 6, fn, "tile must be 0 (auto), 1 (128x64), 2 (128x128, 4 column waves), 3 (128x128, 2x2 waves), 4 (128x64, deep pipeline), 5 / 6 (strips of 160 / 32 rows)");
+  RP_REQUIRE(d->tile >= 0 && d->tile <= 7, fn, "tile must be 0 (auto), 1 (128x64), 2 (128x128, 4 column waves), 3 (128x128, 2x2 waves), 4 (128x64, deep pipeline), 5 / 6 / 7 (strips of 160 / 32 / 96 rows)");
   if (d->tile_stats) RP_REQUIRE(d->epilogue == 0, fn, "tile_stats needs the linear epilogue");
   const long long Mtot = static_cast<long long>(d->B) * Ho * Wo;
   RP_REQUIRE(Mtot < (1LL << 31) - 256 && static_cast<long long>(d->B) * d->H * d->W < (1LL << 31) - 256, fn, "too many pixels");

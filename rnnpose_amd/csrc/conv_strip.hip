@@ -144,6 +144,9 @@ int strip_tiles_per_image(int H, int W, int kh, int kw, int rows) {
 
 static int g_strip_small = 1;        // 32-row strips in the automatic choice (strip_allow_small)
 void strip_allow_small(int on) { g_strip_small = on; }
+#ifndef RS_MID96_WAVES
+#define RS_MID96_WAVES 512
+#endif
 #ifndef RS_SMALL32_WAVES
 #define RS_SMALL32_WAVES 256         // (measurement: -DRS_SMALL32_WAVES=512 also moves the GRU's q and the motion encoder's last layer at B = 4)
 #endif
@@ -168,7 +171,7 @@ int strip_rows(int H, int W, int kh, int kw, int stride, int c_out, int batch, i
     H >>= 1; W >>= 1;
     kh = kw = 3;          // (tiled like a 3x3 layer: 10 x 16 patches)
   }
-  if (request != 0) return (request == 160 || (request == 32 && ni == 1)) ? request : 0;
+  if (request != 0) return (request == 160 || ((request == 32 || request == 96) && ni == 1)) ? request : 0;
   if ((cfg & 15) == 2 && ni == 1 && g_strip_two_wave == 0) return 0;      // (two-wave workgroups, c_out <= 64: see strip_allow_two_wave)
   auto fits = [&](int rows) {
     if (ni == 2 && rows != 160) return false;         // (two tiles per wave: 160-row strips only)
@@ -189,6 +192,10 @@ int strip_rows(int H, int W, int kh, int kw, int stride, int c_out, int batch, i
     // r06: a launch whose 160-row strips are at most 256 WAVES (a quarter of the chip's SIMDs: convf2 128 -> 64 of a half-batch chain =
     // 120 two-wave workgroups) takes 32-row strips instead -- five times the waves; 15 vs 26 us (profiles/r05_conv_layers_alone.txt hl6 / hl5)
     if (g_strip_small32 && stride == 1 && t160 * nb * (cfg & 15) <= RS_SMALL32_WAVES && fits(32)) return 32;
+    // ... and one of at most 512 waves (half the SIMDs: the 128-column layers of a half-batch chain -- GRU q, the motion encoder's last
+    // layer: 120 four-wave workgroups) 96-row strips (three 32-row tiles per wave, 6 x 16 patches): 200 workgroups; q 34 -> 25 us, conv
+    // 256 -> 126 53 -> 40 us at B = 4 (profiles/r06_strip_heights.txt); at B = 8 (960 waves) the 160-row form stays ahead
+    if (g_strip_small32 && stride == 1 && t160 * nb * (cfg & 15) <= RS_MID96_WAVES && fits(96)) return 96;
     return 160;
   }
   if (fits(32) && npix <= 8192 && strip_tiles_per_image(H, W, kh, kw, 32) * ncol * nb >= 24) return 32;
@@ -225,7 +232,7 @@ int strip_launch(KParams& p, int H, int W, int kh, int kw, bool hlin, bool per_i
   const int cfg = strip_waves(p.Cout);
   RP_REQUIRE(cfg != 0, fn, "strip kernel: c_out must exceed 32");
   const int ni = cfg >> 4, nw = cfg & 15;
-  RP_REQUIRE(rows == 160 || (rows == 32 && ni == 1), fn, "strip kernel: strips of 160 or 32 rows (two column tiles per wave: 160 only)");
+  RP_REQUIRE(rows == 160 || ((rows == 32 || rows == 96) && ni == 1), fn, "strip kernel: strips of 160, 96 or 32 rows (two column tiles per wave: 160 only)");
   const bool spatial = kh == 3;
   const bool norm = p.in_mr != nullptr;
   RP_REQUIRE(!norm || (spatial && !hlin), fn, "strip kernel: the fused normalisation is the 3x3 fp32-source form");
@@ -267,6 +274,7 @@ int strip_launch(KParams& p, int H, int W, int kh, int kw, bool hlin, bool per_i
   int bad;
   if (rows == 160 && p.single_product && ni == 1 && p.stride == 1) bad = strip_launch_p1(p, nw, ni, spatial, hlin, norm, nwg, st);      // (the stride-2 forms keep three products)
   else if (rows == 160) bad = strip_launch_height<5>(p, nw, ni, spatial, hlin, norm, nwg, st);
+  else if (rows == 96) bad = strip_launch_r96(p, nw, ni, spatial, hlin, norm, nwg, st);
   else bad = strip_launch_r32(p, nw, ni, spatial, hlin, norm, nwg, st);
   RP_REQUIRE(!bad, fn, "strip kernel: no kernel for this workgroup shape and strip height");
   return rp::check_launch(fn);

@@ -572,7 +572,7 @@ def conv2d_nhwc(pc: PackedConv, srcs, dst, epilogue: int = EPI_LINEAR, aux0=None
     Writes in place into dst (and dst2); returns nothing.
     src_hl / dst_hl / dst2_hl: the sources / dst / dst2 are SPLIT tensors (fp16 hi|lo per 8-channel group in a buffer of the
     fp32 tensor's shape: include/rnnpose_hip.h; split_hl / unsplit_hl convert); dst_split = (tensor, c_offset): an additional
-    split-form copy of the primary result; tile: 0 auto, 1..4 tile shapes of the 128-row kernels, 5 / 6 the strip kernels with 160- / 32-row strips
+    split-form copy of the primary result; tile: 0 auto, 1..4 tile shapes of the 128-row kernels, 5 / 6 / 7 the strip kernels with 160- / 32- / 96-row strips
     (160-row strips, operands by LDS-DMA: include/rnnpose_hip.h)."""
     _apply_conv_env()
     d = _lib.ConvDesc()
@@ -658,7 +658,7 @@ def single_product(enable=None) -> bool:
 def conv_tiles_per_image(H, W, kh, kw, stride=1, c_out=None, tile: int = 0, batch: int = 1, src_counts=None, fused_norm: bool = False) -> int:
     """Records per image of a convolution's tile_stats.  128-row kernels: 3x3 stride 1 on 8 x 16 patches, else runs of 128
     output pixels; with c_out given: for the kernel a launch of `batch` images of that width and `tile` request takes -- the strip
-    kernels (csrc/conv_strip*.hip, tile=5 / 6 or the automatic choice) tile an image into 10 / 2 x 16 patches or runs of 160 / 32 pixels.
+    kernels (csrc/conv_strip*.hip, tile=5 / 6 / 7 or the automatic choice) tile an image into 10 / 2 / 6 x 16 patches or runs of 160 / 32 / 96 pixels.
     src_counts (channel counts of the sources) and fused_norm (the launch passes in_norm) complete the description: sources that are
     not whole 32-channel blocks send an automatic launch to the 128-row kernels (rnnpose_conv_tiles_per_image_desc)."""
     _apply_conv_env()

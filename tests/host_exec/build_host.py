@@ -64,7 +64,7 @@ HEADER_PATCHES = {
          "const unsigned lds0 = hostexec::lds_register(lds);", 1),
     ],
 }
-STRIP_SOURCES = ["conv_strip.hip", "conv_strip_r32.hip", "conv_strip_p1.hip"]      # copied next to the patched header (quote includes look there first)
+STRIP_SOURCES = ["conv_strip.hip", "conv_strip_r32.hip", "conv_strip_r96.hip", "conv_strip_p1.hip"]      # copied next to the patched header (quote includes look there first)
 
 SOURCES = ["pointwise.hip", "corr_pyramid.hip", "corr_lookup.hip", "corr_alt.hip", "conv_igemm.hip", "conv1x1_resident.hip", "stem.hip",
            "nhwc_ops.hip", "eval_metrics.hip", "zoom_crop.hip", "raster.hip", "lm.hip", "mask_upsample.hip"]

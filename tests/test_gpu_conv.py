@@ -668,9 +668,9 @@ STRIP_SHAPES = [
 ]
 
 
-@pytest.fixture(params=[5, 6], ids=["rows160", "rows32"])
+@pytest.fixture(params=[5, 6, 7], ids=["rows160", "rows32", "rows96"])
 def strip_tile(request):
-    """tile code of the strip height under test: 5 = 160-row strips (10 x 16 patches), 6 = 32 rows (2 x 16)."""
+    """tile code of the strip height under test: 5 = 160-row strips (10 x 16 patches), 6 = 32 rows (2 x 16), 7 = 96 rows (6 x 16; r06)."""
     return request.param
 
 
@@ -776,7 +776,7 @@ def test_conv_strip_tile_stats_and_fused_input_norm(ops, strip_mode, strip_tile,
     b1, b2 = syn.uniform("pn.b1", (cin,), 4, -0.5, 0.5), syn.uniform("pn.b2", (cout,), 5, -0.5, 0.5)
     p1, p2 = ops.PackedConv(D(w1), D(b1), [cin]), ops.PackedConv(D(w2), D(b2), [cin])
     tpi = ops.conv_tiles_per_image(H, W, 3, 3, 1, cin, strip_tile, B)
-    assert tpi == -(-H // {5: 10, 6: 2}[strip_tile]) * -(-W // 16)
+    assert tpi == -(-H // {5: 10, 6: 2, 7: 6}[strip_tile]) * -(-W // 16)
     c1 = torch.empty(B, H, W, cin, device="cuda")
     ts = torch.full((B * tpi, cin, 2), -1.0, device="cuda", dtype=torch.float64)
     ops.conv2d_nhwc(p1, [(nhwc(D(x)), 0)], (c1, 0), ops.EPI_LINEAR, tile_stats=ts, tile=strip_tile)
@@ -839,7 +839,9 @@ def test_conv_strip_is_the_automatic_choice_at_the_update_block_shape(ops):
     the K sum of an output element does not depend on the tile)."""
     assert ops.conv_tiles_per_image(60, 80, 3, 3, 1, 192, 0, 8) == 30 and ops.conv_tiles_per_image(60, 80, 3, 3, 1, 192, 1, 8) == 40
     assert ops.conv_tiles_per_image(60, 80, 3, 3, 1, 192, 0, 1) == 150 and ops.conv_tiles_per_image(60, 80, 3, 3, 1, 192, 6, 8) == 150
-    assert ops.conv_tiles_per_image(60, 80, 3, 3, 1, 192, 0, 2) == 30      # (two images: 9600 pixels, 60 strips per image: 160-row strips)
+    assert ops.conv_tiles_per_image(60, 80, 3, 3, 1, 192, 0, 2) == 50      # (two images: 9600 pixels; 160-row strips would be 120 three-wave workgroups = 360 waves: r06 takes 96-row strips, 6 x 16 patches)
+    assert ops.conv_tiles_per_image(60, 80, 3, 3, 1, 192, 7, 8) == 50 and ops.conv_tiles_per_image(60, 80, 3, 3, 1, 64, 0, 4) == 150      # (convf2 of a half-batch chain: 240 waves -> 32-row strips)
+    assert ops.conv_tiles_per_image(60, 80, 3, 3, 1, 126, 0, 4) == 50 and ops.conv_tiles_per_image(60, 80, 3, 3, 1, 126, 0, 8) == 30        # (128-column layers: 480 waves at B = 4 -> 96 rows; 960 at B = 8 -> 160)
     assert ops.conv_tiles_per_image(30, 30, 3, 3, 1, 192, 0, 1) == 30      # LINEMOD crops, one image: 15 x 2 patches of 2 x 16
     B, H, W = 2, 60, 80
     x = D(syn.normal("ax", (B, H, W, 256), 31, std=1.2))
@@ -869,9 +871,9 @@ def test_conv_tile_stats_with_narrow_sources_fall_back_to_the_128_row_kernels(op
     w = syn.normal("nf.w", (cout, cin, 3, 3), 3, std=float(np.sqrt(2.0 / (cin * 9))))
     b = syn.uniform("nf.b", (cout,), 3, -0.5, 0.5)
     pc = ops.PackedConv(D(w), D(b), [cin])
-    tpi_strips = ops.conv_tiles_per_image(H, W, 3, 3, 1, cout, 0, B)                       # shape-only rule: 10 x 16 patches
+    tpi_strips = ops.conv_tiles_per_image(H, W, 3, 3, 1, cout, 0, B)                       # shape-only rule: strips (r06: 60 three-wave workgroups of 160 rows = 180 waves -> 32-row strips, 2 x 16 patches)
     tpi = ops.conv_tiles_per_image(H, W, 3, 3, 1, cout, 0, B, src_counts=[cin])           # this launch: 8 x 16 patches of the 128-row kernel
-    assert tpi_strips == 6 * 5 and tpi == 8 * 5
+    assert tpi_strips == 30 * 5 and ops.conv_tiles_per_image(H, W, 3, 3, 1, cout, 5, B) == 6 * 5 and tpi == 8 * 5
     out = torch.empty(B, H, W, cout, device="cuda")
     ts = torch.full((B * tpi, cout, 2), -1.0, device="cuda", dtype=torch.float64)
     ops.conv2d_nhwc(pc, [(nhwc(D(x)), 0)], (out, 0), ops.EPI_LINEAR, tile_stats=ts)
