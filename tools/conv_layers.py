@@ -25,7 +25,7 @@ shapes = [("convc2 3x3 256->192", [256], 192, 3, 3),
           ("heads 3x3 128->512", [128], 512, 3, 3), ("inp 1x5 128->384", [128], 384, 1, 5),
           ("enc l1 3x3 64->64 @240x320", [64], 64, 3, 3), ("enc l2 3x3 96->96 @120x160", [96], 96, 3, 3),
           ("enc l3 3x3 128->128 @60x80", [128], 128, 3, 3)]
-modes = [("f32", False, 0), ("f32t5", False, 5), ("hl5", True, 5), ("hl6", True, 6), ("f32t6", False, 6), ("f32t1", False, 1), ("f32t2", False, 2), ("hl0", True, 0), ("hl1", True, 1), ("hl2", True, 2), ("hl3", True, 3), ("hl4", True, 4), ("hl7", True, 7),
+modes = [("f32", False, 0), ("f32t5", False, 5), ("hl5", True, 5), ("hl6", True, 6), ("f32t6", False, 6), ("f32t1", False, 1), ("f32t2", False, 2), ("hl0", True, 0), ("hl1", True, 1), ("hl2", True, 2), ("hl3", True, 3), ("hl4", True, 4), ("hl7", True, 7), ("f32t7", False, 7),
          ("f32ks", False, 0)]          # f32ks: fp32 sources with a K-split workspace (small launches split their K loop)
 ksws = ops.conv_ksplit_workspace("cuda")
 for B in batches:
