@@ -400,6 +400,18 @@ int rnnpose_conv1x1_resident_pack_f16x3(const float* weight, int c_out, int c_in
 int rnnpose_conv1x1_resident_f16x3(const float* x, int x_c_stride, int x_c_offset, int c_in, const void* w_packed,
                                    const float* bias, float a_scale, float w_scale, int relu, long long n_pixels, float* dst,
                                    int dst_c_stride, int dst_c_offset, int dst_split, rnnpose_stream_t stream);
+/* r06: the window lookup and convc1 in ONE launch -- corr = CorrBlock.__call__(coords) (thirdparty/raft/corr.py:36-57, bilinear_sampler:
+ * thirdparty/raft/utils/utils.py:57-71) followed by relu(convc1(corr)) (thirdparty/raft/update.py:80,87), as GRU_CFUpdator.forward
+ * chains them (model/CFNet.py:147-152).  The 4 x 81 window features of a 32-pixel tile are computed level by level straight into an LDS ring of
+ * channel blocks that the 1x1 convolution's MFMAs consume (csrc/corr_convc1.hip); the (B,h,w,324) tensor is never written.  (Measured equal
+ * to the two-kernel path, not faster: the engine keeps the two kernels by default.)  pyramid: the buffer of rnnpose_corr_pyramid_* built for B
+ * images; [b0, b1): the images of this launch; coords (b1-b0, 2, h, w) fp32 (channel 0 = x): window centres; w_packed / bias / scales:
+ * convc1 packed by rnnpose_conv1x1_resident_pack_f16x3 with c_in = 324; dst (b1-b0, h, w, dst_c_stride), channels [dst_c_offset, +256),
+ * fp32 or (dst_split) a split tensor.  levels must be 4, radius 4.  Same values as rnnpose_corr_lookup_nhwc_part_f32 followed by
+ * rnnpose_conv1x1_resident_f16x3 (identical operations per element; tests compare them to 1e-6). */
+int rnnpose_corr_lookup_convc1_f16x3(const float* pyramid, const float* coords, int B, int b0, int b1, int h, int w, int levels,
+                                     int radius, const void* w_packed, const float* bias, float a_scale, float w_scale, int relu,
+                                     float* dst, int dst_c_stride, int dst_c_offset, int dst_split, rnnpose_stream_t stream);
 /* mask.2 + convex up-sampling in ONE kernel: mask = post_scale * mask.2(x) (1x1, 256 -> 576, thirdparty/raft/update.py:183-187)
  * is consumed in registers by the softmax / 3x3 convex combination of model/CFNet.py:95-106; the (B,h,w,576) mask tensor is
  * never written.  pack: weight (576,256) fp32 -> fp16 hi / lo MFMA fragments (rnnpose_mask_upsample_packed_bytes() bytes,

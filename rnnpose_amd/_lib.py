@@ -103,6 +103,7 @@ PROTOTYPES = {
     "rnnpose_conv1x1_resident_packed_bytes": (_z, [_i]),
     "rnnpose_conv1x1_resident_pack_f16x3": (_i, [_p, _i, _i, _f, _p, _p]),
     "rnnpose_conv1x1_resident_f16x3": (_i, [_p, _i, _i, _i, _p, _p, _f, _f, _i, _ll, _p, _i, _i, _i, _p]),
+    "rnnpose_corr_lookup_convc1_f16x3": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _f, _f, _i, _p, _i, _i, _i, _p]),
     "rnnpose_mask_upsample_pack_f16x3": (_i, [_p, _f, _f, _p, _p]),
     "rnnpose_instnorm_workspace_bytes": (_z, [_i, _i, _i]),
     "rnnpose_instnorm_tiles_nhwc_f32": (_i, [_p, _i, _i, _i, _f, _i, _p, _p, _i, _p, _i, _p, _p, _p]),

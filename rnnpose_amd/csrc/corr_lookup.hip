@@ -14,27 +14,11 @@
 // One wave per workgroup (one pyramid level x 16 pixels), 6.5 KB LDS.  The gather is latency-bound: r01 ablation =
 // 0.075 of 0.11 ms in the footprint loads; 64 pixels per wave (25.9 KB LDS, 6 waves per CU) ran at 0.111 ms, 32 at
 // 0.067, 16 at 0.057 (16 waves per CU, the VGPR limit) -- phase 2 then only uses 16 lanes, but it is 5 % of the time.
-#include "common.hpp"
-
-
-#ifndef RPL_LB
-#define RPL_LB 8          // pixels whose footprint loads are in flight together (measurement: 16)
-#endif
+#include "corr_lookup.cuh"
 
 namespace {
 
-constexpr int R = 4;
-constexpr int WIN = 2 * R + 1;      // 9
-constexpr int FP = WIN + 1;         // 10: footprint side
-constexpr int FS = FP * FP + 1;     // 101: per-pixel LDS stride (odd -> conflict-free lane-per-pixel reads)
-constexpr int PIX = 16;             // pixels per wave (see the occupancy note above)
-
-struct LookupInfo {
-  long long off[RNNPOSE_MAX_LEVELS];
-  int hl[RNNPOSE_MAX_LEVELS];
-  int wl[RNNPOSE_MAX_LEVELS];
-  int n_px, n_patch;          // level 0 is stored j-patch-major: [image][8 x 16 patch][i][8][16] (csrc/corr_pyramid.hip)
-};
+using namespace rplookup;
 
 __global__ __launch_bounds__(64) void corr_lookup_kernel(const float* __restrict__ pyr, const float* __restrict__ coords,
                                                          float* __restrict__ out, int B, int h, int w, int levels,
@@ -60,61 +44,14 @@ __global__ __launch_bounds__(64) void corr_lookup_kernel(const float* __restrict
     cx = coords[(static_cast<long long>(b) * 2 + 0) * N + pix] * inv;
     cy = coords[(static_cast<long long>(b) * 2 + 1) * N + pix] * inv;
   }
-  // integer base of the footprint; non-finite / far-away coordinates sample only padding -> zeros
-  const bool sane = (cx > -1.0e6f) && (cx < 1.0e6f) && (cy > -1.0e6f) && (cy < 1.0e6f);
-  const float fx0 = floorf(cx), fy0 = floorf(cy);
-  const int bx = sane ? static_cast<int>(fx0) - R : -1000000;
-  const int by = sane ? static_cast<int>(fy0) - R : -1000000;
-  const float ax = sane ? cx - fx0 : 0.f;
-  const float ay = sane ? cy - fy0 : 0.f;
+  int bx, by;
+  float ax, ay;
+  footprint_base(cx, cy, bx, by, ax, ay);
 
-  // ---- phase 1: cooperative footprint fetch ----
-  const float* lvl_base = pyr + info.off[lvl];
-  const long long img = static_cast<long long>(hl) * wl;
-  const int t0 = lane, t1 = lane + 64;
-  const int ty0 = t0 / FP, tx0 = t0 - ty0 * FP;
-  const int ty1 = t1 / FP, tx1 = t1 - ty1 * FP;
+  // ---- phase 1: cooperative footprint fetch (corr_lookup.cuh) ----
   const long long first = static_cast<long long>(blockIdx.x) * PIX;
   const int npix = static_cast<int>(total - first < PIX ? total - first : PIX);
-  // Every footprint load is UNCONDITIONAL (texels outside the level read element 0 of the pixel's map and are zeroed on
-  // the way into LDS; pixel slots past the end of the batch repeat the last pixel) and the loads of LB pixels are issued
-  // before the first LDS store: with the bounds test around the load the compiler waited vmcnt(0) after every pixel --
-  // 16 dependent memory round trips per wave (r02: 46 us per half-batch launch, latency-bound).
-  constexpr int LB = RPL_LB;
-  const bool has1 = t1 < FP * FP;
-#pragma unroll
-  for (int qb = 0; qb < PIX; qb += LB) {
-    float v0[LB], v1[LB];
-    unsigned ok = 0u;
-#pragma unroll
-    for (int j = 0; j < LB; ++j) {
-      const int q = qb + j;
-      const int qq = q < npix ? q : npix - 1;
-      const int qbx = __shfl(bx, qq), qby = __shfl(by, qq);
-      const int xa = qbx + tx0, ya = qby + ty0, xb = qbx + tx1, yb = qby + ty1;
-      const bool oka = xa >= 0 && xa < wl && ya >= 0 && ya < hl;
-      const bool okb = has1 && xb >= 0 && xb < wl && yb >= 0 && yb < hl;
-      // level 0 is j-patch-major: texel (y, x) of pixel i = patch ((y >> 3) n_px + (x >> 4)), row i, cell (y & 7, x & 15); the other
-      // levels are row-major maps per pixel.  Both forms as SELECTS on the (block-uniform) level, not as a branch: a branch around the
-      // loads brought the one-wait-per-load form back (tests/test_isa_guard.py: 24 vmcnt(0) waits for 50 loads)
-      const int qbg = __shfl(bg, qq), qpix = __shfl(pixg, qq);
-      const long long pstride = static_cast<long long>(N) * 128;
-      const bool l0 = lvl == 0;
-      const float* src = lvl_base + (l0 ? (static_cast<long long>(qbg) * info.n_patch * N + qpix) * 128 : (p_off + first + qq) * img);
-      const long long ea = l0 ? ((ya >> 3) * info.n_px + (xa >> 4)) * pstride + (ya & 7) * 16 + (xa & 15) : static_cast<long long>(ya * wl + xa);
-      const long long eb = l0 ? ((yb >> 3) * info.n_px + (xb >> 4)) * pstride + (yb & 7) * 16 + (xb & 15) : static_cast<long long>(yb * wl + xb);
-      v0[j] = src[oka ? ea : 0];
-      v1[j] = src[okb ? eb : 0];
-      ok |= (oka ? 1u : 0u) << (2 * j) | (okb ? 2u : 0u) << (2 * j);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int j = 0; j < LB; ++j) {
-      const int q = qb + j;
-      foot[q * FS + t0] = (ok >> (2 * j)) & 1u ? v0[j] : 0.f;
-      if (has1) foot[q * FS + t1] = (ok >> (2 * j)) & 2u ? v1[j] : 0.f;
-    }
-  }
+  gather16(pyr, info, lvl, N, lane, npix, bx, by, bg, pixg, p_off + first, foot);
   __syncthreads();
   // ---- phase 2: lane = pixel ----
   const float w00 = (1.f - ax) * (1.f - ay), w10 = ax * (1.f - ay), w01 = (1.f - ax) * ay, w11 = ax * ay;

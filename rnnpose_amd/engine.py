@@ -47,6 +47,12 @@ class UpdateEngine:
         self.parts_forced = "RNNPOSE_PARTS" in os.environ                         # explicit part count: no small-batch merging
         self.fused_mask = os.environ.get("RNNPOSE_FUSED_MASK", "1") != "0"       # mask.2 inside the up-sampling kernel
         self.resident_1x1 = os.environ.get("RNNPOSE_RESIDENT_1X1", "1") != "0"    # convc1 through csrc/conv1x1_resident.hip
+        # r06: window lookup + convc1 as ONE launch (csrc/corr_convc1.hip: the 324-channel corr tensor is never written).  Built, parity-
+        # tested and NOT faster: alone 39.8 us against 23.1 + 18.7 us for the two kernels at B = 4 (67 vs 70 at B = 8), on the step 754 vs 756
+        # iters/s (profiles/r06_lookup_convc1_fusion.txt) -- the lookup is bound by the sectors its gather touches (81 MB per launch), and a
+        # one-round launch runs its footprint phases and its MFMA phases in lock step, so the fusion saves the 25-MB round trip of the
+        # tensor and nothing else.  OFF by default; RNNPOSE_FUSED_LOOKUP=1 switches it on.
+        self.fused_lookup = os.environ.get("RNNPOSE_FUSED_LOOKUP", "0") != "0"
         self.ksplit = os.environ.get("RNNPOSE_KSPLIT", "1") != "0"                # small launches (B = 1 crops) split their K loop
         # SPLIT TENSORS (include/rnnpose_hip.h): every activation that only feeds further convolutions is written once, by its
         # producer's epilogue, as fp16 hi|lo pairs and staged by the consumers with a plain 16-byte copy (no per-tile re-split).
@@ -247,12 +253,18 @@ class UpdateEngine:
         W = self._weights()
         view = {k: v[b0:b1] for k, v in self._b.items()}
         view["_ksws"], view["_ksws_side"] = self._ksplit_ws(b0, b1, 0), self._ksplit_ws(b0, b1, 1)
-        ops.corr_lookup_nhwc_part(corr_fn._buf, coords1_part, view["corr"], B, b0, b1, corr_fn.num_levels, corr_fn.radius)
+        fused = (self.fused_lookup and self.resident_1x1 and W["convc1r"] is not None and W["convc1r"].c_in == 324
+                 and corr_fn.num_levels == 4 and corr_fn.radius == 4)
+        if fused:           # update.py:89 on corr.py:36-57 in one launch; the chain below skips its convc1
+            ops.corr_lookup_convc1(W["convc1r"], corr_fn._buf, coords1_part, (view["cor1"], 0), B, b0, b1, relu=True, dst_split=self.hl)
+        else:
+            ops.corr_lookup_nhwc_part(corr_fn._buf, coords1_part, view["corr"], B, b0, b1, corr_fn.num_levels, corr_fn.radius)
         yield
         # helper stream for the flow-feature / flow-head side chain: opt-in (RNNPOSE_SIDE_STREAM=1), and only for a lone SMALL chain; it
         # measured equal at the headline (695-699 iters/s either way) and slower at B = 1 (see __init__)
         small = coords1_part.shape[0] * coords1_part.shape[2] * coords1_part.shape[3] < self.MIN_CHAIN_PIXELS
-        yield from self._chain_gen(W, view, coords1_part, st, self._stream(coords1_part.device, 2) if (single and small and self.side_stream) else None)
+        yield from self._chain_gen(W, view, coords1_part, st, self._stream(coords1_part.device, 2) if (single and small and self.side_stream) else None,
+                                   have_cor1=fused)
         if self.fused_mask:         # mask.2 + up-sampling in one kernel (the chain skipped its mask.2 launch)
             ops.mask_upsample(W["mask2u"], view["heads"], 256, view["flow_lr"], out=flow_up_part)
         else:
@@ -313,7 +325,7 @@ class UpdateEngine:
         for _ in self._chain_gen(W, b, coords1, main, side, flow_is_delta, want_mask):
             pass
 
-    def _chain_gen(self, W, b, coords1, main, side, flow_is_delta=False, want_mask=False):
+    def _chain_gen(self, W, b, coords1, main, side, flow_is_delta=False, want_mask=False, have_cor1=False):
         """The update block on the (sub-)batch views `b`, issued on stream `main` (current) with `side` as helper; yields
         after every launch so that the caller can interleave two chains.
         flow_is_delta: `coords1` holds the flow itself (facade call) instead of absolute coordinates.
@@ -355,11 +367,14 @@ class UpdateEngine:
                     pass
                 join = torch.cuda.Event()
                 join.record(side)
-        if self.resident_1x1 and W["convc1r"] is not None:
+        if have_cor1:                                                               # (r06: convc1 ran inside the lookup launch)
+            pass
+        elif self.resident_1x1 and W["convc1r"] is not None:
             ops.conv1x1_resident(W["convc1r"], (b["corr"], 0), (b["cor1"], 0), relu=True, dst_split=hl)   # update.py:89 (LDS-resident tile)
+            yield
         else:                                                                       # (the looked-up correlation features are fp32)
             ops.conv2d_nhwc(W["convc1"], [(b["corr"], 0)], (b["cor1"], 0), R, dst_hl=hl, single_product=self.single_product)   # update.py:89
-        yield
+            yield
         c("convc2", [(b["cor1"], 0)], (b["corflo"], 0), R, hl_out=True)             # :90
         yield
         if join is not None:

@@ -894,6 +894,23 @@ def conv1x1_resident(pc: PackedConv1x1, src, dst, relu: bool = True, dst_split: 
             pc.w_scale, int(bool(relu)), n, _ptr(y), y.shape[3], int(yo), int(bool(dst_split)), _stream(), work=2.0 * n * 256 * pc.c_in)
 
 
+def corr_lookup_convc1(pc: PackedConv1x1, pyramid_buf, coords, dst, B_total, b0, b1, levels=4, radius=4, relu: bool = True,
+                       dst_split: bool = False):
+    """r06: window lookup + convc1 in one launch (model/CFNet.py:147-152): dst[..., off:off+256] = act(convc1(corr_fn(coords))) for the
+    images [b0, b1) of a pyramid built for B_total images; coords (b1-b0,2,h,w); dst = (tensor (b1-b0,h,w,C), c_offset).  The
+    (B,h,w,324) window-feature tensor is never materialised (csrc/corr_convc1.hip).  Not faster than the two kernels (engine.py): an option."""
+    y, yo = dst
+    _nhwc(y, "dst")
+    coords = _chk(coords, "coords")
+    nb, two, h, w = coords.shape
+    if pc.c_in != 324 or two != 2 or nb != b1 - b0 or tuple(y.shape[:3]) != (nb, h, w):
+        raise ValueError("corr_lookup_convc1: weights packed for c_in = 324, coords (b1-b0,2,h,w), dst (b1-b0,h,w,C)")
+    n = nb * h * w
+    _launch("rnnpose_corr_lookup_convc1_f16x3", _ptr(pyramid_buf), _ptr(coords), int(B_total), int(b0), int(b1), h, w, int(levels), int(radius),
+            _ptr(pc.w_packed), _ptr(pc.bias), pc.a_scale, pc.w_scale, int(bool(relu)), _ptr(y), y.shape[3], int(yo), int(bool(dst_split)),
+            _stream(), work=2.0 * n * 256 * 324, nbytes=4.0 * n * (levels * 100 + 2 + 256))
+
+
 class PackedMaskHead:
     """mask.2 weights (576,256,1,1) + bias, post-scaled (the 0.25 of update.py:187) and split into fp16 hi/lo MFMA fragments
     for the fused mask + up-sampling kernel (csrc/mask_upsample.hip)."""

@@ -219,6 +219,49 @@ def test_corr_lookup_vs_oracle_and_golden(ops, golden):
         close(out[:, :, ::2, ::3], g[f"lookup_{k}"], 1e-4, what=f"lookup {k} vs golden")
 
 
+@pytest.mark.parametrize("B,h,w,b0,b1", [(2, 16, 24, 0, 2), (3, 17, 19, 1, 3), (4, 30, 30, 2, 3), (2, 60, 80, 0, 1)])
+@pytest.mark.parametrize("split", [False, True])
+def test_corr_lookup_convc1_fused_equals_the_two_kernels(ops, B, h, w, b0, b1, split):
+    """r06: window lookup + convc1 as ONE launch (csrc/conv1x1_resident.hip, LOOKUP form; thirdparty/raft/corr.py:36-57
+    -> update.py:80,87) == rnnpose_corr_lookup_nhwc_part_f32 followed by rnnpose_conv1x1_resident_f16x3: the same operations per element
+    (bilinear taps in fp32, one fp16 hi/lo split, the same MFMA sequence), compared at 1e-6 of the output magnitude; sub-pixel, integer,
+    out-of-range and NON-FINITE window centres, ragged pixel counts (17 x 19 x 2 is not a multiple of the 32-pixel tile), image
+    sub-ranges of a larger pyramid, fp32 and split destinations; and against the oracle's lookup + an fp64 1x1 convolution."""
+    import torch.nn.functional as F
+    C = 64
+    f1 = syn.normal("fmap1", (B, C, h, w), 5)
+    f2 = syn.normal("fmap2", (B, C, h, w), 5)
+    buf, _ = ops.corr_pyramid(D(f1), D(f2), 4)
+    nb = b1 - b0
+    c = orc.coords_grid_lowres(nb, h, w) + T(syn.uniform("lk", (nb, 2, h, w), 6, -7.0, 7.0))
+    c[:, :, 0, :] = torch.round(c[:, :, 0, :])                  # a row of integer centres
+    c[0, 0, 1, 1] = float("nan")
+    c[0, 1, 2, 2] = float("inf")
+    c[-1, 0, 3, 3] = -1e30
+    c[-1, :, 4, 4] = 1e4                                         # far outside: zeros
+    cd = D(c)
+    wt = syn.normal("c1w", (256, 324, 1, 1), 7, std=float(np.sqrt(2.0 / 324)))
+    bs = syn.uniform("c1b", (256,), 7, -0.3, 0.3)
+    pc = ops.PackedConv1x1(D(wt), D(bs))
+    corr = torch.empty(nb, h, w, 324, device="cuda")
+    ops.corr_lookup_nhwc_part(buf, cd, corr, B, b0, b1, 4, 4)
+    two = torch.full((nb, h, w, 272), 3.0, device="cuda")
+    one = torch.full((nb, h, w, 272), 3.0, device="cuda")
+    ops.conv1x1_resident(pc, (corr, 0), (two, 8), relu=True, dst_split=split)
+    ops.corr_lookup_convc1(pc, buf, cd, (one, 8), B, b0, b1, relu=True, dst_split=split)
+    a, b = (ops.unsplit_hl(one), ops.unsplit_hl(two)) if split else (one, two)
+    assert bool(torch.isfinite(a).all())
+    mag = float(b[..., 8:264].abs().max())
+    assert float((a[..., 8:264] - b[..., 8:264]).abs().max()) <= 1e-6 * mag, (float((a - b).abs().max()), mag)
+    if not split:
+        assert float((one[..., :8] - 3).abs().max()) == 0 and float((one[..., 264:] - 3).abs().max()) == 0      # bytes around the slice untouched
+        pyr = orc.corr_pyramid(f1, f2)
+        want = orc.corr_lookup([lv.reshape(B, h * w, *lv.shape[-2:])[b0:b1].reshape(nb * h * w, *lv.shape[-2:]) for lv in pyr],
+                               torch.nan_to_num(c, nan=1e9, posinf=1e9, neginf=-1e9))      # (non-finite centres sample padding only: zeros)
+        y64 = F.relu(F.conv2d(want.double(), T(wt).double(), T(bs).double()))
+        assert float((one[..., 8:264].permute(0, 3, 1, 2).double().cpu() - y64).abs().max()) < 2e-5 * max(1.0, float(y64.abs().max()))
+
+
 def test_alternate_corr_block_vs_oracle_lookup_and_golden(ops, golden):
     """AlternateCorrBlock (thirdparty/raft/corr.py:70-98): the window features computed on the fly from fmap1 and the pooled fmap2
     pyramid -- no volume -- equal the pyramid lookup (pooling is linear): the oracle's and the golden vectors' lookup cases at 1e-4,

@@ -64,6 +64,7 @@ for B in (4, 8):
         "induced_coords_lowres": lambda: ops.induced_coords_lowres(depth, K, G, h, w, out=c1),
         "corr_lookup": lambda: ops.corr_lookup_nhwc_part(buf, c1, corr, 8, 0, B),
         "conv1x1_resident": lambda: ops.conv1x1_resident(c1r, (corr, 0), (cor1, 0)),
+        "lookup+convc1 fused": lambda: ops.corr_lookup_convc1(c1r, buf, c1, (cor1, 0), 8, 0, B),
         "flow_features_7x7": lambda: ops.flow_features(c1, w7, b7, flo1, motion, 126),
         "flow_head_out": lambda: ops.flow_head_out(heads, 0, 256, w2, b2, c1, delta, c1out, flow_lr),
         "mask_upsample": lambda: ops.mask_upsample(mhead, heads, 256, flow_lr, out=up),
