@@ -278,8 +278,11 @@ __device__ __forceinline__ void strip_epilogue_fast(const StripEpi p, f32x16 (&a
 // fp16 autocast): ONE product per multiply-add -- a_hi * b_hi on the same MFMA, fp32 accumulation -- instead of three.  The lo planes
 // still arrive (the operands in memory are the same split tensors; activations between layers stay fp32-class, which autocast's are
 // not); their fragments are neither read nor multiplied.  Not the headline arithmetic: narrower than the CPU oracle's fp32.
+#ifndef RS_MINW3
+#define RS_MINW3 0        // measurement (r06): 1 = the two-wave 96-row 3x3 workgroups are compiled for THREE waves per SIMD (<= 168 registers)
+#endif
 template <int NW, int TT, int MODE, int NI, int SMI, bool P1 = false>
-__global__ __launch_bounds__(NW * 64, NI == 2 ? 1 : 2) void conv_strip_f16x3_kernel(const KParams p) {
+__global__ __launch_bounds__(NW * 64, NI == 2 ? 1 : ((RS_MINW3 && NW == 2 && SMI == 3 && TT == 9) ? 3 : 2)) void conv_strip_f16x3_kernel(const KParams p) {
   constexpr bool SPATIAL = TT == 9 || TT == 4;             // TT = 4 (r05): a STRIDE-2 3x3 layer as a 2x2-tap layer over the four parity planes
   constexpr bool S2 = TT == 4;                             // of its input (strided views of the NHWC source: conv_strip.hip, strip_launch)
   constexpr int SM = 32 * SMI;                             // strip rows
@@ -289,7 +292,7 @@ __global__ __launch_bounds__(NW * 64, NI == 2 ? 1 : 2) void conv_strip_f16x3_ker
   // weight ring slots per wave: 2 TT is a multiple (slots are compile-time).  r05: the TWO-wave 3x3 workgroups (64-column layers: the
   // encoder's 240 x 320 residual blocks) take a 3-slot ring -- 40 KB of LDS per workgroup instead of 52: FOUR workgroups per CU = two
   // waves per SIMD instead of three = 1.5.  Their records are requested two steps ahead (L2-resident weights: 36 K values per layer).
-  constexpr bool RING3 = RS_RING3 && TT == 9 && NW == 2 && NI == 1 && SMI == 5;
+  constexpr bool RING3 = RS_RING3 && TT == 9 && NW == 2 && NI == 1 && (SMI == 5 || (RS_MINW3 && SMI == 3));
   constexpr int NBST = SPATIAL ? (RING3 ? 3 : (S2 ? 4 : 6)) : 5;
   static_assert((2 * TT) % NBST == 0 && NBST - 2 < TT - 1, "ring period");
   constexpr int NT_ = NW * 64;

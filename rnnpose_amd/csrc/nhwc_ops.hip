@@ -583,7 +583,10 @@ int rnnpose_flow_head_out_f32(const float* x, int x_c_stride, int x_c_offset, in
   if (c_in <= 256) {
     const long long runs = static_cast<long long>(B) * h * ((w + 3) / 4);
     RP_REQUIRE(runs < (1LL << 31), fn, "too many pixel runs for 32-bit indices");
-    const int nb = static_cast<int>(runs / 4 + 1 < 512 ? runs / 4 + 1 : 512);      // 2 workgroups per CU: a wave keeps its weights for ~5 runs
+#ifndef RP_COUT2_MAXWG
+#define RP_COUT2_MAXWG 512
+#endif
+    const int nb = static_cast<int>(runs / 4 + 1 < RP_COUT2_MAXWG ? runs / 4 + 1 : RP_COUT2_MAXWG);      // 2 workgroups per CU: a wave keeps its weights for ~5 runs
     hipLaunchKernelGGL(conv3x3_cout2_run4_kernel, dim3(nb), dim3(256), 0, rp::as_stream(stream), x, x_c_stride, x_c_offset, c_in,
                        w_oihw, bias, coords1, delta, coords1_out, flow_lr, B, h, w);
     return rp::check_launch(fn);

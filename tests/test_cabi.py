@@ -161,4 +161,9 @@ def test_conv_tiling_rule_is_a_host_function(lib):
     assert f(30, 30, 1, 5, 1, 256, 0, 16) == 8 and f(30, 30, 3, 3, 1, 128, 0, 16) == 8       # 16 crops (14 400 pixels): 128-row kernels
     assert f(240, 320, 3, 3, 1, 64, 0, 8) == 24 * 20                                         # encoder, 64 channels: two-wave strips
     assert f(60, 80, 3, 3, 2, 128, 0, 8) == lib.rnnpose_conv_tiles_per_image(60, 80, 3, 3, 2)    # stride 2: never strips
-    assert f(60, 80, 3, 3, 1, 32, 5, 8) == -1 and f(60, 80, 3, 3, 1, 192, 7, 8) == -1 and f(60, 80, 3, 3, 1, 192, 0, 0) == -1
+    assert f(60, 80, 3, 3, 1, 32, 5, 8) == -1 and f(60, 80, 3, 3, 1, 192, 8, 8) == -1 and f(60, 80, 3, 3, 1, 192, 0, 0) == -1
+    # r06: tile code 7 = 96-row strips (6 x 16 patches / runs of 96 pixels); the automatic choice takes them when the launch's 160-row strips
+    # would be at most 512 waves (the 128-column layers of a half-batch chain), 32-row strips when at most 256 waves (convf2 there)
+    assert f(60, 80, 3, 3, 1, 192, 7, 8) == 50 and f(60, 80, 1, 5, 1, 128, 7, 8) == 50
+    assert f(60, 80, 1, 5, 1, 128, 0, 4) == 50 and f(60, 80, 1, 5, 1, 128, 0, 8) == 30 and f(60, 80, 1, 5, 1, 256, 0, 4) == 30
+    assert f(60, 80, 3, 3, 1, 126, 0, 4) == 50 and f(60, 80, 3, 3, 1, 64, 0, 4) == 150 and f(60, 80, 3, 3, 1, 64, 0, 8) == 50
