@@ -39,6 +39,12 @@ constexpr int ST = 8;     // supertile side (tiles)
 #ifndef RPC_ABL
 #define RPC_ABL 0
 #endif
+#ifndef RPC_DB
+#define RPC_DB 0          // fp16x3 kernel: 0 = single operand buffer, two barriers per slab, four workgroups per CU (r03-r06); 1 = double-buffered
+                          // operand LDS, ONE barrier per slab, 80 KiB = two workgroups per CU -- built in r06 (asked for by the r03-r05 reviews) and
+                          // SLOWER: 465-480 vs 445 us at B = 8 60 x 80, 7.30 vs 6.93 ms at 120 x 160, same box, bit-identical results
+                          // (profiles/r06_corr_double_buffer.txt): the kernel needs its co-resident workgroups more than it needs the barrier
+#endif
 #ifndef RPC_NT
 #define RPC_NT 1          // 1: level-0 rows leave with non-temporal stores (they are never re-read by this kernel: -13 %);
                           // 2: the pooled levels too (their 8-32 byte pieces then miss L2's merging: +30 %)
@@ -383,13 +389,19 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // consumed before the previous tile's stores are acknowledged -- gfx9 counts both on vmcnt).  Kept: non-temporal level-0 stores
 // (-13 %), operands pre-split by their producer (no pre-pass).  Next: a K loop that is fast on its own (double-buffered LDS,
 // one barrier per slab), then stripe-wide tiles.
+#ifndef RPC_MINW
+#define RPC_MINW 2        // waves per SIMD the fp16x3 kernel is compiled for (measurement: 3, 4)
+#endif
 template <bool ALIGNED>
-__global__ __launch_bounds__(NT, 2) void corr_pyramid_h3_kernel(const _Float16* __restrict__ f1, const _Float16* __restrict__ f2,
+__global__ __launch_bounds__(NT, RPC_MINW) void corr_pyramid_h3_kernel(const _Float16* __restrict__ f1, const _Float16* __restrict__ f2,
                                                                 float* __restrict__ pyr, int B, int C, int h, int w, int n_it,
                                                                 int n_py, int n_px, float scale, PyrInfo info, int sti, int stp) {
-  // [A | B][hi | lo][128 rows x HRS] halfs = 40 KiB (single buffer, the next slab waits in registers);
-  // the epilogue's 36 KiB of float staging aliases it
-  __shared__ __attribute__((aligned(16))) _Float16 sT[2 * 2 * 128 * HRS];
+  // [A | B][hi | lo][128 rows x HRS] halfs = 40 KiB per operand buffer; the epilogue's 36 KiB of float staging aliases it.
+  // RPC_DB = 0 (default): ONE buffer, the next slab waits in registers, two barriers per slab (MFMA | barrier | store | barrier), four
+  // workgroups per CU.  RPC_DB = 1 (r06; measured slower, see the macro): TWO buffers, the next slab is stored while
+  // the current one is being multiplied, ONE barrier per slab, two workgroups per CU (80 KiB).
+  constexpr int BUFH = 2 * 2 * 128 * HRS;
+  __shared__ __attribute__((aligned(16))) _Float16 sT[(RPC_DB ? 2 : 1) * BUFH];
   float* smem = reinterpret_cast<float*>(sT);
   const int N = h * w;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -454,20 +466,20 @@ __global__ __launch_bounds__(NT, 2) void corr_pyramid_h3_kernel(const _Float16* 
     rbl1 = *reinterpret_cast<const u32x4*>(f2 + offb1 + (K0_) + 8);                            \
   } while (0)
   // plane p (0 = A hi, 1 = A lo, 2 = B hi, 3 = B lo) x 128 rows x HRS halfs
-#define RPH_ST(V_, M_, P_, R_) *reinterpret_cast<u32x4*>(sT + (P_) * (128 * HRS) + ((tid >> 2) + 64 * (R_)) * HRS + q * 8) = (V_) & (M_)
-#define RPH_STORE                                                                              \
+#define RPH_ST(V_, M_, P_, R_, BO_) *reinterpret_cast<u32x4*>(sT + (BO_) + (P_) * (128 * HRS) + ((tid >> 2) + 64 * (R_)) * HRS + q * 8) = (V_) & (M_)
+#define RPH_STORE(BO_)                                                                         \
   do {                                                                                         \
-    RPH_ST(rah0, ma0, 0, 0); RPH_ST(rah1, ma1, 0, 1); RPH_ST(ral0, ma0, 1, 0); RPH_ST(ral1, ma1, 1, 1); \
-    RPH_ST(rbh0, mb0, 2, 0); RPH_ST(rbh1, mb1, 2, 1); RPH_ST(rbl0, mb0, 3, 0); RPH_ST(rbl1, mb1, 3, 1); \
+    RPH_ST(rah0, ma0, 0, 0, BO_); RPH_ST(rah1, ma1, 0, 1, BO_); RPH_ST(ral0, ma0, 1, 0, BO_); RPH_ST(ral1, ma1, 1, 1, BO_); \
+    RPH_ST(rbh0, mb0, 2, 0, BO_); RPH_ST(rbh1, mb1, 2, 1, BO_); RPH_ST(rbl0, mb0, 3, 0, BO_); RPH_ST(rbl1, mb1, 3, 1, BO_); \
   } while (0)
-#define RPH_MFMA                                                                               \
+#define RPH_MFMA(BO_)                                                                          \
   _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                           \
-    const h8 ah = *reinterpret_cast<const h8*>(sAh + kk * 16);                                 \
-    const h8 al = *reinterpret_cast<const h8*>(sAh + 128 * HRS + kk * 16);                     \
+    const h8 ah = *reinterpret_cast<const h8*>(sAh + (BO_) + kk * 16);                         \
+    const h8 al = *reinterpret_cast<const h8*>(sAh + (BO_) + 128 * HRS + kk * 16);             \
     h8 bh[4], bl[4];                                                                           \
     _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                            \
-      bh[s] = *reinterpret_cast<const h8*>(sBh + s * 32 * HRS + kk * 16);                      \
-      bl[s] = *reinterpret_cast<const h8*>(sBh + 128 * HRS + s * 32 * HRS + kk * 16);          \
+      bh[s] = *reinterpret_cast<const h8*>(sBh + (BO_) + s * 32 * HRS + kk * 16);              \
+      bl[s] = *reinterpret_cast<const h8*>(sBh + (BO_) + 128 * HRS + s * 32 * HRS + kk * 16);  \
     }                                                                                          \
     acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[0], acc0, 0, 0, 0);                   \
     acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[1], acc1, 0, 0, 0);                   \
@@ -484,21 +496,35 @@ __global__ __launch_bounds__(NT, 2) void corr_pyramid_h3_kernel(const _Float16* 
   }
 
   RPH_LOAD(0);
-  RPH_STORE;
+  RPH_STORE(0);
   __syncthreads();
   const int nk = (RPC_ABL & 4) ? 0 : C / HBK;
   const _Float16* sAh = sT + (wave * 32 + l31) * HRS + lh * 8;
   const _Float16* sBh = sT + 2 * 128 * HRS + l31 * HRS + lh * 8;
-  for (int kt = 1; kt < nk; ++kt) {                  // slab kt travels while slab kt - 1 is multiplied
-    if (!(RPC_ABL & 1)) RPH_LOAD(kt * (2 * HBK));
-    RPH_MFMA
-    __syncthreads();
-    if (!(RPC_ABL & 16)) RPH_STORE;
-    __syncthreads();
-  }
-  if (nk > 0) {
-    RPH_MFMA
-    __syncthreads();                                 // every wave is done with the operands: the epilogue re-uses their LDS
+  if (RPC_DB) {
+    for (int kt = 1; kt < nk; ++kt) {                // slab kt travels, then lands in the OTHER buffer, while slab kt - 1 is multiplied
+      const int cur = ((kt - 1) & 1) * BUFH, nxt = (kt & 1) * BUFH;
+      if (!(RPC_ABL & 1)) RPH_LOAD(kt * (2 * HBK));
+      RPH_MFMA(cur)
+      if (!(RPC_ABL & 16)) RPH_STORE(nxt);
+      __syncthreads();                               // slab kt is visible; nobody reads slab kt - 1 any more (its buffer is refilled next turn)
+    }
+    if (nk > 0) {
+      RPH_MFMA(((nk - 1) & 1) * BUFH)
+      __syncthreads();                               // every wave is done with the operands: the epilogue re-uses their LDS
+    }
+  } else {
+    for (int kt = 1; kt < nk; ++kt) {                // slab kt travels while slab kt - 1 is multiplied
+      if (!(RPC_ABL & 1)) RPH_LOAD(kt * (2 * HBK));
+      RPH_MFMA(0)
+      __syncthreads();
+      if (!(RPC_ABL & 16)) RPH_STORE(0);
+      __syncthreads();
+    }
+    if (nk > 0) {
+      RPH_MFMA(0)
+      __syncthreads();                               // every wave is done with the operands: the epilogue re-uses their LDS
+    }
   }
   if (RPC_ABL & 8) {
     if (scale == 1234.5f) pyr[tid] = acc0[0] + acc1[1] + acc2[2] + acc3[3];
