@@ -310,7 +310,8 @@ int rnnpose_conv_strip(int mode);          /* measurement switch: 0 = the automa
                                               tiles per wave (one workgroup per CU), 4 = 160-row strips only (>= 24 per image), 5 = automatic
                                               without the stride-2 form (r05: stride-2 3x3 layers as 2x2-tap strips over the four parity
                                               planes of the input; one fp32 source of whole 32-channel blocks, even H and W), 6 = automatic without r06's
-                                              32-row strips for launches whose 160-row strips would be at most 256 waves */
+                                              32-row strips for launches whose 160-row strips would be at most 256 waves, 7 = automatic WITH persistent launches of the
+                                              fp32-source strip forms (r06: resident workgroups walking the tile list; measured slower, off by default) */
 /* number of fp16 elements of the packed weight array (hi and lo parts interleaved, in the fragment order of the 128-row kernels
  * followed by the record order of the strip kernels); -1 on bad arguments */
 long long rnnpose_conv_packed_halfs(int c_out, int kh, int kw, const int* h_seg_counts, int n_seg);

@@ -15,6 +15,7 @@ constexpr int kWave = 64;  // CDNA wavefront
 void set_error(const char* fmt, ...);
 int fail_arg(const char* fn, const char* what);
 int check_launch(const char* fn);
+int cu_count();                      // compute units of the current device (cached per device; 256 on MI355X)
 unsigned long long* sat_counter();   // fp16x3 range guard: device counter of the current device, NULL while the check is off
 
 inline hipStream_t as_stream(rnnpose_stream_t s) { return reinterpret_cast<hipStream_t>(s); }

@@ -56,6 +56,8 @@ struct KParams {
   const uint4* wpk_strip;    // the same weights in the strip kernel's order (conv_strip.hip), behind the first copy in w_packed
   int single_product;        // strip kernels, 160-row strips, one column tile per wave: a_hi * b_hi only (cfg.raft.mixed_precision)
   int off32;                 // strip kernels: every destination / epilogue operand spans < 2^32 elements (32-bit offsets in the fast epilogue)
+  int stagger;               // persistent strip launches (measurement): 100-MHz ticks of start delay per workgroup slot of a CU
+  int n_tiles;               // strip kernels, r06: > 0 = a PERSISTENT launch -- gridDim.x resident workgroups walk n_tiles tiles (conv_strip_kernel.cuh)
 };
 
 // One output quad (4 consecutive channels starting at channel ch of the pixel row `row`) in split form: the 8-channel group
@@ -99,6 +101,7 @@ void strip_allow_two_wave(int on);                             // measurement: t
 void strip_force_ni(int ni);                                   // measurement: 0 automatic, 1 / 2 column tiles per wave
 void strip_allow_small(int on);                                // measurement: 32-row strips in the automatic choice (default on)
 void strip_allow_s2(int on);                                   // measurement: stride-2 3x3 layers on strips over parity planes (default on)
+void strip_allow_persist(int on);                              // measurement: persistent launches of the fp32-source strip forms (default OFF: slower)
 void strip_allow_small32(int on);                              // measurement: 32-row strips for launches of <= 256 waves of 160-row strips (default on)
 long long strip_s2_halfs(int c_in, int kh, int kw, int ncb, int Npad, int n_seg);   // size of the stride-2 copy of a layer's packed weights (0: none)
 // strip height (160 / 32 rows) a launch of `batch` images takes, 0 = not a strip launch; request: 0 automatic, else the height to force

@@ -848,14 +848,15 @@ int rnnpose_conv_spatial_tiles(int enable) {     // measurement switch: 0 = the 
 }
 
 int rnnpose_conv_strip(int mode) {               // 0 = never the strip kernels, 1 = automatic (default); measurement: 2 = automatic without
-  if (mode < 0 || mode > 6) {                    // the two-wave workgroups of the 64-channel layers, 3 = two 32-column tiles per wave,
-    rp::set_error("rnnpose_conv_strip: mode 0..6");      // 4 = 160-row strips only (by the image shape: r04's first rule),
+  if (mode < 0 || mode > 7) {                    // the two-wave workgroups of the 64-channel layers, 3 = two 32-column tiles per wave,
+    rp::set_error("rnnpose_conv_strip: mode 0..7");      // 4 = 160-row strips only (by the image shape: r04's first rule),
     return 1;                                    // 5 = automatic without the stride-2 form (r05), 6 = automatic without r06's 32-row strips for
   }                                              //     launches of <= 256 waves
   g_conv_strip = mode != 0;
   strip_allow_small(mode != 4);
   strip_allow_s2(mode != 5);
   strip_allow_small32(mode != 6);
+  strip_allow_persist(mode == 7);                // 7 = automatic WITH r06's persistent launches of the fp32-source strip forms (measured slower: off by default)
   strip_allow_two_wave(mode != 2);
   strip_force_ni(mode == 3 ? 2 : 1);
   return 0;

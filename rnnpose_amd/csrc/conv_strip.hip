@@ -151,9 +151,12 @@ void strip_allow_small(int on) { g_strip_small = on; }
 #define RS_SMALL32_WAVES 256         // (measurement: -DRS_SMALL32_WAVES=512 also moves the GRU's q and the motion encoder's last layer at B = 4)
 #endif
 static int g_strip_small32 = 1;      // r06: 32-row strips for launches of <= 256 waves of 160-row strips (rnnpose_conv_strip(6): off)
+static int g_strip_persist = 0;      // r06: persistent launches of the fp32-source forms (rnnpose_conv_strip(7): ON).  Built, bit-identical, and SLOWER: the
+                                     // encoder's 64 -> 64 layer at B = 8 takes 190-255 us instead of 155-190 (profiles/r06_persistent_strips.txt) -- OFF by default
 static int g_strip_s2 = 1;           // stride-2 3x3 layers as strips over parity planes (strip_allow_s2; 0: the 128-row kernel's tap-per-staging mode)
 void strip_allow_s2(int on) { g_strip_s2 = on; }
 void strip_allow_small32(int on) { g_strip_small32 = on; }
+void strip_allow_persist(int on) { g_strip_persist = on; }
 
 // Strip height for a launch of `batch` images: 160 or 32 rows -- or 0: not a strip launch.  request: 0 = automatic, else that height
 // (tests, measurement).  160-row strips when they give the launch >= 240 workgroups (about one per CU) or, failing that, >= 24 per
@@ -270,7 +273,18 @@ int strip_launch(KParams& p, int H, int W, int kh, int kw, bool hlin, bool per_i
     p.tpi = 0;
     p.n_mt = rp::cdiv(static_cast<long long>(p.B) * H * W, rows);
   }
-  const unsigned nwg = static_cast<unsigned>(p.n_mt) * p.n_nt;
+  unsigned nwg = static_cast<unsigned>(p.n_mt) * p.n_nt;
+  // r06 (measured slower, OFF unless rnnpose_conv_strip(7)): a launch of the fp32-source forms (the encoder's
+  // layers) with at least 1.5 rounds of workgroups runs PERSISTENT -- as many workgroups as the chip holds at once (two-wave workgroups:
+  // four per CU, else two), each walking its share of the tile list and pulling tile t + 1's first activations towards the CU in front
+  // of tile t's epilogue (conv_strip_kernel.cuh).
+  p.n_tiles = 0;
+  if (g_strip_persist && !hlin && ni == 1 && spatial && p.stride == 1 && rows == 160 && !p.single_product) {      // (the forms that have a PERSIST instantiation)
+    const unsigned slots = static_cast<unsigned>(rp::cu_count()) * (nw == 2 ? 4u : 2u) & ~7u;
+    if (slots >= 8 && nwg >= slots + slots / 2) { p.n_tiles = static_cast<int>(nwg); nwg = slots; }
+    static const int stagger_env = getenv("RNNPOSE_STRIP_STAGGER") ? atoi(getenv("RNNPOSE_STRIP_STAGGER")) : 0;      // (measurement)
+    p.stagger = stagger_env;
+  }
   int bad;
   if (rows == 160 && p.single_product && ni == 1 && p.stride == 1) bad = strip_launch_p1(p, nw, ni, spatial, hlin, norm, nwg, st);      // (the stride-2 forms keep three products)
   else if (rows == 160) bad = strip_launch_height<5>(p, nw, ni, spatial, hlin, norm, nwg, st);

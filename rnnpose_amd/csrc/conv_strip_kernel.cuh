@@ -281,7 +281,7 @@ __device__ __forceinline__ void strip_epilogue_fast(const StripEpi p, f32x16 (&a
 #ifndef RS_MINW3
 #define RS_MINW3 0        // measurement (r06): 1 = the two-wave 96-row 3x3 workgroups are compiled for THREE waves per SIMD (<= 168 registers)
 #endif
-template <int NW, int TT, int MODE, int NI, int SMI, bool P1 = false>
+template <int NW, int TT, int MODE, int NI, int SMI, bool P1 = false, bool PERSIST = false>
 __global__ __launch_bounds__(NW * 64, NI == 2 ? 1 : ((RS_MINW3 && NW == 2 && SMI == 3 && TT == 9) ? 3 : 2)) void conv_strip_f16x3_kernel(const KParams p) {
   constexpr bool SPATIAL = TT == 9 || TT == 4;             // TT = 4 (r05): a STRIDE-2 3x3 layer as a 2x2-tap layer over the four parity planes
   constexpr bool S2 = TT == 4;                             // of its input (strided views of the NHWC source: conv_strip.hip, strip_launch)
@@ -316,23 +316,39 @@ __global__ __launch_bounds__(NW * 64, NI == 2 ? 1 : ((RS_MINW3 && NW == 2 && SMI
   const int l31 = lane & 31, lh = lane >> 5;
   RS_CLK(0)
 
-  // ---- tile id: XCD-contiguous chunks, column tiles of one strip next to each other (they stage the same activations) ----
-  int bid = static_cast<int>(blockIdx.x);
-  {
-    const int ntl = static_cast<int>(gridDim.x);
-    const int per = ntl >> 3, rem = ntl & 7;
-    const int xcd = bid & 7, idx = bid >> 3;
-    bid = xcd * per + (xcd < rem ? xcd : rem) + idx;
+  // ---- tile walk: XCD-contiguous chunks of the tile list, column tiles of one strip next to each other (they stage the same
+  // activations).  One tile per workgroup (gridDim.x = tiles), or -- r06, p.n_tiles > 0: a PERSISTENT launch of gridDim.x (a multiple of 8)
+  // resident workgroups -- workgroup w walks tiles idx, idx + gridDim.x / 8, ... of the chunk of its XCD (w & 7) and requests the first
+  // two half blocks of tile t + 1 BEFORE the epilogue of tile t (fp32-source forms; see the loop at the end of the prologue).
+  const int t_ntl = PERSIST ? p.n_tiles : static_cast<int>(gridDim.x);
+  const int t_per = t_ntl >> 3, t_rem = t_ntl & 7, t_xcd = static_cast<int>(blockIdx.x) & 7;
+  const int t_base = t_xcd * t_per + (t_xcd < t_rem ? t_xcd : t_rem), t_cnt = t_per + (t_xcd < t_rem ? 1 : 0);
+  const int t_step = PERSIST ? static_cast<int>(gridDim.x) >> 3 : 0x40000000;
+  int t_idx = static_cast<int>(blockIdx.x) >> 3;
+  if constexpr (PERSIST) {           // (measurement, r06: stagger the co-resident workgroups of a CU -- workgroup i of an XCD sits in slot i / 32 of CU i % 32)
+    if (p.stagger > 0) {
+      const unsigned long long t_end = wall_clock64() + static_cast<unsigned long long>(((static_cast<int>(blockIdx.x) >> 3) >> 5) * p.stagger);
+      while (wall_clock64() < t_end) __builtin_amdgcn_s_sleep(32);
+    }
   }
-  const int nt_i = bid % p.n_nt, mt_i = bid / p.n_nt;
   const int UV = p.U * p.V;
   const int Mtot = p.B * UV;
-  const int img_ = p.tpi > 0 ? mt_i / p.tpi : 0;
-  const int pt_ = p.tpi > 0 ? mt_i - img_ * p.tpi : 0;
-  const int py0_ = SPATIAL ? (pt_ / p.sp_tx) * SPH : 0, px0_ = SPATIAL ? (pt_ % p.sp_tx) * SPW : 0;
-  const int m0 = p.tpi > 0 ? img_ * UV + pt_ * SM : mt_i * SM;
-  const int mend = p.tpi > 0 ? (img_ + 1) * UV : Mtot;
-  const int ct32 = (nt_i * NW + wave) * NI;        // this wave's first 32-column tile
+  // geometry of the tile whose activations are being requested ...
+  int nt_i, mt_i, img_, py0_, px0_, m0, mend, ct32;
+  // ... and of the tile the epilogue writes (the same one until the next tile's first requests go out in front of the epilogue)
+  int e_mt_i, e_img, e_py0, e_px0, e_m0, e_mend, e_ct32;
+#define RS_TILE_GEOM(BID_)                                                                                   \
+  {                                                                                                          \
+    const int bid_ = (BID_);                                                                                 \
+    nt_i = bid_ % p.n_nt; mt_i = bid_ / p.n_nt;                                                              \
+    img_ = p.tpi > 0 ? mt_i / p.tpi : 0;                                                                     \
+    const int pt_ = p.tpi > 0 ? mt_i - img_ * p.tpi : 0;                                                     \
+    py0_ = SPATIAL ? (pt_ / p.sp_tx) * SPH : 0; px0_ = SPATIAL ? (pt_ % p.sp_tx) * SPW : 0;                  \
+    m0 = p.tpi > 0 ? img_ * UV + pt_ * SM : mt_i * SM;                                                       \
+    mend = p.tpi > 0 ? (img_ + 1) * UV : Mtot;                                                               \
+    ct32 = (nt_i * NW + wave) * NI;        /* this wave's first 32-column tile */                            \
+  }
+  RS_TILE_GEOM(t_base + t_idx)
   const int ntiles32 = p.Npad >> 5;
   unsigned char* const sB = lds + BOFF + wave * (NBST * BREC);      // this wave's weight ring
   const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) unsigned char*)lds));   // LDS byte address
@@ -363,61 +379,59 @@ __global__ __launch_bounds__(NW * 64, NI == 2 ? 1 : ((RS_MINW3 && NW == 2 && SMI
   // pixel's 64-byte half block ([g0 hi | g0 lo | g1 hi | g1 lo])
   int apix[PA > NQ ? PA : NQ];
   int asrc[MODE == 0 ? PA : 1];
-  if constexpr (MODE == 0) {
-#pragma unroll
-    for (int i = 0; i < PA; ++i) {
-      const int q = wave + NW * i < NPIECE ? wave + NW * i : NPIECE - 1;      // (surplus requests repeat the last piece: identical bytes)
-      const int plane = q / NPP, j = (q - plane * NPP) * 32 + (lane >> 1);
-      RS_ROW_PIXEL(apix[i], j)
-      asrc[i] = (((lane & 1) ^ RS_SWZ(j)) << 5) + (plane << 4);
-    }
-  } else {        // register path: quad idx = tid + NT_ * i -> row idx >> 2, channels 4 (idx & 3) .. +3 of the half block
-#pragma unroll
-    for (int i = 0; i < NQ; ++i) {
-      const int idx = tid + NT_ * i;
-      RS_ROW_PIXEL(apix[i], idx >> 2)
-    }
+#define RS_TILE_ROWS()                                                                                       \
+  {                                                                                                          \
+    if constexpr (MODE == 0) {                                                                               \
+      _Pragma("unroll") for (int i = 0; i < PA; ++i) {                                                       \
+        const int q = wave + NW * i < NPIECE ? wave + NW * i : NPIECE - 1;      /* (surplus requests repeat the last piece: identical bytes) */ \
+        const int plane = q / NPP, j = (q - plane * NPP) * 32 + (lane >> 1);                                 \
+        RS_ROW_PIXEL(apix[i], j)                                                                             \
+        asrc[i] = (((lane & 1) ^ RS_SWZ(j)) << 5) + (plane << 4);                                            \
+      }                                                                                                      \
+    } else {        /* register path: quad idx = tid + NT_ * i -> row idx >> 2, channels 4 (idx & 3) .. +3 of the half block */ \
+      _Pragma("unroll") for (int i = 0; i < NQ; ++i) {                                                       \
+        const int idx = tid + NT_ * i;                                                                       \
+        RS_ROW_PIXEL(apix[i], idx >> 2)                                                                      \
+      }                                                                                                      \
+    }                                                                                                        \
   }
+  RS_TILE_ROWS()
   // fragment addresses of this lane inside an activation slot (hi plane; lo: + PLANE), tile row r = 32 mi + l31:
   //   linear: one per (row tile, tap), the tap mask folded in (taps beyond the image line read the zero row)
   //   3x3:    per row tile the top-left tap of an even-offset line (dy = 0, 2) and of the centre line (dy = 1); tap (dy, dx) adds
   //           the compile-time offset (dy = 2 ? 2 * 18 * 32 : 0) + 32 dx
   int aad[SMI][SPATIAL ? 2 : TT];
-#pragma unroll
-  for (int mi = 0; mi < SMI; ++mi) {
-    const int r = mi * 32 + l31;
-    if constexpr (SPATIAL) {
-      const int hyc = (r >> 4) + 1, xc = (r & 15) + 1;
-      aad[mi][0] = ((hyc - 1) * SHW + xc - 1) * 32 + ((lh ^ ((hyc - 1) & 1)) << 4);
-      aad[mi][1] = (hyc * SHW + xc - 1) * 32 + ((lh ^ (hyc & 1)) << 4);
-    } else {
-      const int m = m0 + r;
-      const int fv = m < mend ? m % p.V : -1000;          // fast-axis coordinate
-#pragma unroll
-      for (int t = 0; t < TT; ++t) {
-        const int dv = p.dv0 + t, row = r + SHALO + dv;
-        const bool ok = static_cast<unsigned>(fv + dv) < static_cast<unsigned>(p.V);
-        aad[mi][t] = ok ? row * 32 + ((lh ^ ((row >> 3) & 1)) << 4) : ZROW + (lh << 4);
-      }
-    }
+#define RS_TILE_FRAG_ADDR()     /* (3x3: the same for every tile; linear strips: the tap masks depend on where the strip starts) */ \
+  {                                                                                                          \
+    _Pragma("unroll") for (int mi = 0; mi < SMI; ++mi) {                                                     \
+      const int r = mi * 32 + l31;                                                                           \
+      if constexpr (SPATIAL) {                                                                               \
+        const int hyc = (r >> 4) + 1, xc = (r & 15) + 1;                                                     \
+        aad[mi][0] = ((hyc - 1) * SHW + xc - 1) * 32 + ((lh ^ ((hyc - 1) & 1)) << 4);                        \
+        aad[mi][1] = (hyc * SHW + xc - 1) * 32 + ((lh ^ (hyc & 1)) << 4);                                    \
+      } else {                                                                                               \
+        const int m = m0 + r;                                                                                \
+        const int fv = m < mend ? m % p.V : -1000;          /* fast-axis coordinate */                       \
+        _Pragma("unroll") for (int t = 0; t < TT; ++t) {                                                     \
+          const int dv = p.dv0 + t, row = r + SHALO + dv;                                                    \
+          const bool ok = static_cast<unsigned>(fv + dv) < static_cast<unsigned>(p.V);                       \
+          aad[mi][t] = ok ? row * 32 + ((lh ^ ((row >> 3) & 1)) << 4) : ZROW + (lh << 4);                    \
+        }                                                                                                    \
+      }                                                                                                      \
+    }                                                                                                        \
   }
+  RS_TILE_FRAG_ADDR()
   const int boff = l31 * 32 + ((lh ^ ((l31 >> 3) & 1)) << 4);      // this lane's hi fragment inside a weight record (lo: + 1024)
   const unsigned lane16 = lane * 16;
 
   f32x16 acc[SMI][NI];
-#pragma unroll
-  for (int i = 0; i < SMI; ++i)
-#pragma unroll
-    for (int j = 0; j < NI; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int NHB = 2 * p.ncb;                 // half blocks (even)
   const int S = NHB * TT;                    // steps
   float4 areg[MODE == 0 ? 1 : NQ];           // register path: the half block in flight
   float4 nrm01 = make_float4(0.f, 1.f, 0.f, 1.f), nrm23 = nrm01;
   int sat_n = 0;
-  const bool sat_here = MODE != 0 && p.sat != nullptr && nt_i == 0;
+  bool sat_here = MODE != 0 && p.sat != nullptr && nt_i == 0;
 
   // ---- activation half blocks are requested in order 0, 1, 2, ...: the per-lane source pointers of the NEXT one to request are
   // kept and advanced by 64 bytes (16 channels) per half block inside a source segment; only at a segment change (virtual concat:
@@ -501,9 +515,9 @@ __global__ __launch_bounds__(NW * 64, NI == 2 ? 1 : ((RS_MINW3 && NW == 2 && SMI
   // weight records are requested in step order from a scalar pointer that advances by one record row per step; past the last
   // step it stays (the surplus requests re-read the last record into slots nobody reads any more: the request counts are the
   // same in every step)
-  const unsigned char* wptr = reinterpret_cast<const unsigned char*>(p.wpk_strip) + static_cast<size_t>(ct32) * 2048;
+  const unsigned char* wptr;
   const size_t wstep = static_cast<size_t>(ntiles32) * 2048;
-  int b_left = S - 1;                        // records behind the one wptr stands at
+  int b_left;                                // records behind the one wptr stands at
 #define RS_ISSUE_B(SL_)                                                                                      \
   {                                                                                                          \
     glds_rec<NI>(wptr, lane16, __builtin_amdgcn_readfirstlane(sB0 + (SL_) * BREC));                          \
@@ -548,10 +562,35 @@ __global__ __launch_bounds__(NW * 64, NI == 2 ? 1 : ((RS_MINW3 && NW == 2 && SMI
   }
 
   // ---- prologue: half blocks 0 and 1, weight records 0 .. NBST-2 ----
-  if constexpr (MODE != 0) {       // the zero row of both planes of both slots (the DMA path refills it with every half block)
-    if (tid < 8) *reinterpret_cast<uint4*>(lds + (tid >> 2) * ASLOT + ((tid >> 1) & 1) * PLANE + ZROW + (tid & 1) * 16) = make_uint4(0u, 0u, 0u, 0u);
+  // fp32-source forms: both half blocks are requested before the first is split (one memory latency instead of two: r04 timeline) --
+  // half block 0 parked in areg0 / n01 / n23, half block 1 in areg / nrm.  RS_PRO_LOADS runs in front of the prologue's weight requests
+  // for a workgroup's first tile and IN FRONT OF THE PREVIOUS TILE'S EPILOGUE for every later tile of a persistent launch (r06).
+  float4 areg0[MODE == 0 ? 1 : NQ];
+  float4 n01 = nrm01, n23 = nrm23;
+#define RS_PRO_LOADS()                                                                                       \
+  {                                                                                                          \
+    RS_LOAD_A()                                                                                              \
+    n01 = nrm01; n23 = nrm23;                                                                                \
+    _Pragma("unroll") for (int i = 0; i < NQ; ++i) areg0[i] = areg[i];                                       \
+    RS_LOAD_A()                                                                                              \
   }
+  bool first_tile = true;
+  for (;;) {
+#pragma unroll
+  for (int i = 0; i < SMI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  wptr = reinterpret_cast<const unsigned char*>(p.wpk_strip) + static_cast<size_t>(ct32) * 2048;
+  b_left = S - 1;
+  e_mt_i = mt_i; e_img = img_; e_py0 = py0_; e_px0 = px0_; e_m0 = m0; e_mend = mend; e_ct32 = ct32;
   RS_CLK(5)
+  if (!first_tile) wg_barrier();     // every wave has left the last tile's main loop and epilogue staging: the activation slots may be rewritten
+  if constexpr (MODE != 0) {       // the zero row of both planes of both slots (the DMA path refills it with every half block; an epilogue
+    if (tid < 8) *reinterpret_cast<uint4*>(lds + (tid >> 2) * ASLOT + ((tid >> 1) & 1) * PLANE + ZROW + (tid & 1) * 16) = make_uint4(0u, 0u, 0u, 0u);      // staged over the slots may have overwritten it)
+  }
+  a_next = 0;
   RS_A_REBUILD()
   if constexpr (MODE == 0) {
     RS_ISSUE_A(0)
@@ -559,13 +598,8 @@ __global__ __launch_bounds__(NW * 64, NI == 2 ? 1 : ((RS_MINW3 && NW == 2 && SMI
   }
 #pragma unroll
   for (int i = 0; i < NBST - 1; ++i) RS_ISSUE_B(i)
-  if constexpr (MODE != 0) {       // both half blocks requested before the first is split (one memory latency instead of two: r04 timeline)
-    RS_LOAD_A()
-    float4 areg0[NQ];
-    const float4 n01 = nrm01, n23 = nrm23;
-#pragma unroll
-    for (int i = 0; i < NQ; ++i) areg0[i] = areg[i];
-    RS_LOAD_A()
+  if constexpr (MODE != 0) {
+    RS_PRO_LOADS()
     {
       float4 areg1[NQ];
       const float4 m01 = nrm01, m23 = nrm23;
@@ -676,12 +710,19 @@ __global__ __launch_bounds__(NW * 64, NI == 2 ? 1 : ((RS_MINW3 && NW == 2 && SMI
   wait_vm<0>();        // (the surplus requests of the last steps land in slots the epilogue is about to reuse)
   wait_lds();
   RS_CLK(2)
-
   // ------------------------------------------- epilogue -------------------------------------------
   // accumulators -> wave-private LDS tile (the wave's own weight ring: every request into it has been waited for, all its
   // fragment reads are done) -> 16-byte row-contiguous stores; the operands of all four row groups of a 32-row block (additive
   // map, h, z) are requested before the block goes through LDS (conv_igemm.hip has the history of this order).
   constexpr int ES = 32 * NI + 4, F4 = 8 * NI, KG = 4 * NI;       // row stride of the staging tile (floats), float4 per row, row groups per block
+  // (persistent form: the epilogue's lane-derived addresses are loop invariants; hoisted out of the tile loop they live through the main
+  //  loop and cost 70-400 spilled registers -- the thread index goes through an opaque move so that they are formed here, per tile)
+  int tid_e_ = tid;
+  if constexpr (PERSIST) asm volatile("" : "+v"(tid_e_));
+  bool more_ = false;
+  {
+  const int tid = tid_e_, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+  (void)l31; (void)lh;
   float* S_ = reinterpret_cast<float*>(sB);              // 32 x ES floats = 4.5 / 8.5 KB <= the ring's 10 / 24 KB
   constexpr bool EPI_IN_ASLOTS = NBST * BREC < 2 * 32 * ES * 4;      // a 3- / 4-slot ring (6 / 8 KB) does not hold the fast epilogue's two staging
   if constexpr (EPI_IN_ASLOTS) {                                      // tiles (9 KB per wave): they are laid over the whole LDS block from its start
@@ -689,7 +730,7 @@ __global__ __launch_bounds__(NW * 64, NI == 2 ? 1 : ((RS_MINW3 && NW == 2 && SMI
     S_ = reinterpret_cast<float*>(lds + wave * (2 * 32 * ES * 4));
     static_assert(!EPI_IN_ASLOTS || NW * 2 * 32 * (32 * NI + 4) * 4 <= LDSB, "epilogue staging inside the workgroup's LDS block");
   }
-  const int colw = ct32 * 32;
+  const int colw = e_ct32 * 32;
   const int colq = colw + (lane % F4) * 4;
   const bool colok = colq < p.Cout;
   const int colc = colok ? colq : 0;
@@ -699,10 +740,41 @@ __global__ __launch_bounds__(NW * 64, NI == 2 ? 1 : ((RS_MINW3 && NW == 2 && SMI
   for (int e = 0; e < 4; ++e) bq[e] = p.bias[colc + (e < nv ? e : 0)];
   const int c2 = colc >= p.gru_c ? colc - p.gru_c : 0;
   double ts0 = 0., ts1 = 0., ts2 = 0., ts3 = 0., tq0 = 0., tq1 = 0., tq2 = 0., tq3 = 0.;
+  // ---- persistent launches (r06): the NEXT tile of this workgroup.  Its geometry and source pointers are formed HERE, in front of this
+  // tile's epilogue, and -- fp32-source forms -- the 128-byte lines of its first two half blocks are PULLED TOWARDS THE CU by LDS-DMA
+  // requests whose LDS destination is a 1-KB sink nobody reads (a free part of the wave's own weight ring): no registers, no wait --
+  // the 3-6 us of first-byte latency that every tile's prologue used to sit out (profiles/r04_strip_timeline.txt: prologue 4.7-6.7 us
+  // of a 30-37 us workgroup in the encoder's layers) run under the epilogue's staging and stores, and the prologue's real loads then
+  // hit L2.  (Loading the half blocks into registers across the epilogue was built first: 165-405 spilled registers.)  The bias
+  // values are passed through a v_mov first so that the compiler's wait for THEIR loads stands in front of the DMA requests: vmcnt is
+  // in order, and a wait behind them would sit out the very latency this hides.
+  t_idx += t_step;
+  more_ = PERSIST && t_idx < t_cnt;                  // (PERSIST is a template parameter: the one-tile forms keep their straight-line code)
+  if (more_ && MODE != 0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) asm volatile("v_mov_b32 %0, %1" : "=v"(bq[e]) : "v"(bq[e]));
+    // (SHADOW copies of the tile variables: the macros fill these, the requests go out, and they die here -- kept alive across the
+    //  epilogue they cost 100-400 spilled registers; the geometry is formed again for real behind the epilogue)
+    int nt_i, mt_i, img_, py0_, px0_, m0, mend, ct32;
+    int apix[PA > NQ ? PA : NQ];
+    int asrc[MODE == 0 ? PA : 1];
+    int a_next = 0, a_seg_end = 0;
+    const unsigned char* asp[MODE == 0 ? PA : NQ];
+    unsigned ainc[MODE == 0 ? PA : NQ];
+    const float* nsp = p.in_mr;
+    RS_TILE_GEOM(t_base + t_idx)
+    RS_TILE_ROWS()
+    RS_A_REBUILD()
+    (void)nt_i; (void)mt_i; (void)mend; (void)ct32; (void)asrc; (void)a_seg_end; (void)ainc; (void)nsp;
+    constexpr int SINK = EPI_IN_ASLOTS ? 0 : 2 * 32 * ES * 4;       // the ring is free (staging in the activation slots) / its tail behind the two staging tiles
+    static_assert(!PERSIST || MODE == 0 || SINK + 1024 <= NBST * BREC, "a 1-KB sink inside the wave's weight ring");
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) glds16(asp[i], __builtin_amdgcn_readfirstlane(sB0 + SINK));
+  }
   // ---- fast path (strip_epilogue_fast above): a wave whose 160 x 32 tile lies inside the problem, with one of the option sets the
   // engines use -- every strip of the update block and the encoder at the headline shapes
   int ev_ = -1;
-  if (NI == 1 && p.off32 && colw + 32 <= p.Cout && (SPATIAL ? (py0_ + SPH <= p.U && px0_ + SPW <= p.V) : (m0 + SM <= mend && p.V >= 8))) {
+  if (NI == 1 && p.off32 && colw + 32 <= p.Cout && (SPATIAL ? (e_py0 + SPH <= p.U && e_px0 + SPW <= p.V) : (e_m0 + SM <= e_mend && p.V >= 8))) {
     if (p.epi <= 1 && !p.addm && !p.dsth) ev_ = p.dst_hl ? (p.tstats ? -1 : 2) : (p.tstats ? 1 : 0);
     else if (p.epi == 2 && p.addm && !p.dst_hl && p.dst2_hl && !p.dsth && (p.gru_c & 31) == 0 && !p.tstats) ev_ = 3;
     else if (p.epi == 3 && p.addm && !p.dst_hl && p.dsth && !p.tstats) ev_ = 4;
@@ -710,9 +782,9 @@ __global__ __launch_bounds__(NW * 64, NI == 2 ? 1 : ((RS_MINW3 && NW == 2 && SMI
   if (NI == 1 && ev_ >= 0) {
     int pixb, lv_ = 0, lu_ = 0;
     if constexpr (SPATIAL) {
-      pixb = img_ * UV + py0_ * p.V + px0_ + (lane >> 3);
+      pixb = e_img * UV + e_py0 * p.V + e_px0 + (lane >> 3);
     } else {
-      const int m = m0 + (lane >> 3);
+      const int m = e_m0 + (lane >> 3);
       const int q = m / p.V;
       lv_ = m - q * p.V;
       const int b = q / p.U;
@@ -758,13 +830,13 @@ __global__ __launch_bounds__(NW * 64, NI == 2 ? 1 : ((RS_MINW3 && NW == 2 && SMI
       const int r = mi * 32 + rl;
       long long pix;
       if (SPATIAL) {
-        const int y = py0_ + (r >> 4), x = px0_ + (r & 15);
+        const int y = e_py0 + (r >> 4), x = e_px0 + (r & 15);
         rowok |= ((y < p.U && x < p.V) ? 1u : 0u) << k;
-        pix = static_cast<long long>(img_) * UV + (y < p.U ? y : p.U - 1) * p.V + (x < p.V ? x : p.V - 1);
+        pix = static_cast<long long>(e_img) * UV + (y < p.U ? y : p.U - 1) * p.V + (x < p.V ? x : p.V - 1);
       } else {
-        const int m = m0 + r;
-        const int mc = m < mend ? m : mend - 1;
-        rowok |= (m < mend ? 1u : 0u) << k;
+        const int m = e_m0 + r;
+        const int mc = m < e_mend ? m : e_mend - 1;
+        rowok |= (m < e_mend ? 1u : 0u) << k;
         pix = mc;
         if (p.sv != 1) {
           const int q = mc / p.V, v = mc - q * p.V;
@@ -845,7 +917,6 @@ __global__ __launch_bounds__(NW * 64, NI == 2 ? 1 : ((RS_MINW3 && NW == 2 && SMI
     }
   }
   }
-  if (p.sat && sat_n) atomicAdd(p.sat, static_cast<unsigned long long>(sat_n));
   if (p.tstats) {
     // a wave owns all 160 rows of its 32 columns: lanes sharing a column quad (same lane % 8) -> lanes 0..7, fixed order; one
     // (sum, sum of squares) pair per tile and column, no atomics, nothing to combine across waves
@@ -860,13 +931,23 @@ __global__ __launch_bounds__(NW * 64, NI == 2 ? 1 : ((RS_MINW3 && NW == 2 && SMI
 #pragma unroll
       for (int e = 0; e < 4; ++e)
         if (col + e < p.Cout) {
-          double* o = p.tstats + (static_cast<long long>(mt_i) * p.Cout + col + e) * 2;
+          double* o = p.tstats + (static_cast<long long>(e_mt_i) * p.Cout + col + e) * 2;
           o[0] = ts[e];
           o[1] = tq[e];
         }
     }
   }
   RS_CLK(3)
+  }      // (epilogue scope)
+  first_tile = false;
+  if constexpr (!PERSIST) break;
+  if (!more_) break;
+  RS_TILE_GEOM(t_base + t_idx)
+  RS_TILE_ROWS()
+  if constexpr (!SPATIAL) { RS_TILE_FRAG_ADDR() }
+  sat_here = MODE != 0 && p.sat != nullptr && nt_i == 0;
+  }      // tile loop
+  if (p.sat && sat_n) atomicAdd(p.sat, static_cast<unsigned long long>(sat_n));
 }
 
 // every kernel of one strip height (SMI_ 32-row tiles per wave): nw waves of ni 32-column tiles, 3x3 (spatial) or 1x5 / 5x1, sources
@@ -887,9 +968,19 @@ int strip_launch_height(const KParams& p, int nw, int ni, bool spatial, bool hli
   }
 #define RS_LAUNCH(NW_, NI_)                                                                                               \
   if (spatial) {                                                                                                          \
-    if (norm) hipLaunchKernelGGL((conv_strip_f16x3_kernel<NW_, 9, 2, NI_, SMI_, P1_>), grid, block, 0, st, p);                 \
+    if (norm) {                                                                                                           \
+      if constexpr (NI_ == 1 && SMI_ == 5 && !P1_) {                                                                      \
+        if (p.n_tiles > 0) hipLaunchKernelGGL((conv_strip_f16x3_kernel<NW_, 9, 2, NI_, SMI_, P1_, true>), grid, block, 0, st, p);   \
+        else hipLaunchKernelGGL((conv_strip_f16x3_kernel<NW_, 9, 2, NI_, SMI_, P1_>), grid, block, 0, st, p);             \
+      } else hipLaunchKernelGGL((conv_strip_f16x3_kernel<NW_, 9, 2, NI_, SMI_, P1_>), grid, block, 0, st, p);             \
+    }                                                                                                                     \
     else if (hlin) hipLaunchKernelGGL((conv_strip_f16x3_kernel<NW_, 9, 0, NI_, SMI_, P1_>), grid, block, 0, st, p);            \
-    else hipLaunchKernelGGL((conv_strip_f16x3_kernel<NW_, 9, 1, NI_, SMI_, P1_>), grid, block, 0, st, p);                      \
+    else {                                                                                                                \
+      if constexpr (NI_ == 1 && SMI_ == 5 && !P1_) {                                                                      \
+        if (p.n_tiles > 0) hipLaunchKernelGGL((conv_strip_f16x3_kernel<NW_, 9, 1, NI_, SMI_, P1_, true>), grid, block, 0, st, p);   \
+        else hipLaunchKernelGGL((conv_strip_f16x3_kernel<NW_, 9, 1, NI_, SMI_, P1_>), grid, block, 0, st, p);             \
+      } else hipLaunchKernelGGL((conv_strip_f16x3_kernel<NW_, 9, 1, NI_, SMI_, P1_>), grid, block, 0, st, p);             \
+    }                                                                                                                     \
   } else {                                                                                                                \
     if (hlin) hipLaunchKernelGGL((conv_strip_f16x3_kernel<NW_, 5, 0, NI_, SMI_, P1_>), grid, block, 0, st, p);                 \
     else hipLaunchKernelGGL((conv_strip_f16x3_kernel<NW_, 5, 1, NI_, SMI_, P1_>), grid, block, 0, st, p);                      \

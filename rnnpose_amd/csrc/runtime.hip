@@ -42,6 +42,20 @@ unsigned long long* sat_counter() {
 
 }  // namespace rp
 
+namespace rp {
+int cu_count() {
+  static int cached[16] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+  if (cached[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cached[dev] = n;
+  }
+  return cached[dev];
+}
+}  // namespace rp
+
 extern "C" {
 
 int rnnpose_f16x3_saturation_check(int enable) {

