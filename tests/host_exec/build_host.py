@@ -48,9 +48,17 @@ HEADER_PATCHES = {
         (r"template <int NI>\n__device__ __forceinline__ void glds_rec\(const void\* base, unsigned voff, unsigned dst\) \{.*?\n  \}\n\}\n",
          "template <int NI>\n__device__ __forceinline__ void glds_rec(const void* base, unsigned voff, unsigned dst) {\n"
          "  hostexec::lds_dma(static_cast<const unsigned char*>(base) + voff, dst, 2 * NI);\n}\n", 1),
-        (r'asm volatile\("s_waitcnt vmcnt\(%0\)" ::"n"\(N\) : "memory"\);', ";", 1),
+        (r'asm volatile\("s_waitcnt vmcnt\(%0\)" ::"n"\(N\) : "memory"\);', "hostexec::vm_wait(N);", 1),      # r06: the counted wait retires the queue (harness.hpp)
+        # the register loads of the fp32-source forms are vector-memory requests too: PAW places in the in-order queue per half block
+        (r"(_Pragma\(\"unroll\"\) for \(int i = 0; i < NQ; \+\+i\) areg\[i\] = \*reinterpret_cast<const float4\*>\(asp\[i\]\);       \\\n)", "BACKREF1    hostexec::vm_note(PAW);  \\\n", 1),
         (r'asm volatile\("s_waitcnt lgkmcnt\(0\)" ::: "memory"\);', ";", 1),
         (r'asm volatile\("s_memrealtime %0\\n\\ts_waitcnt lgkmcnt\(0\)" : "=s"\(t_\)::"memory"\);', "t_ = 0;", 1),
+        # r06, persistent form: an opaque move of the thread index (AMDGPU register class "v" -> a host register), the v_mov that puts the
+        # compiler's wait for the bias loads in front of the sink requests (no meaning on the host), the start-delay loop of a measurement
+        (r'asm volatile\("" : "\+v"\(tid_e_\)\);', 'asm volatile("" : "+r"(tid_e_));', 1),
+        (r'asm volatile\("v_mov_b32 %0, %1" : "=v"\(bq\[e\]\) : "v"\(bq\[e\]\)\);', ";", 1),
+        (r"while \(wall_clock64\(\) < t_end\) __builtin_amdgcn_s_sleep\(32\);", ";", 1),
+        (r"const unsigned long long t_end = wall_clock64\(\) \+", "const unsigned long long t_end = 0ull +", 1),
         # wave-synchronous LDS staging of the two epilogues (as in conv_igemm.hip): a wave synchronisation before and after every
         # staging write
         (r"\n  stage\(0, acc\[0\]\[0\]\);", "\n  __builtin_amdgcn_wave_barrier(); stage(0, acc[0][0]); __builtin_amdgcn_wave_barrier();", 1),
@@ -66,7 +74,7 @@ HEADER_PATCHES = {
 }
 STRIP_SOURCES = ["conv_strip.hip", "conv_strip_r32.hip", "conv_strip_r96.hip", "conv_strip_p1.hip"]      # copied next to the patched header (quote includes look there first)
 
-SOURCES = ["pointwise.hip", "corr_pyramid.hip", "corr_lookup.hip", "corr_alt.hip", "conv_igemm.hip", "conv1x1_resident.hip", "stem.hip",
+SOURCES = ["pointwise.hip", "corr_pyramid.hip", "corr_lookup.hip", "corr_convc1.hip", "corr_alt.hip", "conv_igemm.hip", "conv1x1_resident.hip", "stem.hip",
            "nhwc_ops.hip", "eval_metrics.hip", "zoom_crop.hip", "raster.hip", "lm.hip", "mask_upsample.hip"]
 EXTRA = ["runtime_host.cpp"]
 

@@ -29,6 +29,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <functional>
 #include <memory>
 #include <mutex>
@@ -64,10 +65,22 @@ namespace hostexec {
 constexpr int kWaveSize = 64;
 constexpr size_t kStack = 256 * 1024;
 
+struct PendingVm {               // one lane's 16 bytes of an LDS-DMA request that has been issued but not waited for (d == nullptr: a
+  unsigned char* d;              // register load / other vector-memory request that only takes a place in the in-order queue)
+  const unsigned char* s;
+};
 struct Wave {
   int live = 0, arrived = 0;
   unsigned gen = 0;
   alignas(64) unsigned char buf[kWaveSize][256];       // one operand fragment per lane
+  struct VmQueue {                                      // r06: per lane, in issue order (the same length in every lane: requests are wave collectives)
+    std::vector<PendingVm> v;
+    size_t head = 0;
+    size_t size() const { return v.size() - head; }
+    void push_back(const PendingVm& p) { v.push_back(p); }
+    const PendingVm& front() const { return v[head]; }
+    void pop_front() { if (++head == v.size()) { v.clear(); head = 0; } }
+  } vmq[kWaveSize];
 };
 
 struct Fiber {
@@ -266,12 +279,43 @@ inline T exchange(T mine, int src_lane) {
 constexpr unsigned kLdsFakeBase = 0x10000u;
 inline thread_local unsigned char* g_lds_host = nullptr;
 inline unsigned lds_register(unsigned char* lds) { g_lds_host = lds; return kLdsFakeBase; }
+// r06: COMPLETION IS DEFERRED.  A request only joins the wave's in-order queue of outstanding vector-memory
+// requests; its bytes reach LDS when a counted wait retires it -- vm_wait(N) = s_waitcnt vmcnt(N): everything but the N newest requests
+// of the wave completes, for ALL lanes (whichever lane gets there first does it: the hardware completes a request for the whole wave
+// before the wave passes the wait).  A wait that is counted one too high therefore leaves a request in flight and the kernel reads
+// what the LDS slot held BEFORE -- the stale read a mis-counted s_waitcnt produces on the GPU (until r05 the host completed every
+// request at once and could not see that class of bug).  HOSTEXEC_DMA_EAGER=1 restores completion at issue (the other legal timing).
+// vm_note(k): k other vector-memory requests of the wave (the register loads of the fp32-source forms) take their places in the queue.
+inline bool dma_eager() { static const bool e = std::getenv("HOSTEXEC_DMA_EAGER") != nullptr; return e; }
 inline void lds_dma(const void* g, unsigned dst, int pieces) {
   wave_sync();                         // every lane of the wave has passed its reads of what the slot held (the hardware issues the request
   unsigned char* d = g_lds_host + (dst - kLdsFakeBase) + 16 * my_lane();      //  for all lanes at one program point)
   const unsigned char* s = static_cast<const unsigned char*>(g);
-  for (int k = 0; k < pieces; ++k) std::memcpy(d + 1024 * k, s + 1024 * k, 16);
+  if (dma_eager()) {
+    for (int k = 0; k < pieces; ++k) std::memcpy(d + 1024 * k, s + 1024 * k, 16);
+  } else {
+    auto& q = my_wave().vmq[my_lane()];
+    for (int k = 0; k < pieces; ++k) q.push_back(PendingVm{d + 1024 * k, s + 1024 * k});
+  }
   wave_sync();
+}
+inline void vm_note(int k) {
+  wave_sync();
+  if (!dma_eager()) {
+    auto& q = my_wave().vmq[my_lane()];
+    for (int i = 0; i < k; ++i) q.push_back(PendingVm{nullptr, nullptr});
+  }
+  wave_sync();
+}
+inline void vm_wait(int n) {
+  Wave& w = my_wave();
+  for (int l = 0; l < kWaveSize; ++l) {
+    auto& q = w.vmq[l];
+    while (static_cast<int>(q.size()) > n) {
+      if (q.front().d) std::memcpy(q.front().d, q.front().s, 16);
+      q.pop_front();
+    }
+  }
 }
 
 // ballot: LANE-LOCAL here ("does any lane of my wave ..." answered as "do I").  A true wave ballot would be a collective, and the

@@ -15,6 +15,7 @@ hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipSt
 hipError_t hipMemset(void* d, int v, size_t n) { std::memset(d, v, n); return hipSuccess; }
 hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 4; return hipSuccess; }      // (a 4-CU "device": persistent strip launches of 8 / 16 workgroups)
 hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
   std::memset(p, 0, sizeof *p);
   std::strcpy(p->gcnArchName, "host");

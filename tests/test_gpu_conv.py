@@ -860,14 +860,16 @@ def test_conv_strip_is_the_automatic_choice_at_the_update_block_shape(ops):
     assert not torch.equal(a, b) and float((a - b).abs().max()) < 2e-6 * float(b.abs().max())
 
 
-@pytest.mark.parametrize("cin,cout,H,W,norm", [(64, 64, 240, 320, True), (64, 64, 240, 320, False), (96, 96, 120, 160, True), (128, 128, 96, 160, False)])
-def test_conv_strip_persistent_launch_is_bit_identical(ops, cin, cout, H, W, norm):
+@pytest.mark.parametrize("B,cin,cout,H,W,norm", [(8, 64, 64, 240, 320, True), (8, 64, 64, 240, 320, False), (8, 96, 96, 120, 160, True), (8, 128, 128, 96, 160, False),
+                                                 (2, 64, 64, 40, 48, True), (3, 96, 96, 30, 48, False), (2, 128, 128, 50, 33, True)])
+def test_conv_strip_persistent_launch_is_bit_identical(ops, B, cin, cout, H, W, norm):
     """r06: the PERSISTENT form of the fp32-source strip kernels (ops.conv_strip(7): as many workgroups as the
     chip holds, each walking its share of the tile list and pulling the next tile's first activations towards the CU in front of its
     epilogue) at the encoder's launch sizes -- same tiles, same arithmetic, same order: outputs and tile statistics equal the one-tile-
-    per-workgroup launch bit for bit, with and without the fused input normalisation.  (Measured slower: off by default.)"""
-    B = 8
-    x = torch.randn(B, H, W, cin, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5)) * 1.3 + 0.2
+    per-workgroup launch bit for bit, with and without the fused input normalisation.  (Measured slower: off by default.)  The small
+    shapes are persistent launches on the host-execution tier (a 4-CU "device": 8 / 16 resident workgroups, tests/host_exec), where
+    every workgroup walks 2-3 tiles incl. ragged ones; on the GPU they take the ordinary launch."""
+    x = torch.randn(B, H, W, cin, generator=torch.Generator().manual_seed(5)).mul_(1.3).add_(0.2).to("cuda")
     w = D(syn.normal("pw", (cout, cin, 3, 3), 9, std=float(np.sqrt(2.0 / (cin * 9)))))
     pc = ops.PackedConv(w, D(syn.uniform("pb", (cout,), 9, -0.5, 0.5)), [cin])
     mr = None
@@ -888,7 +890,6 @@ def test_conv_strip_persistent_launch_is_bit_identical(ops, cin, cout, H, W, nor
     finally:
         ops.conv_strip(1)
     assert torch.equal(outs[0], outs[1]) and torch.equal(stats[0], stats[1])
-    assert float(stats[1].min()) > -1.0 or True
     y64 = F.conv2d((F.relu((x - mr[:, None, None, :, 0]) * mr[:, None, None, :, 1]) if norm else x).permute(0, 3, 1, 2).double(), w.double(), pc.bias.double(), padding=1)
     assert float((outs[1].permute(0, 3, 1, 2).double() - y64).abs().max()) < 2e-5 * float(y64.abs().max())
 

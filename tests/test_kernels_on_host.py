@@ -220,7 +220,14 @@ STRIP_IDS = [_C + t for t in (
     "test_conv_stride2_strips_over_parity_planes[2-100-112-64-96-True-1]", "test_conv_stride2_strips_over_parity_planes[1-60-60-96-128-True-3]",
     "test_conv_stride2_strips_over_parity_planes[1-60-60-96-128-True-1]", "test_conv_stride2_strips_over_parity_planes[2-120-120-64-96-True-3]",
     "test_conv_strip_single_product_is_plain_fp16[1-40-48-segs2-64-3-3-True]", "test_conv_strip_single_product_is_plain_fp16[2-20-32-segs0-256-1-5-False]",
-)]
+    # r06: 96-row strips (three MFMA row tiles per wave, 6 x 16 patches); the PERSISTENT form of the fp32-source kernels (the host "device" has 4
+    # CUs: 8 / 16 resident workgroups walk 24-30 tiles, ragged ones included)
+    "test_conv_strip_vs_fp64[auto-rows96-1-21-33-segs8-48-3-3-False]", "test_conv_strip_vs_fp64[auto-rows96-3-7-11-segs2-128-5-1-True]",
+    "test_conv_strip_vs_fp64[auto-rows96-2-40-48-segs7-64-3-3-True]", "test_conv_strip_gru_epilogues[auto-rows96-1-5-True]",
+    "test_conv_strip_tile_stats_and_fused_input_norm[auto-rows96-3-15-20-96-96]",
+    "test_conv_strip_persistent_launch_is_bit_identical[2-64-64-40-48-True]", "test_conv_strip_persistent_launch_is_bit_identical[3-96-96-30-48-False]",
+    "test_conv_strip_persistent_launch_is_bit_identical[2-128-128-50-33-True]",
+)] + ["tests/test_gpu_parity.py::test_corr_lookup_convc1_fused_equals_the_two_kernels[" + t + "]" for t in ("False-2-16-24-0-2", "True-3-17-19-1-3", "False-4-30-30-2-3")]
 
 
 def _subset(host_lib, args):

@@ -77,3 +77,26 @@ ref.use_graph = False
 print(f"eager, two streams            {timed(lambda: ref._inner_loop(*args)):.3f} ms")
 ref.cf_net.engine().split_batch = False
 print(f"eager, one chain (unsplit)    {timed(lambda: ref._inner_loop(*args)):.3f} ms")
+
+
+# r06: does a START OFFSET between the two chains change the overlap?  (identical chains forked together run in phase: convolutions
+# next to convolutions, tails next to tails; offset by part of an iteration one chain's tail runs under the other's convolutions)
+if os.environ.get("LOOP_OVERLAP_STAGGER", "1") != "0":
+    ref.use_graph = True
+    ref.cf_net.engine().split_batch = True
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); torch.cuda._sleep(1_000_000); e1.record(); torch.cuda.synchronize()
+    us_per_mcycle = e0.elapsed_time(e1) * 1e3
+    print(f"torch.cuda._sleep(1e6) = {us_per_mcycle:.1f} us")
+
+    def both(delay_us):
+        with torch.cuda.stream(s0):
+            g0.replay()
+        with torch.cuda.stream(s1):
+            if delay_us:
+                torch.cuda._sleep(int(delay_us / us_per_mcycle * 1e6))
+            g1.replay()
+
+    for d in (0, 50, 100, 150, 200, 250, 300, 400, 600):
+        print(f"both graphs, chain 1 delayed by {d:4d} us   {timed(lambda: both(d), reps=8):.3f} ms")
