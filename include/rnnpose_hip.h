@@ -67,6 +67,8 @@ int rnnpose_corr_pyramid_f16x3(const float* fmap1, const float* fmap2, int layou
 int rnnpose_corr_pyramid_split(const void* fmap1_split, const void* fmap2_split, int B, int C, int h, int w, int levels,
                                float a_scale, float* pyramid, rnnpose_stream_t stream);
 int rnnpose_corr_supertile(int max_side);   /* measurement switch: tile-order supertiles of at most max_side x max_side (default 20) */
+int rnnpose_corr_variant(int variant);      /* which fp16x3 volume kernel rnnpose_corr_pyramid_f16x3 / _split launch: 0 = operands through registers
+                                             * and ds_write (r03-r05), 1 = operands by LDS-DMA, double-buffered 16-channel slabs (r06); bit-identical results */
 
 /* ---- a3': volume-free lookup ---- thirdparty/raft/corr.py:70-98 (AlternateCorrBlock; its alt_cuda_corr extension is not in the
  * reference tree and the reference never enables it, model/CFNet.py:63-64).  The same (levels*81)-channel window features as

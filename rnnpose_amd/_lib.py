@@ -48,6 +48,7 @@ PROTOTYPES = {
     "rnnpose_corr_pyramid_f16x3": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _f, _p, _z, _p, _p]),
     "rnnpose_corr_pyramid_split": (_i, [_p, _p, _i, _i, _i, _i, _i, _f, _p, _p]),
     "rnnpose_corr_supertile": (_i, [_i]),
+    "rnnpose_corr_variant": (_i, [_i]),
     "rnnpose_fmap_pyramid_floats": (_z, [_i, _i, _i, _i, _i]),
     "rnnpose_fmap_pyramid_f32": (_i, [_p, _i, _i, _i, _i, _i, _p, _p]),
     "rnnpose_corr_alt_lookup_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _i, _p]),

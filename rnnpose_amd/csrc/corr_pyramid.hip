@@ -537,6 +537,151 @@ __global__ __launch_bounds__(NT, RPC_MINW) void corr_pyramid_h3_kernel(const _Fl
   pyramid_epilogue<ALIGNED>(acc0, acc1, acc2, acc3, smem, pyr, info, b, N, h, w, i0, y0, x0, scale, wave, lane, patch, n_patch);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// r06: the same tile, products and epilogue with the operands requested by LDS-DMA (global_load_lds_dwordx4: global memory -> LDS, no
+// staging registers, no ds_write).  Why: per 32-channel slab a workgroup moved 32 KB through ds_write_b128 -- ~13 LDS cycles per
+// wave-instruction (MI355X_MICROARCH.md, LDS: the address / data transfer of a wide store, not the array, sets its cost: ~79 B/clk per
+// CU) -- which with four workgroups per CU is ~1660 LDS cycles per slab round next to ~1300 for the fragment reads and 3072 MFMA cycles
+// per SIMD: the LDS was a co-limiter of the K loop (75 % of the pipe with all four workgroups in it), and the 32 staging registers
+// were what kept a second slab from being in flight.  Here:
+//   * slabs of 16 channels, DOUBLE-buffered: [A hi | A lo | B hi | B lo] x 128 rows x 32 bytes = 16 KB per buffer, 32 KB per workgroup
+//     (the epilogue's 36 KB of staging alias them as before: four workgroups per CU); slab k + 1 is requested before slab k's MFMAs,
+//     ONE barrier per slab (16 per tile, as many as the single-buffered form's 2 x 8);
+//   * a row is 32 bytes (two 8-channel groups), stored with a 1-bit XOR swizzle (chunk ^ bit 3 of the row) so that the 16 lanes of a
+//     ds_read_b128 group (rows {0-3, 12-15, 20-27} of a 32-row fragment) hit 16 different 16-byte units.  The DMA image is
+//     lane-linear (lane j -> LDS bytes [16 j, 16 j + 16) of its 1-KB piece), so the swizzle is applied to the SOURCE address: lane j
+//     fetches chunk (j & 1) ^ ((j >> 4) & 1) of row j >> 1;
+//   * wave w requests rows [32 w, 32 w + 32) of all four planes: 4 requests per wave and slab, addresses formed once per tile and
+//     advanced by 64 bytes per slab; rows outside the problem read a zero page (stride 0);
+//   * the same k order and the same three products per k block as the register form: results are BIT-IDENTICAL to it.
+constexpr int DBK = 16;                       // channels per slab
+constexpr int DPL = 128 * 32;                 // bytes per plane
+constexpr int DBUF = 4 * DPL;                 // bytes per slab buffer
+__device__ __attribute__((aligned(64))) const unsigned char g_cp_zero_page[64] = {0};
+
+// (as in conv_strip_kernel.cuh: inline asm, because hipcc models the builtin as a flat access and then waits lgkmcnt(0) / vmcnt(0)
+//  everywhere; M0 = the request's LDS base is saved and restored inside the statement)
+__device__ __forceinline__ void cp_glds16(const void* g, unsigned dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(g), "s"(dst)
+      : "memory");
+}
+__device__ __forceinline__ void cp_wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+template <bool ALIGNED>
+__global__ __launch_bounds__(NT, 4) void corr_pyramid_h3dma_kernel(const _Float16* __restrict__ f1, const _Float16* __restrict__ f2,
+                                                                   float* __restrict__ pyr, int B, int C, int h, int w, int n_it,
+                                                                   int n_py, int n_px, float scale, PyrInfo info, int sti, int stp) {
+  __shared__ __attribute__((aligned(1024))) unsigned char sD[4 * 2304 * 4];      // 36 KB: two 16-KB slab buffers; the epilogue's staging aliases them
+  float* smem = reinterpret_cast<float*>(sD);
+  const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) unsigned char*)sD));   // LDS byte address
+  const int N = h * w;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  const int ntiles = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int per = ntiles >> 3, rem = ntiles & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    bid = xcd * per + (xcd < rem ? xcd : rem) + idx;
+  }
+  const int n_patch = n_py * n_px;
+  const int n_ps = (n_patch + stp - 1) / stp, n_is = (n_it + sti - 1) / sti;
+  const int sts = sti * stp;
+  const int per_img = n_ps * n_is * sts;
+  const int b = bid / per_img;
+  const int tloc = bid - b * per_img;
+  const int sidx = tloc / sts, within = tloc - sidx * sts;
+  const int it = (sidx / n_ps) * sti + within / stp;
+  const int patch = (sidx % n_ps) * stp + within % stp;
+  if (it >= n_it || patch >= n_patch) return;
+  const int i0 = it * BM;
+  const int y0 = (patch / n_px) * PY;
+  const int x0 = (patch % n_px) * PX;
+
+  // request addresses of this lane: tile row 32 wave + (lane >> 1), chunk (lane & 1) ^ bit 3 of the row
+  const unsigned char* pa;
+  const unsigned char* pb;
+  unsigned inca, incb;
+  {
+    const int rr = lane >> 1, ch = (lane & 1) ^ ((rr >> 3) & 1);
+    const int ra = wave * 32 + rr;
+    const unsigned rsb = 4u * C;                      // bytes per pixel of a split tensor
+    const bool va = i0 + ra < N;
+    const int yb = y0 + (ra >> 4), xb = x0 + (ra & 15);
+    const bool vb = yb < h && xb < w;
+    pa = va ? reinterpret_cast<const unsigned char*>(f1) + (static_cast<size_t>(b) * N + i0 + ra) * rsb + ch * 32 : g_cp_zero_page;
+    pb = vb ? reinterpret_cast<const unsigned char*>(f2) + (static_cast<size_t>(b) * N + yb * w + xb) * rsb + ch * 32 : g_cp_zero_page;
+    inca = va ? 64u : 0u;
+    incb = vb ? 64u : 0u;
+  }
+  const unsigned dw = __builtin_amdgcn_readfirstlane(lds0 + wave * 1024);      // (wave-uniform: the request takes its LDS base from M0)
+#define RPD_REQ(BO_)                                       \
+  do {                                                     \
+    cp_glds16(pa, __builtin_amdgcn_readfirstlane(dw + (BO_)));                   \
+    cp_glds16(pa + 16, __builtin_amdgcn_readfirstlane(dw + (BO_) + DPL));        \
+    cp_glds16(pb, __builtin_amdgcn_readfirstlane(dw + (BO_) + 2 * DPL));         \
+    cp_glds16(pb + 16, __builtin_amdgcn_readfirstlane(dw + (BO_) + 3 * DPL));    \
+    pa += inca;                                            \
+    pb += incb;                                            \
+  } while (0)
+
+  f32x16 acc0, acc1, acc2, acc3;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; acc2[r] = 0.f; acc3[r] = 0.f; }
+
+  const int sw = (lh ^ ((l31 >> 3) & 1)) * 16;
+  const unsigned char* sA = sD + (wave * 32 + l31) * 32 + sw;
+  const unsigned char* sB = sD + 2 * DPL + l31 * 32 + sw;
+#define RPD_MFMA(BO_)                                                                          \
+  {                                                                                            \
+    const h8 ah = *reinterpret_cast<const h8*>(sA + (BO_));                                    \
+    const h8 al = *reinterpret_cast<const h8*>(sA + (BO_) + DPL);                              \
+    h8 bh[4], bl[4];                                                                           \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                            \
+      bh[s] = *reinterpret_cast<const h8*>(sB + (BO_) + s * 1024);                             \
+      bl[s] = *reinterpret_cast<const h8*>(sB + (BO_) + DPL + s * 1024);                       \
+    }                                                                                          \
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[0], acc0, 0, 0, 0);                   \
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[1], acc1, 0, 0, 0);                   \
+    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[2], acc2, 0, 0, 0);                   \
+    acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[3], acc3, 0, 0, 0);                   \
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[0], acc0, 0, 0, 0);                   \
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[1], acc1, 0, 0, 0);                   \
+    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[2], acc2, 0, 0, 0);                   \
+    acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[3], acc3, 0, 0, 0);                   \
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[0], acc0, 0, 0, 0);                   \
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[1], acc1, 0, 0, 0);                   \
+    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[2], acc2, 0, 0, 0);                   \
+    acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[3], acc3, 0, 0, 0);                   \
+  }
+
+  const int nk = C / DBK;
+  RPD_REQ(0);
+  cp_wait_vm0();
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = (kt & 1) * DBUF;
+    // slab kt + 1 -> the other buffer: every wave finished reading slab kt - 1 from it before the barrier that ended the last turn
+    if (kt + 1 < nk) RPD_REQ(DBUF - cur);
+    RPD_MFMA(cur)
+    cp_wait_vm0();                                   // my pieces of slab kt + 1 have landed ...
+    __syncthreads();                                 // ... and so have everyone's; nobody reads slab kt any more
+  }
+#undef RPD_MFMA
+#undef RPD_REQ
+  pyramid_epilogue<ALIGNED>(acc0, acc1, acc2, acc3, smem, pyr, info, b, N, h, w, i0, y0, x0, scale, wave, lane, patch, n_patch);
+}
+
 }  // namespace
 
 extern "C" {
@@ -595,6 +740,7 @@ size_t rnnpose_corr_pyramid_f16x3_workspace_bytes(int B, int C, int h, int w) {
 
 namespace {
 int g_corr_supertile = 20;      // (rnnpose_corr_supertile: measurement)
+int g_corr_variant = 0;         // (rnnpose_corr_variant)
 int launch_h3(const char* fn, const _Float16* f1, const _Float16* f2, int B, int C, int h, int w, int levels, float a_scale,
               float* pyramid, hipStream_t st) {
   RP_REQUIRE(C > 0 && C % HBK == 0, fn, "C must be a positive multiple of 32");
@@ -615,7 +761,13 @@ int launch_h3(const char* fn, const _Float16* f1, const _Float16* f2, int B, int
   const float scale = 1.0f / (sqrtf(static_cast<float>(C)) * a_scale * a_scale);
   const bool aligned = (N % 4 == 0) && (w % 4 == 0) && (reinterpret_cast<uintptr_t>(pyramid) % 16 == 0);
   dim3 grid(static_cast<unsigned>(ntiles)), block(NT);
-  if (aligned) {
+  if (g_corr_variant == 1) {          // operands by LDS-DMA (r06), bit-identical to the register form
+    if (aligned) {
+      hipLaunchKernelGGL(corr_pyramid_h3dma_kernel<true>, grid, block, 0, st, f1, f2, pyramid, B, C, h, w, n_it, n_py, n_px, scale, info, sti, stp);
+    } else {
+      hipLaunchKernelGGL(corr_pyramid_h3dma_kernel<false>, grid, block, 0, st, f1, f2, pyramid, B, C, h, w, n_it, n_py, n_px, scale, info, sti, stp);
+    }
+  } else if (aligned) {
     hipLaunchKernelGGL(corr_pyramid_h3_kernel<true>, grid, block, 0, st, f1, f2, pyramid, B, C, h, w, n_it, n_py, n_px, scale, info, sti, stp);
   } else {
     hipLaunchKernelGGL(corr_pyramid_h3_kernel<false>, grid, block, 0, st, f1, f2, pyramid, B, C, h, w, n_it, n_py, n_px, scale, info, sti, stp);
@@ -623,6 +775,15 @@ int launch_h3(const char* fn, const _Float16* f1, const _Float16* f2, int B, int
   return rp::check_launch(fn);
 }
 }  // namespace
+
+int rnnpose_corr_variant(int variant) {       // 0: operands through registers + ds_write (r03-r05); 1: operands by LDS-DMA (r06)
+  if (variant < 0 || variant > 1) {
+    rp::set_error("rnnpose_corr_variant: 0 (register staging) or 1 (LDS-DMA)");
+    return 1;
+  }
+  g_corr_variant = variant;
+  return 0;
+}
 
 int rnnpose_corr_supertile(int max_side) {       // measurement: side limit of the fp16x3 kernel's tile-order supertiles (default 20; 8 = r02)
   if (max_side < 1 || max_side > 64) {

@@ -189,7 +189,18 @@ def corr_pyramid(fmap1, fmap2, levels: int = 4, out=None, precision: str = "f32"
 _pyr_ws = {}
 
 
+CORR_VARIANT_DEFAULT = 0      # (the library's own default: csrc/corr_pyramid.hip g_corr_variant)
+
+
+def corr_variant(variant: int):
+    """Measurement switch (RNNPOSE_CORR_VARIANT): which fp16x3 volume kernel is launched -- 0 operands through registers + ds_write,
+    1 operands by LDS-DMA (r06); bit-identical results."""
+    _apply_conv_env()
+    _lib.call("rnnpose_corr_variant", int(variant))
+
+
 def _corr_pyramid_f16x3(f1, f2, layout, B, Cc, h, w, levels, out, a_scale):
+    _apply_conv_env()
     n = int(_lib.load().rnnpose_corr_pyramid_f16x3_workspace_bytes(B, Cc, h, w))
     key = (f1.device, n)
     ws = _pyr_ws.get(key)
@@ -245,6 +256,7 @@ class SplitTensor:
 
 def corr_pyramid_split(f1: SplitTensor, f2: SplitTensor, levels: int = 4, out=None):
     """Volume + pyramid from operands that are split tensors already (no pre-pass): (buffer, views) as corr_pyramid."""
+    _apply_conv_env()
     if f1.shape != f2.shape or f1.a_scale != f2.a_scale:
         raise ValueError("f1/f2 must have the same shape and scale")
     B, Cc, h, w = f1.shape
@@ -692,6 +704,9 @@ def _apply_conv_env():
         v = _os.environ.get("RNNPOSE_STRIP")               # 0: the automatic tile choice never takes the strip kernels (same-box A/B);
         if v is not None:                                  # 2 / 3: strips with one / two column tiles per wave only
             _lib.call("rnnpose_conv_strip", int(v))
+        v = _os.environ.get("RNNPOSE_CORR_VARIANT")           # 0 / 1: volume kernel with register-staged / LDS-DMA operands (same-box A/B)
+        if v is not None:
+            _lib.call("rnnpose_corr_variant", int(v))
         v = _os.environ.get("RNNPOSE_KSPLIT_LIMITS")          # "max_tiles,max_splits" (measurement)
         if v:
             a, b = (int(t) for t in v.split(","))

@@ -32,6 +32,15 @@ PATCHES = {
         (r"(if \(p\.dsth\) store_quad_hl\(p\.dsth \+ pix \* p\.dsth_cs, p\.dsth_co \+ col, y\[0\], y\[1\], y\[2\], y\[3\], nv, p\.a_scale, sat_n\);\n    \})",
          r"\1\n    __builtin_amdgcn_wave_barrier();", 1),
     ],
+    # r06: the LDS-DMA form of the volume kernel -- request / wait helpers and the LDS base as for the strip kernels (HEADER_PATCHES below)
+    "corr_pyramid.hip": [
+        (r"(?s)__device__ __forceinline__ void cp_glds16\(const void\* g, unsigned dst\) \{.*?\n\}\n",
+         "__device__ __forceinline__ void cp_glds16(const void* g, unsigned dst) { hostexec::lds_dma(g, dst, 1); }\n", 1),
+        (r'__device__ __forceinline__ void cp_wait_vm0\(\) \{ asm volatile\("s_waitcnt vmcnt\(0\)" ::: "memory"\); \}',
+         "__device__ __forceinline__ void cp_wait_vm0() { hostexec::vm_wait(0); }", 1),
+        (r"const unsigned lds0 = static_cast<unsigned>\(reinterpret_cast<size_t>\(\(__attribute__\(\(address_space\(3\)\)\) unsigned char\*\)sD\)\);",
+         "const unsigned lds0 = hostexec::lds_register(sD);", 1),
+    ],
     # an empty asm that only makes a value opaque to the optimiser: AMDGPU register class "v" -> a host register
     "mask_upsample.hip": [(r'asm volatile\("" : "\+v"\(aoff\)\);', 'asm volatile("" : "+r"(aoff));', 1)],
 }

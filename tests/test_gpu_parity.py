@@ -107,6 +107,30 @@ def test_corr_pyramid_split_operands(ops, B, C, h, w, levels):
         ops.corr_pyramid_split(s1, ops.SplitTensor(s2.data, 4.0), levels)
 
 
+@pytest.mark.parametrize("B,C,h,w,levels", [(2, 256, 16, 24, 4), (1, 256, 30, 30, 4), (2, 64, 17, 19, 4), (1, 96, 9, 21, 3), (3, 32, 40, 23, 4),
+                                            (2, 256, 60, 80, 4)])
+def test_corr_pyramid_lds_dma_operands_bit_identical(ops, B, C, h, w, levels):
+    """r06: the volume kernel with its operands requested by LDS-DMA (rnnpose_corr_variant(1): 16-channel slabs, double-buffered, swizzled
+    32-byte rows, zero page for rows outside the problem) multiplies the same fp16 operands in the same k order as the register-staged
+    form: the whole pyramid buffer is equal BIT FOR BIT (ragged tiles and patches included), and it holds the oracle tolerance."""
+    f1, f2 = syn.normal("fmap1", (B, C, h, w), 13, 1.5), syn.normal("fmap2", (B, C, h, w), 13, 1.5)
+    n1, n2 = D(f1).permute(0, 2, 3, 1).contiguous(), D(f2).permute(0, 2, 3, 1).contiguous()
+    s1, s2 = ops.SplitTensor(ops.split_hl(n1), 8.0), ops.SplitTensor(ops.split_hl(n2), 8.0)
+    bufs = []
+    try:
+        for v in (0, 1):
+            ops.corr_variant(v)
+            buf, views = ops.corr_pyramid_split(s1, s2, levels)
+            bufs.append((buf.clone(), [t.clone() for t in views]))
+    finally:
+        ops.corr_variant(int(os.environ.get("RNNPOSE_CORR_VARIANT", ops.CORR_VARIANT_DEFAULT)))
+    assert torch.equal(bufs[0][0], bufs[1][0])
+    if B * h * w <= 2000:
+        want = orc.corr_pyramid(f1, f2, levels)
+        for l in range(levels):
+            close(bufs[1][1][l][:, 0], want[l], 1e-5, what=f"LDS-DMA operands level {l}")
+
+
 def test_encoder_split_output(ops):
     """ImageFeaEncoder.forward_split: the output convolution writes the volume operands itself; they stand for the same maps
     (to the 2^-22 of the split) and the volume built from them equals the one built from the NCHW maps to fp32 round-off."""
