@@ -105,11 +105,11 @@ __global__ __launch_bounds__(8 * MQ) __attribute__((amdgpu_num_vgpr(160))) void 
     for (int j = 0; j < CT; ++j) {
       const h8 bh = __builtin_bit_cast(h8, bq[sl][j][0]), bl = __builtin_bit_cast(h8, bq[sl][j][1]);
 #pragma unroll
-      for (int t = 0; t < 2; ++t) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh, acc[t][j], 0, 0, 0);
+      for (int t = 0; t < 2; ++t) acc[t][j] = rp::mfma16_c32(al[t], bh, acc[t][j]);
 #pragma unroll
-      for (int t = 0; t < 2; ++t) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bl, acc[t][j], 0, 0, 0);
+      for (int t = 0; t < 2; ++t) acc[t][j] = rp::mfma16_c32(ah[t], bl, acc[t][j]);
 #pragma unroll
-      for (int t = 0; t < 2; ++t) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bh, acc[t][j], 0, 0, 0);
+      for (int t = 0; t < 2; ++t) acc[t][j] = rp::mfma16_c32(ah[t], bh, acc[t][j]);
     }
     // (fenced: left alone the compiler sinks the weight loads to just before their MFMAs and waits vmcnt(0) on each)
     __builtin_amdgcn_sched_barrier(0);

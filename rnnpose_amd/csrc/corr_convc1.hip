@@ -174,9 +174,9 @@ __global__ __launch_bounds__(8 * MQ, 3) void corr_convc1_kernel(const CParams p)
       const int st_ = cb & 1;                                                                                             \
       _Pragma("unroll") for (int j = 0; j < CT; ++j) {                                                                    \
         const h8 bh = __builtin_bit_cast(h8, bq[st_][j][0]), bl = __builtin_bit_cast(h8, bq[st_][j][1]);                  \
-        _Pragma("unroll") for (int t = 0; t < 2; ++t) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh, acc[t][j], 0, 0, 0); \
-        _Pragma("unroll") for (int t = 0; t < 2; ++t) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bl, acc[t][j], 0, 0, 0); \
-        _Pragma("unroll") for (int t = 0; t < 2; ++t) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bh, acc[t][j], 0, 0, 0); \
+        _Pragma("unroll") for (int t = 0; t < 2; ++t) acc[t][j] = rp::mfma16_c32(al[t], bh, acc[t][j]); \
+        _Pragma("unroll") for (int t = 0; t < 2; ++t) acc[t][j] = rp::mfma16_c32(ah[t], bl, acc[t][j]); \
+        _Pragma("unroll") for (int t = 0; t < 2; ++t) acc[t][j] = rp::mfma16_c32(ah[t], bh, acc[t][j]); \
       }                                                                                                                   \
       __builtin_amdgcn_sched_barrier(0);                                                                                  \
       if (cb + 2 < NCB) C_LOADB(st_, cb + 2)                                                                              \

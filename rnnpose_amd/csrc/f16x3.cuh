@@ -40,6 +40,31 @@ __device__ __forceinline__ void split4(const float4 v, float s, h4& hi, h4& lo) 
   lo = h4{q01.x, q01.y, q23.x, q23.y};
 }
 
+// One 16 x 16 tile step over a lane's 8 channels (A: row lane & 15, B: column lane & 15, channels 8 (lane >> 4) .. + 7 of a 32-channel block).
+// RP_MFMA16_K32 = 0 (default since r06): TWO v_mfma_f32_16x16x16_f16 over the lane's channels 0-3 and 4-7 (any channel -> (lane group,
+// element) assignment is a valid K order as long as A and B share it, so the operand layouts are those of the K = 32 instruction).
+// RP_MFMA16_K32 = 1: ONE v_mfma_f32_16x16x32_f16 (r02-r05).  Why not the K = 32 shape although it has twice the rate: on MI355X a
+// wave issuing v_mfma_f32_16x16x32_{f16,bf16} makes PACKED fp32 instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32) of OTHER waves
+// on the same SIMD return wrong values for groups of 16 lanes (DESIGN 4 / 5 rule 11, tools/probes/pk_f32_vs_mfma.hip).  This library has
+// no packed fp32 of its own (tests/test_isa_guard.py), but a co-tenant's kernels -- an integrator's renderer built with plain -O3 -- do:
+// next to mask_upsample on the K = 32 shape 1599 of 1600 launches of such a neighbour differed from its solo output, next to the whole
+// refinement loop 367 of 1600 (tools/pk_neighbour_probe.py, profiles/r06_pk_neighbour.txt); next to the 16x16x16 and 32x32x16 shapes:
+// none.  The three kernels built on this step are latency-bound, not matrix-bound: the price is in the same record.
+#ifndef RP_MFMA16_K32
+#define RP_MFMA16_K32 0
+#endif
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 mfma16_c32(const h8 a, const h8 b, f32x4 c) {
+#if RP_MFMA16_K32
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+#else
+  const h4 a0 = {a[0], a[1], a[2], a[3]}, a1 = {a[4], a[5], a[6], a[7]};
+  const h4 b0 = {b[0], b[1], b[2], b[3]}, b1 = {b[4], b[5], b[6], b[7]};
+  c = __builtin_amdgcn_mfma_f32_16x16x16f16(a0, b0, c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x16f16(a1, b1, c, 0, 0, 0);
+#endif
+}
+
 // true if any element of the quad leaves the fp16 range once scaled (|x*s| > 65504) or is not finite
 __device__ __forceinline__ bool quad_saturates(const float4 v, float s) {
   const float lim = 65504.f / s;      // (fmaxf would drop a NaN operand: four ordered compares, NaN fails each)

@@ -160,9 +160,9 @@ __global__ __launch_bounds__(8 * MQ, 3) void mask_upsample_kernel(const MUParams
       }                                                                                           \
       const int sl = cb & 3;                                                                      \
       const h8 bh = __builtin_bit_cast(h8, bq[sl][0]), bl = __builtin_bit_cast(h8, bq[sl][1]);    \
-      _Pragma("unroll") for (int t = 0; t < 2; ++t) ACC_[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh, ACC_[t], 0, 0, 0); \
-      _Pragma("unroll") for (int t = 0; t < 2; ++t) ACC_[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bl, ACC_[t], 0, 0, 0); \
-      _Pragma("unroll") for (int t = 0; t < 2; ++t) ACC_[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bh, ACC_[t], 0, 0, 0); \
+      _Pragma("unroll") for (int t = 0; t < 2; ++t) ACC_[t] = rp::mfma16_c32(al[t], bh, ACC_[t]); \
+      _Pragma("unroll") for (int t = 0; t < 2; ++t) ACC_[t] = rp::mfma16_c32(ah[t], bl, ACC_[t]); \
+      _Pragma("unroll") for (int t = 0; t < 2; ++t) ACC_[t] = rp::mfma16_c32(ah[t], bh, ACC_[t]); \
       /* re-arm the slot with the stage 4 ahead: (k, cb + 4) or (k + 1, cb - 4); past the end: the last tap again */ \
       const int nk = cb < 4 ? (K_) : ((K_) + 1 < NTAP ? (K_) + 1 : NTAP - 1);                     \
       MU_LOADB(sl, nk, (cb + 4) & 7)                                                              \

@@ -377,6 +377,7 @@ inline void __syncthreads() { hostexec::block_sync(); }
 #define __builtin_amdgcn_rcpf(v) (1.0f / (v))
 #define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) hostexec::mfma<32, 8>((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z) hostexec::mfma<16, 8>((a), (b), (c))
+#define __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, x, y, z) hostexec::mfma<16, 4>((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) hostexec::mfma_32x32x2f32((a), (b), (c))
 
 template <class T> inline T __shfl_xor(T v, int m, int = 64) { return hostexec::exchange(v, hostexec::my_lane() ^ m); }

@@ -152,6 +152,30 @@ __global__ __launch_bounds__(256) void mfma16bf_kernel(float* out, int n) {
   if (s == 1.2345f) out[0] = s;
 }
 
+// r06: the volume kernel's issue pattern -- FOUR independent 32x32x16 accumulators, twelve MFMAs back to back (3 products x 4 column
+// tiles), operands that change every burst -- because tools/pk_neighbour_scan.py finds the packed-fp32 neighbour disturbed (rarely:
+// 3-8 of 800 launches, ~13 000 values each) next to corr_pyramid_h3_kernel and stem_conv7x7_s2_kernel, which use this shape only
+__global__ __launch_bounds__(256) void mfma32x4_kernel(float* out, int n) {
+  h8 a0, a1, b[4];
+  for (int i = 0; i < 8; ++i) {
+    a0[i] = (_Float16)(threadIdx.x * 0.001f + i); a1[i] = (_Float16)(0.25f * i - threadIdx.x * 0.002f);
+    for (int s = 0; s < 4; ++s) b[s][i] = (_Float16)(0.5f + i + 0.125f * s);
+  }
+  f16v c0 = {}, c1 = {}, c2 = {}, c3 = {};
+  for (int i = 0; i < n; ++i) {
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b[0], c0, 0, 0, 0); c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b[1], c1, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b[2], c2, 0, 0, 0); c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b[3], c3, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b[1], c0, 0, 0, 0); c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b[2], c1, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b[3], c2, 0, 0, 0); c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b[0], c3, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b[0], c0, 0, 0, 0); c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b[1], c1, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b[2], c2, 0, 0, 0); c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b[3], c3, 0, 0, 0);
+    asm volatile("" : "+v"(a0), "+v"(a1));
+  }
+  float s = 0.f;
+  for (int i = 0; i < 16; ++i) s += c0[i] + c1[i] + c2[i] + c3[i];
+  if (s == 1.2345f) out[0] = s;
+}
+
 __global__ void compare_kernel(const float* a, const float* ref, int n, unsigned* bad) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n && __float_as_uint(a[i]) != __float_as_uint(ref[i])) atomicAdd(bad, 1u);
@@ -179,6 +203,8 @@ int main(int argc, char** argv) {
       {"packed fp32, stream B: v_mfma_f32_32x32x16_f16", 1, 2},
       {"packed fp32, stream B: v_mfma_f32_16x16x16_f16", 1, 3},
       {"packed fp32, stream B: v_mfma_f32_16x16x32_bf16", 1, 4},
+      {"packed fp32, stream B: 32x32x16_f16, 4 accumulators x 12", 1, 5},
+      {"packed fp32, stream B: 32x32x16_f16 x4, 2 workgroups / CU", 1, 6},
       {"packed fp16 (v_pk_*_f16, min / max), alone", 2, 0},
       {"packed fp16, stream B: v_mfma_f32_16x16x32_f16", 2, 1},
       {"packed fp16, stream B: v_mfma_f32_16x16x32_bf16", 2, 4},
@@ -204,6 +230,8 @@ int main(int argc, char** argv) {
       if (c.load == 3) for (int q = 0; q < 2; ++q) hipLaunchKernelGGL(mfma16k16_kernel, dim3(768), dim3(256), 0, sb, bo, 4000);
       if (c.load == 4) for (int q = 0; q < 2; ++q) hipLaunchKernelGGL(mfma16bf_kernel, dim3(768), dim3(256), 0, sb, bo, 4000);
       if (c.load == 2) for (int q = 0; q < 2; ++q) hipLaunchKernelGGL(mfma32_kernel, dim3(768), dim3(256), 0, sb, bo, 4000);
+      if (c.load == 5) for (int q = 0; q < 2; ++q) hipLaunchKernelGGL(mfma32x4_kernel, dim3(768), dim3(256), 0, sb, bo, 700);
+      if (c.load == 6) for (int q = 0; q < 2; ++q) hipLaunchKernelGGL(mfma32x4_kernel, dim3(512), dim3(256), 0, sb, bo, 700);
       if (c.packed == 2) hipLaunchKernelGGL(pkh_kernel, dim3(NWG), dim3(NT), 0, sa, in, out);
       else if (c.packed) hipLaunchKernelGGL(pk_kernel, dim3(NWG), dim3(NT), 0, sa, in, out);
       else hipLaunchKernelGGL(sc_kernel, dim3(NWG), dim3(NT), 0, sa, in, out);
