@@ -366,6 +366,13 @@ int rnnpose_corr_lookup_nhwc_f32(const float* pyramid, const float* coords, int 
  * are the sub-batch tensors, `pyramid` the whole buffer (thirdparty/raft/corr.py:36-57 per image). */
 int rnnpose_corr_lookup_nhwc_part_f32(const float* pyramid, const float* coords, int B, int b0, int b1, int h, int w,
                                       int levels, int radius, float* out, rnnpose_stream_t stream);
+/* r06: the same lookup FORMING its coordinates itself: coords1 = grid + down-sampled pose-induced flow (exactly
+ * rnnpose_induced_coords_lowres_f32's values: geometry/transformation.py:184-198, model/PoseRefiner.py:324-328, model/CFNet.py:136-144) from
+ * depth (b1-b0,1,H,W), K (b1-b0,3,3), G (b1-b0,4,4) of the part's images; coords_out (b1-b0,2,h,w) receives them for the later consumers of
+ * the iteration.  One launch and one dependent kernel boundary fewer per GRU iteration. */
+int rnnpose_corr_lookup_induced_nhwc_part_f32(const float* pyramid, const float* depth, const float* K, const float* G, int H, int W,
+                                              float eps, int B, int b0, int b1, int h, int w, int levels, int radius, float* coords_out,
+                                              float* out, rnnpose_stream_t stream);
 int rnnpose_nchw_to_nhwc_f32(const float* src, int B, int C, int HW, float* dst, int dst_c_stride, int dst_c_offset,
                              rnnpose_stream_t stream);
 int rnnpose_nhwc_to_nchw_f32(const float* src, int B, int C, int HW, int src_c_stride, int src_c_offset, float* dst,
@@ -379,6 +386,12 @@ int rnnpose_flow_conv7x7_relu_f32(const float* flow4, const float* w_t, const fl
 int rnnpose_flow_features_f32(const float* coords1, int subtract_grid, const float* w_t, const float* bias, int B, int h, int w,
                               int c_out, float* out, int out_c_stride, int out_c_offset, float* motion, int motion_c_stride,
                               int motion_c_offset, int out_split, int motion_split, float a_scale, rnnpose_stream_t stream);
+/* r06: rnnpose_flow_features_f32 forming coords1 itself from depth (B,1,H,W), K (B,3,3), G (B,4,4) (see
+ * rnnpose_corr_lookup_induced_nhwc_part_f32), grid subtracted: flow = coords1 - grid -> relu(convf1(flow)), motion[..., co:co+2]. */
+int rnnpose_flow_features_induced_f32(const float* depth, const float* K, const float* G, int H, int W, float eps, const float* w_t,
+                                      const float* bias, int B, int h, int w, int c_out, float* out, int out_c_stride, int out_c_offset,
+                                      float* motion, int motion_c_stride, int motion_c_offset, int out_split, int motion_split,
+                                      float a_scale, rnnpose_stream_t stream);
 /* out_split / motion_split != 0: `out` / `motion` are split tensors (rnnpose_conv_desc_t, "SPLIT TENSORS") with scale a_scale.
  * rnnpose_split_hl_f32: channels [src_c_offset, +c_count) of an fp32 NHWC tensor -> the split form in channels
  * [dst_c_offset, +c_count) of `dst` (c_count, dst offsets / strides multiples of 8): hidden state / context input once per

@@ -96,6 +96,8 @@ PROTOTYPES = {
     "rnnpose_flow_prep_f32": (_i, [_p, _i, _i, _i, _i, _p, _p, _i, _i, _p]),
     "rnnpose_flow_conv7x7_relu_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _i, _i, _p]),
     "rnnpose_flow_features_f32": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _p, _i, _i, _p, _i, _i, _i, _i, _f, _p]),
+    "rnnpose_flow_features_induced_f32": (_i, [_p, _p, _p, _i, _i, _f, _p, _p, _i, _i, _i, _i, _p, _i, _i, _p, _i, _i, _i, _i, _f, _p]),
+    "rnnpose_corr_lookup_induced_nhwc_part_f32": (_i, [_p, _p, _p, _p, _i, _i, _f, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
     "rnnpose_split_hl_f32": (_i, [_p, _i, _i, _ll, _i, _f, _p, _i, _i, _p]),
     "rnnpose_flow_head_out_f32": (_i, [_p, _i, _i, _i, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p]),
     "rnnpose_convex_upsample_nhwc_f32": (_i, [_p, _p, _i, _i, _i, _p, _p]),

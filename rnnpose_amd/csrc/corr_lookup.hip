@@ -14,7 +14,9 @@
 // One wave per workgroup (one pyramid level x 16 pixels), 6.5 KB LDS.  The gather is latency-bound: r01 ablation =
 // 0.075 of 0.11 ms in the footprint loads; 64 pixels per wave (25.9 KB LDS, 6 waves per CU) ran at 0.111 ms, 32 at
 // 0.067, 16 at 0.057 (16 waves per CU, the VGPR limit) -- phase 2 then only uses 16 lanes, but it is 5 % of the time.
+#define RP_CONTRACT_LOCAL 1      // (geometry.cuh / induced.cuh: no fma contraction inside THEIR functions only)
 #include "corr_lookup.cuh"
+#include "induced.cuh"
 
 namespace {
 
@@ -22,7 +24,8 @@ using namespace rplookup;
 
 __global__ __launch_bounds__(64) void corr_lookup_kernel(const float* __restrict__ pyr, const float* __restrict__ coords,
                                                          float* __restrict__ out, int B, int h, int w, int levels,
-                                                         LookupInfo info, int nhwc, long long p_off) {
+                                                         LookupInfo info, int nhwc, long long p_off, const rp::InducedSrc isrc,
+                                                         float* __restrict__ coords_out) {
   __shared__ float foot[PIX * FS];
   const int N = h * w;
   const long long total = static_cast<long long>(B) * N;
@@ -41,8 +44,22 @@ __global__ __launch_bounds__(64) void corr_lookup_kernel(const float* __restrict
   if (live) {
     b = static_cast<int>(p / N);
     pix = static_cast<int>(p - static_cast<long long>(b) * N);
-    cx = coords[(static_cast<long long>(b) * 2 + 0) * N + pix] * inv;
-    cy = coords[(static_cast<long long>(b) * 2 + 1) * N + pix] * inv;
+    if (isrc.depth) {
+      // r06: the pose-induced coordinates are formed HERE (induced.cuh: the very function of induced_coords_lowres_kernel) instead of being
+      // read from the output of a launch of their own; the level-0 workgroup of a pixel writes them out for the later consumers
+      const int Y = pix / w, X = pix - Y * w;
+      const float2 c = rp::induced_coords_at(isrc.depth + static_cast<long long>(b) * isrc.H * isrc.W, X, Y, isrc.H, isrc.W, h, w, isrc.eps,
+                                             rp::load_intr(isrc.K, b), rp::load_pose(isrc.G, b));
+      if (lvl == 0 && coords_out) {
+        coords_out[(static_cast<long long>(b) * 2 + 0) * N + pix] = c.x;
+        coords_out[(static_cast<long long>(b) * 2 + 1) * N + pix] = c.y;
+      }
+      cx = c.x * inv;
+      cy = c.y * inv;
+    } else {
+      cx = coords[(static_cast<long long>(b) * 2 + 0) * N + pix] * inv;
+      cy = coords[(static_cast<long long>(b) * 2 + 1) * N + pix] * inv;
+    }
   }
   int bx, by;
   float ax, ay;
@@ -100,8 +117,9 @@ __global__ __launch_bounds__(64) void corr_lookup_kernel(const float* __restrict
 // B_total: batch the pyramid was built for (its layout); [b0, b1): the images this launch looks up.  coords / out point at
 // image b0 (sub-batch tensors); the pyramid pointer is the whole buffer.
 static int launch_lookup(const char* fn, const float* pyramid, const float* coords, int B_total, int b0, int b1, int h, int w,
-                         int levels, int radius, float* out, int nhwc, rnnpose_stream_t stream) {
-  RP_REQUIRE(pyramid && coords && out, fn, "null pointer");
+                         int levels, int radius, float* out, int nhwc, rnnpose_stream_t stream, const rp::InducedSrc isrc = rp::InducedSrc{},
+                         float* coords_out = nullptr) {
+  RP_REQUIRE(pyramid && (coords || isrc.depth) && out, fn, "null pointer");
   RP_REQUIRE(radius == R, fn, "radius must be 4");
   RP_REQUIRE(b0 >= 0 && b0 < b1 && b1 <= B_total, fn, "image range must satisfy 0 <= b0 < b1 <= B");
   int64_t offs[RNNPOSE_MAX_LEVELS + 1];
@@ -118,7 +136,7 @@ static int launch_lookup(const char* fn, const float* pyramid, const float* coor
   const long long total = static_cast<long long>(B) * h * w;
   dim3 grid(static_cast<unsigned>(rp::cdiv(total, PIX)), static_cast<unsigned>(levels)), block(64);
   hipLaunchKernelGGL(corr_lookup_kernel, grid, block, 0, rp::as_stream(stream), pyramid, coords, out, B, h, w, levels, info,
-                     nhwc, static_cast<long long>(b0) * h * w);
+                     nhwc, static_cast<long long>(b0) * h * w, isrc, coords_out);
   return rp::check_launch(fn);
 }
 
@@ -138,4 +156,17 @@ extern "C" int rnnpose_corr_lookup_nhwc_f32(const float* pyramid, const float* c
 extern "C" int rnnpose_corr_lookup_nhwc_part_f32(const float* pyramid, const float* coords, int B, int b0, int b1, int h, int w,
                                                  int levels, int radius, float* out, rnnpose_stream_t stream) {
   return launch_lookup("rnnpose_corr_lookup_nhwc_part_f32", pyramid, coords, B, b0, b1, h, w, levels, radius, out, 1, stream);
+}
+
+// r06: the same launch forming its coordinates itself -- coords1 = grid + down-sampled pose-induced flow (rnnpose_induced_coords_lowres_f32's
+// arithmetic, bit for bit: csrc/induced.cuh) from depth (b1-b0,1,H,W), K (b1-b0,3,3), G (b1-b0,4,4) of the launch's images; coords_out
+// (b1-b0,2,h,w) receives them for the later consumers of the iteration (flow head).  One launch and one dependent kernel boundary fewer per
+// GRU iteration (model/PoseRefiner.py:324-328 + thirdparty/raft/corr.py:36-57).
+extern "C" int rnnpose_corr_lookup_induced_nhwc_part_f32(const float* pyramid, const float* depth, const float* K, const float* G, int H, int W,
+                                                         float eps, int B, int b0, int b1, int h, int w, int levels, int radius,
+                                                         float* coords_out, float* out, rnnpose_stream_t stream) {
+  const char* fn = "rnnpose_corr_lookup_induced_nhwc_part_f32";
+  RP_REQUIRE(depth && K && G && coords_out, fn, "null pointer");
+  RP_REQUIRE(H >= h && W >= w && h > 0 && w > 0 && W / w >= 1, fn, "the depth map must be at least as large as the low-resolution map");
+  return launch_lookup(fn, pyramid, nullptr, B, b0, b1, h, w, levels, radius, out, 1, stream, rp::InducedSrc{depth, K, G, H, W, eps}, coords_out);
 }

@@ -4,8 +4,12 @@
 #pragma once
 #include "common.hpp"
 
-// keep the reference's rounding points: no fma contraction in the geometric chain
+// keep the reference's rounding points: no fma contraction in the geometric chain -- for the whole including file (pointwise.hip,
+// lm.hip: their own expressions rely on it), or, with RP_CONTRACT_LOCAL defined by the including file, inside the functions of this
+// header and of induced.cuh only (corr_lookup.hip, nhwc_ops.hip since r06: their own multiply-adds keep contracting)
+#ifndef RP_CONTRACT_LOCAL
 #pragma clang fp contract(off)
+#endif
 
 namespace rp {
 
@@ -17,6 +21,7 @@ struct Reproj {
 };
 
 __device__ __forceinline__ Reproj reproject(float Z, float x, float y, const Intr& k, const Pose& g) {
+#pragma clang fp contract(off)
   Reproj r;
   r.Z0 = Z;
   r.X0 = Z * (x - k.cx) / k.fx;                                   // projective_ops.py:87-88

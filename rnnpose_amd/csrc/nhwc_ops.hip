@@ -1,8 +1,10 @@
 // NHWC companions of the fused update-block engine (a4/a5/a6): layout conversion, flow bookkeeping, the two
 // degenerate convolutions of the update block (Cin = 2 is handled by padding in the igemm; Cout = 2 is this
 // file's bandwidth kernel) and the convex upsampling that reads the mask in NHWC.
+#define RP_CONTRACT_LOCAL 1      // (geometry.cuh / induced.cuh: no fma contraction inside THEIR functions only)
 #include "common.hpp"
 #include "f16x3.cuh"
+#include "induced.cuh"
 
 namespace {
 
@@ -420,7 +422,7 @@ __global__ __launch_bounds__(128, 3) void conv7x7_cin2_kernel(const float* __res
                                                            int out_cs, int out_co, int Cout, int h, int w,
                                                            int subtract_grid, float* __restrict__ motion, int motion_cs,
                                                            int motion_co, int out_hl, int motion_hl, float a_scale,
-                                                           unsigned long long* __restrict__ sat) {
+                                                           unsigned long long* __restrict__ sat, const rp::InducedSrc isrc) {
   // rows padded to 28 floats (112 bytes): every row is seven aligned 16-byte LDS reads
   __shared__ __attribute__((aligned(16))) float patch[2][7][F1_ROW];
   const int b = blockIdx.z, Y = blockIdx.y, X0 = blockIdx.x * F1_TX;
@@ -432,8 +434,15 @@ __global__ __launch_bounds__(128, 3) void conv7x7_cin2_kernel(const float* __res
     float2 v = make_float2(0.f, 0.f);
     if (yy >= 0 && yy < h && x >= 0 && x < w) {
       if (PLANAR) {
-        v.x = flow4[(static_cast<long long>(b) * 2 + 0) * n + yy * w + x] - (subtract_grid ? static_cast<float>(x) : 0.f);
-        v.y = flow4[(static_cast<long long>(b) * 2 + 1) * n + yy * w + x] - (subtract_grid ? static_cast<float>(yy) : 0.f);
+        if (isrc.depth) {      // r06: coords1 formed here (induced.cuh: bit-identical to induced_coords_lowres_kernel's), then flow = coords1 - grid as below
+          const float2 cc = rp::induced_coords_at(isrc.depth + static_cast<long long>(b) * isrc.H * isrc.W, x, yy, isrc.H, isrc.W, h, w, isrc.eps,
+                                                  rp::load_intr(isrc.K, b), rp::load_pose(isrc.G, b));
+          v.x = cc.x - (subtract_grid ? static_cast<float>(x) : 0.f);
+          v.y = cc.y - (subtract_grid ? static_cast<float>(yy) : 0.f);
+        } else {
+          v.x = flow4[(static_cast<long long>(b) * 2 + 0) * n + yy * w + x] - (subtract_grid ? static_cast<float>(x) : 0.f);
+          v.y = flow4[(static_cast<long long>(b) * 2 + 1) * n + yy * w + x] - (subtract_grid ? static_cast<float>(yy) : 0.f);
+        }
         if (ky == 3 && xx >= 3 && xx < 3 + F1_TX) {     // this row segment's own pixels: motion[..., co:co+2] = flow (update.py:97)
           float* mrow = motion + (static_cast<long long>(b) * n + yy * w + x) * motion_cs;
           if (motion_hl) {        // split tensor: the two channels are 4 bytes of the hi plane + 4 bytes of the lo plane of their group
@@ -662,26 +671,44 @@ int rnnpose_flow_conv7x7_relu_f32(const float* flow4, const float* w_t, const fl
              "bad output window / flow4 alignment");
   hipLaunchKernelGGL(conv7x7_cin2_kernel<false>, dim3(rp::cdiv(w, F1_TX), h, B), dim3(128), 0, rp::as_stream(stream), flow4, w_t,
                      bias, out, out_c_stride, out_c_offset, c_out, h, w, 0, static_cast<float*>(nullptr), 0, 0, 0, 0, 1.f,
-                     static_cast<unsigned long long*>(nullptr));
+                     static_cast<unsigned long long*>(nullptr), rp::InducedSrc{});
+  return rp::check_launch(fn);
+}
+
+static int launch_flow_features(const char* fn, const float* coords1, const rp::InducedSrc isrc, int subtract_grid, const float* w_t, const float* bias,
+                                int B, int h, int w, int c_out, float* out, int out_c_stride, int out_c_offset, float* motion, int motion_c_stride,
+                                int motion_c_offset, int out_split, int motion_split, float a_scale, rnnpose_stream_t stream) {
+  if (out_split) RP_REQUIRE(c_out % 2 == 0 && out_c_offset % 8 == 0 && out_c_stride % 8 == 0 && reinterpret_cast<uintptr_t>(out) % 32 == 0 && a_scale > 0.f, fn,
+                            "split-form out: even c_out, channel offset/stride multiples of 8, 32-byte aligned");
+  if (motion_split) RP_REQUIRE(motion_c_stride % 8 == 0 && reinterpret_cast<uintptr_t>(motion) % 32 == 0 && a_scale > 0.f, fn,
+                               "split-form motion: channel stride multiple of 8, 32-byte aligned");
+  RP_REQUIRE((coords1 || isrc.depth) && w_t && bias && out && motion, fn, "null pointer");
+  RP_REQUIRE(B > 0 && B < 65536 && h > 0 && h < 65536 && w > 0 && c_out > 0 && c_out <= 128, fn, "bad size (c_out <= 128)");
+  RP_REQUIRE(out_c_offset >= 0 && out_c_offset + c_out <= out_c_stride && motion_c_offset % 2 == 0 && motion_c_stride % 2 == 0 &&
+                 motion_c_offset + 2 <= motion_c_stride, fn, "bad output windows");
+  hipLaunchKernelGGL(conv7x7_cin2_kernel<true>, dim3(rp::cdiv(w, F1_TX), h, B), dim3(128), 0, rp::as_stream(stream), coords1, w_t,
+                     bias, out, out_c_stride, out_c_offset, c_out, h, w, subtract_grid, motion, motion_c_stride, motion_c_offset,
+                     out_split, motion_split, a_scale, rp::sat_counter(), isrc);
   return rp::check_launch(fn);
 }
 
 int rnnpose_flow_features_f32(const float* coords1, int subtract_grid, const float* w_t, const float* bias, int B, int h, int w,
                               int c_out, float* out, int out_c_stride, int out_c_offset, float* motion, int motion_c_stride,
                               int motion_c_offset, int out_split, int motion_split, float a_scale, rnnpose_stream_t stream) {
-  const char* fn = "rnnpose_flow_features_f32";
-  if (out_split) RP_REQUIRE(c_out % 2 == 0 && out_c_offset % 8 == 0 && out_c_stride % 8 == 0 && reinterpret_cast<uintptr_t>(out) % 32 == 0 && a_scale > 0.f, fn,
-                            "split-form out: even c_out, channel offset/stride multiples of 8, 32-byte aligned");
-  if (motion_split) RP_REQUIRE(motion_c_stride % 8 == 0 && reinterpret_cast<uintptr_t>(motion) % 32 == 0 && a_scale > 0.f, fn,
-                               "split-form motion: channel stride multiple of 8, 32-byte aligned");
-  RP_REQUIRE(coords1 && w_t && bias && out && motion, fn, "null pointer");
-  RP_REQUIRE(B > 0 && B < 65536 && h > 0 && h < 65536 && w > 0 && c_out > 0 && c_out <= 128, fn, "bad size (c_out <= 128)");
-  RP_REQUIRE(out_c_offset >= 0 && out_c_offset + c_out <= out_c_stride && motion_c_offset % 2 == 0 && motion_c_stride % 2 == 0 &&
-                 motion_c_offset + 2 <= motion_c_stride, fn, "bad output windows");
-  hipLaunchKernelGGL(conv7x7_cin2_kernel<true>, dim3(rp::cdiv(w, F1_TX), h, B), dim3(128), 0, rp::as_stream(stream), coords1, w_t,
-                     bias, out, out_c_stride, out_c_offset, c_out, h, w, subtract_grid, motion, motion_c_stride, motion_c_offset,
-                     out_split, motion_split, a_scale, rp::sat_counter());
-  return rp::check_launch(fn);
+  return launch_flow_features("rnnpose_flow_features_f32", coords1, rp::InducedSrc{}, subtract_grid, w_t, bias, B, h, w, c_out, out, out_c_stride,
+                              out_c_offset, motion, motion_c_stride, motion_c_offset, out_split, motion_split, a_scale, stream);
+}
+
+// r06: the same launch forming coords1 itself from depth (B,1,H,W), K (B,3,3), G (B,4,4) -- rnnpose_induced_coords_lowres_f32's arithmetic, bit for
+// bit (csrc/induced.cuh) -- then flow = coords1 - grid as above (model/PoseRefiner.py:324-328 + thirdparty/raft/update.py:84,91,97)
+int rnnpose_flow_features_induced_f32(const float* depth, const float* K, const float* G, int H, int W, float eps, const float* w_t,
+                                      const float* bias, int B, int h, int w, int c_out, float* out, int out_c_stride, int out_c_offset,
+                                      float* motion, int motion_c_stride, int motion_c_offset, int out_split, int motion_split, float a_scale,
+                                      rnnpose_stream_t stream) {
+  const char* fn = "rnnpose_flow_features_induced_f32";
+  RP_REQUIRE(depth && K && G && H >= h && W >= w && W / (w > 0 ? w : 1) >= 1, fn, "null pointer / the depth map must be at least as large as the low-resolution map");
+  return launch_flow_features(fn, nullptr, rp::InducedSrc{depth, K, G, H, W, eps}, 1, w_t, bias, B, h, w, c_out, out, out_c_stride, out_c_offset, motion,
+                              motion_c_stride, motion_c_offset, out_split, motion_split, a_scale, stream);
 }
 
 int rnnpose_split_hl_f32(const float* src, int src_c_stride, int src_c_offset, long long n_pixels, int c_count, float a_scale,

@@ -5,7 +5,7 @@
 //   a8  corr_weight                              model/PoseRefiner.py:342-345
 //   a4  SepConvGRU gate / state update           thirdparty/raft/update.py:45-60
 // Every kernel reads each input byte once with lane-contiguous addresses and writes coalesced rows.
-#include "geometry.cuh"
+#include "induced.cuh"
 #include "descriptor_weight.cuh"
 
 namespace {
@@ -13,20 +13,9 @@ namespace {
 using rp::Intr;
 using rp::Pose;
 
-// ------------------------------------------------------------------------------------------------
-// bilinear resize, align_corners=True: src = dst * (in-1)/(out-1)   (F.interpolate semantics)
-struct AcTap {
-  int i0, i1;
-  float f;
-};
-__device__ __forceinline__ AcTap ac_tap(int dst, int in, int out) {
-  const float scale = out > 1 ? static_cast<float>(in - 1) / static_cast<float>(out - 1) : 0.f;
-  const float s = scale * static_cast<float>(dst);
-  int i0 = static_cast<int>(s);            // s >= 0
-  if (i0 > in - 1) i0 = in - 1;
-  const int i1 = i0 + (i0 < in - 1 ? 1 : 0);
-  return AcTap{i0, i1, s - static_cast<float>(i0)};
-}
+using rp::AcTap;
+using rp::ac_tap;
+using rp::flow_at;
 
 // a5: ctx (B,C,H,W) -> net = tanh(first hdim ch), inp = relu(rest) at (h,w)
 __global__ __launch_bounds__(256) void context_prep_kernel(const float* __restrict__ ctx, float* __restrict__ net,
@@ -98,14 +87,6 @@ __global__ __launch_bounds__(256) void induced_flow_kernel(const float* __restri
   if (vmask) vmask[b * P + t] = (r.Z0 > rp::kMinDepthValid && r.Z1 > rp::kMinDepthValid) ? 1.f : 0.f;
 }
 
-__device__ __forceinline__ float2 flow_at(const float* __restrict__ depth_b, int x, int y, int W, float eps, const Intr& k,
-                                          const Pose& g) {
-  const float Z = depth_b[static_cast<long long>(y) * W + x] + eps;
-  const rp::Reproj r = rp::reproject(Z, static_cast<float>(x), static_cast<float>(y), k, g);
-  const float fg = Z > eps ? 1.f : 0.f;
-  return make_float2((r.u - static_cast<float>(x)) * fg, (r.v - static_cast<float>(y)) * fg);
-}
-
 // a7+a5 fused: only the 4 taps each 1/8-res pixel needs are re-projected (P/16 evaluations, no full-res pass)
 __global__ __launch_bounds__(256) void induced_coords_lowres_kernel(const float* __restrict__ depth,
                                                                     const float* __restrict__ K,
@@ -119,15 +100,9 @@ __global__ __launch_bounds__(256) void induced_coords_lowres_kernel(const float*
   const int X = t % w, Y = t / w;
   const Intr k = rp::load_intr(K, b);
   const Pose g = rp::load_pose(G, b);
-  const float ds = static_cast<float>(W / w);
-  const AcTap ty = ac_tap(Y, H, h), tx = ac_tap(X, W, w);
-  const float* d = depth + static_cast<long long>(b) * H * W;
-  const float2 f00 = flow_at(d, tx.i0, ty.i0, W, eps, k, g), f01 = flow_at(d, tx.i1, ty.i0, W, eps, k, g);
-  const float2 f10 = flow_at(d, tx.i0, ty.i1, W, eps, k, g), f11 = flow_at(d, tx.i1, ty.i1, W, eps, k, g);
-  const float topx = (f00.x / ds) * (1.f - tx.f) + (f01.x / ds) * tx.f, botx = (f10.x / ds) * (1.f - tx.f) + (f11.x / ds) * tx.f;
-  const float topy = (f00.y / ds) * (1.f - tx.f) + (f01.y / ds) * tx.f, boty = (f10.y / ds) * (1.f - tx.f) + (f11.y / ds) * tx.f;
-  coords1[(static_cast<long long>(b) * 2 + 0) * n + t] = static_cast<float>(X) + (topx * (1.f - ty.f) + botx * ty.f);
-  coords1[(static_cast<long long>(b) * 2 + 1) * n + t] = static_cast<float>(Y) + (topy * (1.f - ty.f) + boty * ty.f);
+  const float2 c = rp::induced_coords_at(depth + static_cast<long long>(b) * H * W, X, Y, H, W, h, w, eps, k, g);       // (induced.cuh)
+  coords1[(static_cast<long long>(b) * 2 + 0) * n + t] = c.x;
+  coords1[(static_cast<long long>(b) * 2 + 1) * n + t] = c.y;
 }
 
 // ------------------------------------------------------------------------------------------------

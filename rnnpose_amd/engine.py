@@ -53,6 +53,11 @@ class UpdateEngine:
         # one-round launch runs its footprint phases and its MFMA phases in lock step, so the fusion saves the 25-MB round trip of the
         # tensor and nothing else.  OFF by default; RNNPOSE_FUSED_LOOKUP=1 switches it on.
         self.fused_lookup = os.environ.get("RNNPOSE_FUSED_LOOKUP", "0") != "0"
+        # r06: RNNPOSE_FUSED_INDUCED=1 forms the pose-induced coordinates inside their first consumers (window lookup, flow-feature convolution:
+        # ops.InducedCoords) instead of by a 5-us launch of their own in front of every iteration -- bit-identical values (csrc/induced.cuh), one
+        # launch fewer per iteration, and measured EQUAL on the step (750.6 vs 749.5 iters/s, S1 4.08 vs 4.08 ms: what the launch cost, the two
+        # consumers now spend on 4 depth taps per pixel and level / per patch entry; profiles/r06_fused_induced.txt): an option, off by default
+        self.fused_induced = os.environ.get("RNNPOSE_FUSED_INDUCED", "0") != "0"
         self.ksplit = os.environ.get("RNNPOSE_KSPLIT", "1") != "0"                # small launches (B = 1 crops) split their K loop
         # SPLIT TENSORS (include/rnnpose_hip.h): every activation that only feeds further convolutions is written once, by its
         # producer's epilogue, as fp16 hi|lo pairs and staged by the consumers with a plain 16-byte copy (no per-tile re-split).
@@ -244,19 +249,24 @@ class UpdateEngine:
         cuts = [B * i // n for i in range(n + 1)]
         return list(zip(cuts[:-1], cuts[1:]))
 
-    def half_gen(self, corr_fn, coords1_part, B, b0, b1, st, flow_up_part, single=False):
+    def half_gen(self, corr_fn, coords1_part, B, b0, b1, st, flow_up_part, single=False, induced=None):
         """One GRU step of images [b0, b1) on stream `st` (current): window lookup -> update block -> convex up-sampling.
         coords1_part (b1-b0,2,h,w); flow_up_part (b1-b0,2,8h,8w) is written.  Generator: yields after every launch so
         that a caller can issue several chains alternately.  single: this is the only chain (B = 1): the flow-feature /
         flow-head side chain then runs on a helper stream (the only concurrency there is; nested forks inside two
-        concurrent chains segfault hipStreamEndCapture on ROCm 7.2)."""
+        concurrent chains segfault hipStreamEndCapture on ROCm 7.2).
+        induced (ops.InducedCoords with out = coords1_part): coords1_part is not filled yet -- the lookup launch forms the coordinates and
+        writes them there, the flow-feature launch forms them again for its patch (r06)."""
         W = self._weights()
         view = {k: v[b0:b1] for k, v in self._b.items()}
         view["_ksws"], view["_ksws_side"] = self._ksplit_ws(b0, b1, 0), self._ksplit_ws(b0, b1, 1)
         fused = (self.fused_lookup and self.resident_1x1 and W["convc1r"] is not None and W["convc1r"].c_in == 324
                  and corr_fn.num_levels == 4 and corr_fn.radius == 4)
         if fused:           # update.py:89 on corr.py:36-57 in one launch; the chain below skips its convc1
+            assert induced is None
             ops.corr_lookup_convc1(W["convc1r"], corr_fn._buf, coords1_part, (view["cor1"], 0), B, b0, b1, relu=True, dst_split=self.hl)
+        elif induced is not None:
+            ops.corr_lookup_induced_nhwc_part(corr_fn._buf, induced, view["corr"], B, b0, b1, corr_fn.num_levels, corr_fn.radius)
         else:
             ops.corr_lookup_nhwc_part(corr_fn._buf, coords1_part, view["corr"], B, b0, b1, corr_fn.num_levels, corr_fn.radius)
         yield
@@ -264,7 +274,7 @@ class UpdateEngine:
         # measured equal at the headline (695-699 iters/s either way) and slower at B = 1 (see __init__)
         small = coords1_part.shape[0] * coords1_part.shape[2] * coords1_part.shape[3] < self.MIN_CHAIN_PIXELS
         yield from self._chain_gen(W, view, coords1_part, st, self._stream(coords1_part.device, 2) if (single and small and self.side_stream) else None,
-                                   have_cor1=fused)
+                                   have_cor1=fused, induced=induced)
         if self.fused_mask:         # mask.2 + up-sampling in one kernel (the chain skipped its mask.2 launch)
             ops.mask_upsample(W["mask2u"], view["heads"], 256, view["flow_lr"], out=flow_up_part)
         else:
@@ -325,7 +335,7 @@ class UpdateEngine:
         for _ in self._chain_gen(W, b, coords1, main, side, flow_is_delta, want_mask):
             pass
 
-    def _chain_gen(self, W, b, coords1, main, side, flow_is_delta=False, want_mask=False, have_cor1=False):
+    def _chain_gen(self, W, b, coords1, main, side, flow_is_delta=False, want_mask=False, have_cor1=False, induced=None):
         """The update block on the (sub-)batch views `b`, issued on stream `main` (current) with `side` as helper; yields
         after every launch so that the caller can interleave two chains.
         flow_is_delta: `coords1` holds the flow itself (facade call) instead of absolute coordinates.
@@ -349,8 +359,12 @@ class UpdateEngine:
         # there (a parallel branch when the step is captured into a hipGraph).  Same for flow_head.conv2 next to mask.2.
         def flow_chain():
             # flow = coords1 - grid -> motion[126:128] (:97) and relu(convf1(flow)) (:91; direct fp32 kernel, K = 98): one launch
-            ops.flow_features(coords1, W["convf1_wt"], W["convf1_b"], b["flo1"], b["motion"], 126, subtract_grid=not flow_is_delta,
-                              out_split=hl, motion_split=hl, a_scale=ops.A_SCALE)
+            if induced is not None:       # (r06: coords1 formed inside the launch; the lookup launch in front of the chain wrote the tensor)
+                ops.flow_features_induced(induced, W["convf1_wt"], W["convf1_b"], b["flo1"], b["motion"], 126, out_split=hl, motion_split=hl,
+                                          a_scale=ops.A_SCALE)
+            else:
+                ops.flow_features(coords1, W["convf1_wt"], W["convf1_b"], b["flo1"], b["motion"], 126, subtract_grid=not flow_is_delta,
+                                  out_split=hl, motion_split=hl, a_scale=ops.A_SCALE)
             yield
             c("convf2", [(b["flo1"], 0)], (b["corflo"], 192), R, hl_out=True, ks=ks_side)       # :92
             yield

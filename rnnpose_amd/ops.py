@@ -796,6 +796,41 @@ def corr_lookup_nhwc_part(pyramid_buf, coords, out, B, b0, b1, levels: int = 4, 
     return out
 
 
+class InducedCoords:
+    """Where an iteration's coords1 comes from when its first consumers form it themselves (r06): depth (n,1,H,W), K (n,3,3), G (n,4,4) of
+    the chain's images, the low-resolution size, and `out` (n,2,h,w) = the tensor the lookup launch writes the coordinates to (the flow
+    head reads them there).  Same values as induced_coords_lowres(depth, K, G, h, w, eps), bit for bit (csrc/induced.cuh)."""
+
+    def __init__(self, depth, K, G, h, w, eps, out):
+        self.depth, self.K, self.G = _chk(depth, "depth"), _chk(K, "K"), _chk(G, "G")
+        self.h, self.w, self.eps, self.out = int(h), int(w), float(eps), out
+        self.H, self.W = int(depth.shape[-2]), int(depth.shape[-1])
+        n = depth.shape[0]
+        if tuple(K.shape[-2:]) != (3, 3) or tuple(G.shape[-2:]) != (4, 4) or K.reshape(-1, 3, 3).shape[0] != n or G.reshape(-1, 4, 4).shape[0] != n:
+            raise ValueError("K (n,3,3) and G (n,4,4) must match depth (n,1,H,W)")
+        if tuple(out.shape) != (n, 2, self.h, self.w) or not out.is_contiguous():
+            raise ValueError("out must be a contiguous (n,2,h,w) tensor")
+
+
+def corr_lookup_induced_nhwc_part(pyramid_buf, ic: InducedCoords, out, B, b0, b1, levels: int = 4, radius: int = 4):
+    """corr_lookup_nhwc_part with the coordinates formed inside the launch (and written to ic.out)."""
+    if ic.depth.shape[0] != b1 - b0:
+        raise ValueError("the coordinate source must hold the b1 - b0 images of the part")
+    _launch("rnnpose_corr_lookup_induced_nhwc_part_f32", _ptr(pyramid_buf), _ptr(ic.depth), _ptr(ic.K), _ptr(ic.G), ic.H, ic.W, ic.eps, B, b0, b1,
+            ic.h, ic.w, levels, radius, _ptr(ic.out), _ptr(out), _stream(), nbytes=_lookup_bytes(b1 - b0, ic.h, ic.w, levels, radius))
+    return out
+
+
+def flow_features_induced(ic: InducedCoords, w_t, bias, out, motion, motion_c_offset, out_c_offset=0, out_split: bool = False,
+                          motion_split: bool = False, a_scale: float = 8.0):
+    """flow_features with coords1 formed inside the launch (grid subtracted)."""
+    B, c_out = ic.depth.shape[0], w_t.shape[1]
+    _launch("rnnpose_flow_features_induced_f32", _ptr(ic.depth), _ptr(ic.K), _ptr(ic.G), ic.H, ic.W, ic.eps, _ptr(w_t), _ptr(bias), B, ic.h, ic.w,
+            c_out, _ptr(out), out.shape[-1], out_c_offset, _ptr(motion), motion.shape[3], motion_c_offset, int(bool(out_split)),
+            int(bool(motion_split)), float(a_scale), _stream(), work=2.0 * 98 * c_out * B * ic.h * ic.w)
+    return out
+
+
 def nchw_to_nhwc(src, dst=None, c_offset: int = 0):
     """src (B,C,H,W) -> channels [c_offset, c_offset+C) of dst (B,H,W,Cs) (allocated (B,H,W,C) if None)."""
     src = _chk(src, "src")

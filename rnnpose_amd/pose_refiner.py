@@ -252,9 +252,13 @@ class PoseRefiner(nn.Module):
         Gc = G3[b0:b1]
         for i in range(n):
             flow_up, wmap, Gn, Hm, bv, xi, info = (t[b0:b1] for t in bufs["views"][i])
-            coords1 = ops.induced_coords_lowres(depth[b0:b1], K[b0:b1], Gc, h, w, EPS, out=bufs["coords"][i, b0:b1])   # :324-328, CFNet.py:136-144
-            yield
-            yield from eng.half_gen(self.cf_net.corr_fn, coords1, B, b0, b1, st, flow_up, single=single)
+            if eng.fused_induced and not eng.fused_lookup:      # r06: :324-328 + CFNet.py:136-144 evaluated inside the lookup / flow-feature launches
+                coords1 = bufs["coords"][i, b0:b1]
+                ic = ops.InducedCoords(depth[b0:b1], K[b0:b1], Gc, h, w, EPS, coords1)
+            else:
+                coords1, ic = ops.induced_coords_lowres(depth[b0:b1], K[b0:b1], Gc, h, w, EPS, out=bufs["coords"][i, b0:b1]), None   # :324-328, CFNet.py:136-144
+                yield
+            yield from eng.half_gen(self.cf_net.corr_fn, coords1, B, b0, b1, st, flow_up, single=single, induced=ic)
             ops.corr_weight(g1[b0:b1], g2[b0:b1], flow_up, depth[b0:b1], self.sigma[0], out=wmap)                      # :342-345
             yield
             ops.lm_step(flow_up, wmap, depth[b0:b1], K[b0:b1], Gc, num_iters=opt, ep_lambda=ep_l, lm_lambda=lm_l,

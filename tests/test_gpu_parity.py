@@ -243,6 +243,44 @@ def test_corr_lookup_vs_oracle_and_golden(ops, golden):
         close(out[:, :, ::2, ::3], g[f"lookup_{k}"], 1e-4, what=f"lookup {k} vs golden")
 
 
+@pytest.mark.parametrize("B,h,w,b0,b1,bg", [(2, 16, 24, 0, 2, False), (3, 17, 19, 1, 3, True), (4, 30, 30, 2, 3, False), (2, 60, 80, 0, 1, True)])
+def test_induced_coords_formed_inside_lookup_and_flow_features(ops, B, h, w, b0, b1, bg):
+    """r06: the pose-induced coordinates of an iteration (geometry/transformation.py:184-198 -> model/CFNet.py:136-144) formed INSIDE their
+    first consumers -- rnnpose_corr_lookup_induced_nhwc_part_f32 and rnnpose_flow_features_induced_f32 call the device function the
+    stand-alone kernel calls (csrc/induced.cuh) -- instead of read from its output: the coordinate tensor the lookup writes, the window
+    features, relu(convf1(flow)) and the flow channels of the motion tensor are EQUAL BIT FOR BIT to the three-launch sequence; image
+    sub-ranges of a larger pyramid, ragged sizes (the depth map is not 8x the low-resolution map), background pixels (depth 0)."""
+    C, H, W = 64, 8 * h + 3, 8 * w + 5
+    f1 = syn.normal("fmap1", (B, C, h, w), 5)
+    f2 = syn.normal("fmap2", (B, C, h, w), 5)
+    buf, _ = ops.corr_pyramid(D(f1), D(f2), 4)
+    nb = b1 - b0
+    depth = D(syn.uniform("depth", (nb, 1, H, W), 31, 0.6, 1.4))
+    if bg:
+        depth[:, :, : H // 3] = 0
+    K = torch.tensor([[572.4, 0, W / 2.0], [0, 573.6, H / 2.0], [0, 0, 1]], device="cuda").repeat(nb, 1, 1)
+    G = ops.se3_exp(D(syn.normal("xi", (nb, 6), 32, std=0.03))).reshape(nb, 4, 4).contiguous()
+    eps = 1e-5
+    coords = ops.induced_coords_lowres(depth, K, G, h, w, eps)
+    corr = torch.empty(nb, h, w, 324, device="cuda")
+    ops.corr_lookup_nhwc_part(buf, coords, corr, B, b0, b1, 4, 4)
+    wt = D(syn.normal("f1w", (98, 128), 33, std=0.1))
+    bs = D(syn.uniform("f1b", (128,), 33, -0.2, 0.2))
+    for split in (False, True):
+        flo_a, mot_a = torch.zeros(nb, h, w, 128, device="cuda"), torch.zeros(nb, h, w, 128, device="cuda")
+        flo_b, mot_b = torch.zeros_like(flo_a), torch.zeros_like(mot_a)
+        ops.flow_features(coords, wt, bs, flo_a, mot_a, 126, out_split=split, motion_split=split)
+        cout = torch.full((nb, 2, h, w), -7.0, device="cuda")
+        ic = ops.InducedCoords(depth, K, G, h, w, eps, cout)
+        corr_i = torch.empty_like(corr)
+        ops.corr_lookup_induced_nhwc_part(buf, ic, corr_i, B, b0, b1, 4, 4)
+        ops.flow_features_induced(ic, wt, bs, flo_b, mot_b, 126, out_split=split, motion_split=split)
+        assert torch.equal(cout, coords), float((cout - coords).abs().max())
+        assert torch.equal(corr_i, corr)
+        assert torch.equal(flo_a.view(torch.int32), flo_b.view(torch.int32)) and torch.equal(mot_a.view(torch.int32), mot_b.view(torch.int32))
+    assert bool(torch.isfinite(coords).all()) and float((coords - orc.coords_grid_lowres(nb, h, w).cuda()).abs().max()) > 0.05
+
+
 @pytest.mark.parametrize("B,h,w,b0,b1", [(2, 16, 24, 0, 2), (3, 17, 19, 1, 3), (4, 30, 30, 2, 3), (2, 60, 80, 0, 1)])
 @pytest.mark.parametrize("split", [False, True])
 def test_corr_lookup_convc1_fused_equals_the_two_kernels(ops, B, h, w, b0, b1, split):

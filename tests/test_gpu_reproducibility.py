@@ -150,6 +150,22 @@ def test_uneven_chains_are_bit_identical_to_one_chain(ops, monkeypatch, graph):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("shape", [(8, 480, 640, 2, True), (1, 240, 240, 4, True), (3, 480, 640, 2, False)])
+def test_coordinates_formed_inside_their_consumers_change_no_bit(ops, monkeypatch, shape):
+    """r06: with RNNPOSE_FUSED_INDUCED=1 (an option: measured equal) the lookup / flow-feature launches of an iteration form the pose-induced coordinates
+    themselves, with 0 a launch of its own writes them first: every output of every iteration (flow, weight, H, b, xi, G) is the same
+    BITS either way -- headline shape (two chains), the single-image crop, an uneven eager batch."""
+    B, H, W, iters, graph = shape
+    outs = []
+    for v in ("0", "1"):
+        monkeypatch.setenv("RNNPOSE_FUSED_INDUCED", v)
+        o = _instance_outputs(ops, B, H, W, iters, graph, encoder=True)
+        assert o["_weight_mismatch"] == 0
+        outs.append(o)
+    bad = [k for k in outs[0] if not k.startswith("_") and not torch.equal(outs[0][k], outs[1][k])]
+    assert not bad, bad
+
+
 def test_pointwise_kernels_are_exact_next_to_16x16x32_mfma_kernels(ops):
     """The reduced form of r04's finding: a VALU kernel on stream A, mask_upsample / conv1x1_resident (v_mfma_f32_16x16x32_f16) on
     stream B, constant inputs -- every launch must reproduce the kernel's solo output bit for bit.  (With pointwise.hip built by plain
