@@ -42,7 +42,7 @@ PATCHES = {
          "const unsigned lds0 = hostexec::lds_register(sD);", 1),
     ],
     # an empty asm that only makes a value opaque to the optimiser: AMDGPU register class "v" -> a host register
-    "mask_upsample.hip": [(r'asm volatile\("" : "\+v"\(aoff\)\);', 'asm volatile("" : "+r"(aoff));', 1)],
+    "mask_upsample.hip": [(r'asm volatile\("" : "\+v"\(aoff\)\);', 'asm volatile("" : "+r"(aoff));', 2)],          # (both tile geometries)
 }
 
 # The strip convolution kernels request their operands by LDS-DMA (inline assembly).  Their scratch copy gets host versions of the
