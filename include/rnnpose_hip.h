@@ -304,7 +304,9 @@ int rnnpose_conv_products_desc(const rnnpose_conv_desc_t* h_desc);
 /* The same for the kernel a launch of `batch` images with this c_out and `tile` request (0 automatic .. 7) will take: the strip
  * kernels tile an image into ceil(W/16) * ceil(H/10) patches of 10 x 16 pixels (3x3) or ceil(H*W/160) runs of 160 pixels (96-row strips: patches of 6 x 16 pixels, runs of 96; 32-row
  * strips: patches of 2 x 16 pixels, runs of 32).  Shape-only: it assumes source channel counts in multiples of 32 (launches whose
- * sources are not fall back to the 128-row kernels: use rnnpose_conv_tiles_per_image_desc). */
+ * sources are not fall back to the 128-row kernels: use rnnpose_conv_tiles_per_image_desc).  STRIDE 2: -1 whenever the shape alone would
+ * allow the strip form -- whether a stride-2 launch takes it depends on its sources: only rnnpose_conv_tiles_per_image_desc answers.
+ * A launch with statistics requires tile_stats_records == B * (that answer), not merely >= (ABI 3, tightened in r06). */
 int rnnpose_conv_tiles_per_image_ex(int H, int W, int kh, int kw, int stride, int c_out, int tile, int batch);
 int rnnpose_conv_spatial_tiles(int enable);
 int rnnpose_conv_strip(int mode);          /* measurement switch: 0 = the automatic choice never takes the strip kernels, 1 = default,

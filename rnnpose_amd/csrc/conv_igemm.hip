@@ -929,7 +929,10 @@ int rnnpose_conv_tiles_per_image_ex(int H, int W, int kh, int kw, int stride, in
   if (tile >= 5) rows = strip_rows(H, W, kh, kw, stride, c_out, batch, strip_tile_rows(tile));
   else if (tile == 0 && g_conv_strip) rows = strip_rows(H, W, kh, kw, stride, c_out, batch, 0);
   if (tile >= 5 && rows == 0) return -1;
-  if (rows) return stride == 2 ? strip_tiles_per_image(H / 2, W / 2, 3, 3, rows) : strip_tiles_per_image(H, W, kh, kw, rows);
+  // stride 2: whether the launch takes the strip form also depends on its sources (one fp32 source of whole 32-channel blocks,
+  // no fused normalisation) -- a shape-only answer could size the statistics for a tiling the launch then refuses: ask _desc
+  if (rows && stride == 2) return -1;
+  if (rows) return strip_tiles_per_image(H, W, kh, kw, rows);
   return rnnpose_conv_tiles_per_image(H, W, kh, kw, stride);
 }
 
@@ -940,8 +943,10 @@ long long rnnpose_conv_packed_halfs(int c_out, int kh, int kw, const int* h_seg_
   const int ncb = fill_cb_tables(h_seg_counts, n_seg, cs, c0);
   if (ncb < 0) return -1;
   const long long Npad = static_cast<long long>(rp::cdiv(c_out, BN)) * BN;
-  // hi and lo parts interleaved; TWO copies: the 128-row kernels' fragment order, then the strip kernels' record order -- and for a 3x3
-  // layer with one source of whole 32-channel blocks a THIRD one: the stride-2 form over parity planes (conv_strip.hip, r05)
+  // hi and lo parts interleaved; TWO copies: the 128-row kernels' fragment order, then the strip kernels' record order -- and for a 3x3 / 1x1
+  // layer with one source of whole 32-channel blocks a THIRD one: the stride-2 form over parity planes (conv_strip.hip, r05: +32 units next to
+  // 36 for a 3x3 layer, 4x the stride-1 size with three quarters zeros for a 1x1 one; packed whether or not the layer ever runs at stride 2 --
+  // the pack call has no stride argument: ADVICE r05, accepted: weights are packed once per parameter version, 1.6 MB for the whole encoder)
   return 2 * static_cast<long long>(kh) * kw * ncb * Npad * BK * 2 + strip_s2_halfs(h_seg_counts[0], kh, kw, ncb, static_cast<int>(Npad), n_seg);
 }
 
@@ -1091,8 +1096,9 @@ int rnnpose_conv2d_nhwc_f16x3(const rnnpose_conv_desc_t* d, rnnpose_stream_t str
   // launch with per-image tile records tiles as rnnpose_conv_tiles_per_image_ex says for the same shape and batch)
   if (d->tile_stats) {     // the buffer is checked against the tiling of the kernel THIS launch takes (ABI 3)
     const int tpi = rnnpose_conv_tiles_per_image_desc(d);
-    RP_REQUIRE(tpi > 0 && static_cast<long long>(d->tile_stats_records) >= static_cast<long long>(d->B) * tpi, fn,
-               "tile_stats_records is smaller than B * rnnpose_conv_tiles_per_image_desc(desc): size the statistics buffer with that call");
+    RP_REQUIRE(tpi > 0 && static_cast<long long>(d->tile_stats_records) == static_cast<long long>(d->B) * tpi, fn,
+               "tile_stats_records must equal B * rnnpose_conv_tiles_per_image_desc(desc) (a consumer derives the tiling from the record count: "
+               "an oversized buffer would make it sum records this launch never writes): size the statistics buffer with that call");
   }
   {
     const bool per_image = d->tile_stats || d->src0_mean_rstd;

@@ -96,6 +96,11 @@ __global__ void pack_strip_s2_kernel(const float* __restrict__ w, _Float16* __re
   const int g = pos ^ ((n32 >> 3) & 1);
   const int ci = blk * 32 + kk * 16 + g * 8 + j8;
   const int n = ctile * 32 + n32;
+  // The seven empty (plane, tap) slots (three of four for 1x1) carry ZERO weights and are multiplied, not skipped (skipping measured slower:
+  // profiles/r05_ab_s2_skip.txt).  Their activations lie OUTSIDE the output's receptive field (e.g. in(2y-2, 2x-2)): a non-finite or
+  // fp16-saturated activation there gives 0 * inf = NaN in an output that the 128-row kernel and the reference leave finite -- the two
+  // forms agree for finite, in-range inputs only.  The encoder launches these layers on instance-normalised maps
+  // (src_bounded: |x| <= sqrt(H W), two orders of magnitude inside the range); any other caller keeps the range guard on, which counts the event.
   float v = 0.f;
   if (q.kh == 1) {        // 1x1 stride 2 (the encoder's down-sampling branches): plane (0, 0) only, the centre tap only
     if (n < q.Cout && ci < q.Cin && tap == 3) v = w[static_cast<long long>(n) * q.Cin + ci] * q.w_scale;

@@ -255,7 +255,7 @@ def test_conv_tile_stats_feed_instnorm(ops, B, H, W, cin, cout, k, stride):
     Ho, Wo = -(-H // stride), -(-W // stride)
     assert (Ho * Wo) % 128 == 0
     out = torch.empty(B, Ho, Wo, cout, device="cuda")
-    tpi = ops.conv_tiles_per_image(H, W, k, k, stride, cout, 0, B)   # 3x3 stride 1: 8 x 16 patches (strips: 10 x 16 / 2 x 16); else runs of 128 output pixels
+    tpi = ops.conv_tiles_per_image(H, W, k, k, stride, cout, 0, B, src_counts=[cin])   # 3x3 stride 1: 8 x 16 patches (strips: 10 x 16 / 2 x 16); else runs of 128 output pixels
     ts = torch.full((B * tpi, cout, 2), -1.0, device="cuda", dtype=torch.float64)      # fp64 tile statistics
     ops.conv2d_nhwc(pc, [(nhwc(D(x)), 0)], (out, 0), ops.EPI_LINEAR, stride=stride, tile_stats=ts)
     y64 = F.conv2d(D(x).double(), D(w).double(), D(b).double(), stride=stride, padding=k // 2)
@@ -930,6 +930,8 @@ def test_conv_tile_stats_with_narrow_sources_fall_back_to_the_128_row_kernels(op
     lib = _lib.load()
     assert lib.rnnpose_conv_tiles_per_image_desc(C.byref(d)) == tpi
     assert lib.rnnpose_conv2d_nhwc_f16x3(C.byref(d), None) != 0 and b"tile_stats_records" in lib.rnnpose_last_error()
+    d.tile_stats_records = B * tpi + 1                              # r06: an OVERSIZED record count is refused too -- a consumer takes the
+    assert lib.rnnpose_conv2d_nhwc_f16x3(C.byref(d), None) != 0 and b"tile_stats_records" in lib.rnnpose_last_error()      # tiling from the count
     d.tile_stats_records = B * tpi
     assert lib.rnnpose_conv2d_nhwc_f16x3(C.byref(d), None) == 0
     torch.cuda.synchronize()
