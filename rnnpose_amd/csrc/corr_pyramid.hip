@@ -682,6 +682,128 @@ __global__ __launch_bounds__(NT, 4) void corr_pyramid_h3dma_kernel(const _Float1
   pyramid_epilogue<ALIGNED>(acc0, acc1, acc2, acc3, smem, pyr, info, b, N, h, w, i0, y0, x0, scale, wave, lane, patch, n_patch);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// r06, variant 2: WAVE-SPECIALISED and PERSISTENT -- the form that lets the store phase of a tile run under the K loop of the next one.
+// What bounds variants 0 and 1 is the SUM of a K-loop phase and an HBM-write-bound store phase per workgroup (978 MB per launch): a workgroup
+// in its epilogue holds a slot and computes nothing.  A persistent workgroup could fire its stores and go on to the next tile -- but its next
+// operand requests then share vmcnt with those stores (gfx9 counts loads and stores on ONE counter, and they return out of order relative to
+// each other, so only vmcnt(0) is safe), and the K loop waits for store acknowledgements of a saturated write queue: r03's persistent form,
+// +45 %.  Here the two kinds of request live in DIFFERENT WAVES:
+//   * waves 4-7 (LOADERS) do nothing but request operand slabs by LDS-DMA -- loader w the rows [32 w, 32 w + 32) of the four planes, 4 requests
+//     per 16-channel slab -- wait for them (their vmcnt counts only loads) and meet the compute waves at one barrier per slab, one slab ahead
+//     (double-buffered 2 x 16 KB as in variant 1);
+//   * waves 0-3 (COMPUTE) read fragments, multiply, and run the epilogue of a finished tile -- staging LDS of their own (36 KB, NOT aliasing the
+//     operand buffers: the loaders are already filling them for the next tile), stores fired and never waited for -- then start the next tile;
+//   * the workgroup walks its share of the tile list (grid = 2 workgroups per CU; the tiles an XCD has in flight stay neighbours in the
+//     supertile order, so the operand panels stay in its L2): no workgroup dispatch per tile (the 'empty pass' of the one-tile forms was 70 us).
+// LDS 68 KB: two workgroups per CU = two compute + two loader waves per SIMD, <= 128 registers.  Same k order, same products, same epilogue:
+// BIT-IDENTICAL results.  Barrier protocol: barrier s = "slab s has landed and everyone is done with slab s - 1"; a loader requests slab s into
+// buffer s & 1 after barrier s - 1 (the compute waves arrived there after multiplying slab s - 2, the buffer's previous content), waits, arrives
+// at barrier s; a compute wave passes barrier s and multiplies slab s.  Slabs are counted across tiles; the epilogue contains no barrier.
+template <bool ALIGNED>
+__global__ __launch_bounds__(2 * NT, 4) void corr_pyramid_h3ws_kernel(const _Float16* __restrict__ f1, const _Float16* __restrict__ f2,
+                                                                      float* __restrict__ pyr, int B, int C, int h, int w, int n_it,
+                                                                      int n_py, int n_px, float scale, PyrInfo info, int sti, int stp, int ntiles) {
+  __shared__ __attribute__((aligned(1024))) unsigned char sD[2 * DBUF + 4 * 2304 * 4];      // operand slabs | epilogue staging
+  float* smem = reinterpret_cast<float*>(sD + 2 * DBUF);
+  const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) unsigned char*)sD));   // LDS byte address
+  const int N = h * w;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool loader = wave >= 4;
+  const int cw = wave & 3;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  // this workgroup's share of the tile list: XCD x (= blockIdx % 8) owns the contiguous chunk of ids the one-tile forms give it; its
+  // gridDim / 8 workgroups walk the chunk interleaved, so that at any time they are on neighbouring tiles
+  const int nslots = gridDim.x >> 3;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int per = ntiles >> 3, rem = ntiles & 7;
+  const int t_begin = xcd * per + (xcd < rem ? xcd : rem), t_count = per + (xcd < rem ? 1 : 0);
+  const int n_patch = n_py * n_px;
+  const int n_ps = (n_patch + stp - 1) / stp, n_is = (n_it + sti - 1) / sti;
+  const int sts = sti * stp;
+  const int per_img = n_ps * n_is * sts;
+  const int nk = C / DBK;
+  const unsigned dw = __builtin_amdgcn_readfirstlane(lds0 + cw * 1024);
+  const int sw = (lh ^ ((l31 >> 3) & 1)) * 16;
+  const unsigned char* sA = sD + (cw * 32 + l31) * 32 + sw;
+  const unsigned char* sB = sD + 2 * DPL + l31 * 32 + sw;
+  unsigned par = 0;                                   // parity of the running slab count = operand buffer of the next slab
+
+  for (int ti = slot; ti < t_count; ti += nslots) {
+    const int bid = t_begin + ti;
+    const int b = bid / per_img;
+    const int tloc = bid - b * per_img;
+    const int sidx = tloc / sts, within = tloc - sidx * sts;
+    const int it = (sidx / n_ps) * sti + within / stp;
+    const int patch = (sidx % n_ps) * stp + within % stp;
+    if (it >= n_it || patch >= n_patch) continue;     // padding tile of a partial supertile (uniform over the workgroup)
+    const int i0 = it * BM;
+    const int y0 = (patch / n_px) * PY;
+    const int x0 = (patch % n_px) * PX;
+    if (loader) {
+      const unsigned char* pa;
+      const unsigned char* pb;
+      unsigned inca, incb;
+      {
+        const int rr = lane >> 1, ch = (lane & 1) ^ ((rr >> 3) & 1);
+        const int ra = cw * 32 + rr;
+        const unsigned rsb = 4u * C;
+        const bool va = i0 + ra < N;
+        const int yb = y0 + (ra >> 4), xb = x0 + (ra & 15);
+        const bool vb = yb < h && xb < w;
+        pa = va ? reinterpret_cast<const unsigned char*>(f1) + (static_cast<size_t>(b) * N + i0 + ra) * rsb + ch * 32 : g_cp_zero_page;
+        pb = vb ? reinterpret_cast<const unsigned char*>(f2) + (static_cast<size_t>(b) * N + yb * w + xb) * rsb + ch * 32 : g_cp_zero_page;
+        inca = va ? 64u : 0u;
+        incb = vb ? 64u : 0u;
+      }
+      for (int kt = 0; kt < nk; ++kt) {
+        const unsigned bo = par * DBUF;
+        cp_glds16(pa, __builtin_amdgcn_readfirstlane(dw + bo));
+        cp_glds16(pa + 16, __builtin_amdgcn_readfirstlane(dw + bo + DPL));
+        cp_glds16(pb, __builtin_amdgcn_readfirstlane(dw + bo + 2 * DPL));
+        cp_glds16(pb + 16, __builtin_amdgcn_readfirstlane(dw + bo + 3 * DPL));
+        pa += inca;
+        pb += incb;
+        par ^= 1u;
+        cp_wait_vm0();
+        __syncthreads();
+      }
+    } else {
+      f32x16 acc0, acc1, acc2, acc3;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; acc2[r] = 0.f; acc3[r] = 0.f; }
+      for (int kt = 0; kt < nk; ++kt) {
+        const unsigned bo = par * DBUF;
+        par ^= 1u;
+        __syncthreads();
+        const h8 ah = *reinterpret_cast<const h8*>(sA + bo);
+        const h8 al = *reinterpret_cast<const h8*>(sA + bo + DPL);
+        h8 bh[4], bl[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          bh[s] = *reinterpret_cast<const h8*>(sB + bo + s * 1024);
+          bl[s] = *reinterpret_cast<const h8*>(sB + bo + DPL + s * 1024);
+        }
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[1], acc1, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[2], acc2, 0, 0, 0);
+        acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[3], acc3, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[1], acc1, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[2], acc2, 0, 0, 0);
+        acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[3], acc3, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[1], acc1, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[2], acc2, 0, 0, 0);
+        acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[3], acc3, 0, 0, 0);
+      }
+      pyramid_epilogue<ALIGNED>(acc0, acc1, acc2, acc3, smem, pyr, info, b, N, h, w, i0, y0, x0, scale, cw, lane, patch, n_patch);
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -761,7 +883,22 @@ int launch_h3(const char* fn, const _Float16* f1, const _Float16* f2, int B, int
   const float scale = 1.0f / (sqrtf(static_cast<float>(C)) * a_scale * a_scale);
   const bool aligned = (N % 4 == 0) && (w % 4 == 0) && (reinterpret_cast<uintptr_t>(pyramid) % 16 == 0);
   dim3 grid(static_cast<unsigned>(ntiles)), block(NT);
-  if (g_corr_variant == 1) {          // operands by LDS-DMA (r06), bit-identical to the register form
+  if (g_corr_variant == 2) {          // wave-specialised persistent form (r06): loaders + compute waves, stores never waited for
+    static int ncu_cached = 0;          // (CUs of the current device, asked once: one process drives one GPU)
+    if (ncu_cached == 0) {
+      int dev = 0, v = 0;
+      ncu_cached = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+    }
+    const int ncu = ncu_cached;
+    const unsigned nwg = static_cast<unsigned>(((2 * ncu + 7) / 8) * 8);
+    if (aligned) {
+      hipLaunchKernelGGL(corr_pyramid_h3ws_kernel<true>, dim3(nwg), dim3(2 * NT), 0, st, f1, f2, pyramid, B, C, h, w, n_it, n_py, n_px, scale, info, sti, stp,
+                         static_cast<int>(ntiles));
+    } else {
+      hipLaunchKernelGGL(corr_pyramid_h3ws_kernel<false>, dim3(nwg), dim3(2 * NT), 0, st, f1, f2, pyramid, B, C, h, w, n_it, n_py, n_px, scale, info, sti, stp,
+                         static_cast<int>(ntiles));
+    }
+  } else if (g_corr_variant == 1) {          // operands by LDS-DMA (r06), bit-identical to the register form
     if (aligned) {
       hipLaunchKernelGGL(corr_pyramid_h3dma_kernel<true>, grid, block, 0, st, f1, f2, pyramid, B, C, h, w, n_it, n_py, n_px, scale, info, sti, stp);
     } else {
@@ -776,9 +913,9 @@ int launch_h3(const char* fn, const _Float16* f1, const _Float16* f2, int B, int
 }
 }  // namespace
 
-int rnnpose_corr_variant(int variant) {       // 0: operands through registers + ds_write (r03-r05); 1: operands by LDS-DMA (r06)
-  if (variant < 0 || variant > 1) {
-    rp::set_error("rnnpose_corr_variant: 0 (register staging) or 1 (LDS-DMA)");
+int rnnpose_corr_variant(int variant) {       // 0: operands through registers + ds_write (r03-r05); 1: operands by LDS-DMA (r06); 2: loaders + persistent compute waves (r06)
+  if (variant < 0 || variant > 2) {
+    rp::set_error("rnnpose_corr_variant: 0 (register staging), 1 (LDS-DMA) or 2 (wave-specialised, persistent)");
     return 1;
   }
   g_corr_variant = variant;

@@ -39,7 +39,7 @@ PATCHES = {
         (r'__device__ __forceinline__ void cp_wait_vm0\(\) \{ asm volatile\("s_waitcnt vmcnt\(0\)" ::: "memory"\); \}',
          "__device__ __forceinline__ void cp_wait_vm0() { hostexec::vm_wait(0); }", 1),
         (r"const unsigned lds0 = static_cast<unsigned>\(reinterpret_cast<size_t>\(\(__attribute__\(\(address_space\(3\)\)\) unsigned char\*\)sD\)\);",
-         "const unsigned lds0 = hostexec::lds_register(sD);", 1),
+         "const unsigned lds0 = hostexec::lds_register(sD);", 2),          # (variants 1 and 2)
     ],
     # an empty asm that only makes a value opaque to the optimiser: AMDGPU register class "v" -> a host register
     "mask_upsample.hip": [(r'asm volatile\("" : "\+v"\(aoff\)\);', 'asm volatile("" : "+r"(aoff));', 2)],          # (both tile geometries)

@@ -118,13 +118,16 @@ def test_corr_pyramid_lds_dma_operands_bit_identical(ops, B, C, h, w, levels):
     s1, s2 = ops.SplitTensor(ops.split_hl(n1), 8.0), ops.SplitTensor(ops.split_hl(n2), 8.0)
     bufs = []
     try:
-        for v in (0, 1):
+        for v in (0, 1, 2):
             ops.corr_variant(v)
             buf, views = ops.corr_pyramid_split(s1, s2, levels)
             bufs.append((buf.clone(), [t.clone() for t in views]))
     finally:
         ops.corr_variant(int(os.environ.get("RNNPOSE_CORR_VARIANT", ops.CORR_VARIANT_DEFAULT)))
-    assert torch.equal(bufs[0][0], bufs[1][0])
+    assert torch.equal(bufs[0][0], bufs[1][0]), "LDS-DMA operands (variant 1)"
+    # variant 2 (r06): wave-specialised persistent form -- loader waves request the slabs, compute waves multiply and fire the epilogue's
+    # stores without ever waiting for them; workgroups walk the tile list (on the host tier's 4-CU "device": 8 workgroups, many tiles each)
+    assert torch.equal(bufs[0][0], bufs[2][0]), "wave-specialised persistent form (variant 2)"
     if B * h * w <= 2000:
         want = orc.corr_pyramid(f1, f2, levels)
         for l in range(levels):
