@@ -181,7 +181,9 @@ PARITY_K = ("not (full_size or full_shape or loop_480 or timed_configuration or 
             "alternate_corr_block_vs_oracle or alternate_corr_odd or teacher or facade_stateful or context_prep_and_flow_to_coords or "
             "strip or stride2_strips or patch_tiling_equals_row_major or range_guard_is_visible or per_image_tiles or "
             "k_split_matches_single_pass or range_guard_counts_in_every or narrow_sources or zoom_pipeline_full_size or "
-            "coverage_agrees_with_vertex_splat or (split_sources and not segs2) or encoder_split_output or nn_search_bit_exact)")
+            "coverage_agrees_with_vertex_splat or (split_sources and not segs2) or encoder_split_output or nn_search_bit_exact or "
+            # r06: the encoder-in-the-loop S1 fixture (4 min per case under emulation) and the 60 x 80 cases of the r06 kernel-variant tests
+            "loop_S1_shipped or (lds_dma_operands and 60-80) or (fused_equals_the_two_kernels and 60-80) or (induced_coords_formed and 60-80))")
 DESELECT = [
     "tests/test_gpu_parity.py::test_refinement_loop_golden[loop_128-shape0-1-3-1-True]",      # (the literal call sequence of the same loop stays)
     "tests/test_gpu_parity.py::test_refinement_loop_golden[loop_2x2-shape1-2-2-2-True]",
