@@ -341,8 +341,12 @@ int rnnpose_f16x3_saturation_peek(unsigned long long* d_count, rnnpose_stream_t 
  * Weights (64,3,7,7) packed once by rnnpose_stem_pack_weights_f16x3 (2 arrays of rnnpose_stem_packed_halfs() fp16).
  * tile_stats (optional): (N * tiles_per_image, 64, 2) per-tile column sums / sums of squares for
  * rnnpose_instnorm_tiles_nhwc_f32 (8 x 16 output tiles; pixels of a ragged tile outside the image never enter the sums, so the
- * statistics hold for every size -- rnnpose_stem_tiles reports h_exact = 1 always since r03; the field is kept for callers). */
+ * statistics hold for every size -- rnnpose_stem_tiles reports h_exact = 1 always since r03; the field is kept for callers).
+ * r06: the kernel is PERSISTENT -- two workgroups per CU walk the tile list with the packed weights resident in LDS and the patch split
+ * into fp16 hi / lo once per tile; rnnpose_stem_workgroups(n) caps the number of workgroups (tests: many tiles per workgroup at small
+ * sizes; 0 = default).  Results do not depend on it. */
 long long rnnpose_stem_packed_halfs(void);
+int rnnpose_stem_workgroups(int max_workgroups);
 int rnnpose_stem_pack_weights_f16x3(const float* w_oihw, float w_scale, void* w_hi, void* w_lo, rnnpose_stream_t stream);
 int rnnpose_stem_tiles(int H, int W, int* h_tiles_per_image, int* h_exact);
 int rnnpose_stem_conv7x7_s2_f16x3(const float* img_nchw, int N, int H, int W, int normalize, const void* w_hi,

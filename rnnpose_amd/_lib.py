@@ -86,6 +86,7 @@ PROTOTYPES = {
     "rnnpose_f16x3_saturation_count": (_i, [C.POINTER(C.c_ulonglong), _i, _p]),
     "rnnpose_f16x3_saturation_peek": (_i, [_p, _p]),
     "rnnpose_stem_packed_halfs": (C.c_longlong, []),
+    "rnnpose_stem_workgroups": (_i, [_i]),
     "rnnpose_stem_pack_weights_f16x3": (_i, [_p, _f, _p, _p, _p]),
     "rnnpose_stem_tiles": (_i, [_i, _i, C.POINTER(_i), C.POINTER(_i)]),
     "rnnpose_stem_conv7x7_s2_f16x3": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _f, _f, _p, _p, _p]),

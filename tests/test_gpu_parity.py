@@ -769,6 +769,28 @@ def test_encoder_stem_kernel(ops, N, H, W):
         close(got, n64, 2e-5, what="instance norm from (ragged) tile statistics")
 
 
+@pytest.mark.parametrize("N,H,W", [(2, 64, 96), (3, 37, 41), (1, 120, 200)])
+def test_stem_persistent_walk_is_independent_of_the_workgroup_count(ops, N, H, W):
+    """r06: the stem's workgroups are persistent (two per CU walk the tile list of their XCD, weights resident in LDS, the next tile's
+    patch requested under the current tile's MFMAs).  At test sizes every workgroup has one tile; rnnpose_stem_workgroups caps the grid so
+    that 8 / 16 workgroups walk ALL tiles: output and tile statistics must not change by a bit."""
+    from rnnpose_amd import _lib
+    img = D(syn.uniform("img", (N, 3, H, W), 21, 0.0, 255.0))
+    wt = D(syn.normal("w", (64, 3, 7, 7), 21, std=0.1))
+    bias = D(syn.uniform("b", (64,), 21, -0.5, 0.5))
+    ps = ops.PackedStem(wt, bias)
+    out0, ts0 = ops.stem_conv(ps, img, normalize=True)
+    out0, ts0 = out0.clone(), ts0.clone()
+    try:
+        for cap in (8, 16):
+            _lib.call("rnnpose_stem_workgroups", cap)
+            out, ts = ops.stem_conv(ps, img, normalize=True)
+            assert torch.equal(out, out0), cap
+            assert torch.equal(ts, ts0), cap
+    finally:
+        _lib.call("rnnpose_stem_workgroups", 0)
+
+
 def test_stem_statistics_on_a_nearly_constant_image(ops):
     """The reference feeds [0,1] images through 2 (x / 255) - 1 (model/CFNet.py:42-43): the stem sees an almost constant -1
     image, its outputs have mean^2 / var up to ~2e3, and instance norm's var = E[x^2] - mean^2 cancels 3-4 digits.  With fp64

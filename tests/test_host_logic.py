@@ -252,3 +252,19 @@ def test_traffic_record_belongs_to_the_kernel_sources_in_the_tree():
     co = t.get("carried_over")
     if co is not None:
         assert co["measured_on_digest"] != t["csrc_digest"] and "isa_equal" in co["check"] and co["measured_at"]
+
+
+def test_division_by_255_by_correction_step_is_the_correctly_rounded_quotient():
+    """csrc/stem.hip forms x / 255 (model/CFNet.py:42) as q = x * y, r = fma(-255, q, x), q' = fma(r, y, q) with y = fl(1 / 255).  The
+    exhaustive check over all finite non-negative floats is tools/probes/div255_markstein.c (0 differences, profiles/r06_stem.txt);
+    this samples every 257th float and all integers / half-integers an 8-bit image can hold."""
+    import numpy as np
+    bits = np.arange(0, 0x7F800000, 257, dtype=np.uint32)
+    x = np.concatenate([bits.view(np.float32), np.arange(0, 256.5, 0.5, dtype=np.float32)])
+    y = np.float32(1.0) / np.float32(255.0)
+    xd, yd = x.astype(np.float64), np.float64(y)
+    q = (xd * yd).astype(np.float32)                                   # one rounding: the product of two floats is exact in fp64
+    r = (xd - 255.0 * q.astype(np.float64)).astype(np.float32)         # fma(-255, q, x): exact difference, one rounding
+    q1 = (r.astype(np.float64) * yd + q.astype(np.float64)).astype(np.float32)   # fma(r, y, q): |r y| << |q|, the fp64 sum rounds once more -- double
+    want = x / np.float32(255.0)                                       # rounding can differ from a true fma only in 2^-29 of the cases: none here
+    assert np.array_equal(q1, want)

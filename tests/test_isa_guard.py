@@ -19,7 +19,8 @@ EXPECT = {
     "pointwise.hip": {"corr_weight_kernel": (25, 8, 6)},
     "lm.hip": {"lm_normal_eq_kernel": (16, 12, 10)},       # (the fused-tail instantiation adds its hand-off waits, the finalize loads and the inlined solve: 9; the plain one has 1)
     "nhwc_ops.hip": {"convex_upsample_nhwc_kernel": (18, 4, 3), "instnorm_apply_kernel": (6, 2, 2), "conv7x7_cin2_kernel": (50, 5, 40)},
-    "stem.hip": {"stem_conv7x7_s2_kernel": (45, 20, 30)},      # (51 loads; the serialised form has one wait per load; 14-18 depending on the split's instruction mix)
+    "stem.hip": {"stem_conv7x7_s2_kernel": (20, 4, 1)},        # (r06 persistent form: 2 x 10 patch loads + weights + bias; the next tile's patch is waited for once,
+                                                               #  behind the MFMAs; the serialised form has one vmcnt(0) per load)
 }
 
 
