@@ -129,6 +129,8 @@ int rnnpose_induced_coords_lowres_f32(const float* depth, const float* K, const 
 int rnnpose_corr_weight_f32(const float* g1, const float* g2, const float* target, int target_mode,
                             const float* depth, const float* sigma, int B, int D, int H, int W,
                             float* weight, rnnpose_stream_t stream);
+int rnnpose_corr_weight_pairs(int enable);    /* r06 measurement / test switch: 1 (default) = the two taps of an image row arrive as ONE 8-byte load (3 load
+                                               * instructions per channel and pixel instead of 5; same arithmetic, bit-identical weights for finite descriptors), 0 = four 4-byte tap loads */
 
 /* ---- a9: Gauss-Newton normal equations (fp64) -- geometry/transformation.py:274-297,
  *      geometry/projective_ops.py:116-124, geometry/transformation.py:27-46

@@ -58,6 +58,7 @@ PROTOTYPES = {
     "rnnpose_convex_upsample_f32": (_i, [_p, _p, _i, _i, _i, _i, _p, _p]),
     "rnnpose_induced_flow_f32": (_i, [_p, _p, _p, _i, _i, _i, _f, _i, _p, _p, _p]),
     "rnnpose_induced_coords_lowres_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _f, _p, _p]),
+    "rnnpose_corr_weight_pairs": (_i, [_i]),
     "rnnpose_corr_weight_f32": (_i, [_p, _p, _p, _i, _p, _p, _i, _i, _i, _i, _p, _p]),
     "rnnpose_lm_workspace_bytes": (_z, [_i, _i, _i]),
     "rnnpose_lm_normal_eq_f64": (_i, [_p, _i, _p, _p, _f, _p, _p, _i, _i, _i, _p, _z, _p, _p, _p]),

@@ -192,7 +192,11 @@ __global__ __launch_bounds__(256) void convex_upsample_kernel(const float* __res
 #ifndef RP_CW_BATCH
 #define RP_CW_BATCH 4
 #endif
-constexpr int CW_BATCH = RP_CW_BATCH;   // channels whose 5 loads each are in flight together
+constexpr int CW_BATCH = RP_CW_BATCH;   // channels whose 5 (3 with tap pairs) loads each are in flight together
+#ifndef RP_CW_PAIRS
+#define RP_CW_PAIRS 0     // default of rnnpose_corr_weight_pairs: 1 = the two taps of a row as one 8-byte load (r06: bit-identical, 56.6 vs 58.6 us alone, but -0.8 % on the step: profiles/r06_corr_weight_pairs.txt)
+#endif
+template <bool PAIRS>     // PAIRS (r06, W >= 2): the two taps of a row as one 8-byte load (descriptor_weight.cuh)
 __global__ __launch_bounds__(256) void corr_weight_kernel(const float* __restrict__ g1, const float* __restrict__ g2,
                                                           const float* __restrict__ target, int target_mode,
                                                           const float* __restrict__ depth,
@@ -247,8 +251,14 @@ __global__ __launch_bounds__(256) void corr_weight_kernel(const float* __restric
 #if RP_CW_DEBUG == 3   // diagnostics: the descriptor path alone (the target is the pixel itself, the flow map is read and ignored)
   tx = static_cast<float>(x) + 0.f * tx; ty = static_cast<float>(y) + 0.f * ty;
 #endif
-  const rp::DescTaps taps = rp::descriptor_taps(tx, ty, H, W);
-  const float s = rp::descriptor_dot<CW_BATCH>(g1 + static_cast<long long>(b) * D * P + t, g2 + static_cast<long long>(b) * D * P, P, D, taps);
+  float s;
+  if constexpr (PAIRS) {
+    const rp::DescPairs pairs = rp::descriptor_pairs(tx, ty, H, W);
+    s = rp::descriptor_dot_pairs<CW_BATCH>(g1 + static_cast<long long>(b) * D * P + t, g2 + static_cast<long long>(b) * D * P, P, D, pairs);
+  } else {
+    const rp::DescTaps taps = rp::descriptor_taps(tx, ty, H, W);
+    s = rp::descriptor_dot<CW_BATCH>(g1 + static_cast<long long>(b) * D * P + t, g2 + static_cast<long long>(b) * D * P, P, D, taps);
+  }
 #if RP_CW_DEBUG == 1   // diagnostics: what this thread read from the flow map (x / y plane)
   weight[b * P + t] = tx + 0.f * s;
 #elif RP_CW_DEBUG == 2
@@ -350,6 +360,12 @@ int rnnpose_convex_upsample_f32(const float* flow, const float* mask, int B, int
   return rp::check_launch(fn);
 }
 
+static int g_cw_pairs = RP_CW_PAIRS;
+int rnnpose_corr_weight_pairs(int enable) {      // measurement / test switch: 1 (default) the two taps of a row as one 8-byte load, 0 four 4-byte tap loads
+  g_cw_pairs = enable ? 1 : 0;
+  return 0;
+}
+
 int rnnpose_corr_weight_f32(const float* g1, const float* g2, const float* target, int target_mode, const float* depth,
                             const float* sigma, int B, int D, int H, int W, float* weight, rnnpose_stream_t stream) {
   const char* fn = "rnnpose_corr_weight_f32";
@@ -358,8 +374,12 @@ int rnnpose_corr_weight_f32(const float* g1, const float* g2, const float* targe
   RP_REQUIRE(B > 0 && B < 65536 && D > 0 && H > 1 && W > 1 && static_cast<long long>(H) * W < (1LL << 31), fn, "bad size");
   const long long P = static_cast<long long>(H) * W;
   RP_REQUIRE(static_cast<long long>(rp::cdiv(P, 256)) * B < (1LL << 31), fn, "grid too large");
-  hipLaunchKernelGGL(corr_weight_kernel, dim3(static_cast<unsigned>(rp::cdiv(P, 256) * B)), dim3(256), 0, rp::as_stream(stream), g1, g2, target,
-                     target_mode, depth, sigma, weight, D, H, W);
+  if (g_cw_pairs && W >= 2)
+    hipLaunchKernelGGL(corr_weight_kernel<true>, dim3(static_cast<unsigned>(rp::cdiv(P, 256) * B)), dim3(256), 0, rp::as_stream(stream), g1, g2,
+                       target, target_mode, depth, sigma, weight, D, H, W);
+  else
+    hipLaunchKernelGGL(corr_weight_kernel<false>, dim3(static_cast<unsigned>(rp::cdiv(P, 256) * B)), dim3(256), 0, rp::as_stream(stream), g1, g2,
+                       target, target_mode, depth, sigma, weight, D, H, W);
   return rp::check_launch(fn);
 }
 

@@ -493,6 +493,39 @@ def test_corr_weight(ops, golden):
     assert float(wf[~fg].abs().max()) == 0
 
 
+@pytest.mark.parametrize("H,W", [(64, 96), (37, 41), (9, 2)])
+def test_corr_weight_tap_pairs_are_bit_identical_to_four_taps(ops, H, W):
+    """r06: the two taps of an image row arrive as ONE 8-byte load from column clamp(x0, 0, W - 2) and the tap weights move to the pair
+    element that holds their texel (csrc/descriptor_weight.cuh).  Same expression, same order: the weights must equal the four-tap form's
+    bit for bit -- interior, every border (targets up to 3 pixels outside on each side), exactly-on-texel targets, far outside, W = 2
+    (W = 1 keeps the four-tap kernel); against the oracle as well."""
+    from rnnpose_amd import _lib
+    B, Dd = 2, 32
+    g1 = D(syn.normal("g1p", (B, Dd, H, W), 31))
+    g2 = D(syn.normal("g2p", (B, Dd, H, W), 32))
+    depth = D((syn.uniform("dp", (B, 1, H, W), 33) > 0.2).astype(np.float32) * 1.1)
+    sigma = torch.tensor([0.7], device="cuda")
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    grid = torch.stack([xs, ys], -1)[None].expand(B, H, W, 2)
+    cases = {
+        "sub-pixel": grid + T(syn.uniform("tp", (B, H, W, 2), 34, -3.0, 3.0)),
+        "on-texel": grid + T(np.round(syn.uniform("tq", (B, H, W, 2), 35, -3.0, 3.0))),
+        "stretched": grid * 1.08 - 2.0,                      # walks across the right / bottom border
+        "far": grid + 1e5,
+    }
+    try:
+        for name, tgt in cases.items():
+            tgt = D(tgt.contiguous())
+            _lib.call("rnnpose_corr_weight_pairs", 1)
+            wp = ops.corr_weight(g1, g2, tgt, depth, sigma).clone()
+            _lib.call("rnnpose_corr_weight_pairs", 0)
+            w4 = ops.corr_weight(g1, g2, tgt, depth, sigma).clone()
+            assert torch.equal(wp, w4), (name, float((wp - w4).abs().max()))
+            close(wp, orc.corr_weight(g1.cpu().numpy(), g2.cpu().numpy(), tgt.cpu(), depth.cpu().numpy(), sigma.cpu().numpy()), 1e-5, what=f"weight oracle ({name})")
+    finally:
+        _lib.call("rnnpose_corr_weight_pairs", 1)
+
+
 # ------------------------------------------------------------------------------------------------ a9-a11
 def _wpat(g, pat, B, H, W):
     return {
