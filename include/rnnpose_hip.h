@@ -175,6 +175,10 @@ int rnnpose_lm_fused_tail(int enable);
 int rnnpose_se3_exp_f32(const float* xi, int B, float* out, rnnpose_stream_t stream);
 int rnnpose_se3_compose_f32(const float* A, const float* Bm, int B, float* out, rnnpose_stream_t stream);
 int rnnpose_se3_inverse_f32(const float* A, int B, float* out, rnnpose_stream_t stream);
+/* r06: the pose bookkeeping between two outer iterations as one launch (model/PoseRefiner.py:241-244): Ti_out = Tij Ti; Tij_out = Ti_out Ti_out^-1 (literal != 0:
+ * the reference's legacy product) or the exact identity (literal == 0).  Bit-identical to rnnpose_se3_compose_f32 / _inverse_f32 / _compose_f32 in that order.
+ * Tij, Ti, Ti_out, Tij_out: (B,4,4) fp32 row-major; the outputs must not alias the inputs. */
+int rnnpose_se3_outer_update_f32(const float* Tij, const float* Ti, int B, int literal, float* Ti_out, float* Tij_out, rnnpose_stream_t stream);
 
 /* ---- a4: SepConvGRU pointwise stages ---------------------------- thirdparty/raft/update.py:45-60
  * zr (B,2C,h,w) = pre-activation outputs of the fused z|r convolution, hcat (B,Ctot,h,w) whose first

@@ -69,6 +69,7 @@ PROTOTYPES = {
     "rnnpose_se3_exp_f32": (_i, [_p, _i, _p, _p]),
     "rnnpose_se3_compose_f32": (_i, [_p, _p, _i, _p, _p]),
     "rnnpose_se3_inverse_f32": (_i, [_p, _i, _p, _p]),
+    "rnnpose_se3_outer_update_f32": (_i, [_p, _p, _i, _i, _p, _p, _p]),
     "rnnpose_gru_gate_f32": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p]),
     "rnnpose_gru_update_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _i, _p]),
     "rnnpose_conv_tiles_per_image": (_i, [_i, _i, _i, _i, _i]),

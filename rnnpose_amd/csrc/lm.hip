@@ -418,6 +418,35 @@ __global__ void se3_inverse_kernel(const float* __restrict__ A, int B, float* __
   for (int i = 0; i < 16; ++i) out[b * 16 + i] = o[i];
 }
 
+// a12, r06: the pose bookkeeping between two outer iterations as ONE launch (model/PoseRefiner.py:241-244) -- Ti <- Tij Ti, then the legacy start pose
+// Tij <- Ti Ti^-1 (literal != 0: the reference's product, the identity up to fp32 rounding) or the exact identity.  The same three kernels' arithmetic
+// in the same order (se3_compose, se3_inverse, se3_compose above): bit-identical to them; five ~6-us launches fewer per outer iteration.
+__global__ void se3_outer_update_kernel(const float* __restrict__ Tij, const float* __restrict__ Ti, int B, int literal, float* __restrict__ Ti_out,
+                                        float* __restrict__ Tij_out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float a[16], c[16], t[16], inv[16], o[16];
+  for (int i = 0; i < 16; ++i) {
+    a[i] = Tij[b * 16 + i];
+    c[i] = Ti[b * 16 + i];
+  }
+  mat4_mul(a, c, t);
+  for (int i = 0; i < 16; ++i) Ti_out[b * 16 + i] = t[i];
+  if (literal) {
+    for (int i = 0; i < 3; ++i) {
+      for (int j = 0; j < 3; ++j) inv[i * 4 + j] = t[j * 4 + i];
+      float s = 0.f;
+      for (int k = 0; k < 3; ++k) s += t[k * 4 + i] * t[k * 4 + 3];
+      inv[i * 4 + 3] = -s;
+    }
+    inv[12] = 0.f; inv[13] = 0.f; inv[14] = 0.f; inv[15] = 1.f;
+    mat4_mul(t, inv, o);
+  } else {
+    for (int i = 0; i < 16; ++i) o[i] = (i % 5 == 0) ? 1.f : 0.f;
+  }
+  for (int i = 0; i < 16; ++i) Tij_out[b * 16 + i] = o[i];
+}
+
 // workspace = [B arrival counters, 8 bytes each: zero between launches][partial records]
 inline double* lm_partials(void* workspace, int B) { return static_cast<double*>(workspace) + B; }
 
@@ -547,6 +576,13 @@ int rnnpose_se3_compose_f32(const float* A, const float* Bm, int B, float* out, 
   const char* fn = "rnnpose_se3_compose_f32";
   RP_REQUIRE(A && Bm && out && B > 0, fn, "bad argument");
   hipLaunchKernelGGL(se3_compose_kernel, dim3(rp::cdiv(B, 64)), dim3(64), 0, rp::as_stream(stream), A, Bm, B, out);
+  return rp::check_launch(fn);
+}
+
+int rnnpose_se3_outer_update_f32(const float* Tij, const float* Ti, int B, int literal, float* Ti_out, float* Tij_out, rnnpose_stream_t stream) {
+  const char* fn = "rnnpose_se3_outer_update_f32";
+  RP_REQUIRE(Tij && Ti && Ti_out && Tij_out && B > 0, fn, "null pointer / empty batch");
+  hipLaunchKernelGGL(se3_outer_update_kernel, dim3(rp::cdiv(B, 64)), dim3(64), 0, rp::as_stream(stream), Tij, Ti, B, literal, Ti_out, Tij_out);
   return rp::check_launch(fn);
 }
 

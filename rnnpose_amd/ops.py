@@ -508,6 +508,17 @@ def se3_compose(A, Bm):
     return out
 
 
+def se3_outer_update(Tij, Ti, literal: bool = True):
+    """-> (Ti_new, Tij_new) = (Tij Ti, literal ? Ti_new Ti_new^-1 : I): the pose bookkeeping between two outer iterations
+    (model/PoseRefiner.py:241-244) as one launch; bit-identical to se3_compose / se3_inverse / se3_compose."""
+    Tij, Ti = _chk(Tij, "Tij"), _chk(Ti, "Ti")
+    if Tij.shape != Ti.shape:
+        raise ValueError("se3_outer_update needs equal shapes")
+    Ti_new, Tij_new = torch.empty_like(Ti), torch.empty_like(Tij)
+    _launch("rnnpose_se3_outer_update_f32", _ptr(Tij), _ptr(Ti), Ti.numel() // 16, int(bool(literal)), _ptr(Ti_new), _ptr(Tij_new), _stream())
+    return Ti_new, Tij_new
+
+
 def se3_inverse(A):
     A = _chk(A, "A")
     out = torch.empty_like(A)

@@ -416,11 +416,16 @@ class PoseRefiner(nn.Module):
             if ren_iter == 1 and self.profile_rec is not None:          # measurement hook: only the FIRST outer iteration is
                 ops.profile_end(self.profile_rec)                       # event-instrumented (eager), the others replay graphs
                 self.profile_rec = None
-            Ti = Tij * Ti                                               # accumulate (PoseRefiner.py:241)
+            fused_pose = self.fused and Ti.G.is_cuda and self.legacy and Ti.G.shape == Tij.G.shape and os.environ.get("RNNPOSE_FUSED_POSE", "1") != "0"
+            if fused_pose:       # r06: :241-244 as ONE launch (ops.se3_outer_update: bit-identical to the three it replaces)
+                Ti_G, Tij_G = ops.se3_outer_update(Tij.G, Ti.G, self.literal_legacy_pose)
+                Ti = Ti.__class__(matrix=Ti_G, internal=Ti.internal)
+            else:
+                Ti = Tij * Ti                                           # accumulate (PoseRefiner.py:241)
             # the reference calls Tij.identity_() here, which also resets the object it stored in
             # residual_pose_history one line of bookkeeping earlier (same Python object); a fresh object keeps
             # the history intact
-            Tij = Tij.identity()
+            Tij = Tij.__class__(matrix=Tij_G, internal=Tij.internal, eq=Tij.eq) if fused_pose else Tij.identity()
             # The reference's legacy branch forms Tij = Ti * Ti.inv() here (:243-244): the identity up to fp32 rounding of ITS
             # inverse / product (~1e-7, BLAS-dependent).  That noise is not reproducible between implementations, and it is not
             # harmless: it moves the first lookup ~1e-6..1e-5 px off the integer grid, which a correlation surface of
@@ -431,7 +436,7 @@ class PoseRefiner(nn.Module):
             # gains, 960 x 1280) show the literal product CLOSER to the reference's own outputs than the identity on three of four
             # (profiles/r05_fixture_distances.txt), so the product is the default (two 4 x 4 kernels per outer iteration) and the
             # oracle's default follows; `literal_legacy_pose=False` keeps the identity as an option.
-            if self.legacy and self.literal_legacy_pose:
+            if self.legacy and self.literal_legacy_pose and not fused_pose:
                 Tij = Ti * Ti.inv()
             views = self.renderer.render_views(Ti.matrix().squeeze(1), intrinsics, obj_cls=obj_cls, image=image,
                                                fea_3d=fea_3d, geofea_3d=geofea_3d, geofea_2d=geofea_2d)

@@ -493,6 +493,24 @@ def test_corr_weight(ops, golden):
     assert float(wf[~fg].abs().max()) == 0
 
 
+@pytest.mark.parametrize("literal", [True, False])
+def test_se3_outer_update_is_the_three_launches_it_replaces(ops, literal):
+    """r06: Ti <- Tij Ti and the next start pose Tij <- Ti Ti^-1 (model/PoseRefiner.py:241-244) as one launch: bit-identical to
+    se3_compose -> se3_inverse -> se3_compose (literal) / the exact identity."""
+    xi = D(syn.normal("xi_o", (5, 1, 6), 41, std=0.3))
+    xj = D(syn.normal("xj_o", (5, 1, 6), 42, std=0.02))
+    Ti, Tij = ops.se3_exp(xi), ops.se3_exp(xj)
+    Ti_new, Tij_new = ops.se3_outer_update(Tij, Ti, literal)
+    want_Ti = ops.se3_compose(Tij, Ti)
+    assert torch.equal(Ti_new, want_Ti)
+    if literal:
+        want = ops.se3_compose(want_Ti, ops.se3_inverse(want_Ti))
+        assert float((want - torch.eye(4, device="cuda")).abs().max()) < 1e-5
+    else:
+        want = torch.eye(4, device="cuda").expand_as(want_Ti).contiguous()
+    assert torch.equal(Tij_new, want)
+
+
 @pytest.mark.parametrize("H,W", [(64, 96), (37, 41), (9, 2)])
 def test_corr_weight_tap_pairs_are_bit_identical_to_four_taps(ops, H, W):
     """r06: the two taps of an image row arrive as ONE 8-byte load from column clamp(x0, 0, W - 2) and the tap weights move to the pair
