@@ -90,6 +90,8 @@ int rnnpose_corr_alt_lookup_f32(const float* fmap1_nhwc, const float* fmap2_nhwc
  * bilinear, align_corners=True, zero padding.  radius must be 4 (the only value the reference uses). */
 int rnnpose_corr_lookup_f32(const float* pyramid, const float* coords, int B, int h, int w, int levels,
                             int radius, float* out, rnnpose_stream_t stream);
+int rnnpose_corr_lookup_variant(int variant);   /* r06 measurement / test switch: 1 (default) = the lookup kernel at half the instructions per wave (one address form per level
+                                                 * class, scalar pixel bases, phase 2 on 48 lanes), 0 = the r01-r05 kernel.  Bit-identical results. */
 
 /* ---- a5: GRU_CFUpdator glue -------------------------------------------- model/CFNet.py:124-144
  * context_prep: ctx (B,C,H,W) -> bilinear (align_corners=True) resize to (h,w); first `hdim` channels

@@ -52,6 +52,7 @@ PROTOTYPES = {
     "rnnpose_fmap_pyramid_floats": (_z, [_i, _i, _i, _i, _i]),
     "rnnpose_fmap_pyramid_f32": (_i, [_p, _i, _i, _i, _i, _i, _p, _p]),
     "rnnpose_corr_alt_lookup_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _i, _p]),
+    "rnnpose_corr_lookup_variant": (_i, [_i]),
     "rnnpose_corr_lookup_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p]),
     "rnnpose_context_prep_f32": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
     "rnnpose_flow_to_coords_f32": (_i, [_p, _i, _i, _i, _i, _i, _p, _p]),

@@ -87,6 +87,67 @@ __device__ __forceinline__ void gather_px(const float* __restrict__ pyr, const L
   }
 }
 
+// r06: the same fetch with a third of the instructions (the lookup is bound by INSTRUCTIONS per wave, not by a pipe: ~1600 per 16 pixels of one
+// level, ~1000 of them here -- per load a 64-bit patch-stride multiply, both address forms evaluated and selected, four bpermutes per pixel):
+//   * L0 (level 0, j-patch-major) or not is a TEMPLATE parameter: one address form, chosen by one wave-uniform branch around the whole body;
+//   * the pixel's footprint base / image / index come from v_readlane (the pixel slot is wave-uniform): scalars, and the pixel's map base is a
+//     scalar 64-bit address; a lane's texel is an unsigned 32-bit BYTE offset from it (a level-0 image is N^2 floats <= 1.5 GB at 120 x 160);
+//   * bounds tests as unsigned compares.
+// Same texels into the same LDS slots: the results do not change by a bit.
+template <int NP, bool L0>
+__device__ __forceinline__ void gather_px_fast(const float* __restrict__ pyr, const LookupInfo& info, int lvl, int N, int lane, int npix,
+                                              int bx, int by, int bg, int pixg, long long first_row, float* foot) {
+  const int hl = info.hl[lvl], wl = info.wl[lvl];
+  const char* const lvl_base = reinterpret_cast<const char*>(pyr + info.off[lvl]);
+  const unsigned img_b = static_cast<unsigned>(hl * wl) * 4u;               // bytes of one pixel's map (levels >= 1)
+  const unsigned pstride = static_cast<unsigned>(N) * 128u;                 // level 0: floats from one j patch to the next
+  const int t0 = lane, t1 = lane + 64;
+  const int ty0 = t0 / FP, tx0 = t0 - ty0 * FP;
+  const int ty1 = t1 / FP, tx1 = t1 - ty1 * FP;
+  constexpr int LB = RPL_LB < NP ? RPL_LB : NP;
+  const bool has1 = t1 < FP * FP;
+  const unsigned uw = static_cast<unsigned>(wl), uh = static_cast<unsigned>(hl);
+#pragma unroll
+  for (int qb = 0; qb < NP; qb += LB) {
+    float v0[LB], v1[LB];
+    unsigned ok = 0u;
+#pragma unroll
+    for (int j = 0; j < LB; ++j) {
+      const int q = qb + j;
+      const int qq = q < npix ? q : npix - 1;                               // (wave-uniform)
+      const int qbx = __builtin_amdgcn_readlane(bx, qq), qby = __builtin_amdgcn_readlane(by, qq);
+      const char* src;
+      if constexpr (L0) {
+        const int qbg = __builtin_amdgcn_readlane(bg, qq), qpix = __builtin_amdgcn_readlane(pixg, qq);
+        src = lvl_base + (static_cast<long long>(qbg) * info.n_patch * N + qpix) * 512;
+      } else {
+        src = lvl_base + (first_row + qq) * static_cast<long long>(img_b);
+      }
+      const int xa = qbx + tx0, ya = qby + ty0, xb = qbx + tx1, yb = qby + ty1;
+      const bool oka = static_cast<unsigned>(xa) < uw && static_cast<unsigned>(ya) < uh;
+      const bool okb = has1 && static_cast<unsigned>(xb) < uw && static_cast<unsigned>(yb) < uh;
+      unsigned ea, eb;
+      if constexpr (L0) {     // texel (y, x) of pixel i = patch ((y >> 3) n_px + (x >> 4)), row i, cell (y & 7, x & 15)
+        ea = (static_cast<unsigned>((ya >> 3) * info.n_px + (xa >> 4)) * pstride + static_cast<unsigned>(((ya & 7) << 4) | (xa & 15))) * 4u;
+        eb = (static_cast<unsigned>((yb >> 3) * info.n_px + (xb >> 4)) * pstride + static_cast<unsigned>(((yb & 7) << 4) | (xb & 15))) * 4u;
+      } else {
+        ea = static_cast<unsigned>(ya * wl + xa) * 4u;
+        eb = static_cast<unsigned>(yb * wl + xb) * 4u;
+      }
+      v0[j] = *reinterpret_cast<const float*>(src + (oka ? ea : 0u));
+      v1[j] = *reinterpret_cast<const float*>(src + (okb ? eb : 0u));
+      ok |= (oka ? 1u : 0u) << (2 * j) | (okb ? 2u : 0u) << (2 * j);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < LB; ++j) {
+      const int q = qb + j;
+      foot[q * FS + t0] = (ok >> (2 * j)) & 1u ? v0[j] : 0.f;
+      if (has1) foot[q * FS + t1] = (ok >> (2 * j)) & 2u ? v1[j] : 0.f;
+    }
+  }
+}
+
 __device__ __forceinline__ void gather16(const float* __restrict__ pyr, const LookupInfo& info, int lvl, int N, int lane, int npix,
                                          int bx, int by, int bg, int pixg, long long first_row, float* foot) {
   gather_px<PIX>(pyr, info, lvl, N, lane, npix, bx, by, bg, pixg, first_row, foot);

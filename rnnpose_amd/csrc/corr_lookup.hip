@@ -112,7 +112,123 @@ __global__ __launch_bounds__(64) void corr_lookup_kernel(const float* __restrict
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// r06: the same lookup at half the instructions per wave (RPL_V2 = 1, default; 0 keeps the r01-r05 kernel above for A/B).  The kernel is
+// bound by instructions, not by HBM (98 MB per half-batch launch in 26 us) -- ~1600 per wave for 16 pixels of one level:
+//   * phase 1 by gather_px_fast (corr_lookup.cuh): one address form per level class, scalar pixel bases, 32-bit byte offsets;
+//   * every lane carries the coordinates of pixel (lane & 15), so that phase 2 runs on 48 lanes instead of 16: lane (q, part) slides the
+//     two-row window over footprint rows 3 part .. 3 part + 3 and produces the 27 channels i * 9 + j, j in [3 part, 3 part + 3) -- the
+//     same expression per channel, bit-identical values -- and writes them into the transposition buffer itself;
+//   * the NHWC rows leave as before (a pixel's 81 values of the level = one contiguous 324-byte run).
+template <bool L0>
+__device__ __forceinline__ void lookup_body_v2(const float* __restrict__ pyr, const float* __restrict__ coords, float* __restrict__ out, int B,
+                                               int h, int w, int levels, const LookupInfo& info, int nhwc, long long p_off,
+                                               const rp::InducedSrc& isrc, float* __restrict__ coords_out, float* foot, int lvl) {
+  const int N = h * w;
+  const long long total = static_cast<long long>(B) * N;
+  const int lane = threadIdx.x;
+  const int q16 = lane & 15, part = lane >> 4;
+  const long long first = static_cast<long long>(blockIdx.x) * PIX;
+  const long long p = first + q16;                                        // flat (b, Y, X) of this lane's pixel
+  const bool live = p < total;
+  const float inv = 1.0f / static_cast<float>(1 << lvl);
+
+  float cx = 0.f, cy = 0.f;
+  int b = 0, pix = 0;
+  const long long prow = p_off + (p < total ? p : total - 1);
+  const int bg = static_cast<int>(prow / N), pixg = static_cast<int>(prow - static_cast<long long>(bg) * N);
+  if (live) {
+    b = static_cast<int>(p / N);
+    pix = static_cast<int>(p - static_cast<long long>(b) * N);
+    if (isrc.depth) {
+      const int Y = pix / w, X = pix - Y * w;
+      const float2 c = rp::induced_coords_at(isrc.depth + static_cast<long long>(b) * isrc.H * isrc.W, X, Y, isrc.H, isrc.W, h, w, isrc.eps,
+                                             rp::load_intr(isrc.K, b), rp::load_pose(isrc.G, b));
+      if (lvl == 0 && coords_out && part == 0) {
+        coords_out[(static_cast<long long>(b) * 2 + 0) * N + pix] = c.x;
+        coords_out[(static_cast<long long>(b) * 2 + 1) * N + pix] = c.y;
+      }
+      cx = c.x * inv;
+      cy = c.y * inv;
+    } else {
+      cx = coords[(static_cast<long long>(b) * 2 + 0) * N + pix] * inv;
+      cy = coords[(static_cast<long long>(b) * 2 + 1) * N + pix] * inv;
+    }
+  }
+  int bx, by;
+  float ax, ay;
+  footprint_base(cx, cy, bx, by, ax, ay);
+
+  // ---- phase 1: cooperative footprint fetch ----
+  const int npix = static_cast<int>(total - first < PIX ? total - first : PIX);
+  gather_px_fast<PIX, L0>(pyr, info, lvl, N, lane, npix, bx, by, bg, pixg, p_off + first, foot);
+  __syncthreads();
+  // ---- phase 2: lane = (pixel, third of the window rows) ----
+  const float w00 = (1.f - ax) * (1.f - ay), w10 = ax * (1.f - ay), w01 = (1.f - ax) * ay, w11 = ax * ay;
+  const int pr = part < 3 ? part : 2;                                     // (the fourth lane group repeats the third one's work and writes nothing)
+  const float* f = foot + q16 * FS + 3 * pr * FP;
+  float res[3][WIN];
+  {
+    float prev[FP], cur[FP];
+#pragma unroll
+    for (int x = 0; x < FP; ++x) prev[x] = f[x];
+#pragma unroll
+    for (int jj = 0; jj < 3; ++jj) {         // y offset 3 part + jj - 4 -> footprint rows 3 part + jj, + 1
+#pragma unroll
+      for (int x = 0; x < FP; ++x) cur[x] = f[(jj + 1) * FP + x];
+#pragma unroll
+      for (int i = 0; i < WIN; ++i)          // x offset i - 4 -> footprint cols i, i + 1; channel i * 9 + j
+        res[jj][i] = w00 * prev[i] + w10 * prev[i + 1] + w01 * cur[i] + w11 * cur[i + 1];
+#pragma unroll
+      for (int x = 0; x < FP; ++x) prev[x] = cur[x];
+    }
+  }
+  __syncthreads();                                                        // every lane is done reading the footprints: the buffer is re-used
+  if (part < 3) {
+#pragma unroll
+    for (int jj = 0; jj < 3; ++jj)
+#pragma unroll
+      for (int i = 0; i < WIN; ++i) foot[q16 * (WIN * WIN) + i * WIN + 3 * part + jj] = res[jj][i];
+  }
+  __syncthreads();
+  if (!nhwc) {
+    // (B, L*81, h, w): lanes 0..15 = the 16 pixels; a channel row of 16 consecutive pixels is one 64-byte run
+    if (lane < PIX && live) {
+      float* o = out + (static_cast<long long>(b) * levels * (WIN * WIN) + static_cast<long long>(lvl) * (WIN * WIN)) * N + pix;
+#pragma unroll
+      for (int c = 0; c < WIN * WIN; ++c) o[static_cast<long long>(c) * N] = foot[lane * (WIN * WIN) + c];
+    }
+  } else {
+    const int ctot = levels * WIN * WIN;
+    float* o = out + first * ctot + lvl * (WIN * WIN);
+    for (int q = 0; q < npix; ++q) {
+      o[static_cast<long long>(q) * ctot + lane] = foot[q * (WIN * WIN) + lane];
+      if (lane < WIN * WIN - 64) o[static_cast<long long>(q) * ctot + 64 + lane] = foot[q * (WIN * WIN) + 64 + lane];
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void corr_lookup_v2_kernel(const float* __restrict__ pyr, const float* __restrict__ coords,
+                                                            float* __restrict__ out, int B, int h, int w, int levels,
+                                                            LookupInfo info, int nhwc, long long p_off, const rp::InducedSrc isrc,
+                                                            float* __restrict__ coords_out) {
+  __shared__ float foot[PIX * FS];
+  const int lvl = blockIdx.y;
+  if (lvl == 0) lookup_body_v2<true>(pyr, coords, out, B, h, w, levels, info, nhwc, p_off, isrc, coords_out, foot, lvl);
+  else lookup_body_v2<false>(pyr, coords, out, B, h, w, levels, info, nhwc, p_off, isrc, coords_out, foot, lvl);
+}
+
+#ifndef RPL_V2
+#define RPL_V2 1
+#endif
+
 }  // namespace
+
+static int g_lookup_v2 = RPL_V2;
+extern "C" int rnnpose_corr_lookup_variant(int variant) {      // measurement / test switch: 1 (default) = the r06 kernel, 0 = the r01-r05 kernel; bit-identical results
+  g_lookup_v2 = variant ? 1 : 0;
+  return 0;
+}
 
 // B_total: batch the pyramid was built for (its layout); [b0, b1): the images this launch looks up.  coords / out point at
 // image b0 (sub-batch tensors); the pyramid pointer is the whole buffer.
@@ -135,8 +251,14 @@ static int launch_lookup(const char* fn, const float* pyramid, const float* coor
   const int B = b1 - b0;
   const long long total = static_cast<long long>(B) * h * w;
   dim3 grid(static_cast<unsigned>(rp::cdiv(total, PIX)), static_cast<unsigned>(levels)), block(64);
-  hipLaunchKernelGGL(corr_lookup_kernel, grid, block, 0, rp::as_stream(stream), pyramid, coords, out, B, h, w, levels, info,
-                     nhwc, static_cast<long long>(b0) * h * w, isrc, coords_out);
+  // (the r06 kernel addresses a level-0 image by unsigned 32-bit byte offsets: N^2 floats below 4 GB -- true up to 180 x 180 maps; larger ones keep the r05 kernel)
+  const bool v2 = g_lookup_v2 && static_cast<long long>(info.n_patch) * h * w * 512 < (1LL << 32);
+  if (v2)
+    hipLaunchKernelGGL(corr_lookup_v2_kernel, grid, block, 0, rp::as_stream(stream), pyramid, coords, out, B, h, w, levels, info,
+                       nhwc, static_cast<long long>(b0) * h * w, isrc, coords_out);
+  else
+    hipLaunchKernelGGL(corr_lookup_kernel, grid, block, 0, rp::as_stream(stream), pyramid, coords, out, B, h, w, levels, info,
+                       nhwc, static_cast<long long>(b0) * h * w, isrc, coords_out);
   return rp::check_launch(fn);
 }
 

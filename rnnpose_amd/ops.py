@@ -712,6 +712,9 @@ def _apply_conv_env():
         v = _os.environ.get("RNNPOSE_KSPLIT")
         if v is not None:
             _lib.call("rnnpose_conv_ksplit", int(v != "0"))
+        v = _os.environ.get("RNNPOSE_LOOKUP_VARIANT")      # 0: the r01-r05 window-lookup kernel (same-box A/B; bit-identical results)
+        if v is not None:
+            _lib.call("rnnpose_corr_lookup_variant", int(v != "0"))
         v = _os.environ.get("RNNPOSE_STRIP")               # 0: the automatic tile choice never takes the strip kernels (same-box A/B);
         if v is not None:                                  # 2 / 3: strips with one / two column tiles per wave only
             _lib.call("rnnpose_conv_strip", int(v))

@@ -390,6 +390,7 @@ template <class T> inline T __shfl_up(T v, unsigned d, int = 64) {
   return hostexec::exchange(v, s >= 0 ? s : hostexec::my_lane());
 }
 template <class T> inline T __shfl(T v, int src, int = 64) { return hostexec::exchange(v, src); }
+inline int __builtin_amdgcn_readlane(int v, int src) { return hostexec::exchange(v, src); }      // v_readlane_b32: lane `src` (wave-uniform) of v, to every lane
 
 inline int __double2loint(double v) { long long b; std::memcpy(&b, &v, 8); return static_cast<int>(b); }
 inline int __double2hiint(double v) { long long b; std::memcpy(&b, &v, 8); return static_cast<int>(b >> 32); }

@@ -493,6 +493,39 @@ def test_corr_weight(ops, golden):
     assert float(wf[~fg].abs().max()) == 0
 
 
+@pytest.mark.parametrize("B,h,w", [(2, 16, 24), (1, 17, 19), (3, 30, 30), (2, 16, 41)])
+def test_corr_lookup_r06_kernel_is_bit_identical_to_the_r05_kernel(ops, B, h, w):
+    """r06: the window lookup at half the instructions per wave (csrc/corr_lookup.hip, corr_lookup_v2_kernel: level-0 / other-level address
+    forms as a template parameter, scalar pixel bases from v_readlane, 32-bit byte offsets, the two-row window of phase 2 on 48 lanes).
+    Same texels, same expression per channel: NCHW and NHWC outputs, sub-batch launches, integer / sub-pixel / out-of-bounds / NaN
+    coordinates must equal the r01-r05 kernel bit for bit."""
+    from rnnpose_amd import _lib
+    f1 = D(syn.normal("lk1", (B, 64, h, w), 51))
+    f2 = D(syn.normal("lk2", (B, 64, h, w), 52))
+    pyr, _ = ops.corr_pyramid(f1, f2)
+    ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
+    grid = torch.stack([xs, ys], 0)[None].expand(B, 2, h, w)
+    jitter = T(syn.uniform("lkj", (B, 2, h, w), 53, -6.0, 6.0))
+    cases = {"integer": grid.clone(), "sub-pixel": grid + jitter, "far": grid + 1e4}
+    nanc = (grid + jitter).clone()
+    nanc[:, :, ::3, ::4] = float("nan")
+    cases["nan"] = nanc
+    try:
+        for name, c in cases.items():
+            c = D(c.contiguous())
+            got = {}
+            for v in (1, 0):
+                _lib.call("rnnpose_corr_lookup_variant", v)
+                part = torch.empty(1, h, w, 4 * 81, device="cuda")
+                ops.corr_lookup_nhwc_part(pyr, c[B - 1:].contiguous(), part, B, B - 1, B)
+                got[v] = (ops.corr_lookup(pyr, c).clone(), ops.corr_lookup_nhwc(pyr, c).clone(), part)
+            for a, b_ in zip(got[1], got[0]):
+                assert torch.equal(a.nan_to_num(123.0), b_.nan_to_num(123.0)), name
+            assert torch.equal(got[1][2][0].nan_to_num(123.0), got[1][1][B - 1].nan_to_num(123.0)), name      # the sub-batch launch == the last image of the full one
+    finally:
+        _lib.call("rnnpose_corr_lookup_variant", 1)
+
+
 @pytest.mark.parametrize("literal", [True, False])
 def test_se3_outer_update_is_the_three_launches_it_replaces(ops, literal):
     """r06: Ti <- Tij Ti and the next start pose Tij <- Ti Ti^-1 (model/PoseRefiner.py:241-244) as one launch: bit-identical to
